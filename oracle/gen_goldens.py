@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- golden-vector generator.
+
+Runs ONLY in the build container, where the real reference is mounted at
+/root/reference.  It imports ``models/FastEGNN.py`` from there (with a stand-in
+for the one third-party symbol it needs, ``torch_geometric.nn.global_mean_pool``,
+torch_geometric==2.5.2 being absent), runs forward + autograd backward on small
+seeded cases and stores plain arrays under ``tests/golden/*.npz``:
+
+    in/<name>      inputs
+    p/<name>       state_dict tensors (reference key names)
+    out/loc, out/vloc, out/layer<i>/{h,x,Hv,Z}
+    gp/<name>      d loss / d parameter
+    gin/<name>     d loss / d {node_feat,node_loc,node_vel,loc_mean}
+    meta/*         constructor flags, loss definition
+
+No reference source, bytecode or pickled class leaves /root/reference; the
+fixtures are data only.  Usage:  python oracle/gen_goldens.py
+"""
+import os
+import sys
+import types
+import random
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _install_pyg_stand_in():
+    """Per-graph mean with PyG 2.5.2 semantics (size = batch.max()+1, empty -> 0),
+    written as an explicit loop so that it is independent of the oracle's helper."""
+    def global_mean_pool(x, batch, size=None):
+        n = int(batch.max()) + 1 if size is None else size
+        rows = []
+        for b in range(n):
+            sel = x[batch == b]
+            rows.append(sel.mean(0) if sel.size(0) > 0 else x.new_zeros(x.size(1)))
+        return torch.stack(rows, 0)
+
+    tg = types.ModuleType("torch_geometric")
+    tgnn = types.ModuleType("torch_geometric.nn")
+    tgnn.global_mean_pool = global_mean_pool
+    tg.nn = tgnn
+    sys.modules["torch_geometric"] = tg
+    sys.modules["torch_geometric.nn"] = tgnn
+
+
+def _import_reference():
+    _install_pyg_stand_in()
+    sys.path.insert(0, REF)
+    from models.FastEGNN import FastEGNN  # noqa
+    return FastEGNN
+
+
+def _rand_graph_batch(gen, sizes, edges_per_graph, self_loops=True, isolate=None):
+    """Ragged batch: random directed edges inside each graph (duplicates allowed)."""
+    rows, cols, batch = [], [], []
+    off = 0
+    for g, (n, e) in enumerate(zip(sizes, edges_per_graph)):
+        r = torch.randint(0, n, (e,), generator=gen)
+        c = torch.randint(0, n, (e,), generator=gen)
+        if not self_loops:
+            c = torch.where(c == r, (c + 1) % n, c)
+        if isolate is not None and isolate[0] == g:
+            k = isolate[1]
+            r = torch.where(r == k, (r + 1) % n, r)   # node k never aggregates
+        rows.append(r + off)
+        cols.append(c + off)
+        batch += [g] * n
+        off += n
+    ei = torch.stack([torch.cat(rows), torch.cat(cols)]).long()
+    perm = torch.randperm(ei.size(1), generator=gen)  # datasets emit edges unsorted by row
+    return ei[:, perm], torch.tensor(batch, dtype=torch.long)
+
+
+def _loc_mean(loc, batch, C):
+    B = int(batch.max()) + 1
+    cm = torch.stack([loc[batch == b].mean(0) for b in range(B)])   # [B,3]
+    return cm.unsqueeze(-1).repeat(1, 1, C)
+
+
+def run_case(FastEGNN, name, *, sizes, edges, nf, na, ea, C, H=64, L=4, seed=0,
+             attention=False, normalize=False, tanh=False, gravity=None, residual=True,
+             coord_scale=1.0, loc_scale=3.0, isolate=None, dtype=torch.float32,
+             explicit=None):
+    torch.manual_seed(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    model = FastEGNN(node_feat_nf=nf, node_attr_nf=na, edge_attr_nf=ea, hidden_nf=H,
+                     virtual_channels=C, device="cpu", n_layers=L, residual=residual,
+                     attention=attention, normalize=normalize, tanh=tanh, gravity=gravity)
+    with torch.no_grad():
+        for k, v in model.named_parameters():
+            if k.endswith("coord_mlp_r.2.weight") or k.endswith("coord_mlp_r_virtual.2.weight") \
+                    or k.endswith("coord_mlp_v_virtual.2.weight"):
+                v.mul_(coord_scale)
+    model = model.to(dtype)
+
+    if explicit is not None:
+        inp = {k: v.to(dtype) if v.is_floating_point() else v for k, v in explicit.items()}
+        ei, batch = inp["edge_index"], inp["data_batch"]
+        N = inp["node_loc"].size(0)
+    else:
+        ei, batch = _rand_graph_batch(gen, sizes, edges, isolate=isolate)
+        N = batch.numel()
+        loc = (torch.randn(N, 3, generator=gen) * loc_scale).to(dtype)
+        inp = dict(
+            node_feat=torch.rand(N, nf, generator=gen).to(dtype),
+            node_loc=loc,
+            node_vel=(torch.randn(N, 3, generator=gen) * 0.5).to(dtype),
+            edge_index=ei, data_batch=batch,
+            loc_mean=_loc_mean(loc, batch, C),
+            edge_attr=torch.rand(ei.size(1), ea, generator=gen).to(dtype),
+        )
+        if na > 0:
+            inp["node_attr"] = torch.rand(N, na, generator=gen).to(dtype)
+    B = int(batch.max()) + 1
+    target = (inp["node_loc"] + torch.randn(N, 3, generator=gen).to(dtype))
+    wv = torch.randn(B, 3, C, generator=gen).to(dtype)
+
+    leaf = {}
+    for k in ("node_feat", "node_loc", "node_vel", "loc_mean"):
+        leaf[k] = inp[k].clone().requires_grad_(True)
+
+    # per-layer intermediates via forward hooks on the gcl_i modules
+    layer_out = {}
+    hooks = []
+    for i in range(L):
+        def mk(i):
+            def hook(_m, _a, out):
+                layer_out[i] = [o.detach().clone() for o in out]
+            return hook
+        hooks.append(model._modules[f"gcl_{i}"].register_forward_hook(mk(i)))
+
+    loc_pred, vloc = model(node_feat=leaf["node_feat"], node_loc=leaf["node_loc"],
+                           node_vel=leaf["node_vel"], edge_index=ei, data_batch=batch,
+                           loc_mean=leaf["loc_mean"], edge_attr=inp["edge_attr"],
+                           node_attr=inp.get("node_attr"))
+    for h in hooks:
+        h.remove()
+    # loss touching both outputs (the harness's MSE + a linear probe of the virtual coords)
+    loss = torch.nn.functional.mse_loss(loc_pred, target) + 0.3 * (vloc * wv).sum() / vloc.numel()
+    loss.backward()
+
+    rec = {}
+    for k, v in inp.items():
+        rec[f"in/{k}"] = v.numpy()
+    rec["in/target"] = target.numpy()
+    rec["in/wv"] = wv.numpy()
+    for k, v in model.state_dict().items():
+        rec[f"p/{k}"] = v.detach().numpy()
+    rec["out/loc"] = loc_pred.detach().numpy()
+    rec["out/vloc"] = vloc.detach().numpy()
+    rec["out/loss"] = np.array(loss.item())
+    for i in range(L):
+        # E_GCL_vel.forward returns (node_feat, coord, virtual_node_feat, virtual_coord)
+        h_, x_, Hv_, Z_ = layer_out[i]
+        rec[f"out/layer{i}/h"] = h_.numpy()
+        rec[f"out/layer{i}/x"] = x_.numpy()
+        rec[f"out/layer{i}/Hv"] = Hv_.numpy()
+        rec[f"out/layer{i}/Z"] = Z_.numpy()
+    for k, v in model.named_parameters():
+        rec[f"gp/{k}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
+    for k, v in leaf.items():
+        rec[f"gin/{k}"] = v.grad.numpy()
+    meta = dict(nf=nf, na=na, ea=ea, C=C, H=H, L=L, attention=int(attention),
+                normalize=int(normalize), tanh=int(tanh), residual=int(residual),
+                has_gravity=int(gravity is not None))
+    for k, v in meta.items():
+        rec[f"meta/{k}"] = np.array(v)
+    rec["meta/gravity"] = np.array(gravity if gravity is not None else [0, 0, 0], dtype=np.float64)
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: N={N} E={ei.size(1)} B={B} loss={loss.item():.6f} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
+def nbody_case(n_systems=6, n_balls=5, C=3, cutoff_rate=0.5, seed=43):
+    """cfg-1 inputs from the reference's own simulator (datasets/nbody/datagen) and the
+    dataset's edge/feature construction (datasets/nbody/dataset.py:87-113), restated."""
+    sys.path.insert(0, os.path.join(REF, "datasets", "nbody", "datagen"))
+    from system import System
+    np.random.seed(seed)
+    locs, vels, chs = [], [], []
+    for _ in range(n_systems):
+        s = System(n_isolated=n_balls, n_stick=0, n_hinge=0)
+        X, V = [], []
+        for t in range(4100):
+            s.simulate_one_step()
+            if t % 100 == 0:
+                X.append(s.X.copy()); V.append(s.V.copy())
+        locs.append(np.array(X)); vels.append(np.array(V)); chs.append(s.charges.copy())
+    node_feat, loc0, vel0, loct, eis, eas, lms, batch = [], [], [], [], [], [], [], []
+    off = 0
+    for g in range(n_systems):
+        l0 = torch.tensor(locs[g][30], dtype=torch.float32)
+        lt = torch.tensor(locs[g][40], dtype=torch.float32)
+        v0 = torch.tensor(vels[g][30], dtype=torch.float32)
+        ch = torch.tensor(chs[g], dtype=torch.float32)
+        n = l0.size(0)
+        dist = torch.cdist(l0, l0) + torch.eye(n) * 1e18
+        k = int(n * (n - 1) * (1 - cutoff_rate))
+        _, idc = torch.topk(dist.view(-1), k, largest=False)
+        ei = torch.stack([idc // n, idc % n]).long()
+        ea = (l0[ei[0]] - l0[ei[1]]).norm(dim=1, keepdim=True)
+        node_feat.append(torch.cat([v0.norm(dim=1, keepdim=True), ch / ch.max()], 1))
+        loc0.append(l0); vel0.append(v0); loct.append(lt)
+        eis.append(ei + off); eas.append(ea)
+        lms.append(l0.mean(0).unsqueeze(-1).repeat(1, C).unsqueeze(0))
+        batch += [g] * n
+        off += n
+    loc0 = torch.cat(loc0); ei = torch.cat(eis, 1)
+    ea = torch.cat(eas)
+    # harness augmentation (utils/train.py:41-43): [dataset dist || recomputed dist]
+    ea2 = torch.cat([ea, (loc0[ei[0]] - loc0[ei[1]]).pow(2).sum(1).sqrt().unsqueeze(1)], 1)
+    return dict(node_feat=torch.cat(node_feat), node_loc=loc0, node_vel=torch.cat(vel0),
+                edge_index=ei, data_batch=torch.tensor(batch), loc_mean=torch.cat(lms),
+                edge_attr=ea2)
+
+
+def main():
+    FastEGNN = _import_reference()
+    # equivariant_test.py shape: 10 nodes, 20 random directed edges, nf=1, ea=1, C=3
+    run_case(FastEGNN, "equiv10", sizes=[10], edges=[20], nf=1, na=0, ea=1, C=3, seed=1,
+             loc_scale=5.0)
+    # ragged 3-graph batch, isolated node, gravity on, trained-like coordinate heads
+    common = dict(sizes=[7, 4, 9], edges=[25, 10, 25], nf=2, na=0, ea=2, C=4, isolate=(2, 3))
+    run_case(FastEGNN, "ragged3_gravity", seed=2, gravity=[0, -1, 0], coord_scale=300.0, **common)
+    run_case(FastEGNN, "ragged3_default_init", L=2, seed=3, **common)
+    run_case(FastEGNN, "ragged3_attention", L=2, seed=4, attention=True, coord_scale=300.0, **common)
+    run_case(FastEGNN, "ragged3_normalize", L=2, seed=5, normalize=True, coord_scale=300.0, **common)
+    run_case(FastEGNN, "ragged3_tanh", L=2, seed=6, tanh=True, coord_scale=300.0, **common)
+    run_case(FastEGNN, "ragged3_allflags", L=2, seed=7, attention=True, normalize=True, tanh=True,
+             gravity=[0, -1, 0], coord_scale=300.0, **common)
+    run_case(FastEGNN, "ragged3_noresidual", L=2, seed=8, residual=False, coord_scale=300.0, **common)
+    run_case(FastEGNN, "ragged3_nodeattr", L=2, seed=9, coord_scale=300.0,
+             **{**common, "na": 3})
+    run_case(FastEGNN, "ragged3_gravity_fp64", seed=2, gravity=[0, -1, 0], coord_scale=300.0,
+             dtype=torch.float64, **common)
+    # C=16 / two layers: the cfg-4 channel count on a small graph (tile/loop coverage)
+    run_case(FastEGNN, "c16_two_graphs", sizes=[40, 23], edges=[300, 150], nf=2, na=0, ea=2,
+             C=16, L=2, seed=10, gravity=[0, -1, 0], coord_scale=100.0, loc_scale=1.0)
+    # cfg-1: reference simulator frames, top-k cutoff edges, harness edge_attr augmentation
+    nb = nbody_case()
+    run_case(FastEGNN, "nbody5_cfg1", sizes=None, edges=None, nf=2, na=0, ea=2, C=3, seed=43,
+             explicit=nb)
+    run_case(FastEGNN, "nbody5_cfg1_trained", sizes=None, edges=None, nf=2, na=0, ea=2, C=3,
+             seed=43, explicit=nb, coord_scale=100.0)
+
+
+if __name__ == "__main__":
+    main()
