@@ -63,3 +63,54 @@ def rel_err(a, b):
     b = torch.as_tensor(b, dtype=torch.float64).cpu()
     den = b.abs().max().item()
     return (a - b).abs().max().item() / (den if den > 0 else 1.0)
+
+
+# --------------------------------------------------------------------------
+# calibrated parity check (hard part 2)
+# --------------------------------------------------------------------------
+def fp64_truth(g):
+    """Oracle in fp64 on the golden's fp32 weights/inputs: outputs and all gradients."""
+    dt = torch.float64
+    p = {k: v.clone().requires_grad_(True) for k, v in g.tensors(g.params, dtype=dt).items()}
+    kw, target, wv = g.model_kwargs(dtype=dt)
+    leaf = {k: kw[k].clone().requires_grad_(True) for k in ("node_feat", "node_loc", "node_vel", "loc_mean")}
+    kw.update(leaf)
+    loc, vloc = R.forward(p, g.cfg, **kw)
+    golden_loss(loc, vloc, target, wv).backward()
+    G = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
+    gin = {k: v.grad for k, v in leaf.items()}
+    return loc.detach(), vloc.detach(), G, gin
+
+
+OUT_TOL = 1e-5        # north_star: outputs within 1e-5 rel fp32 of the reference
+GRAD_FACTOR = 10.0    # build's fp32 error vs fp64 may be this multiple of the reference's own
+GRAD_FLOOR = 5e-6
+
+
+def check_parity(g, loc, vloc, G=None, gin=None, truth=None):
+    """loc/vloc: <=1e-5 rel of the reference golden.  Displacement and gradients: the fp32
+    reference itself is 1e-7..1e-3 away from exact arithmetic depending on the tensor, so the
+    build's error against the fp64 oracle must stay within GRAD_FACTOR x the reference's own
+    fp32 error (+ floor)."""
+    t_loc, t_vloc, t_G, t_gin = truth if truth is not None else fp64_truth(g)
+    msgs = []
+    e = rel_err(loc, g.out["loc"]); msgs += [f"loc {e:.2e}"] if e >= OUT_TOL else []
+    e = rel_err(vloc, g.out["vloc"]); msgs += [f"vloc {e:.2e}"] if e >= OUT_TOL else []
+    x0 = torch.from_numpy(g.inp["node_loc"]).double()
+    d_t = t_loc - x0
+    e_ref = rel_err(torch.from_numpy(g.out["loc"]).double() - x0, d_t)
+    e_got = rel_err(torch.as_tensor(loc).double().cpu() - x0, d_t)
+    if e_got > GRAD_FACTOR * e_ref + GRAD_FLOOR:
+        msgs.append(f"displacement {e_got:.2e} (ref {e_ref:.2e})")
+    for got, ref, tru, tag in ((G, g.gp, t_G, "gp"), (gin, g.gin, t_gin, "gin")):
+        if got is None:
+            continue
+        for k in ref:
+            if k not in got or got[k] is None:
+                msgs.append(f"{tag}/{k} missing")
+                continue
+            e_ref = rel_err(ref[k], tru[k])
+            e_got = rel_err(got[k], tru[k])
+            if e_got > GRAD_FACTOR * e_ref + GRAD_FLOOR:
+                msgs.append(f"{tag}/{k} {e_got:.2e} (ref {e_ref:.2e})")
+    return msgs
