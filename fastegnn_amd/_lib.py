@@ -1,0 +1,124 @@
+"""ctypes binding of libfastegnn_hip.so (C ABI: include/fastegnn_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C fastegnn_amd/csrc``.
+There is no CPU fallback: if the shared object is missing, or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfastegnn_hip.so")
+
+H = 64
+QX_LD = 68
+FEATW = 8
+
+# flags (fastegnn_hip.h)
+F_ATTENTION, F_NORMALIZE, F_TANH, F_RESIDUAL, F_GRAVITY, F_COORDS_SUM = 1, 2, 4, 8, 16, 32
+
+# per-layer parameter slots, in header order -> reference state_dict suffix (models/FastEGNN.py:28-99)
+PARAM_SLOTS = [
+    "edge_mlp.0.weight", "edge_mlp.0.bias", "edge_mlp.2.weight", "edge_mlp.2.bias",
+    "edge_mlp_virtual.0.weight", "edge_mlp_virtual.0.bias", "edge_mlp_virtual.2.weight", "edge_mlp_virtual.2.bias",
+    "att_mlp.0.weight", "att_mlp.0.bias", "att_mlp_virtual.0.weight", "att_mlp_virtual.0.bias",
+    "coord_mlp_r.0.weight", "coord_mlp_r.0.bias", "coord_mlp_r.2.weight",
+    "coord_mlp_r_virtual.0.weight", "coord_mlp_r_virtual.0.bias", "coord_mlp_r_virtual.2.weight",
+    "coord_mlp_v_virtual.0.weight", "coord_mlp_v_virtual.0.bias", "coord_mlp_v_virtual.2.weight",
+    "coord_mlp_vel.0.weight", "coord_mlp_vel.0.bias", "coord_mlp_vel.2.weight", "coord_mlp_vel.2.bias",
+    "gravity_mlp.0.weight", "gravity_mlp.0.bias", "gravity_mlp.2.weight", "gravity_mlp.2.bias",
+    "node_mlp.0.weight", "node_mlp.0.bias", "node_mlp.2.weight", "node_mlp.2.bias",
+    "node_mlp_virtual.0.weight", "node_mlp_virtual.0.bias", "node_mlp_virtual.2.weight", "node_mlp_virtual.2.bias",
+]
+P_COUNT = len(PARAM_SLOTS)
+assert P_COUNT == 37
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+
+
+class GraphT(C.Structure):
+    _fields_ = [("n_rows", _i32), ("n_src", _i32), ("n_edges", _i32), ("n_chunks", _i32),
+                ("rowptr", _vp), ("erow", _vp), ("col", _vp), ("perm", _vp),
+                ("cscptr", _vp), ("csc_eid", _vp), ("chunk_row", _vp)]
+
+
+_LAYER_PTRS_A = ["batch", "gptr", "ea_sorted", "vel", "node_attr", "params", "grads", "wpack",
+                 "h", "x", "Z", "HvT", "h_out", "x_out", "Z_out", "HvT_out",
+                 "P", "QX", "QX_src", "A", "svel", "sgrav", "xsum", "Bc", "aggm", "aggx", "npre", "poolV", "poolX",
+                 "g_h_out", "g_x_out", "g_Z_out", "g_HvT_out", "g_h", "g_x", "g_Z", "g_HvT", "g_vel",
+                 "g_poolV", "g_poolX", "g_Bc", "g_Zp", "g_xbar", "g_A", "g_P", "g_aggm", "g_aggx",
+                 "g_svel", "g_sgrav", "g_QXe", "g_QX_src", "g_QX", "g_xrow", "wg_edge", "wg_virt", "wg_node"]
+
+
+class LayerT(C.Structure):
+    _fields_ = ([("N", _i32), ("B", _i32), ("C", _i32), ("ea", _i32), ("na", _i32), ("flags", _i32),
+                 ("gravity", C.c_float * 3), ("epsilon", C.c_float), ("graph", GraphT)]
+                + [(n, _vp) for n in _LAYER_PTRS_A])
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"fastegnn_amd: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C fastegnn_amd/csrc`. There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.fastegnn_last_error.restype = C.c_char_p
+    L.fastegnn_version.restype = C.c_int
+    L.fastegnn_wpack_floats.restype = C.c_size_t
+    L.fastegnn_wpack_floats.argtypes = [_i32]
+    L.fastegnn_csr_tmp_bytes.restype = C.c_size_t
+    L.fastegnn_csr_tmp_bytes.argtypes = [_i32, _i32, _i32]
+    L.fastegnn_build_csr.argtypes = [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     C.POINTER(_i32), _vp, C.c_size_t, _vp]
+    L.fastegnn_permute_rows.argtypes = [_vp, _vp, _i32, _i32, _vp, _vp]
+    L.fastegnn_build_batch.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp]
+    L.fastegnn_embed_forward.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp]
+    L.fastegnn_embed_backward.argtypes = [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]
+    L.fastegnn_virtual_init.argtypes = [_vp, _i32, _i32, _vp, _vp]
+    L.fastegnn_virtual_init_backward.argtypes = [_vp, _i32, _i32, _vp, _vp]
+    L.fastegnn_selftest_gemm.argtypes = [_vp, _vp, _vp, _i32, _vp]
+    L.fastegnn_selftest_wgrad.argtypes = [_vp, _vp, _i32, _vp, _vp, _vp]
+    for name in STAGE_FUNCS + ["fastegnn_layer_forward", "fastegnn_layer_backward"]:
+        f = getattr(L, name)
+        f.argtypes = [C.POINTER(LayerT), _vp]
+        f.restype = C.c_int
+    _lib = L
+    return L
+
+
+STAGE_FUNCS = [
+    "fastegnn_pack_weights", "fastegnn_node_pre_forward", "fastegnn_graph_xsum", "fastegnn_graph_pre_forward",
+    "fastegnn_edge_forward", "fastegnn_virt_forward", "fastegnn_graph_post_forward",
+    "fastegnn_graph_post_backward", "fastegnn_virt_backward", "fastegnn_graph_pre_backward",
+    "fastegnn_edge_backward", "fastegnn_edge_col_reduce", "fastegnn_node_pre_backward",
+]
+
+# every symbol include/fastegnn_hip.h declares (checked by tests/test_abi_cpu.py)
+EXPORTED = STAGE_FUNCS + [
+    "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_csr_tmp_bytes",
+    "fastegnn_build_csr", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
+    "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
+    "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_wgrad",
+]
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().fastegnn_last_error()
+        raise RuntimeError(f"fastegnn_amd: {what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,172 @@
+// Wave-level toolkit shared by every FastEGNN kernel (gfx950 / CDNA4, wave64).
+//
+// Layout convention ("D layout"): a wave works on a tile of 16 items (edges, nodes or
+// (graph,channel) rows).  lane = 16*q + j, j = item in the tile, q = 0..3.  A 64-wide hidden
+// vector of item j is held by the four lanes (j,0..3) as 4 x f32x4:
+//        Vec.t[t][r]  ==  element  16*t + 4*q + r
+// This is exactly the C/D fragment map of v_mfma_f32_16x16x4_f32 when the GEMM is oriented
+//        D[out][item] = sum_k W[out][k] * X[k][item]           (weights = A operand, items = B)
+// so the output of one 64x64 layer is already the B operand of the next one: MLP chains
+// never leave registers.  The weight matrix is read as a pre-permuted "image" (img_index)
+// so that each lane fetches its A operands for four k-steps with one 16-byte load.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H = 64;
+constexpr int QXLD = 68;      // Q[64] | x[3] | pad
+constexpr int TS = 68;        // row stride (floats) of the 16x64 transpose tiles in LDS
+constexpr int IMG = 4096;     // floats per 64x64 weight image
+constexpr int FEATW = 8;      // row stride of the per-edge scalar-feature rows (r | edge_attr)
+
+struct Vec {
+  f32x4 t[4];
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---- activations (fp32; v_exp_f32 / v_rcp_f32 are ~1 ulp) ----
+__device__ __forceinline__ float sigmoid_f(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+__device__ __forceinline__ float silu_f(float z) { return z * sigmoid_f(z); }
+__device__ __forceinline__ float dsilu_f(float z) {
+  float s = sigmoid_f(z);
+  return s * (1.0f + z * (1.0f - s));
+}
+__device__ __forceinline__ float tanh_f(float z) {
+  // tanh(z) = 2*sigmoid(2z) - 1
+  return 2.0f * sigmoid_f(2.0f * z) - 1.0f;
+}
+
+__device__ __forceinline__ Vec vzero() {
+  Vec v;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v.t[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  return v;
+}
+template <typename F>
+__device__ __forceinline__ Vec vmap(const Vec &a, F f) {
+  Vec o;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o.t[t][r] = f(a.t[t][r]);
+  return o;
+}
+template <typename F>
+__device__ __forceinline__ Vec vmap2(const Vec &a, const Vec &b, F f) {
+  Vec o;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o.t[t][r] = f(a.t[t][r], b.t[t][r]);
+  return o;
+}
+__device__ __forceinline__ Vec vsilu(const Vec &a) { return vmap(a, [](float z) { return silu_f(z); }); }
+__device__ __forceinline__ Vec vscale(const Vec &a, float s) { return vmap(a, [s](float z) { return z * s; }); }
+__device__ __forceinline__ void vaxpy(Vec &acc, float s, const Vec &a) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc.t[t] += s * a.t[t];
+}
+__device__ __forceinline__ void vadd(Vec &acc, const Vec &a) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc.t[t] += a.t[t];
+}
+
+// natural-order 64-vector (bias, head weight, ...) -> this lane's 16 elements
+__device__ __forceinline__ Vec vload_vec(const float *w, int q) {
+  Vec v;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v.t[t] = *reinterpret_cast<const f32x4 *>(w + 16 * t + 4 * q);
+  return v;
+}
+// row-major [*,ld] row -> D layout (16-byte loads; row base and ld must be 16-byte aligned)
+__device__ __forceinline__ Vec vload_row(const float *row, int q) { return vload_vec(row, q); }
+__device__ __forceinline__ void vstore_row(float *row, int q, const Vec &v) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(row + 16 * t + 4 * q) = v.t[t];
+}
+
+// sum over the four q-lanes of an item (xor 16, xor 32)
+__device__ __forceinline__ float qsum(float p) {
+  p += __shfl_xor(p, 16);
+  p += __shfl_xor(p, 32);
+  return p;
+}
+// sum over the 16 items of a tile that share q (xor 1,2,4,8)
+__device__ __forceinline__ float jsum(float p) {
+  p += __shfl_xor(p, 1);
+  p += __shfl_xor(p, 2);
+  p += __shfl_xor(p, 4);
+  p += __shfl_xor(p, 8);
+  return p;
+}
+// <v, w> over the hidden dimension; every q-lane of the item gets the full dot product
+__device__ __forceinline__ float vdot(const Vec &v, const Vec &w) {
+  float p = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p += v.t[t][r] * w.t[t][r];
+  return qsum(p);
+}
+
+// ---- weight images ----
+// Image of A[o][k] (64x64) for gemm64: float index ((t*4+tp)*64 + lane)*4 + r holds
+// A[16t + (lane&15)][16tp + 4(lane>>4) + r].
+__host__ __device__ __forceinline__ int img_index(int o, int k) {
+  int t = o >> 4, i = o & 15, tp = k >> 4, q = (k >> 2) & 3, r = k & 3;
+  return ((t * 4 + tp) * 64 + q * 16 + i) * 4 + r;
+}
+
+// acc[o][item] += sum_k A[o][k] * in[k][item].  img may live in LDS or global memory.
+__device__ __forceinline__ void gemm64(const float *img, const Vec &in, Vec &acc) {
+  const f32x4 *ip = reinterpret_cast<const f32x4 *>(img) + lane_id();
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp) {
+    f32x4 a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = ip[(t * 4 + tp) * 64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][r], in.t[tp][r], acc.t[t], 0, 0, 0);
+  }
+}
+
+// cooperative copy of n_img consecutive images global -> LDS (16-byte moves)
+__device__ __forceinline__ void load_images(float *dst, const float *src, int n_img) {
+  const f32x4 *s = reinterpret_cast<const f32x4 *>(src);
+  f32x4 *d = reinterpret_cast<f32x4 *>(dst);
+  for (int i = threadIdx.x; i < n_img * (IMG / 4); i += blockDim.x) d[i] = s[i];
+}
+__device__ __forceinline__ void load_floats(float *dst, const float *src, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src ? src[i] : 0.f;
+}
+
+// ---- transpose tile (per wave, [16][TS]) ----
+__device__ __forceinline__ void tile_store(float *tile, int j, int q, const Vec &v) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(tile + j * TS + 16 * t + 4 * q) = v.t[t];
+}
+
+// ---- packed weight-image table (one per layer), see pack.hip ----
+enum ImgId {
+  I_W2 = 0, I_WX1, I_W2T, I_WX1T,                       // edge stage (fwd pair first)
+  I_V2, I_WXV0, I_WXX0, I_V2T, I_WXV0T, I_WXX0T,         // virtual stage
+  I_W1A, I_W1B, I_V1A, I_WVEL0, I_WG0,                   // node_pre forward
+  I_W1AT, I_W1BT, I_V1AT, I_WVEL0T, I_WG0T,              // node_pre backward
+  I_W5A, I_W5B, I_W6, I_W5AT, I_W5BT, I_W6T,             // graph_post
+  I_V1B, I_V1BT,                                         // graph_pre
+  I_W3A, I_W3B, I_W4, I_W3AT, I_W3BT, I_W4T,             // node MLP
+  I_FIXED,                                               // then W3c[0..C) and W3cT[0..C)
+};
+__host__ __device__ inline int img_w3c(int c) { return I_FIXED + c; }
+__host__ __device__ inline int img_w3ct(int C, int c) { return I_FIXED + C + c; }
+__host__ __device__ inline size_t wpack_floats(int C) { return (size_t)(I_FIXED + 2 * C) * IMG; }
+
+}  // namespace fe

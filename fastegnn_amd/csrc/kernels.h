@@ -1,0 +1,48 @@
+// Internal launcher interface between api.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include "../../include/fastegnn_hip.h"
+#include "common.h"
+
+namespace fe {
+
+void set_error(const std::string &msg);
+int check_launch(const char *what);
+
+#define FE_REQUIRE(cond, msg)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      fe::set_error(msg);                \
+      return FASTEGNN_E_INVALID;         \
+    }                                    \
+  } while (0)
+
+inline bool has(const fastegnn_layer_t *L, int f) { return (L->flags & f) != 0; }
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// generic weight-gradient kernels (misc.hip)
+//   dW[o*lddw + c0 + k*ks] += sum_m G[m*ldg + o] * T[m*ldt + k]   (o,k < 64),  db[o] += sum_m G[m*ldg+o]
+//   batched over `nb` with strides (sG, sT, sW) in floats.
+int launch_wgrad_tn(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks,
+                    float *db, int nb, long sG, long sT, long sW, hipStream_t st);
+//   dW[o*lddw + c0 + a] += sum_m G[m*ldg + o] * F[m*ldf + a],  a < kf <= 8
+int launch_wgrad_small(const float *G, int ldg, const float *F, int ldf, int kf, long M, float *dW, int lddw, int c0,
+                       hipStream_t st);
+
+// stage launchers
+int pack_weights(const fastegnn_layer_t *L, hipStream_t st);
+int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st);
+int graph_xsum(const fastegnn_layer_t *L, hipStream_t st);
+int graph_pre_forward(const fastegnn_layer_t *L, hipStream_t st);
+int edge_forward(const fastegnn_layer_t *L, hipStream_t st);
+int virt_forward(const fastegnn_layer_t *L, hipStream_t st);
+int graph_post_forward(const fastegnn_layer_t *L, hipStream_t st);
+int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st);
+int virt_backward(const fastegnn_layer_t *L, hipStream_t st);
+int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st);
+int edge_backward(const fastegnn_layer_t *L, hipStream_t st);
+int edge_col_reduce(const fastegnn_layer_t *L, hipStream_t st);
+int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st);
+
+}  // namespace fe

@@ -1,0 +1,462 @@
+// Forward stages S1..S5 of one E_GCL_vel layer (reference: models/FastEGNN.py:192-223).
+// Math per stage: oracle/factored.py (same stage names); layout conventions: common.h.
+#include "stages.h"
+
+namespace fe {
+
+// =====================================================================================
+// S1 node_pre:  P = h W1a^T + b1, Q = h W1b^T, A = h V1a^T  (first-Linear factorisation of
+// edge_mlp.0 / edge_mlp_virtual.0, FastEGNN.py:103,114), velocity / gravity heads (:139-142).
+// =====================================================================================
+struct NodePreArgs {
+  const float *h, *x, *wpack;
+  const float *b1, *bv0, *wv2, *bv2, *bg0, *wg2, *bg2;
+  float *P, *QX, *A, *svel, *sgrav;
+  int N, gravity;
+};
+
+__global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *img = lds;            // 5 images: W1A W1B V1A WVEL0 WG0
+  float *vec = lds + 5 * IMG;  // b1 bv0 wv2 bg0 wg2
+  const int nimg = a.gravity ? 5 : 4;
+  load_images(img, a.wpack + (size_t)I_W1A * IMG, nimg);
+  load_floats(vec + 0 * H, a.b1, H);
+  load_floats(vec + 1 * H, a.bv0, H);
+  load_floats(vec + 2 * H, a.wv2, H);
+  load_floats(vec + 3 * H, a.bg0, H);
+  load_floats(vec + 4 * H, a.wg2, H);
+  __syncthreads();
+  const int l = lane_id(), j = l & 15, q = l >> 4;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int ntiles = (a.N + 15) >> 4;
+  const float bv2 = a.bv2[0];
+  const float bg2 = a.gravity ? a.bg2[0] : 0.f;
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int n = tile * 16 + j;
+    const bool valid = n < a.N;
+    const int nc = valid ? n : a.N - 1;
+    const Vec hv = vload_row(a.h + (size_t)nc * H, q);
+    Vec acc = vload_vec(vec, q);
+    gemm64(img + 0 * IMG, hv, acc);
+    if (valid) vstore_row(a.P + (size_t)n * H, q, acc);
+    acc = vzero();
+    gemm64(img + 1 * IMG, hv, acc);
+    if (valid) {
+      vstore_row(a.QX + (size_t)n * QXLD, q, acc);
+      if (q == 0) {
+        f32x4 xv = {a.x[(size_t)n * 3], a.x[(size_t)n * 3 + 1], a.x[(size_t)n * 3 + 2], 0.f};
+        *reinterpret_cast<f32x4 *>(a.QX + (size_t)n * QXLD + H) = xv;
+      }
+    }
+    acc = vzero();
+    gemm64(img + 2 * IMG, hv, acc);
+    if (valid) vstore_row(a.A + (size_t)n * H, q, acc);
+    acc = vload_vec(vec + 1 * H, q);
+    gemm64(img + 3 * IMG, hv, acc);
+    float s = vdot(vsilu(acc), vload_vec(vec + 2 * H, q)) + bv2;
+    if (valid && q == 0) a.svel[n] = s;
+    if (a.gravity) {
+      acc = vload_vec(vec + 3 * H, q);
+      gemm64(img + 4 * IMG, hv, acc);
+      s = vdot(vsilu(acc), vload_vec(vec + 4 * H, q)) + bg2;
+      if (valid && q == 0) a.sgrav[n] = s;
+    }
+  }
+}
+
+int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->h && L->x && L->wpack && L->P && L->QX && L->A && L->svel, "node_pre_forward: null buffer");
+  if (L->N == 0) return FASTEGNN_OK;
+  const bool grav = has(L, FASTEGNN_F_GRAVITY);
+  FE_REQUIRE(!grav || L->sgrav, "node_pre_forward: sgrav null");
+  const float *const *p = L->params;
+  NodePreArgs a{L->h, L->x, L->wpack, p[FASTEGNN_P_EDGE0_B], p[FASTEGNN_P_VEL0_B], p[FASTEGNN_P_VEL2_W],
+                p[FASTEGNN_P_VEL2_B], p[FASTEGNN_P_GRAV0_B], p[FASTEGNN_P_GRAV2_W], p[FASTEGNN_P_GRAV2_B],
+                L->P, L->QX, L->A, L->svel, L->sgrav, L->N, grav ? 1 : 0};
+  const int ntiles = (L->N + 15) / 16;
+  int grid = cdiv(ntiles, 4);
+  if (grid > 512) grid = 512;
+  const size_t lds = (5 * IMG + 5 * H) * sizeof(float);
+  hipLaunchKernelGGL(node_pre_fwd_kernel, dim3(grid), dim3(256), lds, st, a);
+  return check_launch("node_pre_fwd_kernel");
+}
+
+// =====================================================================================
+// S2a graph_xsum: per-graph sum of coordinates and node count (global_mean_pool(coord), :212)
+// =====================================================================================
+__global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const int32_t *batch, int N, float *xsum) {
+  constexpr int PER = 4096;
+  __shared__ float red[4][4];
+  const int n0 = blockIdx.x * PER;
+  const int n1 = min(N, n0 + PER);
+  if (n0 >= n1) return;
+  const int bf = batch[n0], bl = batch[n1 - 1];
+  const int l = lane_id(), w = threadIdx.x >> 6;
+  if (bf == bl) {  // whole block inside one graph: tree-reduce, one atomic set per block
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = n0 + threadIdx.x; n < n1; n += 256) {
+      s[0] += x[(size_t)n * 3];
+      s[1] += x[(size_t)n * 3 + 1];
+      s[2] += x[(size_t)n * 3 + 2];
+      s[3] += 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = s[k];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (l == 0) red[w][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      atomicAdd(&xsum[bf * 4 + threadIdx.x], v);
+    }
+  } else {  // ragged block: per-thread runs
+    int cur = -1;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    // contiguous slice per thread keeps runs long
+    const int per = (n1 - n0 + 255) / 256;
+    const int a0 = n0 + threadIdx.x * per, a1 = min(n1, a0 + per);
+    for (int n = a0; n < a1; ++n) {
+      int b = batch[n];
+      if (b != cur) {
+        if (cur >= 0)
+          for (int k = 0; k < 4; ++k) atomicAdd(&xsum[cur * 4 + k], s[k]);
+        cur = b;
+        s[0] = s[1] = s[2] = s[3] = 0.f;
+      }
+      s[0] += x[(size_t)n * 3];
+      s[1] += x[(size_t)n * 3 + 1];
+      s[2] += x[(size_t)n * 3 + 2];
+      s[3] += 1.f;
+    }
+    if (cur >= 0)
+      for (int k = 0; k < 4; ++k) atomicAdd(&xsum[cur * 4 + k], s[k]);
+  }
+}
+
+int graph_xsum(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->xsum && L->batch && L->x, "graph_xsum: null buffer");
+  (void)hipMemsetAsync(L->xsum, 0, (size_t)L->B * 4 * sizeof(float), st);
+  if (L->N > 0) hipLaunchKernelGGL(graph_xsum_kernel, dim3(cdiv(L->N, 4096)), dim3(256), 0, st, L->x, L->batch, L->N, L->xsum);
+  return check_launch("graph_xsum_kernel");
+}
+
+// =====================================================================================
+// S2b graph_pre: centroid, Gram matrix m_X (:212-214) and the per-(graph,channel) part of
+// edge_mlp_virtual.0:  Bc[b,c,:] = V1b Hv[b,:,c] + V1d mX[b][:,c] + c1   (:114)
+// =====================================================================================
+struct GraphPreArgs {
+  const float *xsum, *Z, *HvT, *V0W, *V0B;
+  float *Bc;
+  int B, C;
+};
+__global__ __launch_bounds__(256) void graph_pre_fwd_kernel(GraphPreArgs a) {
+  extern __shared__ float sm[];
+  const int C = a.C, b = blockIdx.x, ld = 2 * H + 1 + C;
+  float *mz = sm;           // [3][C]
+  float *mX = sm + 3 * C;   // [C][C]
+  const float cnt = fmaxf(a.xsum[b * 4 + 3], 1.f);
+  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+    int k = i / C;
+    mz[i] = a.Z[(size_t)b * 3 * C + i] - a.xsum[b * 4 + k] / cnt;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * C; i += 256) {
+    int c = i / C, d = i % C;
+    mX[i] = mz[c] * mz[d] + mz[C + c] * mz[C + d] + mz[2 * C + c] * mz[2 * C + d];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * H; i += 256) {
+    int c = i >> 6, o = i & 63;
+    const float *w = a.V0W + (size_t)o * ld;
+    const float *hv = a.HvT + ((size_t)b * C + c) * H;
+    float acc = a.V0B[o];
+    for (int k = 0; k < H; ++k) acc += w[H + k] * hv[k];
+    for (int d = 0; d < C; ++d) acc += w[2 * H + 1 + d] * mX[d * C + c];
+    a.Bc[((size_t)b * C + c) * H + o] = acc;
+  }
+}
+int graph_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->xsum && L->Z && L->HvT && L->Bc, "graph_pre_forward: null buffer");
+  GraphPreArgs a{L->xsum, L->Z, L->HvT, L->params[FASTEGNN_P_VIRT0_W], L->params[FASTEGNN_P_VIRT0_B], L->Bc, L->B, L->C};
+  const size_t lds = (size_t)(3 * L->C + L->C * L->C) * sizeof(float);
+  hipLaunchKernelGGL(graph_pre_fwd_kernel, dim3(L->B), dim3(256), lds, st, a);
+  return check_launch("graph_pre_fwd_kernel");
+}
+
+// =====================================================================================
+// S3 edge: coord2radial (:180-189) + edge_model (:102-108) + real part of coord_model_vel
+// (:125-133) + the segment means of node_model / coord_model_vel (:155, :287-294), fused.
+// One wave walks an edge-balanced chunk of CSR rows in 16-edge tiles; sums stay in registers
+// until the row changes, so every row is written exactly once (no atomics, deterministic).
+// =====================================================================================
+__global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *img = lds;                    // W2, WX1
+  float *vec = lds + 2 * IMG;          // EV_COUNT vectors
+  float *tiles = vec + EV_COUNT * H;   // per wave: [16][TS] + [16][4]
+  load_images(img, a.wpack + (size_t)I_W2 * IMG, 2);
+  edge_load_vecs(vec, a);
+  __syncthreads();
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
+  float *mt = tiles + wv * (16 * TS + 64);
+  float *xt = mt + 16 * TS;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);
+  for (int ch = wave; ch < a.n_chunks; ch += nwaves) {
+    const int r0 = a.chunk_row[ch], r1 = a.chunk_row[ch + 1];
+    if (r0 >= r1) continue;
+    const int e0 = a.rowptr[r0], e1 = a.rowptr[r1];
+    int cur = -1;
+    float acc = 0.f, accx = 0.f;
+    auto flush = [&]() {
+      const int dg = a.rowptr[cur + 1] - a.rowptr[cur];
+      const float inv = 1.0f / (float)(dg > 1 ? dg : 1);
+      a.aggm[(size_t)cur * H + l] = acc * inv;
+      if (l < 3) a.aggx[(size_t)cur * 3 + l] = mean ? accx * inv : accx;
+    };
+    for (int base = e0; base < e1; base += 16) {
+      const int nvalid = min(16, e1 - base);
+      const int e = min(base + j, e1 - 1);
+      EdgeFwdState S;
+      Vec pre;
+      edge_tile_forward(a, img, vec, e, q, S, pre);
+      tile_store(mt, j, q, S.m);
+      if (q == 0) {
+        xt[j * 4 + 0] = S.dn[0] * S.s;
+        xt[j * 4 + 1] = S.dn[1] * S.s;
+        xt[j * 4 + 2] = S.dn[2] * S.s;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int rowv = S.row;
+#pragma unroll
+      for (int ee = 0; ee < 16; ++ee) {
+        if (ee < nvalid) {
+          const int rw = __builtin_amdgcn_readlane(rowv, ee);
+          if (rw != cur) {
+            if (cur >= 0) flush();
+            cur = rw;
+            acc = 0.f;
+            accx = 0.f;
+          }
+          acc += mt[ee * TS + l];
+          if (l < 3) accx += xt[ee * 4 + l];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (cur >= 0) flush();
+  }
+}
+
+int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->P && L->QX && L->aggm && L->aggx && L->wpack, "edge_forward: null buffer");
+  FE_REQUIRE(L->ea <= 7, "edge_forward: edge_attr_nf > 7 unsupported");
+  FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (L->params[FASTEGNN_P_ATT_W] && L->params[FASTEGNN_P_ATT_B]),
+             "edge_forward: attention params null");
+  const fastegnn_graph_t &g = L->graph;
+  (void)hipMemsetAsync(L->aggm, 0, (size_t)L->N * H * sizeof(float), st);
+  (void)hipMemsetAsync(L->aggx, 0, (size_t)L->N * 3 * sizeof(float), st);
+  if (g.n_edges == 0 || L->N == 0) return check_launch("edge_forward(memset)");
+  FE_REQUIRE(g.rowptr && g.erow && g.col && g.chunk_row && (L->ea == 0 || L->ea_sorted), "edge_forward: null graph");
+  EdgeArgs a = make_edge_args(L);
+  int grid = cdiv(g.n_chunks, 4);
+  if (grid > 768) grid = 768;
+  const size_t lds = (2 * IMG + EV_COUNT * H + 4 * (16 * TS + 64)) * sizeof(float);
+  hipLaunchKernelGGL(edge_fwd_kernel, dim3(grid), dim3(256), lds, st, a);
+  return check_launch("edge_fwd_kernel");
+}
+
+// =====================================================================================
+// S4 virt: edge_mode_virtual (:111-119), virtual part of coord_model_vel (:136-142),
+// coord_model_virtual (:146-150), node_model (:153-166) and the pools of node_model_virtual
+// (:170), fused.  A wave owns 16 nodes and loops over the C virtual channels; the K = H*C
+// contraction of node_mlp.0 accumulates in MFMA registers, v [N,C,H] never reaches HBM.
+// =====================================================================================
+
+__global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int C = a.C;
+  float *img = lds;                              // V2, WXV0, WXX0
+  float *vec = lds + 3 * IMG;                    // VV_COUNT vectors
+  float *tiles = vec + VV_COUNT * H;             // per wave [16][TS]
+  float *poolV_l = tiles + VIRT_WAVES * 16 * TS; // [C][64]
+  float *poolX_l = poolV_l + C * H;              // [3][C]
+  load_images(img, a.wpack + (size_t)I_V2 * IMG, 3);
+  virt_load_vecs(vec, a);
+  for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) poolV_l[i] = 0.f;
+  __syncthreads();
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
+  float *tile = tiles + wv * 16 * TS;
+  constexpr int GROUP = 16 * VIRT_WAVES;
+  const int ntg = (a.N + GROUP - 1) / GROUP;
+  const float invC = 1.0f / (float)C;
+  int cur = -1;  // graph the LDS pool accumulators belong to
+  auto flush_pools = [&]() {
+    for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
+      atomicAdd(&a.poolV[(size_t)cur * C * H + i], poolV_l[i]);
+      poolV_l[i] = 0.f;
+    }
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+      atomicAdd(&a.poolX[(size_t)cur * 3 * C + i], poolX_l[i]);
+      poolX_l[i] = 0.f;
+    }
+  };
+  for (int tg = blockIdx.x; tg < ntg; tg += gridDim.x) {
+    const int n0 = tg * GROUP, nend = min(a.N, n0 + GROUP);
+    const int bfirst = a.batch[n0], blast = a.batch[nend - 1];
+    const bool fast = bfirst == blast;
+    if (fast && bfirst != cur) {
+      __syncthreads();
+      if (cur >= 0) flush_pools();
+      __syncthreads();
+      cur = bfirst;
+    }
+    const int nb = n0 + wv * 16;
+    const int nvalid = max(0, min(16, nend - nb));
+    if (nvalid > 0) {
+      const int n = nb + j;
+      const bool valid = n < nend;
+      const int nc = valid ? n : nend - 1;
+      const int b = a.batch[nc];
+      const Vec Ai = vload_row(a.A + (size_t)nc * H, q);
+      const float xi[3] = {a.x[(size_t)nc * 3], a.x[(size_t)nc * 3 + 1], a.x[(size_t)nc * 3 + 2]};
+      float transv[3] = {0.f, 0.f, 0.f};
+      Vec nodeacc = vload_vec(vec + VV_B3 * H, q);
+      for (int c = 0; c < C; ++c) {
+        VirtFwdState S;
+        virt_tile_forward(a, img, vec, Ai, xi, b, c, q, S);
+        transv[0] -= S.vd[0] * S.sx;
+        transv[1] -= S.vd[1] * S.sx;
+        transv[2] -= S.vd[2] * S.sx;
+        // pools: sum over the nodes of the tile
+        __builtin_amdgcn_wave_barrier();
+        tile_store(tile, j, q, valid ? S.v : vzero());
+        __builtin_amdgcn_wave_barrier();
+        if (fast) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            float pv = (valid && q == 0) ? S.vd[k] * S.sX : 0.f;
+            pv = jsum(pv);
+            if (l == 0) atomicAdd(&poolX_l[k * C + c], pv);
+          }
+          float s = 0.f;
+#pragma unroll
+          for (int ee = 0; ee < 16; ++ee) s += tile[ee * TS + l];
+          atomicAdd(&poolV_l[c * H + l], s);
+        } else {
+          if (valid && q == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) atomicAdd(&a.poolX[((size_t)b * 3 + k) * C + c], S.vd[k] * S.sX);
+          }
+#pragma unroll
+          for (int ee = 0; ee < 16; ++ee) {
+            if (ee < nvalid) {
+              const int be = __builtin_amdgcn_readlane(b, ee);
+              atomicAdd(&a.poolV[((size_t)be * C + c) * H + l], tile[ee * TS + l]);
+            }
+          }
+        }
+        gemm64(a.wpack + (size_t)img_w3c(c) * IMG, S.v, nodeacc);
+      }
+      // node_model: node_mlp.0 on [h | agg | flat(v) | node_attr]  (:153-166)
+      const Vec hv = vload_row(a.h + (size_t)nc * H, q);
+      gemm64(a.wpack + (size_t)I_W3A * IMG, hv, nodeacc);
+      gemm64(a.wpack + (size_t)I_W3B * IMG, vload_row(a.aggm + (size_t)nc * H, q), nodeacc);
+      if (a.na > 0) {
+        const int ld = 2 * H + H * C + a.na;
+        for (int k = 0; k < a.na; ++k) {
+          const float av = a.node_attr[(size_t)nc * a.na + k];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              nodeacc.t[t][r] += av * a.N0W[(size_t)(16 * t + 4 * q + r) * ld + 2 * H + H * C + k];
+        }
+      }
+      if (valid) vstore_row(a.npre + (size_t)n * H, q, nodeacc);
+      Vec out = vload_vec(vec + VV_B4 * H, q);
+      gemm64(a.wpack + (size_t)I_W4 * IMG, vsilu(nodeacc), out);
+      if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
+      if (valid) {
+        vstore_row(a.h_out + (size_t)n * H, q, out);
+        if (q == 0) {
+          const float sv = a.svel[n];
+          const float sg = (a.flags & FASTEGNN_F_GRAVITY) ? a.sgrav[n] : 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            a.x_out[(size_t)n * 3 + k] = xi[k] + a.aggx[(size_t)n * 3 + k] + transv[k] * invC +
+                                         sv * a.vel[(size_t)n * 3 + k] + sg * a.g[k];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (cur >= 0) flush_pools();
+}
+
+int virt_forward(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->h && L->A && L->Bc && L->x && L->vel && L->Z && L->aggm && L->aggx && L->svel && L->npre &&
+                 L->h_out && L->x_out && L->poolV && L->poolX && L->batch && L->wpack,
+             "virt_forward: null buffer");
+  FE_REQUIRE(L->C >= 1 && L->C <= 64, "virt_forward: virtual_channels must be in [1,64]");
+  FE_REQUIRE(L->na == 0 || L->node_attr, "virt_forward: node_attr null");
+  (void)hipMemsetAsync(L->poolV, 0, (size_t)L->B * L->C * H * sizeof(float), st);
+  (void)hipMemsetAsync(L->poolX, 0, (size_t)L->B * 3 * L->C * sizeof(float), st);
+  if (L->N == 0) return check_launch("virt_forward(memset)");
+  VirtArgs a = make_virt_args(L);
+  const int ntg = cdiv(L->N, 16 * VIRT_WAVES);
+  int grid = ntg < 512 ? ntg : 512;
+  hipLaunchKernelGGL(virt_fwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(L->C, 3), st, a);
+  return check_launch("virt_fwd_kernel");
+}
+
+// =====================================================================================
+// S5 graph_post: coord_model_virtual's mean + residual (:148-149) and node_model_virtual
+// (:168-177) on the B*C (graph, channel) rows.
+// =====================================================================================
+struct GraphPostArgs {
+  const float *xsum, *Z, *HvT, *poolV, *poolX, *wpack, *b5, *b6;
+  float *Z_out, *HvT_out;
+  int B, C, flags;
+};
+__global__ __launch_bounds__(256) void graph_post_fwd_kernel(GraphPostArgs a) {
+  const int l = lane_id(), j = l & 15, q = l >> 4;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int M = a.B * a.C, ntiles = (M + 15) >> 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.B * 3 * a.C; i += gridDim.x * blockDim.x) {
+    const int b = i / (3 * a.C);
+    a.Z_out[i] = a.Z[i] + a.poolX[i] / fmaxf(a.xsum[b * 4 + 3], 1.f);
+  }
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int m = tile * 16 + j;
+    const bool valid = m < M;
+    const int mc = valid ? m : M - 1;
+    const int b = mc / a.C;
+    const float inv = 1.0f / fmaxf(a.xsum[b * 4 + 3], 1.f);
+    const Vec hv = vload_row(a.HvT + (size_t)mc * H, q);
+    const Vec pm = vscale(vload_row(a.poolV + (size_t)mc * H, q), inv);
+    Vec z5 = vload_vec(a.b5, q);
+    gemm64(a.wpack + (size_t)I_W5A * IMG, hv, z5);
+    gemm64(a.wpack + (size_t)I_W5B * IMG, pm, z5);
+    Vec out = vload_vec(a.b6, q);
+    gemm64(a.wpack + (size_t)I_W6 * IMG, vsilu(z5), out);
+    if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
+    if (valid) vstore_row(a.HvT_out + (size_t)m * H, q, out);
+  }
+}
+int graph_post_forward(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->xsum && L->Z && L->HvT && L->poolV && L->poolX && L->Z_out && L->HvT_out && L->wpack,
+             "graph_post_forward: null buffer");
+  GraphPostArgs a{L->xsum, L->Z, L->HvT, L->poolV, L->poolX, L->wpack, L->params[FASTEGNN_P_NODEV0_B],
+                  L->params[FASTEGNN_P_NODEV2_B], L->Z_out, L->HvT_out, L->B, L->C, L->flags};
+  int grid = cdiv(cdiv((long)L->B * L->C, 16), 4);
+  if (grid > 256) grid = 256;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(graph_post_fwd_kernel, dim3(grid), dim3(256), 0, st, a);
+  return check_launch("graph_post_fwd_kernel");
+}
+
+}  // namespace fe

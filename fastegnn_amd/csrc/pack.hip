@@ -1,0 +1,98 @@
+// Weight packing: reference state_dict tensors ([out,in] row-major) -> MFMA operand images.
+// One workgroup per 64x64 image; see common.h (img_index) for the layout.
+#include "kernels.h"
+
+namespace fe {
+
+struct PackDesc {
+  const float *src;  // null -> zero image
+  int ld, c0, ks, transposed;
+};
+
+struct PackArgs {
+  const float *p[FASTEGNN_P_COUNT];
+  float *wpack;
+  int C, ea, na;
+};
+
+__device__ __forceinline__ PackDesc pack_desc(const PackArgs &a, int id) {
+  const int C = a.C;
+  const int ld_e0 = 2 * H + 1 + a.ea, ld_v0 = 2 * H + 1 + C, ld_n0 = 2 * H + H * C + a.na;
+  PackDesc d{nullptr, H, 0, 1, 0};
+  auto set = [&](int slot, int ld, int c0, int tr) {
+    d.src = a.p[slot];
+    d.ld = ld;
+    d.c0 = c0;
+    d.transposed = tr;
+  };
+  switch (id) {
+    case I_W2: set(FASTEGNN_P_EDGE2_W, H, 0, 0); break;
+    case I_WX1: set(FASTEGNN_P_CR0_W, H, 0, 0); break;
+    case I_W2T: set(FASTEGNN_P_EDGE2_W, H, 0, 1); break;
+    case I_WX1T: set(FASTEGNN_P_CR0_W, H, 0, 1); break;
+    case I_V2: set(FASTEGNN_P_VIRT2_W, H, 0, 0); break;
+    case I_WXV0: set(FASTEGNN_P_CRV0_W, H, 0, 0); break;
+    case I_WXX0: set(FASTEGNN_P_CVV0_W, H, 0, 0); break;
+    case I_V2T: set(FASTEGNN_P_VIRT2_W, H, 0, 1); break;
+    case I_WXV0T: set(FASTEGNN_P_CRV0_W, H, 0, 1); break;
+    case I_WXX0T: set(FASTEGNN_P_CVV0_W, H, 0, 1); break;
+    case I_W1A: set(FASTEGNN_P_EDGE0_W, ld_e0, 0, 0); break;
+    case I_W1B: set(FASTEGNN_P_EDGE0_W, ld_e0, H, 0); break;
+    case I_V1A: set(FASTEGNN_P_VIRT0_W, ld_v0, 0, 0); break;
+    case I_WVEL0: set(FASTEGNN_P_VEL0_W, H, 0, 0); break;
+    case I_WG0: set(FASTEGNN_P_GRAV0_W, H, 0, 0); break;
+    case I_W1AT: set(FASTEGNN_P_EDGE0_W, ld_e0, 0, 1); break;
+    case I_W1BT: set(FASTEGNN_P_EDGE0_W, ld_e0, H, 1); break;
+    case I_V1AT: set(FASTEGNN_P_VIRT0_W, ld_v0, 0, 1); break;
+    case I_WVEL0T: set(FASTEGNN_P_VEL0_W, H, 0, 1); break;
+    case I_WG0T: set(FASTEGNN_P_GRAV0_W, H, 0, 1); break;
+    case I_W5A: set(FASTEGNN_P_NODEV0_W, 2 * H, 0, 0); break;
+    case I_W5B: set(FASTEGNN_P_NODEV0_W, 2 * H, H, 0); break;
+    case I_W6: set(FASTEGNN_P_NODEV2_W, H, 0, 0); break;
+    case I_W5AT: set(FASTEGNN_P_NODEV0_W, 2 * H, 0, 1); break;
+    case I_W5BT: set(FASTEGNN_P_NODEV0_W, 2 * H, H, 1); break;
+    case I_W6T: set(FASTEGNN_P_NODEV2_W, H, 0, 1); break;
+    case I_V1B: set(FASTEGNN_P_VIRT0_W, ld_v0, H, 0); break;
+    case I_V1BT: set(FASTEGNN_P_VIRT0_W, ld_v0, H, 1); break;
+    case I_W3A: set(FASTEGNN_P_NODE0_W, ld_n0, 0, 0); break;
+    case I_W3B: set(FASTEGNN_P_NODE0_W, ld_n0, H, 0); break;
+    case I_W4: set(FASTEGNN_P_NODE2_W, H, 0, 0); break;
+    case I_W3AT: set(FASTEGNN_P_NODE0_W, ld_n0, 0, 1); break;
+    case I_W3BT: set(FASTEGNN_P_NODE0_W, ld_n0, H, 1); break;
+    case I_W4T: set(FASTEGNN_P_NODE2_W, H, 0, 1); break;
+    default: {
+      // flat(v)[h*C + c] column of node_mlp.0.weight: W3c[o][h] = W[o][2H + h*C + c]
+      int k = id - I_FIXED;
+      int c = k < C ? k : k - C;
+      set(FASTEGNN_P_NODE0_W, ld_n0, 2 * H + c, k < C ? 0 : 1);
+      d.ks = C;
+    }
+  }
+  return d;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+  const int id = blockIdx.x;
+  const PackDesc d = pack_desc(a, id);
+  float *dst = a.wpack + (size_t)id * IMG;
+  for (int idx = threadIdx.x; idx < IMG; idx += 256) {
+    int o = idx >> 6, k = idx & 63;
+    float v = 0.f;
+    if (d.src) v = d.transposed ? d.src[(size_t)k * d.ld + d.c0 + o * d.ks] : d.src[(size_t)o * d.ld + d.c0 + k * d.ks];
+    dst[img_index(o, k)] = v;
+  }
+}
+
+int pack_weights(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->params && L->wpack, "pack_weights: params/wpack null");
+  PackArgs a;
+  for (int i = 0; i < FASTEGNN_P_COUNT; ++i) a.p[i] = L->params[i];
+  a.wpack = L->wpack;
+  a.C = L->C;
+  a.ea = L->ea;
+  a.na = L->na;
+  hipLaunchKernelGGL(pack_kernel, dim3(I_FIXED + 2 * L->C), dim3(256), 0, st, a);
+  return check_launch("pack_kernel");
+}
+
+}  // namespace fe

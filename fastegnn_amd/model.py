@@ -1,0 +1,360 @@
+"""Drop-in ``FastEGNN`` nn.Module backed by the gfx950 HIP library.
+
+Mirrors the reference module surface (``/root/reference/models/FastEGNN.py:226-276``):
+same class name (the reference harness dispatches on ``model.__class__.__name__``,
+``utils/train.py:51``), same constructor and ``forward`` signatures, same ``state_dict``
+keys/shapes and the same parameter-construction order (so a given ``torch.manual_seed``
+yields the same initial weights).  The arithmetic runs in ``libfastegnn_hip.so`` through the
+C ABI of ``include/fastegnn_hip.h``; there is no CPU path -- CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib as K
+
+H = K.H
+
+
+# ------------------------------------------------------------------------------------------
+# parameter containers (never called: they only give the reference's state_dict layout)
+# ------------------------------------------------------------------------------------------
+class E_GCL_vel(nn.Module):
+    """Parameter holder of one layer; construction order follows models/FastEGNN.py:27-99."""
+
+    def __init__(self, hidden_nf, node_attr_nf, edge_attr_nf, virtual_channels, act_fn, attention, tanh, gravity):
+        super().__init__()
+        Hn, Cn = hidden_nf, virtual_channels
+        self.edge_mlp = nn.Sequential(nn.Linear(2 * Hn + 1 + edge_attr_nf, Hn), act_fn, nn.Linear(Hn, Hn), act_fn)
+        self.edge_mlp_virtual = nn.Sequential(nn.Linear(2 * Hn + 1 + Cn, Hn), act_fn, nn.Linear(Hn, Hn), act_fn)
+        if attention:
+            self.att_mlp = nn.Sequential(nn.Linear(Hn, 1), nn.Sigmoid())
+            self.att_mlp_virtual = nn.Sequential(nn.Linear(Hn, 1), nn.Sigmoid())
+
+        def coord_mlp():
+            last = nn.Linear(Hn, 1, bias=False)
+            torch.nn.init.xavier_uniform_(last.weight, gain=0.001)
+            mods = [nn.Linear(Hn, Hn), act_fn, last]
+            if tanh:
+                mods.append(nn.Tanh())
+            return nn.Sequential(*mods)
+
+        self.coord_mlp_r = coord_mlp()
+        self.coord_mlp_r_virtual = coord_mlp()
+        self.coord_mlp_v_virtual = coord_mlp()
+        self.coord_mlp_vel = nn.Sequential(nn.Linear(Hn, Hn), act_fn, nn.Linear(Hn, 1))
+        if gravity is not None:
+            self.gravity_mlp = nn.Sequential(nn.Linear(Hn, Hn), act_fn, nn.Linear(Hn, 1))
+        self.node_mlp = nn.Sequential(nn.Linear(Hn + Hn + Cn * Hn + node_attr_nf, Hn), act_fn, nn.Linear(Hn, Hn))
+        self.node_mlp_virtual = nn.Sequential(nn.Linear(Hn + Hn, Hn), act_fn, nn.Linear(Hn, Hn))
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("E_GCL_vel is evaluated inside FastEGNN.forward by the HIP library")
+
+
+# ------------------------------------------------------------------------------------------
+# sorted graph handle
+# ------------------------------------------------------------------------------------------
+class SortedGraph:
+    """Device-side CSR + col-keyed index of a COO ``edge_index`` (fastegnn_build_csr)."""
+
+    def __init__(self, edge_index: torch.Tensor, n_rows: int, n_src: Optional[int] = None, row_begin: int = 0):
+        assert edge_index.is_cuda and edge_index.dtype == torch.int64 and edge_index.dim() == 2
+        edge_index = edge_index.contiguous()
+        dev = edge_index.device
+        E = edge_index.size(1)
+        n_src = n_rows if n_src is None else n_src
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.n_rows, self.n_src, self.E = n_rows, n_src, E
+        self.rowptr = torch.empty(n_rows + 1, **i32)
+        self.erow = torch.empty(max(E, 1), **i32)
+        self.col = torch.empty(max(E, 1), **i32)
+        self.perm = torch.empty(max(E, 1), **i32)
+        self.cscptr = torch.empty(n_src + 1, **i32)
+        self.csc_eid = torch.empty(max(E, 1), **i32)
+        self.chunk_row = torch.empty(E // 256 + 2, **i32)
+        L = K.lib()
+        nbytes = L.fastegnn_csr_tmp_bytes(E, n_rows, n_src)
+        tmp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        nch = C.c_int32(0)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        K.check(L.fastegnn_build_csr(K.ptr(edge_index), E, row_begin, n_rows, n_src, K.ptr(self.rowptr),
+                                     K.ptr(self.erow), K.ptr(self.col), K.ptr(self.perm), K.ptr(self.cscptr),
+                                     K.ptr(self.csc_eid), K.ptr(self.chunk_row), C.byref(nch), K.ptr(tmp), nbytes,
+                                     C.c_void_p(st)), "fastegnn_build_csr")
+        self.n_chunks = nch.value
+        self._key = (edge_index.data_ptr(), E, edge_index._version, n_rows, n_src, row_begin)
+
+    def struct(self) -> K.GraphT:
+        g = K.GraphT()
+        g.n_rows, g.n_src, g.n_edges, g.n_chunks = self.n_rows, self.n_src, self.E, self.n_chunks
+        for n in ("rowptr", "erow", "col", "perm", "cscptr", "csc_eid", "chunk_row"):
+            setattr(g, n, getattr(self, n).data_ptr())
+        return g
+
+    def permute(self, edge_attr: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        if edge_attr is None or edge_attr.size(1) == 0:
+            return None
+        edge_attr = edge_attr.contiguous().float()
+        out = torch.empty_like(edge_attr)
+        st = torch.cuda.current_stream(edge_attr.device).cuda_stream
+        K.check(K.lib().fastegnn_permute_rows(K.ptr(edge_attr), K.ptr(self.perm), self.E, edge_attr.size(1),
+                                              K.ptr(out), C.c_void_p(st)), "fastegnn_permute_rows")
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _PtrTable:
+    """HOST array of device pointers in FASTEGNN_P_* order for one layer."""
+
+    def __init__(self, tensors: List[Optional[torch.Tensor]]):
+        self.keep = tensors
+        self.arr = (C.c_void_p * K.P_COUNT)(*[(t.data_ptr() if t is not None else None) for t in tensors])
+
+    def addr(self):
+        return C.cast(self.arr, C.c_void_p)
+
+
+def _fill(layer: K.LayerT, **tensors):
+    for name, t in tensors.items():
+        setattr(layer, name, t.data_ptr() if isinstance(t, torch.Tensor) else t)
+
+
+class _Spec:
+    """Static description shared by forward and backward."""
+
+    def __init__(self, model: "FastEGNN"):
+        self.C = model.virtual_channels
+        self.n_layers = model.n_layers
+        self.ea = model.edge_attr_nf
+        self.na = model.node_attr_nf
+        self.nf = model.node_feat_nf
+        flags = 0
+        flags |= K.F_ATTENTION if model.attention else 0
+        flags |= K.F_NORMALIZE if model.normalize else 0
+        flags |= K.F_TANH if model.tanh else 0
+        flags |= K.F_RESIDUAL if model.residual else 0
+        flags |= K.F_GRAVITY if model.gravity is not None else 0
+        self.flags = flags
+        self.gravity = [float(v) for v in model.gravity] if model.gravity is not None else [0.0, 0.0, 0.0]
+        # parameter order handed to the autograd function
+        self.names = ["virtual_node_feat", "embedding_in.weight", "embedding_in.bias"]
+        self.layer_slots: List[List[Optional[int]]] = []
+        for i in range(model.n_layers):
+            slots = []
+            for suffix in K.PARAM_SLOTS:
+                key = f"gcl_{i}.{suffix}"
+                if key in model._param_index:
+                    slots.append(len(self.names))
+                    self.names.append(key)
+                else:
+                    slots.append(None)
+            self.layer_slots.append(slots)
+
+
+def _new_layer(spec: _Spec, N: int, B: int, graph: SortedGraph) -> K.LayerT:
+    L = K.LayerT()
+    L.N, L.B, L.C, L.ea, L.na, L.flags = N, B, spec.C, spec.ea, spec.na, spec.flags
+    L.gravity = (C.c_float * 3)(*spec.gravity)
+    L.epsilon = 1e-8
+    L.graph = graph.struct()
+    return L
+
+
+class _FastEGNNFunction(torch.autograd.Function):
+    """Whole-model forward/backward on the HIP library (one C-ABI call per layer and direction)."""
+
+    @staticmethod
+    def forward(ctx, spec: _Spec, graph: SortedGraph, batch32, gptr, ea_sorted, node_attr,
+                node_feat, node_loc, node_vel, loc_mean, *params):
+        lib = K.lib()
+        dev = node_loc.device
+        st = _stream(dev)
+        N, B, Cn = node_loc.size(0), loc_mean.size(0), spec.C
+        f32 = dict(dtype=torch.float32, device=dev)
+        params = [p.detach() for p in params]
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.data_ptr() % 16:
+                raise RuntimeError("fastegnn_amd: parameters must be contiguous, 16-byte aligned fp32 tensors")
+        node_feat, node_loc, node_vel, loc_mean = (t.detach().contiguous().float()
+                                                   for t in (node_feat, node_loc, node_vel, loc_mean))
+        h = torch.empty(N, H, **f32)
+        K.check(lib.fastegnn_embed_forward(K.ptr(node_feat), N, spec.nf, K.ptr(params[1]), K.ptr(params[2]),
+                                           K.ptr(h), st), "fastegnn_embed_forward")
+        HvT = torch.empty(B, Cn, H, **f32)
+        K.check(lib.fastegnn_virtual_init(K.ptr(params[0]), B, Cn, K.ptr(HvT), st), "fastegnn_virtual_init")
+        x, Z = node_loc, loc_mean
+        saved = []
+        nwp = lib.fastegnn_wpack_floats(Cn)
+        for i in range(spec.n_layers):
+            tab = _PtrTable([params[s] if s is not None else None for s in spec.layer_slots[i]])
+            b = dict(
+                h=h, x=x, Z=Z, HvT=HvT, wpack=torch.empty(nwp, **f32),
+                P=torch.empty(N, H, **f32), QX=torch.empty(N, K.QX_LD, **f32), A=torch.empty(N, H, **f32),
+                svel=torch.empty(N, **f32), sgrav=torch.empty(N, **f32), xsum=torch.empty(B, 4, **f32),
+                Bc=torch.empty(B, Cn, H, **f32), aggm=torch.empty(N, H, **f32), aggx=torch.empty(N, 3, **f32),
+                npre=torch.empty(N, H, **f32), poolV=torch.empty(B, Cn, H, **f32), poolX=torch.empty(B, 3, Cn, **f32),
+                h_out=torch.empty(N, H, **f32), x_out=torch.empty(N, 3, **f32),
+                Z_out=torch.empty(B, 3, Cn, **f32), HvT_out=torch.empty(B, Cn, H, **f32))
+            L = _new_layer(spec, N, B, graph)
+            _fill(L, batch=batch32, gptr=gptr, vel=node_vel, params=tab.addr(), **b)
+            L.QX_src = b["QX"].data_ptr()
+            if ea_sorted is not None:
+                L.ea_sorted = ea_sorted.data_ptr()
+            if node_attr is not None:
+                L.node_attr = node_attr.data_ptr()
+            K.check(lib.fastegnn_layer_forward(C.byref(L), st), f"fastegnn_layer_forward[{i}]")
+            saved.append(b)
+            h, x, Z, HvT = b["h_out"], b["x_out"], b["Z_out"], b["HvT_out"]
+            # outputs of layer i are the inputs of layer i+1; drop what backward does not need
+            for k in ("aggx", "poolX", "h_out", "x_out", "Z_out", "HvT_out"):
+                del b[k]
+        ctx.spec, ctx.graph, ctx.saved = spec, graph, saved
+        ctx.misc = (batch32, gptr, ea_sorted, node_attr, node_feat, node_vel, params)
+        return x, Z
+
+    @staticmethod
+    def backward(ctx, g_loc, g_vloc):
+        lib = K.lib()
+        spec, graph, saved = ctx.spec, ctx.graph, ctx.saved
+        batch32, gptr, ea_sorted, node_attr, node_feat, node_vel, params = ctx.misc
+        dev = node_vel.device
+        st = _stream(dev)
+        N, B, Cn, E = node_vel.size(0), saved[0]["Z"].size(0), spec.C, graph.E
+        f32 = dict(dtype=torch.float32, device=dev)
+        # gradient buffers: one flat zero-filled allocation, 16-byte aligned slices
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]
+        flat = torch.zeros(sum(sizes), **f32)
+        grads, off = [], 0
+        for p, s in zip(params, sizes):
+            grads.append(flat[off:off + p.numel()].view_as(p))
+            off += s
+        g_h = torch.zeros(N, H, **f32)
+        g_x = (g_loc if g_loc is not None else torch.zeros(N, 3, **f32)).contiguous().float()
+        g_Z = (g_vloc if g_vloc is not None else torch.zeros(B, 3, Cn, **f32)).contiguous().float()
+        g_HvT = torch.zeros(B, Cn, H, **f32)
+        g_vel = torch.zeros(N, 3, **f32)
+        M = max(N, B * Cn)
+        scratch = dict(
+            g_poolV=torch.empty(B, Cn, H, **f32), g_poolX=torch.empty(B, 3, Cn, **f32),
+            g_Bc=torch.empty(B, Cn, H, **f32), g_Zp=torch.empty(B, 3, Cn, **f32), g_xbar=torch.empty(B, 4, **f32),
+            g_A=torch.empty(N, H, **f32), g_P=torch.empty(N, H, **f32), g_aggm=torch.empty(N, H, **f32),
+            g_aggx=torch.empty(N, 3, **f32), g_svel=torch.empty(N, **f32), g_sgrav=torch.empty(N, **f32),
+            g_QXe=torch.empty(max(E, 1), K.QX_LD, **f32), g_QX_src=torch.empty(N, K.QX_LD, **f32),
+            g_xrow=torch.empty(N, 3, **f32),
+            wg_edge=torch.empty(max(E, 1) * (4 * H + K.FEATW), **f32),
+            wg_virt=torch.empty(5 * N * Cn * H, **f32), wg_node=torch.empty(8 * M * H, **f32))
+        for i in reversed(range(spec.n_layers)):
+            b = saved[i]
+            ptab = _PtrTable([params[s] if s is not None else None for s in spec.layer_slots[i]])
+            gtab = _PtrTable([grads[s] if s is not None else None for s in spec.layer_slots[i]])
+            L = _new_layer(spec, N, B, graph)
+            out = dict(g_h=torch.empty(N, H, **f32), g_x=torch.empty(N, 3, **f32),
+                       g_Z=torch.empty(B, 3, Cn, **f32), g_HvT=torch.empty(B, Cn, H, **f32))
+            _fill(L, batch=batch32, gptr=gptr, vel=node_vel, params=ptab.addr(), grads=gtab.addr(),
+                  g_h_out=g_h, g_x_out=g_x, g_Z_out=g_Z, g_HvT_out=g_HvT, g_vel=g_vel, **b, **out, **scratch)
+            L.QX_src = b["QX"].data_ptr()
+            L.g_QX = scratch["g_QX_src"].data_ptr()
+            if ea_sorted is not None:
+                L.ea_sorted = ea_sorted.data_ptr()
+            if node_attr is not None:
+                L.node_attr = node_attr.data_ptr()
+            K.check(lib.fastegnn_layer_backward(C.byref(L), st), f"fastegnn_layer_backward[{i}]")
+            g_h, g_x, g_Z, g_HvT = out["g_h"], out["g_x"], out["g_Z"], out["g_HvT"]
+            saved[i] = None
+        K.check(lib.fastegnn_virtual_init_backward(K.ptr(g_HvT), B, Cn, K.ptr(grads[0]), st),
+                "fastegnn_virtual_init_backward")
+        g_nf = torch.empty_like(node_feat) if ctx.needs_input_grad[6] else None
+        K.check(lib.fastegnn_embed_backward(K.ptr(node_feat), K.ptr(g_h), N, spec.nf, K.ptr(params[1]),
+                                            K.ptr(grads[1]), K.ptr(grads[2]), K.ptr(g_nf), st),
+                "fastegnn_embed_backward")
+        return (None, None, None, None, None, None, g_nf, g_x, g_vel, g_Z, *grads)
+
+
+# ------------------------------------------------------------------------------------------
+# the module
+# ------------------------------------------------------------------------------------------
+class FastEGNN(nn.Module):
+    """MI355X-native drop-in for the reference ``FastEGNN`` (models/FastEGNN.py:226-276)."""
+
+    def __init__(self, node_feat_nf, node_attr_nf, edge_attr_nf, hidden_nf, virtual_channels, device='cpu',
+                 act_fn=nn.SiLU(), n_layers=4, residual=True, attention=False, normalize=False, tanh=False,
+                 gravity=None):
+        super().__init__()
+        assert virtual_channels > 0, f'Channels of virtual node must greater than 0 (got {virtual_channels})'
+        if hidden_nf != H:
+            raise NotImplementedError(f"fastegnn_amd: hidden_nf must be {H} in this build (got {hidden_nf})")
+        if not isinstance(act_fn, nn.SiLU):
+            raise NotImplementedError("fastegnn_amd: the HIP kernels implement SiLU (the reference default) only")
+        if virtual_channels > 64 or edge_attr_nf > 7 or node_feat_nf > 8:
+            raise NotImplementedError("fastegnn_amd: supports virtual_channels<=64, edge_attr_nf<=7, node_feat_nf<=8")
+        self.hidden_nf = hidden_nf
+        self.device = device
+        self.n_layers = n_layers
+        self.virtual_channels = virtual_channels
+        self.node_feat_nf, self.node_attr_nf, self.edge_attr_nf = node_feat_nf, node_attr_nf, edge_attr_nf
+        self.residual, self.attention, self.normalize, self.tanh = residual, attention, normalize, tanh
+        self.gravity = list(gravity) if gravity is not None else None
+        self.virtual_node_feat = nn.Parameter(data=torch.randn(size=(1, hidden_nf, virtual_channels)),
+                                              requires_grad=True)
+        self.embedding_in = nn.Linear(node_feat_nf, self.hidden_nf)
+        for i in range(n_layers):
+            self.add_module("gcl_%d" % i, E_GCL_vel(hidden_nf, node_attr_nf, edge_attr_nf, virtual_channels, act_fn,
+                                                    attention, tanh, gravity))
+        self._graph_cache: Dict[tuple, SortedGraph] = {}
+        self.cache_graphs = True
+        self.to(self.device)
+
+    @property
+    def _param_index(self):
+        return dict(self.named_parameters())
+
+    def sorted_graph(self, edge_index: torch.Tensor, n_nodes: int) -> SortedGraph:
+        key = (edge_index.data_ptr(), edge_index.size(1), edge_index._version, n_nodes, n_nodes, 0)
+        g = self._graph_cache.get(key) if self.cache_graphs else None
+        if g is None:
+            g = SortedGraph(edge_index, n_nodes)
+            if self.cache_graphs:
+                if len(self._graph_cache) >= 8:
+                    self._graph_cache.pop(next(iter(self._graph_cache)))
+                g._keepalive = edge_index  # the key holds a data_ptr: keep the tensor alive with it
+                self._graph_cache[key] = g
+        return g
+
+    def forward(self, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None,
+                node_attr=None):
+        if not node_loc.is_cuda:
+            raise RuntimeError("fastegnn_amd.FastEGNN runs on a gfx950 GPU only (no CPU fallback): move the model "
+                               "and its inputs to 'cuda'")
+        for name, t in (("edge_attr", edge_attr), ("node_attr", node_attr)):
+            if t is not None and t.requires_grad:
+                raise NotImplementedError(f"fastegnn_amd: gradient w.r.t. {name} is not implemented")
+        if (edge_attr.size(1) if edge_attr is not None else 0) != self.edge_attr_nf:
+            raise ValueError("edge_attr width does not match edge_attr_nf")
+        if (node_attr.size(1) if node_attr is not None else 0) != self.node_attr_nf:
+            raise ValueError("node_attr width does not match node_attr_nf")
+        dev = node_loc.device
+        N, B = node_loc.size(0), loc_mean.size(0)   # B from loc_mean: no .item() sync (cf. :267)
+        spec = _Spec(self)
+        graph = edge_index if isinstance(edge_index, SortedGraph) else self.sorted_graph(edge_index, N)
+        lib = K.lib()
+        batch32 = torch.empty(N, dtype=torch.int32, device=dev)
+        gptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        K.check(lib.fastegnn_build_batch(K.ptr(data_batch.contiguous()), N, B, K.ptr(batch32), K.ptr(gptr), _stream(dev)),
+                "fastegnn_build_batch")
+        ea_sorted = graph.permute(edge_attr.detach() if edge_attr is not None else None)
+        na = node_attr.detach().contiguous().float() if node_attr is not None else None
+        pidx = self._param_index
+        params = [pidx[n] for n in spec.names]
+        return _FastEGNNFunction.apply(spec, graph, batch32, gptr, ea_sorted, na, node_feat, node_loc, node_vel,
+                                       loc_mean, *params)

@@ -1,0 +1,243 @@
+/*
+ * fastegnn_hip.h -- C ABI of libfastegnn_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for ONE path of GLAD-RUC/FastEGNN: the forward and backward of the
+ * FastEGNN model (reference: models/FastEGNN.py:192-276 + autograd, utils/train.py:169).
+ * The reference has no FFI for this path (it is a Python nn.Module calling ATen); the entry
+ * points below are what a binding for it needs: plain pointers + sizes + a hipStream_t, the
+ * caller allocates every buffer, no torch types, no global mutable state, re-entrant per
+ * stream.  Each function returns 0 on success or a negative FASTEGNN_E_* code;
+ * fastegnn_last_error() gives the message of the calling thread's last failure.
+ *
+ * All device arrays are fp32 row-major unless noted; indices are int32.
+ * H (hidden_nf) is fixed to 64 in this build.
+ *
+ * One E_GCL_vel layer (models/FastEGNN.py:192-223) is evaluated as five stages; on one GPU
+ * fastegnn_layer_forward/backward chain them, a sharded caller runs the stages itself and
+ * exchanges the marked buffers between them (DESIGN.md "Multi-GPU").
+ *
+ *   forward                              backward (reverse order)
+ *   S1 node_pre   h -> P, QX, A, heads    B1 node_pre_bwd
+ *   S2 graph_pre  x,Z,Hv -> Bc            B3 graph_pre_bwd
+ *   S3 edge       P,QX,CSR -> aggm,aggx   B2 edge_bwd (+ col-keyed reduce)
+ *   S4 virt       ... -> h',x',pools      B4 virt_bwd
+ *   S5 graph_post pools -> Z',Hv'         B5 graph_post_bwd
+ */
+#ifndef FASTEGNN_HIP_H
+#define FASTEGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASTEGNN_H 64
+#define FASTEGNN_QX_LD 68 /* source-table row: Q[64] | x[3] | pad */
+
+enum {
+  FASTEGNN_OK = 0,
+  FASTEGNN_E_INVALID = -1, /* bad argument (null pointer, unsupported size) */
+  FASTEGNN_E_LAUNCH = -2,  /* HIP launch / runtime failure */
+  FASTEGNN_E_NODEVICE = -3 /* no gfx950 device visible */
+};
+
+/* constructor flags of the reference model (models/FastEGNN.py:227-228, :11-12) */
+enum {
+  FASTEGNN_F_ATTENTION = 1,
+  FASTEGNN_F_NORMALIZE = 2,
+  FASTEGNN_F_TANH = 4,
+  FASTEGNN_F_RESIDUAL = 8,
+  FASTEGNN_F_GRAVITY = 16,
+  FASTEGNN_F_COORDS_SUM = 32 /* coords_agg='sum' (default 'mean') */
+};
+
+/* Per-layer parameter slots: the reference state_dict tensors of gcl_<i>, untouched
+ * ([out,in] row-major as torch stores them).  models/FastEGNN.py:28-99. */
+enum {
+  FASTEGNN_P_EDGE0_W = 0, /* edge_mlp.0.weight          [64, 128+1+ea] */
+  FASTEGNN_P_EDGE0_B,     /* edge_mlp.0.bias            [64] */
+  FASTEGNN_P_EDGE2_W,     /* edge_mlp.2.weight          [64,64] */
+  FASTEGNN_P_EDGE2_B,
+  FASTEGNN_P_VIRT0_W,     /* edge_mlp_virtual.0.weight  [64, 128+1+C] */
+  FASTEGNN_P_VIRT0_B,
+  FASTEGNN_P_VIRT2_W,     /* edge_mlp_virtual.2.weight  [64,64] */
+  FASTEGNN_P_VIRT2_B,
+  FASTEGNN_P_ATT_W,       /* att_mlp.0.weight           [1,64]   (null unless attention) */
+  FASTEGNN_P_ATT_B,       /* att_mlp.0.bias             [1] */
+  FASTEGNN_P_ATTV_W,      /* att_mlp_virtual.0.weight   [1,64] */
+  FASTEGNN_P_ATTV_B,
+  FASTEGNN_P_CR0_W,       /* coord_mlp_r.0.weight       [64,64] */
+  FASTEGNN_P_CR0_B,
+  FASTEGNN_P_CR2_W,       /* coord_mlp_r.2.weight       [1,64] (no bias) */
+  FASTEGNN_P_CRV0_W,      /* coord_mlp_r_virtual.*      */
+  FASTEGNN_P_CRV0_B,
+  FASTEGNN_P_CRV2_W,
+  FASTEGNN_P_CVV0_W,      /* coord_mlp_v_virtual.*      */
+  FASTEGNN_P_CVV0_B,
+  FASTEGNN_P_CVV2_W,
+  FASTEGNN_P_VEL0_W,      /* coord_mlp_vel.0.weight     [64,64] */
+  FASTEGNN_P_VEL0_B,
+  FASTEGNN_P_VEL2_W,      /* coord_mlp_vel.2.weight     [1,64] */
+  FASTEGNN_P_VEL2_B,      /* [1] */
+  FASTEGNN_P_GRAV0_W,     /* gravity_mlp.*  (null unless gravity) */
+  FASTEGNN_P_GRAV0_B,
+  FASTEGNN_P_GRAV2_W,
+  FASTEGNN_P_GRAV2_B,
+  FASTEGNN_P_NODE0_W,     /* node_mlp.0.weight          [64, 128+64*C+na] */
+  FASTEGNN_P_NODE0_B,
+  FASTEGNN_P_NODE2_W,     /* node_mlp.2.weight          [64,64] */
+  FASTEGNN_P_NODE2_B,
+  FASTEGNN_P_NODEV0_W,    /* node_mlp_virtual.0.weight  [64,128] */
+  FASTEGNN_P_NODEV0_B,
+  FASTEGNN_P_NODEV2_W,    /* node_mlp_virtual.2.weight  [64,64] */
+  FASTEGNN_P_NODEV2_B,
+  FASTEGNN_P_COUNT
+};
+
+/* Sorted graph produced by fastegnn_build_csr (replaces the implicit scatter indices of
+ * unsorted_segment_sum/mean, models/FastEGNN.py:279-294). */
+typedef struct {
+  int32_t n_rows;          /* aggregation targets owned by this rank (== N on one GPU) */
+  int32_t n_src;           /* rows of the source table the col indices address */
+  int32_t n_edges;
+  int32_t n_chunks;        /* edge-balanced row chunks (work items of the edge kernels) */
+  const int32_t *rowptr;   /* [n_rows+1] */
+  const int32_t *erow;     /* [E] row of sorted edge */
+  const int32_t *col;      /* [E] source-table index of sorted edge */
+  const int32_t *perm;     /* [E] sorted edge k == input edge perm[k] */
+  const int32_t *cscptr;   /* [n_src+1] */
+  const int32_t *csc_eid;  /* [E] sorted-edge ids grouped by col */
+  const int32_t *chunk_row;/* [n_chunks+1] first row of each chunk */
+} fastegnn_graph_t;
+
+/* Everything one layer call touches.  "in"/"out" are w.r.t. the forward; the backward reads
+ * the saved buffers and the g_* inputs and writes the g_* outputs (accumulating into grads). */
+typedef struct {
+  /* sizes / flags */
+  int32_t N, B, C, ea, na, flags;
+  float gravity[3];
+  float epsilon;           /* models/FastEGNN.py:21 */
+  fastegnn_graph_t graph;
+  const int32_t *batch;    /* [N] graph id per node, ascending */
+  const int32_t *gptr;     /* [B+1] node range of each graph */
+  const float *ea_sorted;  /* [E,ea] edge_attr in sorted-edge order */
+  const float *vel;        /* [N,3] */
+  const float *node_attr;  /* [N,na] or null */
+
+  const float *const *params; /* HOST array [FASTEGNN_P_COUNT] of device pointers */
+  float *const *grads;        /* HOST array [FASTEGNN_P_COUNT] of device pointers (+=), backward only */
+  float *wpack;               /* packed MFMA weight images, fastegnn_wpack_floats(C) floats */
+
+  /* layer inputs (saved for backward by the caller) */
+  const float *h;          /* [N,64] */
+  const float *x;          /* [N,3] */
+  const float *Z;          /* [B,3,C]   virtual coordinates (reference layout) */
+  const float *HvT;        /* [B,C,64]  virtual features, channel-major */
+  /* layer outputs */
+  float *h_out, *x_out, *Z_out, *HvT_out;
+
+  /* stage products (saved for backward) */
+  float *P;                /* [N,64]   S1 */
+  float *QX;               /* [N,68]   S1: Q | x | pad.  (sharded: all-gathered into QX_src) */
+  const float *QX_src;     /* [n_src,68] table the edge kernels gather from (== QX on one GPU) */
+  float *A;                /* [N,64]   S1 */
+  float *svel, *sgrav;     /* [N]      S1 */
+  float *xsum;             /* [B,4]    S2: per-graph sum of x | node count (sharded: all-reduced) */
+  float *Bc;               /* [B,C,64] S2 */
+  float *aggm;             /* [N,64]   S3 */
+  float *aggx;             /* [N,3]    S3 */
+  float *npre;             /* [N,64]   S4: node_mlp pre-activation */
+  float *poolV;            /* [B,C,64] S4 (sum over nodes; sharded: all-reduced) */
+  float *poolX;            /* [B,3,C]  S4 (sum over nodes; sharded: all-reduced) */
+
+  /* backward inputs: d loss / d layer outputs */
+  const float *g_h_out, *g_x_out, *g_Z_out, *g_HvT_out;
+  /* backward outputs: d loss / d layer inputs */
+  float *g_h, *g_x, *g_Z, *g_HvT;
+  float *g_vel;            /* [N,3] accumulated (+=), may be null */
+
+  /* backward scratch (caller allocates; sizes from fastegnn_scratch_floats) */
+  float *g_poolV, *g_poolX;   /* [B,C,64], [B,3,C] */
+  float *g_Bc;                /* [B,C,64] (sharded: all-reduced before B3) */
+  float *g_Zp;                /* [B,3,C]  partial from B4 (sharded: all-reduced) */
+  float *g_xbar;              /* [B,3]    per-node share of d/d centroid */
+  float *g_A, *g_P, *g_aggm;  /* [N,64] */
+  float *g_aggx;              /* [N,3] */
+  float *g_svel, *g_sgrav;    /* [N] */
+  float *g_QXe;               /* [E,68]  per-edge d/d(Q|x) of the col side */
+  float *g_QX_src;            /* [n_src,68] col-keyed sums (sharded: reduce-scattered) */
+  float *g_QX;                /* [N,68]  this rank's slice of g_QX_src (== g_QX_src on one GPU) */
+  float *g_xrow;              /* [N,3]   row-side d/dx of the edge stage */
+  float *wg_edge;             /* [4*E*64 + E*8] weight-gradient operands of the edge stage */
+  float *wg_virt;             /* [5*N*C*64]     weight-gradient operands of the virtual stage */
+  float *wg_node;             /* [8*max(N,B*C)*64] node-level weight-gradient operands */
+} fastegnn_layer_t;
+
+/* ---- library ---- */
+const char *fastegnn_last_error(void);
+int fastegnn_version(void);
+/* floats of the packed weight-image buffer for C virtual channels */
+size_t fastegnn_wpack_floats(int32_t C);
+
+/* ---- graph preprocessing (COO int64, any order -> row-sorted CSR + col-keyed index) ----
+ * edge_index: device int64 [2,E] as the reference passes it (models/FastEGNN.py:204).
+ * Rows must lie in [row_begin, row_begin+n_rows) and are stored relative to row_begin; cols
+ * address the source table [0,n_src).  All outputs caller-allocated:
+ * rowptr[n_rows+1], erow/col/perm/csc_eid[E], cscptr[n_src+1], chunk_row[E/256+2];
+ * tmp: fastegnn_csr_tmp_bytes(E, n_rows, n_src) bytes.  *n_chunks is a host int. */
+size_t fastegnn_csr_tmp_bytes(int32_t E, int32_t n_rows, int32_t n_src);
+int fastegnn_build_csr(const int64_t *edge_index, int32_t E, int32_t row_begin, int32_t n_rows,
+                       int32_t n_src, int32_t *rowptr, int32_t *erow, int32_t *col, int32_t *perm,
+                       int32_t *cscptr, int32_t *csc_eid, int32_t *chunk_row, int32_t *n_chunks,
+                       void *tmp, size_t tmp_bytes, void *stream);
+/* out[k,:] = in[perm[k],:]   (edge_attr into sorted order) */
+int fastegnn_permute_rows(const float *in, const int32_t *perm, int32_t E, int32_t width, float *out,
+                          void *stream);
+/* batch int64 [N] (ascending) -> batch int32 [N], gptr int32 [B+1] */
+int fastegnn_build_batch(const int64_t *batch64, int32_t N, int32_t B, int32_t *batch, int32_t *gptr,
+                         void *stream);
+
+/* ---- model prologue / epilogue (models/FastEGNN.py:267-271) ---- */
+/* h = node_feat @ W^T + b   (embedding_in) */
+int fastegnn_embed_forward(const float *node_feat, int32_t N, int32_t nf, const float *W, const float *b,
+                           float *h, void *stream);
+/* gW += g_h^T node_feat, gb += colsum g_h, g_node_feat = g_h W (nullable) */
+int fastegnn_embed_backward(const float *node_feat, const float *g_h, int32_t N, int32_t nf, const float *W,
+                            float *gW, float *gb, float *g_node_feat, void *stream);
+/* HvT[b,c,:] = virtual_node_feat[0,:,c]  (the .repeat(B,1,1) of :268, channel-major) */
+int fastegnn_virtual_init(const float *vnf, int32_t B, int32_t C, float *HvT, void *stream);
+/* g_vnf[0,h,c] += sum_b g_HvT[b,c,h] */
+int fastegnn_virtual_init_backward(const float *g_HvT, int32_t B, int32_t C, float *g_vnf, void *stream);
+
+/* ---- one layer, staged ---- */
+int fastegnn_pack_weights(const fastegnn_layer_t *L, void *stream);
+int fastegnn_node_pre_forward(const fastegnn_layer_t *L, void *stream);   /* S1 */
+int fastegnn_graph_xsum(const fastegnn_layer_t *L, void *stream);         /* S2a: local xsum */
+int fastegnn_graph_pre_forward(const fastegnn_layer_t *L, void *stream);  /* S2b: xsum -> Bc */
+int fastegnn_edge_forward(const fastegnn_layer_t *L, void *stream);       /* S3 */
+int fastegnn_virt_forward(const fastegnn_layer_t *L, void *stream);       /* S4 (zeroes + fills pools) */
+int fastegnn_graph_post_forward(const fastegnn_layer_t *L, void *stream); /* S5 */
+
+int fastegnn_graph_post_backward(const fastegnn_layer_t *L, void *stream); /* B5 */
+int fastegnn_virt_backward(const fastegnn_layer_t *L, void *stream);       /* B4 */
+int fastegnn_graph_pre_backward(const fastegnn_layer_t *L, void *stream);  /* B3 */
+int fastegnn_edge_backward(const fastegnn_layer_t *L, void *stream);       /* B2a: per-edge */
+int fastegnn_edge_col_reduce(const fastegnn_layer_t *L, void *stream);     /* B2b: g_QXe -> g_QX_src */
+int fastegnn_node_pre_backward(const fastegnn_layer_t *L, void *stream);   /* B1 */
+
+/* ---- one layer, whole (single GPU): pack + S1..S5 / B5..B1 on the stream ---- */
+int fastegnn_layer_forward(const fastegnn_layer_t *L, void *stream);
+int fastegnn_layer_backward(const fastegnn_layer_t *L, void *stream);
+
+/* ---- diagnostics (used by tests/ only) ----
+ * Y[j][o] = sum_k A[o][k] X[j][k] for one 16-row tile through the MFMA image path (A = W or W^T,
+ * W 64x64 row-major);  dW += G^T T, db += colsum(G) over M rows of 64. */
+int fastegnn_selftest_gemm(const float *W, const float *X, float *Y, int32_t transposed, void *stream);
+int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTEGNN_HIP_H */

@@ -1,0 +1,64 @@
+"""-m gpu: building blocks of the HIP library through the C ABI (MFMA image path, weight-gradient
+GEMM, CSR build) against plain torch / the oracle's CSR."""
+import ctypes as C
+
+import pytest
+import torch
+
+from fastegnn_amd import _lib as K
+from fastegnn_amd.model import SortedGraph
+from oracle import factored as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("transposed", [0, 1])
+def test_mfma_image_gemm(transposed):
+    g = torch.Generator().manual_seed(5)
+    # asymmetric integer data: exact in fp32, catches any row/col or k-permutation slip
+    W = torch.randint(-8, 9, (64, 64), generator=g).float().cuda()
+    X = torch.randint(-8, 9, (16, 64), generator=g).float().cuda()
+    Y = torch.zeros(16, 64, device="cuda")
+    K.check(K.lib().fastegnn_selftest_gemm(K.ptr(W), K.ptr(X), K.ptr(Y), transposed, _st()), "selftest_gemm")
+    A = W.T if transposed else W
+    assert torch.equal(Y.cpu(), (X.cpu() @ A.cpu().T))
+
+
+@pytest.mark.parametrize("M", [1, 15, 16, 257, 5000])
+def test_wgrad_tn(M):
+    g = torch.Generator().manual_seed(M)
+    G = torch.randint(-4, 5, (M, 64), generator=g).float().cuda()
+    T = torch.randint(-4, 5, (M, 64), generator=g).float().cuda()
+    dW = torch.zeros(64, 64, device="cuda")
+    db = torch.zeros(64, device="cuda")
+    K.check(K.lib().fastegnn_selftest_wgrad(K.ptr(G), K.ptr(T), M, K.ptr(dW), K.ptr(db), _st()), "selftest_wgrad")
+    assert torch.equal(dW.cpu(), G.cpu().T @ T.cpu())
+    assert torch.equal(db.cpu(), G.cpu().sum(0))
+
+
+@pytest.mark.parametrize("N,E", [(1, 0), (5, 3), (37, 400), (1000, 20000), (300, 70000)])
+def test_build_csr_matches_oracle(N, E):
+    g = torch.Generator().manual_seed(N + E)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    if N > 3:
+        ei[0][ei[0] == 2] = 3     # node 2 has no in-edges
+    ref = F.build_csr(ei, N)
+    sg = SortedGraph(ei.cuda(), N)
+    torch.cuda.synchronize()
+    assert torch.equal(sg.rowptr.cpu().long(), ref.rowptr)
+    assert torch.equal(sg.cscptr.cpu().long(), ref.cscptr)
+    if E:
+        assert torch.equal(sg.erow.cpu().long(), ref.row)
+        assert torch.equal(sg.perm.cpu().long(), ref.perm)          # stable sort: identical order
+        assert torch.equal(sg.col.cpu().long(), ref.col)
+        assert torch.equal(sg.csc_eid.cpu().long(), ref.csc_eid)
+    cr = sg.chunk_row.cpu()[: sg.n_chunks + 1]
+    assert cr[0] == 0 and cr[-1] == N and bool((cr[1:] >= cr[:-1]).all())
+    rp = sg.rowptr.cpu()
+    for k in range(sg.n_chunks):   # chunk k owns the rows whose first edge lies in [256k, 256(k+1))
+        for r in range(int(cr[k]), int(cr[k + 1])):
+            assert 256 * k <= int(rp[r]) and (int(rp[r]) < 256 * (k + 1) or k == sg.n_chunks - 1)
