@@ -25,7 +25,7 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   dW[o*lddw + c0 + k*ks] += sum_m G[m*ldg + o] * T[m*ldt + k]   (o,k < 64),  db[o] += sum_m G[m*ldg+o]
 //   batched over `nb` with strides (sG, sT, sW) in floats.
 int launch_wgrad_tn(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks,
-                    float *db, int nb, long sG, long sT, long sW, hipStream_t st);
+                    float *db, int nb, long sG, long sT, long sW, hipStream_t st, int kmax = 64);
 //   dW[o*lddw + c0 + a] += sum_m G[m*ldg + o] * F[m*ldf + a],  a < kf <= 8
 int launch_wgrad_small(const float *G, int ldg, const float *F, int ldf, int kf, long M, float *dW, int lddw, int c0,
                        hipStream_t st);

@@ -1,10 +1,722 @@
-#include "kernels.h"
+// Backward stages B5..B1 of one E_GCL_vel layer: the hand-derived adjoint of layer_fwd.hip
+// (what autograd computes for models/FastEGNN.py:192-223 at utils/train.py:169).
+// Math per stage: oracle/factored.py (*_bwd).  Activations are recomputed per tile; the
+// operands of the 64x64 weight gradients are written once ([rows,64]) and contracted by the
+// generic wgrad_tn kernel (misc.hip).
+#include "stages.h"
+
 namespace fe {
-#define NOTIMPL(name) int name(const fastegnn_layer_t *, hipStream_t) { set_error(#name ": not implemented"); return FASTEGNN_E_INVALID; }
-NOTIMPL(graph_post_backward)
-NOTIMPL(virt_backward)
-NOTIMPL(graph_pre_backward)
-NOTIMPL(edge_backward)
-NOTIMPL(edge_col_reduce)
-NOTIMPL(node_pre_backward)
+
+__device__ __forceinline__ Vec vdsilu_mul(const Vec &g, const Vec &z) {
+  return vmap2(g, z, [](float a, float b) { return a * dsilu_f(b); });
 }
+__device__ __forceinline__ Vec vmask(const Vec &v, bool keep) { return keep ? v : vzero(); }
+
+// reduce a per-lane D-layout accumulator over the 16 items of the tile and add it to a
+// natural-order 64-vector in global memory
+__device__ __forceinline__ void vec_reduce_atomic(float *dst, const Vec &acc, int j, int q) {
+  if (!dst) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s = jsum(acc.t[t][r]);
+      if (j == 0) atomicAdd(&dst[16 * t + 4 * q + r], s);
+    }
+}
+
+// =====================================================================================
+// B5 graph_post_bwd
+// =====================================================================================
+struct GraphPostBwdArgs {
+  const float *xsum, *HvT, *poolV, *g_Z_out, *g_HvT_out, *wpack, *b5;
+  float *g_Z, *g_HvT, *g_poolV, *g_poolX, *wg_u, *wg_gz5, *wg_pm;
+  int B, C, flags;
+};
+__global__ __launch_bounds__(256) void graph_post_bwd_kernel(GraphPostBwdArgs a) {
+  const int l = lane_id(), j = l & 15, q = l >> 4;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int M = a.B * a.C, ntiles = (M + 15) >> 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.B * 3 * a.C; i += gridDim.x * blockDim.x) {
+    const int b = i / (3 * a.C);
+    const float g = a.g_Z_out[i];
+    a.g_Z[i] = g;
+    a.g_poolX[i] = g / fmaxf(a.xsum[b * 4 + 3], 1.f);
+  }
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int m = tile * 16 + j;
+    const bool valid = m < M;
+    const int mc = valid ? m : M - 1;
+    const int b = mc / a.C;
+    const float inv = 1.0f / fmaxf(a.xsum[b * 4 + 3], 1.f);
+    const Vec hv = vload_row(a.HvT + (size_t)mc * H, q);
+    const Vec pm = vscale(vload_row(a.poolV + (size_t)mc * H, q), inv);
+    Vec z5 = vload_vec(a.b5, q);
+    gemm64(a.wpack + (size_t)I_W5A * IMG, hv, z5);
+    gemm64(a.wpack + (size_t)I_W5B * IMG, pm, z5);
+    const Vec g_out = vload_row(a.g_HvT_out + (size_t)mc * H, q);
+    Vec g_u = vzero();
+    gemm64(a.wpack + (size_t)I_W6T * IMG, g_out, g_u);
+    const Vec g_z5 = vdsilu_mul(g_u, z5);
+    Vec g_hv = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
+    gemm64(a.wpack + (size_t)I_W5AT * IMG, g_z5, g_hv);
+    Vec g_pm = vzero();
+    gemm64(a.wpack + (size_t)I_W5BT * IMG, g_z5, g_pm);
+    if (valid) {
+      vstore_row(a.wg_u + (size_t)m * H, q, vsilu(z5));
+      vstore_row(a.wg_gz5 + (size_t)m * H, q, g_z5);
+      vstore_row(a.wg_pm + (size_t)m * H, q, pm);
+      vstore_row(a.g_HvT + (size_t)m * H, q, g_hv);
+      vstore_row(a.g_poolV + (size_t)m * H, q, vscale(g_pm, inv));
+    }
+  }
+}
+
+int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->xsum && L->HvT && L->poolV && L->g_Z_out && L->g_HvT_out && L->g_Z && L->g_HvT && L->g_poolV &&
+                 L->g_poolX && L->wg_node && L->grads && L->wpack,
+             "graph_post_backward: null buffer");
+  const long M = (long)L->B * L->C;
+  float *wg_u = L->wg_node, *wg_gz5 = L->wg_node + M * H, *wg_pm = L->wg_node + 2 * M * H;
+  GraphPostBwdArgs a{L->xsum, L->HvT, L->poolV, L->g_Z_out, L->g_HvT_out, L->wpack, L->params[FASTEGNN_P_NODEV0_B],
+                     L->g_Z, L->g_HvT, L->g_poolV, L->g_poolX, wg_u, wg_gz5, wg_pm, L->B, L->C, L->flags};
+  int grid = cdiv(cdiv(M, 16), 4);
+  if (grid > 256) grid = 256;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(graph_post_bwd_kernel, dim3(grid), dim3(256), 0, st, a);
+  int rc = check_launch("graph_post_bwd_kernel");
+  if (rc) return rc;
+  float *const *g = L->grads;
+  // node_mlp_virtual.2: dW6 += g_out^T u, db6 += colsum g_out
+  if ((rc = launch_wgrad_tn(L->g_HvT_out, H, wg_u, H, M, g[FASTEGNN_P_NODEV2_W], H, 0, 1, g[FASTEGNN_P_NODEV2_B], 1, 0, 0, 0, st))) return rc;
+  // node_mlp_virtual.0: [Hv | pooled v]
+  if ((rc = launch_wgrad_tn(wg_gz5, H, L->HvT, H, M, g[FASTEGNN_P_NODEV0_W], 2 * H, 0, 1, g[FASTEGNN_P_NODEV0_B], 1, 0, 0, 0, st))) return rc;
+  return launch_wgrad_tn(wg_gz5, H, wg_pm, H, M, g[FASTEGNN_P_NODEV0_W], 2 * H, H, 1, nullptr, 1, 0, 0, 0, st);
+}
+
+// =====================================================================================
+// B4 virt_bwd
+// =====================================================================================
+struct VirtBwdArgs {
+  VirtArgs f;
+  const float *g_h_out, *g_x_out, *g_poolV, *g_poolX, *npre_in;
+  float *g_h, *g_x, *g_A, *g_aggm, *g_aggx, *g_svel, *g_sgrav, *g_Bc, *g_Zp;
+  float *wg_t3, *wg_gnp;                     // [N,64] node-level operands
+  float *wg_v, *wg_t, *wg_gux, *wg_guX, *wg_gvp;  // [N*C,64] (node,channel) operands
+  float *d_wxv2, *d_wxx2, *d_wvr, *d_attw, *d_attb;  // rank-1 gradients (d_wvr strided by ld)
+  int ld_v0;
+};
+
+__global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const VirtArgs &a = A.f;
+  const int C = a.C;
+  float *img = lds;                              // V2 WXV0 WXX0 V2T WXV0T WXX0T
+  float *vec = lds + 6 * IMG;
+  float *tiles = vec + 16 * H;
+  float *gBc_l = tiles + VIRT_WAVES * 16 * TS;   // [C][64]
+  float *gZ_l = gBc_l + C * H;                   // [3][C]
+  load_images(img, a.wpack + (size_t)I_V2 * IMG, 6);
+  virt_load_vecs(vec, a);
+  for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) gBc_l[i] = 0.f;
+  __syncthreads();
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
+  float *tile = tiles + wv * 16 * TS;
+  constexpr int GROUP = 16 * VIRT_WAVES;
+  const int ntg = (a.N + GROUP - 1) / GROUP;
+  const float invC = 1.0f / (float)C;
+  const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION;
+  Vec acc_wxv2 = vzero(), acc_wxx2 = vzero(), acc_wvr = vzero(), acc_att = vzero();
+  float acc_attb = 0.f;
+  int cur = -1;
+  auto flush_pools = [&]() {
+    for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
+      atomicAdd(&A.g_Bc[(size_t)cur * C * H + i], gBc_l[i]);
+      gBc_l[i] = 0.f;
+    }
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+      atomicAdd(&A.g_Zp[(size_t)cur * 3 * C + i], gZ_l[i]);
+      gZ_l[i] = 0.f;
+    }
+  };
+  for (int tg = blockIdx.x; tg < ntg; tg += gridDim.x) {
+    const int n0 = tg * GROUP, nend = min(a.N, n0 + GROUP);
+    const int bfirst = a.batch[n0], blast = a.batch[nend - 1];
+    const bool fast = bfirst == blast;
+    if (fast && bfirst != cur) {
+      __syncthreads();
+      if (cur >= 0) flush_pools();
+      __syncthreads();
+      cur = bfirst;
+    }
+    const int nb = n0 + wv * 16;
+    const int nvalid = max(0, min(16, nend - nb));
+    if (nvalid > 0) {
+      const int n = nb + j;
+      const bool valid = n < nend;
+      const int nc = valid ? n : nend - 1;
+      const int b = a.batch[nc];
+      // ---- node MLP adjoint (node_model, :153-166)
+      const Vec g_out = vmask(vload_row(A.g_h_out + (size_t)nc * H, q), valid);
+      const Vec npre = vload_row(A.npre_in + (size_t)nc * H, q);
+      Vec g_t3 = vzero();
+      gemm64(a.wpack + (size_t)I_W4T * IMG, g_out, g_t3);
+      const Vec g_np = vdsilu_mul(g_t3, npre);
+      Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
+      gemm64(a.wpack + (size_t)I_W3AT * IMG, g_np, g_h);
+      Vec g_am = vzero();
+      gemm64(a.wpack + (size_t)I_W3BT * IMG, g_np, g_am);
+      float gxn[3], xi[3], gx[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gxn[k] = valid ? A.g_x_out[(size_t)nc * 3 + k] : 0.f;
+        xi[k] = a.x[(size_t)nc * 3 + k];
+        gx[k] = gxn[k];
+      }
+      if (valid) {
+        vstore_row(A.wg_t3 + (size_t)n * H, q, vsilu(npre));
+        vstore_row(A.wg_gnp + (size_t)n * H, q, g_np);
+        vstore_row(A.g_h + (size_t)n * H, q, g_h);
+        vstore_row(A.g_aggm + (size_t)n * H, q, g_am);
+        if (q == 0) {
+          float sv = 0.f, sg = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            A.g_aggx[(size_t)n * 3 + k] = gxn[k];
+            sv += gxn[k] * a.vel[(size_t)n * 3 + k];
+            sg += gxn[k] * a.g[k];
+          }
+          A.g_svel[n] = sv;
+          if (a.flags & FASTEGNN_F_GRAVITY) A.g_sgrav[n] = sg;
+        }
+      }
+      const Vec Ai = vload_row(a.A + (size_t)nc * H, q);
+      Vec g_A = vzero();
+      for (int c = 0; c < C; ++c) {
+        VirtFwdState S;
+        virt_tile_forward(a, img, vec, Ai, xi, b, c, q, S);
+        const size_t rc = (size_t)nc * C + c;
+        if (valid) {
+          vstore_row(A.wg_v + rc * H, q, S.v);
+          vstore_row(A.wg_t + rc * H, q, S.t);
+        }
+        // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
+        Vec g_v = vmask(vload_row(A.g_poolV + ((size_t)b * C + c) * H, q), valid);
+        gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np, g_v);
+        float gpX[3], g_vd[3];
+        float g_sx = 0.f, g_sX = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          gpX[k] = valid ? A.g_poolX[((size_t)b * 3 + k) * C + c] : 0.f;
+          g_sx -= S.vd[k] * invC * gxn[k];
+          g_vd[k] = -S.sx * invC * gxn[k] + S.sX * gpX[k];
+          g_sX += S.vd[k] * gpX[k];
+        }
+        {  // coord_mlp_r_virtual head
+          const float g_sr = tanh_on ? g_sx * (1.f - S.sx * S.sx) : g_sx;
+          vaxpy(acc_wxv2, g_sr, vsilu(S.uxp));
+          const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), S.uxp);
+          if (valid) vstore_row(A.wg_gux + rc * H, q, g_up);
+          gemm64(img + 4 * IMG, g_up, g_v);
+        }
+        {  // coord_mlp_v_virtual head
+          const float g_sr = tanh_on ? g_sX * (1.f - S.sX * S.sX) : g_sX;
+          vaxpy(acc_wxx2, g_sr, vsilu(S.uXp));
+          const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), S.uXp);
+          if (valid) vstore_row(A.wg_guX + rc * H, q, g_up);
+          gemm64(img + 5 * IMG, g_up, g_v);
+        }
+        Vec g_v0 = g_v;
+        if (att_on) {
+          const float g_a = vdot(g_v, S.v0);
+          const float g_z = g_a * S.att * (1.f - S.att);
+          vaxpy(acc_att, g_z, S.v0);
+          if (q == 0) acc_attb += g_z;
+          g_v0 = vscale(g_v, S.att);
+          vaxpy(g_v0, g_z, vload_vec(vec + VV_ATT * H, q));
+        }
+        const Vec g_vp = vdsilu_mul(g_v0, S.vp);
+        if (valid) vstore_row(A.wg_gvp + rc * H, q, g_vp);
+        Vec g_t = vzero();
+        gemm64(img + 3 * IMG, g_vp, g_t);
+        const Vec g_pre = vdsilu_mul(g_t, S.pre);
+        vadd(g_A, g_pre);
+        vaxpy(acc_wvr, S.vr, g_pre);
+        const float g_vr = vdot(g_pre, vload_vec(vec + VV_WVR * H, q));
+        const float ivr = S.vr > 0.f ? g_vr / S.vr : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          g_vd[k] += ivr * S.vd[k];
+          gx[k] -= g_vd[k];
+        }
+        // pools over the nodes of the tile: g_Bc[b,c,:] += g_pre, g_Zp[b,:,c] += g_vd
+        __builtin_amdgcn_wave_barrier();
+        tile_store(tile, j, q, g_pre);
+        __builtin_amdgcn_wave_barrier();
+        if (fast) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            float pv = (valid && q == 0) ? g_vd[k] : 0.f;
+            pv = jsum(pv);
+            if (l == 0) atomicAdd(&gZ_l[k * C + c], pv);
+          }
+          float s = 0.f;
+#pragma unroll
+          for (int ee = 0; ee < 16; ++ee) s += tile[ee * TS + l];
+          atomicAdd(&gBc_l[c * H + l], s);
+        } else {
+          if (valid && q == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) atomicAdd(&A.g_Zp[((size_t)b * 3 + k) * C + c], g_vd[k]);
+          }
+#pragma unroll
+          for (int ee = 0; ee < 16; ++ee) {
+            if (ee < nvalid) {
+              const int be = __builtin_amdgcn_readlane(b, ee);
+              atomicAdd(&A.g_Bc[((size_t)be * C + c) * H + l], tile[ee * TS + l]);
+            }
+          }
+        }
+      }
+      if (valid) {
+        vstore_row(A.g_A + (size_t)n * H, q, g_A);
+        if (q == 0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) A.g_x[(size_t)n * 3 + k] = gx[k];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (cur >= 0) flush_pools();
+  // rank-1 weight gradients held per lane
+  vec_reduce_atomic(A.d_wxv2, acc_wxv2, j, q);
+  vec_reduce_atomic(A.d_wxx2, acc_wxx2, j, q);
+  if (att_on) {
+    vec_reduce_atomic(A.d_attw, acc_att, j, q);
+    float s = jsum(acc_attb);
+    if (l == 0) atomicAdd(A.d_attb, s);
+  }
+  // w_vr is column 2H of edge_mlp_virtual.0.weight (row stride ld_v0)
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s = jsum(acc_wvr.t[t][r]);
+      if (j == 0) atomicAdd(&A.d_wvr[(size_t)(16 * t + 4 * q + r) * A.ld_v0], s);
+    }
+}
+
+int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->h && L->A && L->Bc && L->x && L->vel && L->Z && L->aggm && L->npre && L->batch && L->wpack,
+             "virt_backward: null saved buffer");
+  FE_REQUIRE(L->g_h_out && L->g_x_out && L->g_poolV && L->g_poolX && L->g_h && L->g_x && L->g_A && L->g_aggm &&
+                 L->g_aggx && L->g_svel && L->g_Bc && L->g_Zp && L->wg_node && L->wg_virt && L->grads,
+             "virt_backward: null gradient buffer");
+  const int N = L->N, C = L->C;
+  (void)hipMemsetAsync(L->g_Bc, 0, (size_t)L->B * C * H * sizeof(float), st);
+  (void)hipMemsetAsync(L->g_Zp, 0, (size_t)L->B * 3 * C * sizeof(float), st);
+  if (N == 0) return check_launch("virt_backward(memset)");
+  float *const *g = L->grads;
+  const long NC = (long)N * C;
+  VirtBwdArgs A;
+  A.f = make_virt_args(L);
+  A.g_h_out = L->g_h_out; A.g_x_out = L->g_x_out; A.g_poolV = L->g_poolV; A.g_poolX = L->g_poolX; A.npre_in = L->npre;
+  A.g_h = L->g_h; A.g_x = L->g_x; A.g_A = L->g_A; A.g_aggm = L->g_aggm; A.g_aggx = L->g_aggx;
+  A.g_svel = L->g_svel; A.g_sgrav = L->g_sgrav; A.g_Bc = L->g_Bc; A.g_Zp = L->g_Zp;
+  A.wg_t3 = L->wg_node; A.wg_gnp = L->wg_node + (size_t)N * H;
+  A.wg_v = L->wg_virt; A.wg_t = L->wg_virt + NC * H; A.wg_gux = L->wg_virt + 2 * NC * H;
+  A.wg_guX = L->wg_virt + 3 * NC * H; A.wg_gvp = L->wg_virt + 4 * NC * H;
+  A.ld_v0 = 2 * H + 1 + C;
+  A.d_wxv2 = g[FASTEGNN_P_CRV2_W]; A.d_wxx2 = g[FASTEGNN_P_CVV2_W];
+  A.d_wvr = g[FASTEGNN_P_VIRT0_W] + 2 * H;
+  A.d_attw = g[FASTEGNN_P_ATTV_W]; A.d_attb = g[FASTEGNN_P_ATTV_B];
+  FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (A.d_attw && A.d_attb), "virt_backward: attention grads null");
+  FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
+  const int ntg = cdiv(N, 16 * VIRT_WAVES);
+  int grid = ntg < 256 ? ntg : 256;
+  hipLaunchKernelGGL(virt_bwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(C, 6), st, A);
+  int rc = check_launch("virt_bwd_kernel");
+  if (rc) return rc;
+  const int ld_n0 = 2 * H + H * C + L->na;
+  // node_mlp.2
+  if ((rc = launch_wgrad_tn(L->g_h_out, H, A.wg_t3, H, N, g[FASTEGNN_P_NODE2_W], H, 0, 1, g[FASTEGNN_P_NODE2_B], 1, 0, 0, 0, st))) return rc;
+  // node_mlp.0: [h | agg | flat(v) | node_attr]
+  if ((rc = launch_wgrad_tn(A.wg_gnp, H, L->h, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 0, 1, g[FASTEGNN_P_NODE0_B], 1, 0, 0, 0, st))) return rc;
+  if ((rc = launch_wgrad_tn(A.wg_gnp, H, L->aggm, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, H, 1, nullptr, 1, 0, 0, 0, st))) return rc;
+  if ((rc = launch_wgrad_tn(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1, st))) return rc;
+  if (L->na > 0)
+    if ((rc = launch_wgrad_small(A.wg_gnp, H, L->node_attr, L->na, L->na, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H + H * C, st))) return rc;
+  // coordinate heads and edge_mlp_virtual.2 over the N*C (node, channel) rows
+  if ((rc = launch_wgrad_tn(A.wg_gux, H, A.wg_v, H, NC, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], 1, 0, 0, 0, st))) return rc;
+  if ((rc = launch_wgrad_tn(A.wg_guX, H, A.wg_v, H, NC, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], 1, 0, 0, 0, st))) return rc;
+  return launch_wgrad_tn(A.wg_gvp, H, A.wg_t, H, NC, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], 1, 0, 0, 0, st);
+}
+
+// =====================================================================================
+// B3 graph_pre_bwd: adjoint of Bc / Gram / centroid
+// =====================================================================================
+struct GraphPreBwdArgs {
+  const float *xsum, *Z, *g_Bc, *g_Zp, *V0W;
+  float *g_Z, *g_HvT, *g_xbar, *wg_mxt;
+  int B, C;
+};
+__global__ __launch_bounds__(256) void graph_pre_bwd_kernel(GraphPreBwdArgs a) {
+  extern __shared__ float sm[];
+  const int C = a.C, b = blockIdx.x, ld = 2 * H + 1 + C;
+  float *mz = sm;               // [3][C]
+  float *gmX = sm + 3 * C;      // [C][C]  d/d mX[c'][c] stored at [c'*C + c]
+  float *gmz = gmX + C * C;     // [3][C]
+  const float cnt = fmaxf(a.xsum[b * 4 + 3], 1.f);
+  for (int i = threadIdx.x; i < 3 * C; i += 256) mz[i] = a.Z[(size_t)b * 3 * C + i] - a.xsum[b * 4 + i / C] / cnt;
+  __syncthreads();
+  // mX^T rows (feature vector of channel c = column c of mX), zero padded to 64, for dV1d
+  for (int i = threadIdx.x; i < C * H; i += 256) {
+    int c = i >> 6, d = i & 63;
+    float v = 0.f;
+    if (d < C) v = mz[c] * mz[d] + mz[C + c] * mz[C + d] + mz[2 * C + c] * mz[2 * C + d];
+    a.wg_mxt[((size_t)b * C + c) * H + d] = v;
+  }
+  // g_HvT[b,c,k] += sum_o g_Bc[b,c,o] V1b[o,k]
+  for (int i = threadIdx.x; i < C * H; i += 256) {
+    int c = i >> 6, k = i & 63;
+    const float *gb = a.g_Bc + ((size_t)b * C + c) * H;
+    float acc = 0.f;
+    for (int o = 0; o < H; ++o) acc += gb[o] * a.V0W[(size_t)o * ld + H + k];
+    a.g_HvT[((size_t)b * C + c) * H + k] += acc;
+  }
+  // g_mX[c'][c] = sum_o g_Bc[b,c,o] V1d[o,c']
+  for (int i = threadIdx.x; i < C * C; i += 256) {
+    int cp = i / C, c = i % C;
+    const float *gb = a.g_Bc + ((size_t)b * C + c) * H;
+    float acc = 0.f;
+    for (int o = 0; o < H; ++o) acc += gb[o] * a.V0W[(size_t)o * ld + 2 * H + 1 + cp];
+    gmX[cp * C + c] = acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+    int k = i / C, c = i % C;
+    float acc = 0.f;
+    for (int d = 0; d < C; ++d) acc += (gmX[c * C + d] + gmX[d * C + c]) * mz[k * C + d];
+    gmz[i] = acc;
+    a.g_Z[(size_t)b * 3 * C + i] += acc + a.g_Zp[(size_t)b * 3 * C + i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc += gmz[threadIdx.x * C + c];
+    a.g_xbar[b * 3 + threadIdx.x] = -acc / cnt;
+  }
+}
+int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->xsum && L->Z && L->HvT && L->g_Bc && L->g_Zp && L->g_Z && L->g_HvT && L->g_xbar && L->wg_node && L->grads,
+             "graph_pre_backward: null buffer");
+  const long M = (long)L->B * L->C;
+  float *wg_mxt = L->wg_node;
+  GraphPreBwdArgs a{L->xsum, L->Z, L->g_Bc, L->g_Zp, L->params[FASTEGNN_P_VIRT0_W], L->g_Z, L->g_HvT, L->g_xbar, wg_mxt,
+                    L->B, L->C};
+  const size_t lds = (size_t)(6 * L->C + L->C * L->C) * sizeof(float);
+  hipLaunchKernelGGL(graph_pre_bwd_kernel, dim3(L->B), dim3(256), lds, st, a);
+  int rc = check_launch("graph_pre_bwd_kernel");
+  if (rc) return rc;
+  float *const *g = L->grads;
+  const int ld = 2 * H + 1 + L->C;
+  // edge_mlp_virtual.0: columns [H,2H) <- Hv, columns [2H+1, 2H+1+C) <- mX[:,c], bias
+  if ((rc = launch_wgrad_tn(L->g_Bc, H, L->HvT, H, M, g[FASTEGNN_P_VIRT0_W], ld, H, 1, g[FASTEGNN_P_VIRT0_B], 1, 0, 0, 0, st))) return rc;
+  return launch_wgrad_tn(L->g_Bc, H, wg_mxt, H, M, g[FASTEGNN_P_VIRT0_W], ld, 2 * H + 1, 1, nullptr, 1, 0, 0, 0, st, L->C);
+}
+
+// =====================================================================================
+// B2 edge_bwd
+// =====================================================================================
+struct EdgeBwdArgs {
+  EdgeArgs f;
+  const float *g_aggm, *g_aggx;
+  float *g_P, *g_xrow, *g_QXe;
+  float *wg_gmp, *wg_t, *wg_gup, *wg_m, *feat;
+  float *d_wx2, *d_attw, *d_attb;
+};
+
+__global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const EdgeArgs &a = A.f;
+  float *img = lds;                    // W2, WX1, W2T, WX1T
+  float *vec = lds + 4 * IMG;
+  float *tiles = vec + EV_COUNT * H;
+  load_images(img, a.wpack + (size_t)I_W2 * IMG, 4);
+  edge_load_vecs(vec, a);
+  __syncthreads();
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
+  float *pt = tiles + wv * (16 * TS + 64);
+  float *xt = pt + 16 * TS;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);
+  const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION,
+             norm_on = a.flags & FASTEGNN_F_NORMALIZE;
+  Vec acc_wx2 = vzero(), acc_att = vzero();
+  float acc_attb = 0.f;
+  for (int ch = wave; ch < a.n_chunks; ch += nwaves) {
+    const int r0 = a.chunk_row[ch], r1 = a.chunk_row[ch + 1];
+    if (r0 >= r1) continue;
+    const int e0 = a.rowptr[r0], e1 = a.rowptr[r1];
+    int cur = -1;
+    float acc = 0.f, accx = 0.f;
+    auto flush = [&]() {
+      A.g_P[(size_t)cur * H + l] = acc;
+      if (l < 3) A.g_xrow[(size_t)cur * 3 + l] = accx;
+    };
+    for (int base = e0; base < e1; base += 16) {
+      const int nvalid = min(16, e1 - base);
+      const bool valid = j < nvalid;
+      const int e = min(base + j, e1 - 1);
+      EdgeFwdState S;
+      Vec pre;
+      edge_tile_forward(a, img, vec, e, q, S, pre);
+      const int dg = a.rowptr[S.row + 1] - a.rowptr[S.row];
+      const float inv = valid ? 1.0f / (float)(dg > 1 ? dg : 1) : 0.f;
+      const float invx = valid ? (mean ? inv : 1.f) : 0.f;
+      if (valid) {
+        vstore_row(A.wg_t + (size_t)e * H, q, S.t);
+        vstore_row(A.wg_m + (size_t)e * H, q, S.m);
+      }
+      // coordinate head adjoint (coord_mlp_r, :125)
+      float g_tr[3], g_dn[3], g_s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        g_tr[k] = A.g_aggx[(size_t)S.row * 3 + k] * invx;
+        g_s += S.dn[k] * g_tr[k];
+        g_dn[k] = S.s * g_tr[k];
+      }
+      const float g_sr = tanh_on ? g_s * (1.f - S.s * S.s) : g_s;
+      vaxpy(acc_wx2, g_sr, S.u);
+      const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + EV_WX2 * H, q), g_sr), S.up);
+      if (valid) vstore_row(A.wg_gup + (size_t)e * H, q, g_up);
+      Vec g_m = vscale(vload_row(A.g_aggm + (size_t)S.row * H, q), inv);
+      gemm64(img + 3 * IMG, g_up, g_m);
+      Vec g_m0 = g_m;
+      if (att_on) {
+        const float g_a = vdot(g_m, S.m0);
+        const float g_z = g_a * S.att * (1.f - S.att);
+        vaxpy(acc_att, g_z, S.m0);
+        if (q == 0) acc_attb += g_z;
+        g_m0 = vscale(g_m, S.att);
+        vaxpy(g_m0, g_z, vload_vec(vec + EV_ATT * H, q));
+      }
+      const Vec g_mp = vdsilu_mul(g_m0, S.mp);
+      if (valid) vstore_row(A.wg_gmp + (size_t)e * H, q, g_mp);
+      Vec g_t = vzero();
+      gemm64(img + 2 * IMG, g_mp, g_t);
+      const Vec g_pre = vdsilu_mul(g_t, pre);
+      const float g_r = vdot(g_pre, vload_vec(vec + EV_WR * H, q));
+      float g_d[3];
+      const float invn = norm_on ? 1.0f / (S.nrm + a.eps) : 1.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g_d[k] = g_dn[k] * invn + 2.f * g_r * S.d[k];
+      if (valid) {
+        float *qe = A.g_QXe + (size_t)e * QXLD;
+        vstore_row(qe, q, g_pre);
+        if (q == 0) {
+          *reinterpret_cast<f32x4 *>(qe + H) = f32x4{-g_d[0], -g_d[1], -g_d[2], 0.f};
+          float *fe_ = A.feat + (size_t)e * FEATW;
+          *reinterpret_cast<f32x4 *>(fe_) = f32x4{S.r, S.eav[0], S.eav[1], S.eav[2]};
+          *reinterpret_cast<f32x4 *>(fe_ + 4) = f32x4{S.eav[3], S.eav[4], S.eav[5], S.eav[6]};
+        }
+      }
+      // row-side segment sums: g_P[row] = sum g_pre, g_xrow[row] = sum g_d
+      tile_store(pt, j, q, g_pre);
+      if (q == 0) {
+        xt[j * 4 + 0] = g_d[0];
+        xt[j * 4 + 1] = g_d[1];
+        xt[j * 4 + 2] = g_d[2];
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int rowv = S.row;
+#pragma unroll
+      for (int ee = 0; ee < 16; ++ee) {
+        if (ee < nvalid) {
+          const int rw = __builtin_amdgcn_readlane(rowv, ee);
+          if (rw != cur) {
+            if (cur >= 0) flush();
+            cur = rw;
+            acc = 0.f;
+            accx = 0.f;
+          }
+          acc += pt[ee * TS + l];
+          if (l < 3) accx += xt[ee * 4 + l];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (cur >= 0) flush();
+  }
+  vec_reduce_atomic(A.d_wx2, acc_wx2, j, q);
+  if (att_on) {
+    vec_reduce_atomic(A.d_attw, acc_att, j, q);
+    float s = jsum(acc_attb);
+    if (l == 0) atomicAdd(A.d_attb, s);
+  }
+}
+
+int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->P && L->QX && L->g_aggm && L->g_aggx && L->g_P && L->g_xrow && L->g_QXe && L->wg_edge && L->grads &&
+                 L->wpack,
+             "edge_backward: null buffer");
+  const fastegnn_graph_t &gr = L->graph;
+  (void)hipMemsetAsync(L->g_P, 0, (size_t)L->N * H * sizeof(float), st);
+  (void)hipMemsetAsync(L->g_xrow, 0, (size_t)L->N * 3 * sizeof(float), st);
+  if (gr.n_edges == 0 || L->N == 0) return check_launch("edge_backward(memset)");
+  const long E = gr.n_edges;
+  float *const *g = L->grads;
+  EdgeBwdArgs A;
+  A.f = make_edge_args(L);
+  A.g_aggm = L->g_aggm; A.g_aggx = L->g_aggx; A.g_P = L->g_P; A.g_xrow = L->g_xrow; A.g_QXe = L->g_QXe;
+  A.wg_gmp = L->wg_edge; A.wg_t = L->wg_edge + E * H; A.wg_gup = L->wg_edge + 2 * E * H;
+  A.wg_m = L->wg_edge + 3 * E * H; A.feat = L->wg_edge + 4 * E * H;
+  A.d_wx2 = g[FASTEGNN_P_CR2_W]; A.d_attw = g[FASTEGNN_P_ATT_W]; A.d_attb = g[FASTEGNN_P_ATT_B];
+  FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (A.d_attw && A.d_attb), "edge_backward: attention grads null");
+  int grid = cdiv(gr.n_chunks, EDGE_WAVES);
+  if (grid > 256) grid = 256;
+  const size_t lds = (4 * IMG + EV_COUNT * H + EDGE_WAVES * (16 * TS + 64)) * sizeof(float);
+  hipLaunchKernelGGL(edge_bwd_kernel, dim3(grid), dim3(64 * EDGE_WAVES), lds, st, A);
+  int rc = check_launch("edge_bwd_kernel");
+  if (rc) return rc;
+  const int ld = 2 * H + 1 + L->ea;
+  // edge_mlp.2, coord_mlp_r.0, and the scalar-feature columns [radial | edge_attr] of edge_mlp.0
+  if ((rc = launch_wgrad_tn(A.wg_gmp, H, A.wg_t, H, E, g[FASTEGNN_P_EDGE2_W], H, 0, 1, g[FASTEGNN_P_EDGE2_B], 1, 0, 0, 0, st))) return rc;
+  if ((rc = launch_wgrad_tn(A.wg_gup, H, A.wg_m, H, E, g[FASTEGNN_P_CR0_W], H, 0, 1, g[FASTEGNN_P_CR0_B], 1, 0, 0, 0, st))) return rc;
+  return launch_wgrad_small(L->g_QXe, QXLD, A.feat, FEATW, 1 + L->ea, E, g[FASTEGNN_P_EDGE0_W], ld, 2 * H, st);
+}
+
+// B2b: col-keyed reduction of the per-edge d/d(Q|x) rows into the source table
+__global__ __launch_bounds__(256) void edge_col_reduce_kernel(const float *g_QXe, const int32_t *cscptr,
+                                                              const int32_t *csc_eid, int n_src, float *g_QXs) {
+  const int l = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int n = wave; n < n_src; n += nwaves) {
+    const int s = cscptr[n], e = cscptr[n + 1];
+    float acc = 0.f, accx = 0.f;
+    for (int k = s; k < e; ++k) {
+      const float *row = g_QXe + (size_t)csc_eid[k] * QXLD;
+      acc += row[l];
+      if (l < 4) accx += row[H + l];
+    }
+    g_QXs[(size_t)n * QXLD + l] = acc;
+    if (l < 4) g_QXs[(size_t)n * QXLD + H + l] = accx;
+  }
+}
+int edge_col_reduce(const fastegnn_layer_t *L, hipStream_t st) {
+  const fastegnn_graph_t &gr = L->graph;
+  FE_REQUIRE(L->g_QX_src && (gr.n_edges == 0 || (L->g_QXe && gr.cscptr && gr.csc_eid)), "edge_col_reduce: null buffer");
+  if (gr.n_src == 0) return FASTEGNN_OK;
+  if (gr.n_edges == 0) {
+    (void)hipMemsetAsync(L->g_QX_src, 0, (size_t)gr.n_src * QXLD * sizeof(float), st);
+    return check_launch("edge_col_reduce(memset)");
+  }
+  int grid = cdiv(gr.n_src, 4);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(edge_col_reduce_kernel, dim3(grid), dim3(256), 0, st, L->g_QXe, gr.cscptr, gr.csc_eid, gr.n_src,
+                     L->g_QX_src);
+  return check_launch("edge_col_reduce_kernel");
+}
+
+// =====================================================================================
+// B1 node_pre_bwd: adjoint of S1, completes g_h / g_x / g_vel of the layer inputs
+// =====================================================================================
+struct NodePreBwdArgs {
+  const float *h, *wpack, *g_P, *g_QX, *g_A, *g_svel, *g_sgrav, *g_xrow, *g_xbar, *g_x_out, *svel;
+  const float *bv0, *wv2, *bg0, *wg2;
+  const int32_t *batch;
+  float *g_h, *g_x, *g_vel, *wg_gzv, *wg_gzg;
+  float *d_wv2, *d_bv2, *d_wg2, *d_bg2;
+  int N, gravity;
+};
+__global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
+  const int l = lane_id(), j = l & 15, q = l >> 4;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int ntiles = (a.N + 15) >> 4;
+  Vec acc_wv2 = vzero(), acc_wg2 = vzero();
+  float acc_bv2 = 0.f, acc_bg2 = 0.f;
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int n = tile * 16 + j;
+    const bool valid = n < a.N;
+    const int nc = valid ? n : a.N - 1;
+    const Vec hv = vload_row(a.h + (size_t)nc * H, q);
+    Vec g_h = vload_row(a.g_h + (size_t)nc * H, q);
+    gemm64(a.wpack + (size_t)I_W1AT * IMG, vload_row(a.g_P + (size_t)nc * H, q), g_h);
+    gemm64(a.wpack + (size_t)I_W1BT * IMG, vload_row(a.g_QX + (size_t)nc * QXLD, q), g_h);
+    gemm64(a.wpack + (size_t)I_V1AT * IMG, vload_row(a.g_A + (size_t)nc * H, q), g_h);
+    {  // coord_mlp_vel head (:139)
+      Vec z = vload_vec(a.bv0, q);
+      gemm64(a.wpack + (size_t)I_WVEL0 * IMG, hv, z);
+      const float gs = valid ? a.g_svel[nc] : 0.f;
+      vaxpy(acc_wv2, gs, vsilu(z));
+      if (q == 0) acc_bv2 += gs;
+      const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z);
+      if (valid) vstore_row(a.wg_gzv + (size_t)n * H, q, g_z);
+      gemm64(a.wpack + (size_t)I_WVEL0T * IMG, g_z, g_h);
+    }
+    if (a.gravity) {  // gravity_mlp head (:142)
+      Vec z = vload_vec(a.bg0, q);
+      gemm64(a.wpack + (size_t)I_WG0 * IMG, hv, z);
+      const float gs = valid ? a.g_sgrav[nc] : 0.f;
+      vaxpy(acc_wg2, gs, vsilu(z));
+      if (q == 0) acc_bg2 += gs;
+      const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wg2, q), gs), z);
+      if (valid) vstore_row(a.wg_gzg + (size_t)n * H, q, g_z);
+      gemm64(a.wpack + (size_t)I_WG0T * IMG, g_z, g_h);
+    }
+    if (valid) {
+      vstore_row(a.g_h + (size_t)n * H, q, g_h);
+      if (q == 0) {
+        const int b = a.batch[n];
+        const float sv = a.svel[n];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          a.g_x[(size_t)n * 3 + k] += a.g_xrow[(size_t)n * 3 + k] + a.g_QX[(size_t)n * QXLD + H + k] + a.g_xbar[b * 3 + k];
+          if (a.g_vel) a.g_vel[(size_t)n * 3 + k] += sv * a.g_x_out[(size_t)n * 3 + k];
+        }
+      }
+    }
+  }
+  vec_reduce_atomic(a.d_wv2, acc_wv2, j, q);
+  float s = jsum(acc_bv2);
+  if (l == 0 && a.d_bv2) atomicAdd(a.d_bv2, s);
+  if (a.gravity) {
+    vec_reduce_atomic(a.d_wg2, acc_wg2, j, q);
+    s = jsum(acc_bg2);
+    if (l == 0 && a.d_bg2) atomicAdd(a.d_bg2, s);
+  }
+}
+
+int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->h && L->wpack && L->g_P && L->g_QX && L->g_A && L->g_svel && L->g_xrow && L->g_xbar && L->g_x_out &&
+                 L->svel && L->g_h && L->g_x && L->wg_node && L->grads && L->batch,
+             "node_pre_backward: null buffer");
+  if (L->N == 0) return FASTEGNN_OK;
+  const bool grav = has(L, FASTEGNN_F_GRAVITY);
+  const float *const *p = L->params;
+  float *const *g = L->grads;
+  const int N = L->N;
+  float *wg_gzv = L->wg_node, *wg_gzg = L->wg_node + (size_t)N * H;
+  NodePreBwdArgs a{L->h, L->wpack, L->g_P, L->g_QX, L->g_A, L->g_svel, L->g_sgrav, L->g_xrow, L->g_xbar, L->g_x_out,
+                   L->svel, p[FASTEGNN_P_VEL0_B], p[FASTEGNN_P_VEL2_W], p[FASTEGNN_P_GRAV0_B], p[FASTEGNN_P_GRAV2_W],
+                   L->batch, L->g_h, L->g_x, L->g_vel, wg_gzv, wg_gzg,
+                   g[FASTEGNN_P_VEL2_W], g[FASTEGNN_P_VEL2_B], g[FASTEGNN_P_GRAV2_W], g[FASTEGNN_P_GRAV2_B], N, grav ? 1 : 0};
+  int grid = cdiv(cdiv(N, 16), 4);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(node_pre_bwd_kernel, dim3(grid), dim3(256), 0, st, a);
+  int rc = check_launch("node_pre_bwd_kernel");
+  if (rc) return rc;
+  const int ld_e0 = 2 * H + 1 + L->ea, ld_v0 = 2 * H + 1 + L->C;
+  // edge_mlp.0 columns [0,H) <- h[row] (P), [H,2H) <- h[col] (Q), bias through P
+  if ((rc = launch_wgrad_tn(L->g_P, H, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, 0, 1, g[FASTEGNN_P_EDGE0_B], 1, 0, 0, 0, st))) return rc;
+  if ((rc = launch_wgrad_tn(L->g_QX, QXLD, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, H, 1, nullptr, 1, 0, 0, 0, st))) return rc;
+  // edge_mlp_virtual.0 columns [0,H) <- h (A)
+  if ((rc = launch_wgrad_tn(L->g_A, H, L->h, H, N, g[FASTEGNN_P_VIRT0_W], ld_v0, 0, 1, nullptr, 1, 0, 0, 0, st))) return rc;
+  if ((rc = launch_wgrad_tn(wg_gzv, H, L->h, H, N, g[FASTEGNN_P_VEL0_W], H, 0, 1, g[FASTEGNN_P_VEL0_B], 1, 0, 0, 0, st))) return rc;
+  if (grav)
+    if ((rc = launch_wgrad_tn(wg_gzg, H, L->h, H, N, g[FASTEGNN_P_GRAV0_W], H, 0, 1, g[FASTEGNN_P_GRAV0_B], 1, 0, 0, 0, st))) return rc;
+  return FASTEGNN_OK;
+}
+
+}  // namespace fe

@@ -192,7 +192,7 @@ int graph_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // One wave walks an edge-balanced chunk of CSR rows in 16-edge tiles; sums stay in registers
 // until the row changes, so every row is written exactly once (no atomics, deterministic).
 // =====================================================================================
-__global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeArgs a) {
+__global__ __launch_bounds__(64 * EDGE_WAVES) void edge_fwd_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *img = lds;                    // W2, WX1
   float *vec = lds + 2 * IMG;          // EV_COUNT vectors
@@ -262,10 +262,10 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
   if (g.n_edges == 0 || L->N == 0) return check_launch("edge_forward(memset)");
   FE_REQUIRE(g.rowptr && g.erow && g.col && g.chunk_row && (L->ea == 0 || L->ea_sorted), "edge_forward: null graph");
   EdgeArgs a = make_edge_args(L);
-  int grid = cdiv(g.n_chunks, 4);
-  if (grid > 768) grid = 768;
-  const size_t lds = (2 * IMG + EV_COUNT * H + 4 * (16 * TS + 64)) * sizeof(float);
-  hipLaunchKernelGGL(edge_fwd_kernel, dim3(grid), dim3(256), lds, st, a);
+  int grid = cdiv(g.n_chunks, EDGE_WAVES);
+  if (grid > 512) grid = 512;
+  const size_t lds = (2 * IMG + EV_COUNT * H + EDGE_WAVES * (16 * TS + 64)) * sizeof(float);
+  hipLaunchKernelGGL(edge_fwd_kernel, dim3(grid), dim3(64 * EDGE_WAVES), lds, st, a);
   return check_launch("edge_fwd_kernel");
 }
 

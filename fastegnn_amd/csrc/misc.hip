@@ -64,7 +64,7 @@ struct WgArgs {
   const float *G, *T;
   float *dW, *db;
   long M, sG, sT, sW;
-  int ldg, ldt, lddw, c0, ks, rows_per_wg;
+  int ldg, ldt, lddw, c0, ks, rows_per_wg, kmax;
 };
 
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgArgs a) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int o = 16 * ti + 4 * q + r, k = 16 * tk + i;
-        atomicAdd(&dW[(size_t)o * a.lddw + a.c0 + (size_t)k * a.ks], acc[ti][tk][r]);
+        if (k < a.kmax) atomicAdd(&dW[(size_t)o * a.lddw + a.c0 + (size_t)k * a.ks], acc[ti][tk][r]);
       }
   if (a.db) {
 #pragma unroll
@@ -117,10 +117,10 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgArgs a) {
 }
 
 int launch_wgrad_tn(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks,
-                    float *db, int nb, long sG, long sT, long sW, hipStream_t st) {
+                    float *db, int nb, long sG, long sT, long sW, hipStream_t st, int kmax) {
   if (M <= 0 || !dW) return FASTEGNN_OK;
   FE_REQUIRE(G && T, "wgrad_tn: null operand");
-  WgArgs a{G, T, dW, db, M, sG, sT, sW, ldg, ldt, lddw, c0, ks, 0};
+  WgArgs a{G, T, dW, db, M, sG, sT, sW, ldg, ldt, lddw, c0, ks, 0, kmax};
   long nsplit = (M + 255) / 256;
   long cap = nb > 1 ? 2048 / nb : 2048;
   if (cap < 16) cap = 16;
