@@ -87,6 +87,11 @@ def lib():
     L.fastegnn_virtual_init_backward.argtypes = [_vp, _i32, _i32, _vp, _vp]
     L.fastegnn_selftest_gemm.argtypes = [_vp, _vp, _vp, _i32, _vp]
     L.fastegnn_selftest_wgrad.argtypes = [_vp, _vp, _i32, _vp, _vp, _vp]
+    L.fastegnn_profile_enable.argtypes = [_i32]
+    L.fastegnn_profile_kernels.restype = _i32
+    L.fastegnn_profile_name.restype = C.c_char_p
+    L.fastegnn_profile_name.argtypes = [_i32]
+    L.fastegnn_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in STAGE_FUNCS + ["fastegnn_layer_forward", "fastegnn_layer_backward"]:
         f = getattr(L, name)
         f.argtypes = [C.POINTER(LayerT), _vp]
@@ -108,7 +113,18 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_build_csr", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_wgrad",
+    "fastegnn_profile_enable", "fastegnn_profile_kernels", "fastegnn_profile_name", "fastegnn_profile_collect",
 ]
+
+
+def profile_collect():
+    """-> {kernel name: (total ms, launches)} since the last collect (HIP events on the launch stream)."""
+    L = lib()
+    n = L.fastegnn_profile_kernels()
+    ms = (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    check(L.fastegnn_profile_collect(ms, cnt), "fastegnn_profile_collect")
+    return {L.fastegnn_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i] > 0}
 
 
 def check(rc: int, what: str):

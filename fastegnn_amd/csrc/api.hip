@@ -1,4 +1,5 @@
 // extern "C" surface of libfastegnn_hip.so (declared in include/fastegnn_hip.h).
+#include <vector>
 #include "kernels.h"
 
 namespace fe {
@@ -14,6 +15,34 @@ int check_launch(const char *what) {
     return FASTEGNN_E_LAUNCH;
   }
   return FASTEGNN_OK;
+}
+
+// ---- per-kernel HIP-event profiler -------------------------------------------------------
+bool g_prof_on = false;
+namespace {
+struct ProfRec { int id; hipEvent_t a, b; };
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_free;
+std::vector<hipEvent_t> g_open(K_COUNT, nullptr);
+hipEvent_t get_event() {
+  if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+const char *kKernelNames[K_COUNT] = {
+  "pack_kernel", "node_pre_fwd_kernel", "graph_xsum_kernel", "graph_pre_fwd_kernel", "edge_fwd_kernel",
+  "virt_fwd_kernel", "graph_post_fwd_kernel", "graph_post_bwd_kernel", "virt_bwd_kernel", "graph_pre_bwd_kernel",
+  "edge_bwd_kernel", "edge_col_reduce_kernel", "node_pre_bwd_kernel", "wgrad_tn_kernel", "wgrad_small_kernel",
+  "build_csr", "misc"};
+}  // namespace
+void prof_begin(int id, hipStream_t st) {
+  hipEvent_t e = get_event();
+  (void)hipEventRecord(e, st);
+  g_open[id] = e;
+}
+void prof_end(int id, hipStream_t st) {
+  hipEvent_t e = get_event();
+  (void)hipEventRecord(e, st);
+  g_recs.push_back({id, g_open[id], e});
 }
 
 static int check_layer(const fastegnn_layer_t *L, const char *who) {
@@ -62,6 +91,30 @@ STAGE(fastegnn_graph_pre_backward, graph_pre_backward)
 STAGE(fastegnn_edge_backward, edge_backward)
 STAGE(fastegnn_edge_col_reduce, edge_col_reduce)
 STAGE(fastegnn_node_pre_backward, node_pre_backward)
+
+int fastegnn_profile_enable(int32_t on) {
+  g_prof_on = on != 0;
+  return FASTEGNN_OK;
+}
+int32_t fastegnn_profile_kernels(void) { return K_COUNT; }
+const char *fastegnn_profile_name(int32_t id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+int fastegnn_profile_collect(double *total_ms, int64_t *launches) {
+  if (!total_ms || !launches) { set_error("profile_collect: null output"); return FASTEGNN_E_INVALID; }
+  for (int i = 0; i < K_COUNT; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+  for (auto &r : g_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) {
+      set_error("profile_collect: event query failed");
+      return FASTEGNN_E_LAUNCH;
+    }
+    total_ms[r.id] += ms;
+    launches[r.id] += 1;
+    g_free.push_back(r.a);
+    g_free.push_back(r.b);
+  }
+  g_recs.clear();
+  return FASTEGNN_OK;
+}
 
 int fastegnn_layer_forward(const fastegnn_layer_t *L, void *stream) {
   int rc = check_layer(L, "fastegnn_layer_forward");

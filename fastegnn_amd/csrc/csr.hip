@@ -69,6 +69,7 @@ int fastegnn_build_csr(const int64_t *edge_index, int32_t E, int32_t row_begin, 
   FE_REQUIRE(E == 0 || (edge_index && erow && col && perm && csc_eid && tmp), "build_csr: null pointer");
   FE_REQUIRE(tmp_bytes >= fastegnn_csr_tmp_bytes(E, n_rows, n_src), "build_csr: tmp too small");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope _ps(K_CSR, st);
   const int nch = E / CHUNK_EDGES + 1;
   *n_chunks = nch;
   if (E > 0) {

@@ -21,6 +21,21 @@ int check_launch(const char *what);
 inline bool has(const fastegnn_layer_t *L, int f) { return (L->flags & f) != 0; }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- per-kernel HIP-event profiler (api.hip); off unless fastegnn_profile_enable(1) ----
+enum KernelId {
+  K_PACK = 0, K_NODE_PRE_FWD, K_XSUM, K_GRAPH_PRE_FWD, K_EDGE_FWD, K_VIRT_FWD, K_GRAPH_POST_FWD,
+  K_GRAPH_POST_BWD, K_VIRT_BWD, K_GRAPH_PRE_BWD, K_EDGE_BWD, K_COL_REDUCE, K_NODE_PRE_BWD,
+  K_WGRAD_TN, K_WGRAD_SMALL, K_CSR, K_MISC, K_COUNT
+};
+extern bool g_prof_on;
+void prof_begin(int id, hipStream_t st);
+void prof_end(int id, hipStream_t st);
+struct ProfScope {
+  int id; hipStream_t st; bool on;
+  ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on(g_prof_on) { if (on) prof_begin(id, st); }
+  ~ProfScope() { if (on) prof_end(id, st); }
+};
+
 // generic weight-gradient kernels (misc.hip)
 //   dW[o*lddw + c0 + k*ks] += sum_m G[m*ldg + o] * T[m*ldt + k]   (o,k < 64),  db[o] += sum_m G[m*ldg+o]
 //   batched over `nb` with strides (sG, sT, sW) in floats.

@@ -83,7 +83,7 @@ int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st) {
   int grid = cdiv(cdiv(M, 16), 4);
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(graph_post_bwd_kernel, dim3(grid), dim3(256), 0, st, a);
+  { ProfScope _ps_graph_post_bwd_kernel(K_GRAPH_POST_BWD, st); hipLaunchKernelGGL(graph_post_bwd_kernel, dim3(grid), dim3(256), 0, st, a); }
   int rc = check_launch("graph_post_bwd_kernel");
   if (rc) return rc;
   float *const *g = L->grads;
@@ -335,7 +335,7 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
   const int ntg = cdiv(N, 16 * VIRT_WAVES);
   int grid = ntg < 256 ? ntg : 256;
-  hipLaunchKernelGGL(virt_bwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(C, 6), st, A);
+  { ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st); hipLaunchKernelGGL(virt_bwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(C, 6), st, A); }
   int rc = check_launch("virt_bwd_kernel");
   if (rc) return rc;
   const int ld_n0 = 2 * H + H * C + L->na;
@@ -416,7 +416,7 @@ int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   GraphPreBwdArgs a{L->xsum, L->Z, L->g_Bc, L->g_Zp, L->params[FASTEGNN_P_VIRT0_W], L->g_Z, L->g_HvT, L->g_xbar, wg_mxt,
                     L->B, L->C};
   const size_t lds = (size_t)(6 * L->C + L->C * L->C) * sizeof(float);
-  hipLaunchKernelGGL(graph_pre_bwd_kernel, dim3(L->B), dim3(256), lds, st, a);
+  { ProfScope _ps_graph_pre_bwd_kernel(K_GRAPH_PRE_BWD, st); hipLaunchKernelGGL(graph_pre_bwd_kernel, dim3(L->B), dim3(256), lds, st, a); }
   int rc = check_launch("graph_pre_bwd_kernel");
   if (rc) return rc;
   float *const *g = L->grads;
@@ -577,7 +577,7 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   int grid = cdiv(gr.n_chunks, EDGE_WAVES);
   if (grid > 256) grid = 256;
   const size_t lds = (4 * IMG + EV_COUNT * H + EDGE_WAVES * (16 * TS + 64)) * sizeof(float);
-  hipLaunchKernelGGL(edge_bwd_kernel, dim3(grid), dim3(64 * EDGE_WAVES), lds, st, A);
+  { ProfScope _ps_edge_bwd_kernel(K_EDGE_BWD, st); hipLaunchKernelGGL(edge_bwd_kernel, dim3(grid), dim3(64 * EDGE_WAVES), lds, st, A); }
   int rc = check_launch("edge_bwd_kernel");
   if (rc) return rc;
   const int ld = 2 * H + 1 + L->ea;
@@ -614,8 +614,8 @@ int edge_col_reduce(const fastegnn_layer_t *L, hipStream_t st) {
   }
   int grid = cdiv(gr.n_src, 4);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(edge_col_reduce_kernel, dim3(grid), dim3(256), 0, st, L->g_QXe, gr.cscptr, gr.csc_eid, gr.n_src,
-                     L->g_QX_src);
+  { ProfScope _ps_edge_col_reduce_kernel(K_COL_REDUCE, st); hipLaunchKernelGGL(edge_col_reduce_kernel, dim3(grid), dim3(256), 0, st, L->g_QXe, gr.cscptr, gr.csc_eid, gr.n_src,
+                     L->g_QX_src); }
   return check_launch("edge_col_reduce_kernel");
 }
 
@@ -704,7 +704,7 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
                    g[FASTEGNN_P_VEL2_W], g[FASTEGNN_P_VEL2_B], g[FASTEGNN_P_GRAV2_W], g[FASTEGNN_P_GRAV2_B], N, grav ? 1 : 0};
   int grid = cdiv(cdiv(N, 16), 4);
   if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(node_pre_bwd_kernel, dim3(grid), dim3(256), 0, st, a);
+  { ProfScope _ps_node_pre_bwd_kernel(K_NODE_PRE_BWD, st); hipLaunchKernelGGL(node_pre_bwd_kernel, dim3(grid), dim3(256), 0, st, a); }
   int rc = check_launch("node_pre_bwd_kernel");
   if (rc) return rc;
   const int ld_e0 = 2 * H + 1 + L->ea, ld_v0 = 2 * H + 1 + L->C;

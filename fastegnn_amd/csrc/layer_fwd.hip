@@ -78,7 +78,7 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
   int grid = cdiv(ntiles, 4);
   if (grid > 512) grid = 512;
   const size_t lds = (5 * IMG + 5 * H) * sizeof(float);
-  hipLaunchKernelGGL(node_pre_fwd_kernel, dim3(grid), dim3(256), lds, st, a);
+  { ProfScope _ps_node_pre_fwd_kernel(K_NODE_PRE_FWD, st); hipLaunchKernelGGL(node_pre_fwd_kernel, dim3(grid), dim3(256), lds, st, a); }
   return check_launch("node_pre_fwd_kernel");
 }
 
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const i
 int graph_xsum(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(L->xsum && L->batch && L->x, "graph_xsum: null buffer");
   (void)hipMemsetAsync(L->xsum, 0, (size_t)L->B * 4 * sizeof(float), st);
-  if (L->N > 0) hipLaunchKernelGGL(graph_xsum_kernel, dim3(cdiv(L->N, 4096)), dim3(256), 0, st, L->x, L->batch, L->N, L->xsum);
+  if (L->N > 0) { ProfScope _ps_graph_xsum_kernel(K_XSUM, st); hipLaunchKernelGGL(graph_xsum_kernel, dim3(cdiv(L->N, 4096)), dim3(256), 0, st, L->x, L->batch, L->N, L->xsum); }
   return check_launch("graph_xsum_kernel");
 }
 
@@ -182,7 +182,7 @@ int graph_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(L->xsum && L->Z && L->HvT && L->Bc, "graph_pre_forward: null buffer");
   GraphPreArgs a{L->xsum, L->Z, L->HvT, L->params[FASTEGNN_P_VIRT0_W], L->params[FASTEGNN_P_VIRT0_B], L->Bc, L->B, L->C};
   const size_t lds = (size_t)(3 * L->C + L->C * L->C) * sizeof(float);
-  hipLaunchKernelGGL(graph_pre_fwd_kernel, dim3(L->B), dim3(256), lds, st, a);
+  { ProfScope _ps_graph_pre_fwd_kernel(K_GRAPH_PRE_FWD, st); hipLaunchKernelGGL(graph_pre_fwd_kernel, dim3(L->B), dim3(256), lds, st, a); }
   return check_launch("graph_pre_fwd_kernel");
 }
 
@@ -265,7 +265,7 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
   int grid = cdiv(g.n_chunks, EDGE_WAVES);
   if (grid > 512) grid = 512;
   const size_t lds = (2 * IMG + EV_COUNT * H + EDGE_WAVES * (16 * TS + 64)) * sizeof(float);
-  hipLaunchKernelGGL(edge_fwd_kernel, dim3(grid), dim3(64 * EDGE_WAVES), lds, st, a);
+  { ProfScope _ps_edge_fwd_kernel(K_EDGE_FWD, st); hipLaunchKernelGGL(edge_fwd_kernel, dim3(grid), dim3(64 * EDGE_WAVES), lds, st, a); }
   return check_launch("edge_fwd_kernel");
 }
 
@@ -409,7 +409,7 @@ int virt_forward(const fastegnn_layer_t *L, hipStream_t st) {
   VirtArgs a = make_virt_args(L);
   const int ntg = cdiv(L->N, 16 * VIRT_WAVES);
   int grid = ntg < 512 ? ntg : 512;
-  hipLaunchKernelGGL(virt_fwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(L->C, 3), st, a);
+  { ProfScope _ps_virt_fwd_kernel(K_VIRT_FWD, st); hipLaunchKernelGGL(virt_fwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(L->C, 3), st, a); }
   return check_launch("virt_fwd_kernel");
 }
 
@@ -455,7 +455,7 @@ int graph_post_forward(const fastegnn_layer_t *L, hipStream_t st) {
   int grid = cdiv(cdiv((long)L->B * L->C, 16), 4);
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(graph_post_fwd_kernel, dim3(grid), dim3(256), 0, st, a);
+  { ProfScope _ps_graph_post_fwd_kernel(K_GRAPH_POST_FWD, st); hipLaunchKernelGGL(graph_post_fwd_kernel, dim3(grid), dim3(256), 0, st, a); }
   return check_launch("graph_post_fwd_kernel");
 }
 

@@ -129,7 +129,7 @@ int launch_wgrad_tn(const float *G, int ldg, const float *T, int ldt, long M, fl
   rows = (rows + 15) / 16 * 16;
   a.rows_per_wg = (int)rows;
   nsplit = (M + rows - 1) / rows;
-  hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)nsplit, (unsigned)nb), dim3(256), 0, st, a);
+  { ProfScope _ps_wgrad_tn_kernel(K_WGRAD_TN, st); hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)nsplit, (unsigned)nb), dim3(256), 0, st, a); }
   return check_launch("wgrad_tn_kernel");
 }
 
@@ -169,7 +169,7 @@ static int launch_wgrad_small_b(const float *G, int ldg, const float *F, int ldf
   long rows = (M + nsplit - 1) / nsplit;
   a.rows_per_wg = (int)rows;
   nsplit = (M + rows - 1) / rows;
-  hipLaunchKernelGGL(wgrad_small_kernel, dim3((unsigned)nsplit), dim3(256), 0, st, a);
+  { ProfScope _ps_wgrad_small_kernel(K_WGRAD_SMALL, st); hipLaunchKernelGGL(wgrad_small_kernel, dim3((unsigned)nsplit), dim3(256), 0, st, a); }
   return check_launch("wgrad_small_kernel");
 }
 int launch_wgrad_small(const float *G, int ldg, const float *F, int ldf, int kf, long M, float *dW, int lddw, int c0,

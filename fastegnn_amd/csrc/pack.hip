@@ -91,7 +91,7 @@ int pack_weights(const fastegnn_layer_t *L, hipStream_t st) {
   a.C = L->C;
   a.ea = L->ea;
   a.na = L->na;
-  hipLaunchKernelGGL(pack_kernel, dim3(I_FIXED + 2 * L->C), dim3(256), 0, st, a);
+  { ProfScope _ps_pack_kernel(K_PACK, st); hipLaunchKernelGGL(pack_kernel, dim3(I_FIXED + 2 * L->C), dim3(256), 0, st, a); }
   return check_launch("pack_kernel");
 }
 

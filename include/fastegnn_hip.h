@@ -231,6 +231,15 @@ int fastegnn_node_pre_backward(const fastegnn_layer_t *L, void *stream);   /* B1
 int fastegnn_layer_forward(const fastegnn_layer_t *L, void *stream);
 int fastegnn_layer_backward(const fastegnn_layer_t *L, void *stream);
 
+/* ---- per-kernel timing with HIP events recorded on the launch stream (bench.py) ----
+ * enable(1) brackets every kernel launch of this library with two events; collect() waits for
+ * them and returns, per kernel id in [0, fastegnn_profile_kernels()), the summed duration in ms
+ * and the launch count since the previous collect().  Not thread-safe; off by default. */
+int fastegnn_profile_enable(int32_t on);
+int32_t fastegnn_profile_kernels(void);
+const char *fastegnn_profile_name(int32_t id);
+int fastegnn_profile_collect(double *total_ms, int64_t *launches);
+
 /* ---- diagnostics (used by tests/ only) ----
  * Y[j][o] = sum_k A[o][k] X[j][k] for one 16-row tile through the MFMA image path (A = W or W^T,
  * W 64x64 row-major);  dW += G^T T, db += colsum(G) over M rows of 64. */
