@@ -49,7 +49,7 @@ _LAYER_PTRS_A = ["batch", "gptr", "ea_sorted", "vel", "node_attr", "params", "gr
                  "P", "QX", "QX_src", "A", "svel", "sgrav", "xsum", "Bc", "aggm", "aggx", "npre", "poolV", "poolX",
                  "g_h_out", "g_x_out", "g_Z_out", "g_HvT_out", "g_h", "g_x", "g_Z", "g_HvT", "g_vel",
                  "g_poolV", "g_poolX", "g_Bc", "g_Zp", "g_xbar", "g_A", "g_P", "g_aggm", "g_aggx",
-                 "g_svel", "g_sgrav", "g_QXe", "g_QX_src", "g_QX", "g_xrow", "wg_edge", "wg_virt", "wg_node"]
+                 "g_svel", "g_sgrav", "g_QXe", "g_QX_src", "g_QX", "g_xrow", "wg_edge", "wg_virt", "wg_node", "wg_slab"]
 
 
 class LayerT(C.Structure):
@@ -86,7 +86,8 @@ def lib():
     L.fastegnn_virtual_init.argtypes = [_vp, _i32, _i32, _vp, _vp]
     L.fastegnn_virtual_init_backward.argtypes = [_vp, _i32, _i32, _vp, _vp]
     L.fastegnn_selftest_gemm.argtypes = [_vp, _vp, _vp, _i32, _vp]
-    L.fastegnn_selftest_wgrad.argtypes = [_vp, _vp, _i32, _vp, _vp, _vp]
+    L.fastegnn_selftest_wgrad.argtypes = [_vp, _vp, _i32, _vp, _vp, _vp, _vp]
+    L.fastegnn_wg_slab_floats.restype = C.c_size_t
     L.fastegnn_profile_enable.argtypes = [_i32]
     L.fastegnn_profile_kernels.restype = _i32
     L.fastegnn_profile_name.restype = C.c_char_p
@@ -109,7 +110,7 @@ STAGE_FUNCS = [
 
 # every symbol include/fastegnn_hip.h declares (checked by tests/test_abi_cpu.py)
 EXPORTED = STAGE_FUNCS + [
-    "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_csr_tmp_bytes",
+    "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_csr_tmp_bytes",
     "fastegnn_build_csr", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_wgrad",

@@ -32,7 +32,7 @@ const char *kKernelNames[K_COUNT] = {
   "pack_kernel", "node_pre_fwd_kernel", "graph_xsum_kernel", "graph_pre_fwd_kernel", "edge_fwd_kernel",
   "virt_fwd_kernel", "graph_post_fwd_kernel", "graph_post_bwd_kernel", "virt_bwd_kernel", "graph_pre_bwd_kernel",
   "edge_bwd_kernel", "edge_col_reduce_kernel", "node_pre_bwd_kernel", "wgrad_tn_kernel", "wgrad_small_kernel",
-  "build_csr", "misc"};
+  "build_csr", "misc", "wgrad_reduce_kernel"};
 }  // namespace
 void prof_begin(int id, hipStream_t st) {
   hipEvent_t e = get_event();
@@ -77,6 +77,7 @@ extern "C" {
 const char *fastegnn_last_error(void) { return g_last_error.c_str(); }
 int fastegnn_version(void) { return 100; }
 size_t fastegnn_wpack_floats(int32_t C) { return wpack_floats(C); }
+size_t fastegnn_wg_slab_floats(void) { return wg_slab_floats(); }
 
 STAGE(fastegnn_pack_weights, pack_weights)
 STAGE(fastegnn_node_pre_forward, node_pre_forward)

@@ -25,7 +25,7 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 enum KernelId {
   K_PACK = 0, K_NODE_PRE_FWD, K_XSUM, K_GRAPH_PRE_FWD, K_EDGE_FWD, K_VIRT_FWD, K_GRAPH_POST_FWD,
   K_GRAPH_POST_BWD, K_VIRT_BWD, K_GRAPH_PRE_BWD, K_EDGE_BWD, K_COL_REDUCE, K_NODE_PRE_BWD,
-  K_WGRAD_TN, K_WGRAD_SMALL, K_CSR, K_MISC, K_COUNT
+  K_WGRAD_TN, K_WGRAD_SMALL, K_CSR, K_MISC, K_WGRAD_REDUCE, K_COUNT
 };
 extern bool g_prof_on;
 void prof_begin(int id, hipStream_t st);
@@ -36,11 +36,32 @@ struct ProfScope {
   ~ProfScope() { if (on) prof_end(id, st); }
 };
 
-// generic weight-gradient kernels (misc.hip)
-//   dW[o*lddw + c0 + k*ks] += sum_m G[m*ldg + o] * T[m*ldt + k]   (o,k < 64),  db[o] += sum_m G[m*ldg+o]
-//   batched over `nb` with strides (sG, sT, sW) in floats.
-int launch_wgrad_tn(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks,
-                    float *db, int nb, long sG, long sT, long sW, hipStream_t st, int kmax = 64);
+// generic weight-gradient contraction (misc.hip):
+//   dW[o*lddw + c0 + k*ks] += sum_m G[m*ldg + o] * T[m*ldt + k]   (o < 64, k < kmax),  db[o] += sum_m G[m*ldg+o]
+//   batched over `nb` with strides (sG, sT, sW) in floats.  Jobs are queued and run by finish().
+constexpr int WG_MAX_JOBS = 12;
+constexpr int WG_SLABS = 4608;   // 64x64 partial slabs in the wg_slab workspace (+ 64-float bias slabs)
+struct WgJob {
+  const float *G, *T;
+  float *dW, *db;
+  long M, sG, sT, sW;
+  int ldg, ldt, lddw, c0, ks, kmax, rows_per_wg, nsplit, nb, wg_begin, slab_begin;
+};
+struct WgTable {
+  WgJob job[WG_MAX_JOBS];
+  float *slab, *slab_b;
+  int n_jobs;
+};
+struct WgradBatch {
+  WgTable tab;
+  hipStream_t st;
+  int n_wg, n_slab, max_nb;
+  WgradBatch(float *slab, hipStream_t st);
+  int add(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks, float *db,
+          int nb = 1, long sG = 0, long sT = 0, long sW = 0, int kmax = 64);
+  int finish();
+};
+inline size_t wg_slab_floats() { return (size_t)WG_SLABS * (IMG + H); }
 //   dW[o*lddw + c0 + a] += sum_m G[m*ldg + o] * F[m*ldf + a],  a < kf <= 8
 int launch_wgrad_small(const float *G, int ldg, const float *F, int ldf, int kf, long M, float *dW, int lddw, int c0,
                        hipStream_t st);

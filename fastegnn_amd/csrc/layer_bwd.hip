@@ -12,16 +12,16 @@ __device__ __forceinline__ Vec vdsilu_mul(const Vec &g, const Vec &z) {
 }
 __device__ __forceinline__ Vec vmask(const Vec &v, bool keep) { return keep ? v : vzero(); }
 
-// reduce a per-lane D-layout accumulator over the 16 items of the tile and add it to a
-// natural-order 64-vector in global memory
-__device__ __forceinline__ void vec_reduce_atomic(float *dst, const Vec &acc, int j, int q) {
-  if (!dst) return;
+// Rank-1 weight gradients are accumulated per lane (D layout) over a wave's tiles.  At kernel end
+// they are summed over the 16 items of the tile (shuffles), over the workgroup's waves (LDS) and
+// leave the workgroup as one atomic per element: red is a zeroed [n][64] LDS array.
+__device__ __forceinline__ void vec_reduce_lds(float *red_row, const Vec &acc, int j, int q) {
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float s = jsum(acc.t[t][r]);
-      if (j == 0) atomicAdd(&dst[16 * t + 4 * q + r], s);
+      if (j == 0) atomicAdd(&red_row[16 * t + 4 * q + r], s);
     }
 }
 
@@ -87,11 +87,13 @@ int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st) {
   int rc = check_launch("graph_post_bwd_kernel");
   if (rc) return rc;
   float *const *g = L->grads;
+  WgradBatch wb(L->wg_slab, st);
   // node_mlp_virtual.2: dW6 += g_out^T u, db6 += colsum g_out
-  if ((rc = launch_wgrad_tn(L->g_HvT_out, H, wg_u, H, M, g[FASTEGNN_P_NODEV2_W], H, 0, 1, g[FASTEGNN_P_NODEV2_B], 1, 0, 0, 0, st))) return rc;
+  if ((rc = wb.add(L->g_HvT_out, H, wg_u, H, M, g[FASTEGNN_P_NODEV2_W], H, 0, 1, g[FASTEGNN_P_NODEV2_B]))) return rc;
   // node_mlp_virtual.0: [Hv | pooled v]
-  if ((rc = launch_wgrad_tn(wg_gz5, H, L->HvT, H, M, g[FASTEGNN_P_NODEV0_W], 2 * H, 0, 1, g[FASTEGNN_P_NODEV0_B], 1, 0, 0, 0, st))) return rc;
-  return launch_wgrad_tn(wg_gz5, H, wg_pm, H, M, g[FASTEGNN_P_NODEV0_W], 2 * H, H, 1, nullptr, 1, 0, 0, 0, st);
+  if ((rc = wb.add(wg_gz5, H, L->HvT, H, M, g[FASTEGNN_P_NODEV0_W], 2 * H, 0, 1, g[FASTEGNN_P_NODEV0_B]))) return rc;
+  if ((rc = wb.add(wg_gz5, H, wg_pm, H, M, g[FASTEGNN_P_NODEV0_W], 2 * H, H, 1, nullptr))) return rc;
+  return wb.finish();
 }
 
 // =====================================================================================
@@ -190,63 +192,100 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A
           if (a.flags & FASTEGNN_F_GRAVITY) A.g_sgrav[n] = sg;
         }
       }
-      const Vec Ai = vload_row(a.A + (size_t)nc * H, q);
       Vec g_A = vzero();
+      const float *Zb = a.Z + (size_t)b * 3 * C;
       for (int c = 0; c < C; ++c) {
-        VirtFwdState S;
-        virt_tile_forward(a, img, vec, Ai, xi, b, c, q, S);
+        // Recompute the forward of (tile, c) interleaved with its adjoint so that each activation is
+        // dead as soon as its gradient is formed (register pressure: 2 waves/SIMD without spills).
+        asm volatile("" ::: "memory");  // keep loop-invariant LDS weight reads inside the loop (no LICM -> no spills)
         const size_t rc = (size_t)nc * C + c;
-        if (valid) {
-          vstore_row(A.wg_v + rc * H, q, S.v);
-          vstore_row(A.wg_t + rc * H, q, S.t);
+        float vd[3];
+        vd[0] = Zb[c] - xi[0];
+        vd[1] = Zb[C + c] - xi[1];
+        vd[2] = Zb[2 * C + c] - xi[2];
+        const float vr = sqrtf(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
+        auto make_pre = [&]() {
+          Vec p = vload_row(a.A + (size_t)nc * H, q);
+          vadd(p, vload_row(a.Bc + ((size_t)b * C + c) * H, q));
+          vaxpy(p, vr, vload_vec(vec + VV_WVR * H, q));
+          return p;
+        };
+        Vec vp = vload_vec(vec + VV_C2 * H, q);
+        {
+          const Vec t = vsilu(make_pre());
+          if (valid) vstore_row(A.wg_t + rc * H, q, t);
+          gemm64(img + 0 * IMG, t, vp);
         }
+        const Vec v0 = vsilu(vp);
+        float att = 1.f;
+        Vec v = v0;
+        if (att_on) {
+          att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + a.attb[0]);
+          v = vscale(v0, att);
+        }
+        if (valid) vstore_row(A.wg_v + rc * H, q, v);
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
         Vec g_v = vmask(vload_row(A.g_poolV + ((size_t)b * C + c) * H, q), valid);
-        gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np, g_v);
+        gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, vmask(vload_row(A.wg_gnp + (size_t)nc * H, q), valid), g_v);
         float gpX[3], g_vd[3];
-        float g_sx = 0.f, g_sX = 0.f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          gpX[k] = valid ? A.g_poolX[((size_t)b * 3 + k) * C + c] : 0.f;
-          g_sx -= S.vd[k] * invC * gxn[k];
-          g_vd[k] = -S.sx * invC * gxn[k] + S.sX * gpX[k];
-          g_sX += S.vd[k] * gpX[k];
-        }
-        {  // coord_mlp_r_virtual head
-          const float g_sr = tanh_on ? g_sx * (1.f - S.sx * S.sx) : g_sx;
-          vaxpy(acc_wxv2, g_sr, vsilu(S.uxp));
-          const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), S.uxp);
+        for (int k = 0; k < 3; ++k) gpX[k] = valid ? A.g_poolX[((size_t)b * 3 + k) * C + c] : 0.f;
+        float sx, sX;
+        {  // coord_mlp_r_virtual head: forward, then its adjoint
+          Vec uxp = vload_vec(vec + VV_BXV0 * H, q);
+          gemm64(img + 1 * IMG, v, uxp);
+          const Vec ux = vsilu(uxp);
+          const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
+          sx = tanh_on ? tanh_f(sr) : sr;
+          float g_sx = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) g_sx -= vd[k] * invC * gxn[k];
+          const float g_sr = tanh_on ? g_sx * (1.f - sx * sx) : g_sx;
+          vaxpy(acc_wxv2, g_sr, ux);
+          const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
           if (valid) vstore_row(A.wg_gux + rc * H, q, g_up);
           gemm64(img + 4 * IMG, g_up, g_v);
         }
         {  // coord_mlp_v_virtual head
-          const float g_sr = tanh_on ? g_sX * (1.f - S.sX * S.sX) : g_sX;
-          vaxpy(acc_wxx2, g_sr, vsilu(S.uXp));
-          const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), S.uXp);
+          Vec uXp = vload_vec(vec + VV_BXX0 * H, q);
+          gemm64(img + 2 * IMG, v, uXp);
+          const Vec uX = vsilu(uXp);
+          const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
+          sX = tanh_on ? tanh_f(sr) : sr;
+          float g_sX = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) g_sX += vd[k] * gpX[k];
+          const float g_sr = tanh_on ? g_sX * (1.f - sX * sX) : g_sX;
+          vaxpy(acc_wxx2, g_sr, uX);
+          const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
           if (valid) vstore_row(A.wg_guX + rc * H, q, g_up);
           gemm64(img + 5 * IMG, g_up, g_v);
         }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g_vd[k] = -sx * invC * gxn[k] + sX * gpX[k];
         Vec g_v0 = g_v;
         if (att_on) {
-          const float g_a = vdot(g_v, S.v0);
-          const float g_z = g_a * S.att * (1.f - S.att);
-          vaxpy(acc_att, g_z, S.v0);
+          const float g_a = vdot(g_v, v0);
+          const float g_z = g_a * att * (1.f - att);
+          vaxpy(acc_att, g_z, v0);
           if (q == 0) acc_attb += g_z;
-          g_v0 = vscale(g_v, S.att);
+          g_v0 = vscale(g_v, att);
           vaxpy(g_v0, g_z, vload_vec(vec + VV_ATT * H, q));
         }
-        const Vec g_vp = vdsilu_mul(g_v0, S.vp);
-        if (valid) vstore_row(A.wg_gvp + rc * H, q, g_vp);
         Vec g_t = vzero();
-        gemm64(img + 3 * IMG, g_vp, g_t);
-        const Vec g_pre = vdsilu_mul(g_t, S.pre);
+        {
+          const Vec g_vp = vdsilu_mul(g_v0, vp);
+          if (valid) vstore_row(A.wg_gvp + rc * H, q, g_vp);
+          gemm64(img + 3 * IMG, g_vp, g_t);
+        }
+        const Vec g_pre = vdsilu_mul(g_t, make_pre());
         vadd(g_A, g_pre);
-        vaxpy(acc_wvr, S.vr, g_pre);
+        vaxpy(acc_wvr, vr, g_pre);
         const float g_vr = vdot(g_pre, vload_vec(vec + VV_WVR * H, q));
-        const float ivr = S.vr > 0.f ? g_vr / S.vr : 0.f;
+        const float ivr = vr > 0.f ? g_vr / vr : 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          g_vd[k] += ivr * S.vd[k];
+          g_vd[k] += ivr * vd[k];
           gx[k] -= g_vd[k];
         }
         // pools over the nodes of the tile: g_Bc[b,c,:] += g_pre, g_Zp[b,:,c] += g_vd
@@ -289,22 +328,31 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A
   }
   __syncthreads();
   if (cur >= 0) flush_pools();
-  // rank-1 weight gradients held per lane
-  vec_reduce_atomic(A.d_wxv2, acc_wxv2, j, q);
-  vec_reduce_atomic(A.d_wxx2, acc_wxx2, j, q);
+  // rank-1 weight gradients held per lane -> LDS (reuse the vector area) -> one atomic set per workgroup
+  float *red = vec;   // [5][64]; the weight vectors are dead now
+  __syncthreads();
+  for (int i = threadIdx.x; i < 5 * H; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  vec_reduce_lds(red + 0 * H, acc_wxv2, j, q);
+  vec_reduce_lds(red + 1 * H, acc_wxx2, j, q);
+  vec_reduce_lds(red + 2 * H, acc_wvr, j, q);
   if (att_on) {
-    vec_reduce_atomic(A.d_attw, acc_att, j, q);
+    vec_reduce_lds(red + 3 * H, acc_att, j, q);
     float s = jsum(acc_attb);
-    if (l == 0) atomicAdd(A.d_attb, s);
+    if (l == 0) atomicAdd(&red[4 * H], s);
   }
-  // w_vr is column 2H of edge_mlp_virtual.0.weight (row stride ld_v0)
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s = jsum(acc_wvr.t[t][r]);
-      if (j == 0) atomicAdd(&A.d_wvr[(size_t)(16 * t + 4 * q + r) * A.ld_v0], s);
+  __syncthreads();
+  if (threadIdx.x < H) {
+    const int o = threadIdx.x;
+    atomicAdd(&A.d_wxv2[o], red[o]);
+    atomicAdd(&A.d_wxx2[o], red[H + o]);
+    // w_vr is column 2H of edge_mlp_virtual.0.weight (row stride ld_v0)
+    atomicAdd(&A.d_wvr[(size_t)o * A.ld_v0], red[2 * H + o]);
+    if (att_on) {
+      atomicAdd(&A.d_attw[o], red[3 * H + o]);
+      if (o == 0) atomicAdd(A.d_attb, red[4 * H]);
     }
+  }
 }
 
 int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
@@ -339,18 +387,21 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   int rc = check_launch("virt_bwd_kernel");
   if (rc) return rc;
   const int ld_n0 = 2 * H + H * C + L->na;
+  WgradBatch wb(L->wg_slab, st);
   // node_mlp.2
-  if ((rc = launch_wgrad_tn(L->g_h_out, H, A.wg_t3, H, N, g[FASTEGNN_P_NODE2_W], H, 0, 1, g[FASTEGNN_P_NODE2_B], 1, 0, 0, 0, st))) return rc;
+  if ((rc = wb.add(L->g_h_out, H, A.wg_t3, H, N, g[FASTEGNN_P_NODE2_W], H, 0, 1, g[FASTEGNN_P_NODE2_B]))) return rc;
   // node_mlp.0: [h | agg | flat(v) | node_attr]
-  if ((rc = launch_wgrad_tn(A.wg_gnp, H, L->h, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 0, 1, g[FASTEGNN_P_NODE0_B], 1, 0, 0, 0, st))) return rc;
-  if ((rc = launch_wgrad_tn(A.wg_gnp, H, L->aggm, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, H, 1, nullptr, 1, 0, 0, 0, st))) return rc;
-  if ((rc = launch_wgrad_tn(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1, st))) return rc;
+  if ((rc = wb.add(A.wg_gnp, H, L->h, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 0, 1, g[FASTEGNN_P_NODE0_B]))) return rc;
+  if ((rc = wb.add(A.wg_gnp, H, L->aggm, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, H, 1, nullptr))) return rc;
+  if ((rc = wb.add(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
+  // coordinate heads and edge_mlp_virtual.2 over the N*C (node, channel) rows
+  if ((rc = wb.add(A.wg_gux, H, A.wg_v, H, NC, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B]))) return rc;
+  if ((rc = wb.add(A.wg_guX, H, A.wg_v, H, NC, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B]))) return rc;
+  if ((rc = wb.add(A.wg_gvp, H, A.wg_t, H, NC, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B]))) return rc;
+  if ((rc = wb.finish())) return rc;
   if (L->na > 0)
     if ((rc = launch_wgrad_small(A.wg_gnp, H, L->node_attr, L->na, L->na, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H + H * C, st))) return rc;
-  // coordinate heads and edge_mlp_virtual.2 over the N*C (node, channel) rows
-  if ((rc = launch_wgrad_tn(A.wg_gux, H, A.wg_v, H, NC, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], 1, 0, 0, 0, st))) return rc;
-  if ((rc = launch_wgrad_tn(A.wg_guX, H, A.wg_v, H, NC, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], 1, 0, 0, 0, st))) return rc;
-  return launch_wgrad_tn(A.wg_gvp, H, A.wg_t, H, NC, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], 1, 0, 0, 0, st);
+  return FASTEGNN_OK;
 }
 
 // =====================================================================================
@@ -422,8 +473,10 @@ int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   float *const *g = L->grads;
   const int ld = 2 * H + 1 + L->C;
   // edge_mlp_virtual.0: columns [H,2H) <- Hv, columns [2H+1, 2H+1+C) <- mX[:,c], bias
-  if ((rc = launch_wgrad_tn(L->g_Bc, H, L->HvT, H, M, g[FASTEGNN_P_VIRT0_W], ld, H, 1, g[FASTEGNN_P_VIRT0_B], 1, 0, 0, 0, st))) return rc;
-  return launch_wgrad_tn(L->g_Bc, H, wg_mxt, H, M, g[FASTEGNN_P_VIRT0_W], ld, 2 * H + 1, 1, nullptr, 1, 0, 0, 0, st, L->C);
+  WgradBatch wb(L->wg_slab, st);
+  if ((rc = wb.add(L->g_Bc, H, L->HvT, H, M, g[FASTEGNN_P_VIRT0_W], ld, H, 1, g[FASTEGNN_P_VIRT0_B]))) return rc;
+  if ((rc = wb.add(L->g_Bc, H, wg_mxt, H, M, g[FASTEGNN_P_VIRT0_W], ld, 2 * H + 1, 1, nullptr, 1, 0, 0, 0, L->C))) return rc;
+  return wb.finish();
 }
 
 // =====================================================================================
@@ -433,9 +486,11 @@ struct EdgeBwdArgs {
   EdgeArgs f;
   const float *g_aggm, *g_aggx;
   float *g_P, *g_xrow, *g_QXe;
-  float *wg_gmp, *wg_t, *wg_gup, *wg_m, *feat;
-  float *d_wx2, *d_attw, *d_attb;
+  float *wg_gmp, *wg_t, *wg_gup, *wg_m;
+  float *d_wx2, *d_attw, *d_attb, *d_w1tail;   // d_w1tail: edge_mlp.0.weight grad at column 2H (row stride ld)
+  int ld_e0;
 };
+constexpr int XT = 12;  // per-edge scalar row in LDS: g_d[3] | radial | edge_attr[<=7]
 
 __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -447,10 +502,11 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
   edge_load_vecs(vec, a);
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
-  float *pt = tiles + wv * (16 * TS + 64);
+  float *pt = tiles + wv * (16 * TS + 16 * XT);
   float *xt = pt + 16 * TS;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);
+  float accW[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // [radial | edge_attr] columns of edge_mlp.0, lane = out
   const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION,
              norm_on = a.flags & FASTEGNN_F_NORMALIZE;
   Vec acc_wx2 = vzero(), acc_att = vzero();
@@ -466,6 +522,7 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
       if (l < 3) A.g_xrow[(size_t)cur * 3 + l] = accx;
     };
     for (int base = e0; base < e1; base += 16) {
+      asm volatile("" ::: "memory");  // no LICM of LDS weight reads (register pressure)
       const int nvalid = min(16, e1 - base);
       const bool valid = j < nvalid;
       const int e = min(base + j, e1 - 1);
@@ -515,19 +572,14 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
       if (valid) {
         float *qe = A.g_QXe + (size_t)e * QXLD;
         vstore_row(qe, q, g_pre);
-        if (q == 0) {
-          *reinterpret_cast<f32x4 *>(qe + H) = f32x4{-g_d[0], -g_d[1], -g_d[2], 0.f};
-          float *fe_ = A.feat + (size_t)e * FEATW;
-          *reinterpret_cast<f32x4 *>(fe_) = f32x4{S.r, S.eav[0], S.eav[1], S.eav[2]};
-          *reinterpret_cast<f32x4 *>(fe_ + 4) = f32x4{S.eav[3], S.eav[4], S.eav[5], S.eav[6]};
-        }
+        if (q == 0) *reinterpret_cast<f32x4 *>(qe + H) = f32x4{-g_d[0], -g_d[1], -g_d[2], 0.f};
       }
       // row-side segment sums: g_P[row] = sum g_pre, g_xrow[row] = sum g_d
       tile_store(pt, j, q, g_pre);
       if (q == 0) {
-        xt[j * 4 + 0] = g_d[0];
-        xt[j * 4 + 1] = g_d[1];
-        xt[j * 4 + 2] = g_d[2];
+        *reinterpret_cast<f32x4 *>(xt + j * XT) = f32x4{g_d[0], g_d[1], g_d[2], S.r};
+        *reinterpret_cast<f32x4 *>(xt + j * XT + 4) = f32x4{S.eav[0], S.eav[1], S.eav[2], S.eav[3]};
+        *reinterpret_cast<f32x4 *>(xt + j * XT + 8) = f32x4{S.eav[4], S.eav[5], S.eav[6], 0.f};
       }
       __builtin_amdgcn_wave_barrier();
       const int rowv = S.row;
@@ -541,19 +593,41 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
             acc = 0.f;
             accx = 0.f;
           }
-          acc += pt[ee * TS + l];
-          if (l < 3) accx += xt[ee * 4 + l];
+          const float gp = pt[ee * TS + l];
+          acc += gp;
+          if (l < 3) accx += xt[ee * XT + l];
+          // d edge_mlp.0.weight[:, 2H + k] += g_pre * [radial | edge_attr][k]   (lane = output row)
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (k <= a.ea_dim) accW[k] += gp * xt[ee * XT + 3 + k];
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
     if (cur >= 0) flush();
   }
-  vec_reduce_atomic(A.d_wx2, acc_wx2, j, q);
+  float *red = vec;   // [3 + 8][64]; the weight vectors are dead now
+  __syncthreads();
+  for (int i = threadIdx.x; i < 11 * H; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k <= a.ea_dim) atomicAdd(&red[(3 + k) * H + l], accW[k]);
+  vec_reduce_lds(red, acc_wx2, j, q);
   if (att_on) {
-    vec_reduce_atomic(A.d_attw, acc_att, j, q);
+    vec_reduce_lds(red + H, acc_att, j, q);
     float s = jsum(acc_attb);
-    if (l == 0) atomicAdd(A.d_attb, s);
+    if (l == 0) atomicAdd(&red[2 * H], s);
+  }
+  __syncthreads();
+  if (threadIdx.x < H) {
+    atomicAdd(&A.d_wx2[threadIdx.x], red[threadIdx.x]);
+    if (att_on) {
+      atomicAdd(&A.d_attw[threadIdx.x], red[H + threadIdx.x]);
+      if (threadIdx.x == 0) atomicAdd(A.d_attb, red[2 * H]);
+    }
+    for (int k = 0; k <= a.ea_dim; ++k)
+      atomicAdd(&A.d_w1tail[(size_t)threadIdx.x * A.ld_e0 + k], red[(3 + k) * H + threadIdx.x]);
   }
 }
 
@@ -571,20 +645,22 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   A.f = make_edge_args(L);
   A.g_aggm = L->g_aggm; A.g_aggx = L->g_aggx; A.g_P = L->g_P; A.g_xrow = L->g_xrow; A.g_QXe = L->g_QXe;
   A.wg_gmp = L->wg_edge; A.wg_t = L->wg_edge + E * H; A.wg_gup = L->wg_edge + 2 * E * H;
-  A.wg_m = L->wg_edge + 3 * E * H; A.feat = L->wg_edge + 4 * E * H;
+  A.wg_m = L->wg_edge + 3 * E * H;
+  A.ld_e0 = 2 * H + 1 + L->ea;
+  A.d_w1tail = g[FASTEGNN_P_EDGE0_W] + 2 * H;
   A.d_wx2 = g[FASTEGNN_P_CR2_W]; A.d_attw = g[FASTEGNN_P_ATT_W]; A.d_attb = g[FASTEGNN_P_ATT_B];
   FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (A.d_attw && A.d_attb), "edge_backward: attention grads null");
   int grid = cdiv(gr.n_chunks, EDGE_WAVES);
   if (grid > 256) grid = 256;
-  const size_t lds = (4 * IMG + EV_COUNT * H + EDGE_WAVES * (16 * TS + 64)) * sizeof(float);
+  const size_t lds = (4 * IMG + EV_COUNT * H + EDGE_WAVES * (16 * TS + 16 * XT)) * sizeof(float);
   { ProfScope _ps_edge_bwd_kernel(K_EDGE_BWD, st); hipLaunchKernelGGL(edge_bwd_kernel, dim3(grid), dim3(64 * EDGE_WAVES), lds, st, A); }
   int rc = check_launch("edge_bwd_kernel");
   if (rc) return rc;
-  const int ld = 2 * H + 1 + L->ea;
-  // edge_mlp.2, coord_mlp_r.0, and the scalar-feature columns [radial | edge_attr] of edge_mlp.0
-  if ((rc = launch_wgrad_tn(A.wg_gmp, H, A.wg_t, H, E, g[FASTEGNN_P_EDGE2_W], H, 0, 1, g[FASTEGNN_P_EDGE2_B], 1, 0, 0, 0, st))) return rc;
-  if ((rc = launch_wgrad_tn(A.wg_gup, H, A.wg_m, H, E, g[FASTEGNN_P_CR0_W], H, 0, 1, g[FASTEGNN_P_CR0_B], 1, 0, 0, 0, st))) return rc;
-  return launch_wgrad_small(L->g_QXe, QXLD, A.feat, FEATW, 1 + L->ea, E, g[FASTEGNN_P_EDGE0_W], ld, 2 * H, st);
+  // edge_mlp.2 and coord_mlp_r.0 (the [radial | edge_attr] columns of edge_mlp.0 are summed in-kernel)
+  WgradBatch wb(L->wg_slab, st);
+  if ((rc = wb.add(A.wg_gmp, H, A.wg_t, H, E, g[FASTEGNN_P_EDGE2_W], H, 0, 1, g[FASTEGNN_P_EDGE2_B]))) return rc;
+  if ((rc = wb.add(A.wg_gup, H, A.wg_m, H, E, g[FASTEGNN_P_CR0_W], H, 0, 1, g[FASTEGNN_P_CR0_B]))) return rc;
+  return wb.finish();
 }
 
 // B2b: col-keyed reduction of the per-edge d/d(Q|x) rows into the source table
@@ -678,13 +754,25 @@ __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
       }
     }
   }
-  vec_reduce_atomic(a.d_wv2, acc_wv2, j, q);
+  __shared__ float red[2 * H + 2];
+  for (int i = threadIdx.x; i < 2 * H + 2; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  vec_reduce_lds(red, acc_wv2, j, q);
   float s = jsum(acc_bv2);
-  if (l == 0 && a.d_bv2) atomicAdd(a.d_bv2, s);
+  if (l == 0) atomicAdd(&red[2 * H], s);
   if (a.gravity) {
-    vec_reduce_atomic(a.d_wg2, acc_wg2, j, q);
+    vec_reduce_lds(red + H, acc_wg2, j, q);
     s = jsum(acc_bg2);
-    if (l == 0 && a.d_bg2) atomicAdd(a.d_bg2, s);
+    if (l == 0) atomicAdd(&red[2 * H + 1], s);
+  }
+  __syncthreads();
+  if (threadIdx.x < H) {
+    atomicAdd(&a.d_wv2[threadIdx.x], red[threadIdx.x]);
+    if (threadIdx.x == 0) atomicAdd(a.d_bv2, red[2 * H]);
+    if (a.gravity) {
+      atomicAdd(&a.d_wg2[threadIdx.x], red[H + threadIdx.x]);
+      if (threadIdx.x == 0) atomicAdd(a.d_bg2, red[2 * H + 1]);
+    }
   }
 }
 
@@ -703,20 +791,21 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
                    L->batch, L->g_h, L->g_x, L->g_vel, wg_gzv, wg_gzg,
                    g[FASTEGNN_P_VEL2_W], g[FASTEGNN_P_VEL2_B], g[FASTEGNN_P_GRAV2_W], g[FASTEGNN_P_GRAV2_B], N, grav ? 1 : 0};
   int grid = cdiv(cdiv(N, 16), 4);
-  if (grid > 1024) grid = 1024;
+  if (grid > 512) grid = 512;
   { ProfScope _ps_node_pre_bwd_kernel(K_NODE_PRE_BWD, st); hipLaunchKernelGGL(node_pre_bwd_kernel, dim3(grid), dim3(256), 0, st, a); }
   int rc = check_launch("node_pre_bwd_kernel");
   if (rc) return rc;
   const int ld_e0 = 2 * H + 1 + L->ea, ld_v0 = 2 * H + 1 + L->C;
   // edge_mlp.0 columns [0,H) <- h[row] (P), [H,2H) <- h[col] (Q), bias through P
-  if ((rc = launch_wgrad_tn(L->g_P, H, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, 0, 1, g[FASTEGNN_P_EDGE0_B], 1, 0, 0, 0, st))) return rc;
-  if ((rc = launch_wgrad_tn(L->g_QX, QXLD, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, H, 1, nullptr, 1, 0, 0, 0, st))) return rc;
+  WgradBatch wb(L->wg_slab, st);
+  if ((rc = wb.add(L->g_P, H, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, 0, 1, g[FASTEGNN_P_EDGE0_B]))) return rc;
+  if ((rc = wb.add(L->g_QX, QXLD, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, H, 1, nullptr))) return rc;
   // edge_mlp_virtual.0 columns [0,H) <- h (A)
-  if ((rc = launch_wgrad_tn(L->g_A, H, L->h, H, N, g[FASTEGNN_P_VIRT0_W], ld_v0, 0, 1, nullptr, 1, 0, 0, 0, st))) return rc;
-  if ((rc = launch_wgrad_tn(wg_gzv, H, L->h, H, N, g[FASTEGNN_P_VEL0_W], H, 0, 1, g[FASTEGNN_P_VEL0_B], 1, 0, 0, 0, st))) return rc;
+  if ((rc = wb.add(L->g_A, H, L->h, H, N, g[FASTEGNN_P_VIRT0_W], ld_v0, 0, 1, nullptr))) return rc;
+  if ((rc = wb.add(wg_gzv, H, L->h, H, N, g[FASTEGNN_P_VEL0_W], H, 0, 1, g[FASTEGNN_P_VEL0_B]))) return rc;
   if (grav)
-    if ((rc = launch_wgrad_tn(wg_gzg, H, L->h, H, N, g[FASTEGNN_P_GRAV0_W], H, 0, 1, g[FASTEGNN_P_GRAV0_B], 1, 0, 0, 0, st))) return rc;
-  return FASTEGNN_OK;
+    if ((rc = wb.add(wg_gzg, H, L->h, H, N, g[FASTEGNN_P_GRAV0_W], H, 0, 1, g[FASTEGNN_P_GRAV0_B]))) return rc;
+  return wb.finish();
 }
 
 }  // namespace fe

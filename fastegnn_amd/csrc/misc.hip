@@ -60,77 +60,183 @@ __global__ void build_batch_kernel(const int64_t *b64, int N, int B, int32_t *ba
 }
 
 // ---------------------------------------------------------------- dW += G^T T  (K = rows)
-struct WgArgs {
-  const float *G, *T;
-  float *dW, *db;
-  long M, sG, sT, sW;
-  int ldg, ldt, lddw, c0, ks, rows_per_wg, kmax;
-};
+// A stage queues its 64x64 weight-gradient contractions as jobs (WgradBatch, kernels.h).  One launch
+// contracts all of them: every workgroup owns a row range of one (job, batch) pair and writes its
+// 64x64 partial as a plain 16 KB slab; a second small kernel sums the slabs in a fixed order and
+// adds them to the gradient tensors.  No float atomics: deterministic, and no same-address
+// contention (4096 atomics x hundreds of workgroups onto one 16 KB tile cost ~50 us per launch).
+constexpr int WTS = 80;  // LDS row stride of the staged operand tiles (conflict-free b32 column reads)
 
-__global__ __launch_bounds__(256) void wgrad_tn_kernel(WgArgs a) {
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
+  __shared__ __attribute__((aligned(16))) float stage[4][2][16 * WTS];
+  __shared__ float red[IMG];
+  __shared__ float redb[H];
+  // locate the job of this workgroup
+  int jb = 0;
+#pragma unroll 1
+  while (jb + 1 < tab.n_jobs && (int)blockIdx.x >= tab.job[jb + 1].wg_begin) ++jb;
+  const WgJob &a = tab.job[jb];
+  const int local = blockIdx.x - a.wg_begin;
+  // batch index varies fastest: co-resident workgroups read the same row range of every batch slice
+  const int bidx = local % a.nb, split = local / a.nb;
   const int l = lane_id(), i = l & 15, q = l >> 4, w = threadIdx.x >> 6;
-  const float *G = a.G + (size_t)blockIdx.y * a.sG;
-  const float *T = a.T + (size_t)blockIdx.y * a.sT;
-  float *dW = a.dW + (size_t)blockIdx.y * a.sW;
-  const long m0 = (long)blockIdx.x * a.rows_per_wg;
+  const float *G = a.G + (size_t)bidx * a.sG;
+  const float *T = a.T + (size_t)bidx * a.sT;
+  const long m0 = (long)split * a.rows_per_wg;
   long m1 = m0 + a.rows_per_wg;
   if (m1 > a.M) m1 = a.M;
+  for (int k = threadIdx.x; k < IMG; k += 256) red[k] = 0.f;
+  if (threadIdx.x < H) redb[threadIdx.x] = 0.f;
+  float *gt = stage[w][0], *tt = stage[w][1];
   f32x4 acc[4][4];
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
     for (int tk = 0; tk < 4; ++tk) acc[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (long m = m0 + 4 * w; m < m1; m += 16) {
-    const long row = m + q;
-    const bool ok = row < m1;
-    float av[4], bv[4];
+  // lane l loads 16 bytes of row (4s + q), columns 4i..4i+3: full 256-byte lines per row
+  f32x4 gv[4], tv[4];
+  auto issue = [&](long m) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      av[t] = ok ? G[(size_t)row * a.ldg + 16 * t + i] : 0.f;
-      bv[t] = ok ? T[(size_t)row * a.ldt + 16 * t + i] : 0.f;
+    for (int s = 0; s < 4; ++s) {
+      const long row = m + 4 * s + q;
+      const bool ok = row < m1;
+      const long rc = ok ? row : m0;
+      const f32x4 g4 = *reinterpret_cast<const f32x4 *>(G + (size_t)rc * a.ldg + 4 * i);
+      const f32x4 t4 = *reinterpret_cast<const f32x4 *>(T + (size_t)rc * a.ldt + 4 * i);
+      gv[s] = ok ? g4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      tv[s] = ok ? t4 : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  long m = m0 + 16 * w;
+  if (m < m1) issue(m);
+  for (; m < m1; m += 64) {
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      bsum[ti] += av[ti];
+    for (int s = 0; s < 4; ++s) {
+      *reinterpret_cast<f32x4 *>(gt + (4 * s + q) * WTS + 4 * i) = gv[s];
+      *reinterpret_cast<f32x4 *>(tt + (4 * s + q) * WTS + 4 * i) = tv[s];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (m + 64 < m1) issue(m + 64);
 #pragma unroll
-      for (int tk = 0; tk < 4; ++tk)
-        acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti], bv[tk], acc[ti][tk], 0, 0, 0);
+    for (int s = 0; s < 4; ++s) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        av[t] = gt[(4 * s + q) * WTS + 16 * t + i];
+        bv[t] = tt[(4 * s + q) * WTS + 16 * t + i];
+      }
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        bsum[ti] += av[ti];
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+          acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti], bv[tk], acc[ti][tk], 0, 0, 0);
+      }
     }
   }
+  __syncthreads();
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
     for (int tk = 0; tk < 4; ++tk)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int o = 16 * ti + 4 * q + r, k = 16 * tk + i;
-        if (k < a.kmax) atomicAdd(&dW[(size_t)o * a.lddw + a.c0 + (size_t)k * a.ks], acc[ti][tk][r]);
-      }
-  if (a.db) {
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * ti + 4 * q + r) * H + 16 * tk + i], acc[ti][tk][r]);
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      float s = qsum(bsum[ti]);
-      if (q == 0) atomicAdd(&a.db[16 * ti + i], s);
+  for (int ti = 0; ti < 4; ++ti) {
+    float s = qsum(bsum[ti]);
+    if (q == 0) atomicAdd(&redb[16 * ti + i], s);
+  }
+  __syncthreads();
+  // slab order: [job slabs][batch][split] so that the reducer walks splits contiguously
+  const size_t sidx = (size_t)a.slab_begin + (size_t)bidx * a.nsplit + split;
+  f32x4 *dst = reinterpret_cast<f32x4 *>(tab.slab + sidx * IMG);
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(red);
+  for (int k = threadIdx.x; k < IMG / 4; k += 256) dst[k] = src[k];
+  if (threadIdx.x < H) tab.slab_b[sidx * H + threadIdx.x] = redb[threadIdx.x];
+}
+
+// Sum the partial slabs of every (job, batch) and accumulate into the gradients.  A workgroup owns
+// 64 consecutive elements of one 64x64 tile; its 8 waves sum interleaved subsets of the splits
+// (8 independent loads in flight per thread) and the 8 partials are added in a fixed order.
+__global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
+  __shared__ float part[8][H];
+  const WgJob &a = tab.job[blockIdx.x];
+  const int bidx = blockIdx.y;
+  if (bidx >= a.nb) return;
+  const size_t s0 = (size_t)a.slab_begin + (size_t)bidx * a.nsplit;
+  float *dW = a.dW + (size_t)bidx * a.sW;
+  const int e = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const bool bias_block = blockIdx.z == IMG / H;      // last z-block reduces the bias slabs
+  const float *base = bias_block ? tab.slab_b + s0 * H + e : tab.slab + s0 * IMG + blockIdx.z * H + e;
+  const size_t stride = bias_block ? H : IMG;
+  if (bias_block && !a.db) return;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int p = pl;
+  for (; p + 56 < a.nsplit; p += 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += base[(size_t)(p + 8 * u) * stride];
+  }
+  for (; p < a.nsplit; p += 8) s[0] += base[(size_t)p * stride];
+  part[pl][e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (pl == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += part[u][e];
+    if (bias_block) {
+      a.db[e] += t;
+    } else {
+      const int o = blockIdx.z, k = e;
+      if (k < a.kmax) dW[(size_t)o * a.lddw + a.c0 + (size_t)k * a.ks] += t;
     }
   }
 }
 
-int launch_wgrad_tn(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks,
-                    float *db, int nb, long sG, long sT, long sW, hipStream_t st, int kmax) {
+WgradBatch::WgradBatch(float *slab, hipStream_t st_) : st(st_) {
+  tab.n_jobs = 0;
+  tab.slab = slab;
+  tab.slab_b = slab ? slab + (size_t)WG_SLABS * IMG : nullptr;
+  n_wg = 0;
+  n_slab = 0;
+  max_nb = 1;
+}
+
+int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks,
+                    float *db, int nb, long sG, long sT, long sW, int kmax) {
   if (M <= 0 || !dW) return FASTEGNN_OK;
-  FE_REQUIRE(G && T, "wgrad_tn: null operand");
-  WgArgs a{G, T, dW, db, M, sG, sT, sW, ldg, ldt, lddw, c0, ks, 0, kmax};
-  long nsplit = (M + 255) / 256;
-  long cap = nb > 1 ? 2048 / nb : 2048;
-  if (cap < 16) cap = 16;
+  FE_REQUIRE(G && T, "wgrad: null operand");
+  FE_REQUIRE(tab.slab, "wgrad: wg_slab workspace is null");
+  FE_REQUIRE(tab.n_jobs < WG_MAX_JOBS, "wgrad: too many jobs in one batch");
+  FE_REQUIRE((ldg % 4) == 0 && (ldt % 4) == 0, "wgrad: operand rows must be 16-byte aligned");
+  long nsplit = (M + 1023) / 1024;            // >= 1024 rows per workgroup
+  long cap = 512 / nb;
+  if (cap < 4) cap = 4;
   if (nsplit > cap) nsplit = cap;
   long rows = (M + nsplit - 1) / nsplit;
-  rows = (rows + 15) / 16 * 16;
-  a.rows_per_wg = (int)rows;
+  rows = (rows + 63) / 64 * 64;
   nsplit = (M + rows - 1) / rows;
-  { ProfScope _ps_wgrad_tn_kernel(K_WGRAD_TN, st); hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)nsplit, (unsigned)nb), dim3(256), 0, st, a); }
-  return check_launch("wgrad_tn_kernel");
+  FE_REQUIRE(n_slab + nsplit * nb <= WG_SLABS, "wgrad: slab workspace exhausted");
+  WgJob &j = tab.job[tab.n_jobs++];
+  j.G = G; j.T = T; j.dW = dW; j.db = db; j.M = M; j.sG = sG; j.sT = sT; j.sW = sW;
+  j.ldg = ldg; j.ldt = ldt; j.lddw = lddw; j.c0 = c0; j.ks = ks; j.kmax = kmax;
+  j.rows_per_wg = (int)rows; j.nsplit = (int)nsplit; j.nb = nb;
+  j.wg_begin = n_wg; j.slab_begin = n_slab;
+  n_wg += (int)(nsplit * nb);
+  n_slab += (int)(nsplit * nb);
+  if (nb > max_nb) max_nb = nb;
+  return FASTEGNN_OK;
+}
+
+int WgradBatch::finish() {
+  if (tab.n_jobs == 0) return FASTEGNN_OK;
+  { ProfScope _ps(K_WGRAD_TN, st); hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, tab); }
+  int rc = check_launch("wgrad_tn_kernel");
+  if (rc) return rc;
+  { ProfScope _ps(K_WGRAD_REDUCE, st); hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tab.n_jobs, (unsigned)max_nb, IMG / H + 1), dim3(512), 0, st, tab); }
+  tab.n_jobs = 0;
+  return check_launch("wgrad_reduce_kernel");
 }
 
 // ---------------------------------------------------------------- dW[:, c0+a] += G^T F, a < kf <= 8
@@ -154,10 +260,18 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgsArgs a) {
     for (int k = 0; k < 8; ++k)
       if (k < a.kf) acc[k] += g * a.F[(size_t)m * a.ldf + k];
   }
+  __shared__ float red[9][H];
+  for (int k = threadIdx.x; k < 9 * H; k += 256) (&red[0][0])[k] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < 8; ++k)
-    if (k < a.kf) atomicAdd(&a.dW[(size_t)o * a.lddw + a.c0 + k], acc[k]);
-  if (a.db) atomicAdd(&a.db[o], bs);
+    if (k < a.kf) atomicAdd(&red[k][o], acc[k]);
+  atomicAdd(&red[8][o], bs);
+  __syncthreads();
+  if (w == 0) {
+    for (int k = 0; k < a.kf; ++k) atomicAdd(&a.dW[(size_t)o * a.lddw + a.c0 + k], red[k][o]);
+    if (a.db) atomicAdd(&a.db[o], red[8][o]);
+  }
 }
 static int launch_wgrad_small_b(const float *G, int ldg, const float *F, int ldf, int kf, long M, float *dW, int lddw,
                                 int c0, float *db, hipStream_t st) {
@@ -165,7 +279,7 @@ static int launch_wgrad_small_b(const float *G, int ldg, const float *F, int ldf
   FE_REQUIRE(kf >= 0 && kf <= 8, "wgrad_small: kf > 8 unsupported");
   WgsArgs a{G, F, dW, db, M, ldg, ldf, kf, lddw, c0, 0};
   long nsplit = (M + 255) / 256;
-  if (nsplit > 1024) nsplit = 1024;
+  if (nsplit > 512) nsplit = 512;
   long rows = (M + nsplit - 1) / nsplit;
   a.rows_per_wg = (int)rows;
   nsplit = (M + rows - 1) / rows;
@@ -260,8 +374,12 @@ int fastegnn_selftest_gemm(const float *W, const float *X, float *Y, int32_t tra
   return check_launch("selftest_gemm_kernel");
 }
 
-int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, void *stream) {
-  return launch_wgrad_tn(G, H, T, H, M, dW, H, 0, 1, db, 1, 0, 0, 0, (hipStream_t)stream);
+int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, float *slab,
+                            void *stream) {
+  WgradBatch wb(slab, (hipStream_t)stream);
+  int rc = wb.add(G, H, T, H, M, dW, H, 0, 1, db, 1, 0, 0, 0);
+  if (rc) return rc;
+  return wb.finish();
 }
 
 }  // extern "C"

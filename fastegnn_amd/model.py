@@ -253,7 +253,8 @@ class _FastEGNNFunction(torch.autograd.Function):
             g_QXe=torch.empty(max(E, 1), K.QX_LD, **f32), g_QX_src=torch.empty(N, K.QX_LD, **f32),
             g_xrow=torch.empty(N, 3, **f32),
             wg_edge=torch.empty(max(E, 1) * (4 * H + K.FEATW), **f32),
-            wg_virt=torch.empty(5 * N * Cn * H, **f32), wg_node=torch.empty(8 * M * H, **f32))
+            wg_virt=torch.empty(5 * N * Cn * H, **f32), wg_node=torch.empty(8 * M * H, **f32),
+            wg_slab=torch.empty(lib.fastegnn_wg_slab_floats(), **f32))
         for i in reversed(range(spec.n_layers)):
             b = saved[i]
             ptab = _PtrTable([params[s] if s is not None else None for s in spec.layer_slots[i]])

@@ -173,6 +173,7 @@ typedef struct {
   float *wg_edge;             /* [4*E*64 + E*8] weight-gradient operands of the edge stage */
   float *wg_virt;             /* [5*N*C*64]     weight-gradient operands of the virtual stage */
   float *wg_node;             /* [8*max(N,B*C)*64] node-level weight-gradient operands */
+  float *wg_slab;             /* [fastegnn_wg_slab_floats()] partial 64x64 slabs of the weight-gradient GEMMs */
 } fastegnn_layer_t;
 
 /* ---- library ---- */
@@ -180,6 +181,8 @@ const char *fastegnn_last_error(void);
 int fastegnn_version(void);
 /* floats of the packed weight-image buffer for C virtual channels */
 size_t fastegnn_wpack_floats(int32_t C);
+/* floats of the weight-gradient slab workspace (independent of the problem size) */
+size_t fastegnn_wg_slab_floats(void);
 
 /* ---- graph preprocessing (COO int64, any order -> row-sorted CSR + col-keyed index) ----
  * edge_index: device int64 [2,E] as the reference passes it (models/FastEGNN.py:204).
@@ -244,7 +247,8 @@ int fastegnn_profile_collect(double *total_ms, int64_t *launches);
  * Y[j][o] = sum_k A[o][k] X[j][k] for one 16-row tile through the MFMA image path (A = W or W^T,
  * W 64x64 row-major);  dW += G^T T, db += colsum(G) over M rows of 64. */
 int fastegnn_selftest_gemm(const float *W, const float *X, float *Y, int32_t transposed, void *stream);
-int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, void *stream);
+int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, float *slab,
+                            void *stream);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,9 @@ def test_wgrad_tn(M):
     T = torch.randint(-4, 5, (M, 64), generator=g).float().cuda()
     dW = torch.zeros(64, 64, device="cuda")
     db = torch.zeros(64, device="cuda")
-    K.check(K.lib().fastegnn_selftest_wgrad(K.ptr(G), K.ptr(T), M, K.ptr(dW), K.ptr(db), _st()), "selftest_wgrad")
+    slab = torch.empty(K.lib().fastegnn_wg_slab_floats(), device="cuda")
+    K.check(K.lib().fastegnn_selftest_wgrad(K.ptr(G), K.ptr(T), M, K.ptr(dW), K.ptr(db), K.ptr(slab), _st()),
+            "selftest_wgrad")
     assert torch.equal(dW.cpu(), G.cpu().T @ T.cpu())
     assert torch.equal(db.cpu(), G.cpu().sum(0))
 
