@@ -88,6 +88,10 @@ def lib():
     L.fastegnn_selftest_gemm.argtypes = [_vp, _vp, _vp, _i32, _vp]
     L.fastegnn_selftest_wgrad.argtypes = [_vp, _vp, _i32, _vp, _vp, _vp, _vp]
     L.fastegnn_wg_slab_floats.restype = C.c_size_t
+    L.fastegnn_sizeof_layer.restype = C.c_size_t
+    L.fastegnn_sizeof_graph.restype = C.c_size_t
+    if L.fastegnn_sizeof_layer() != C.sizeof(LayerT) or L.fastegnn_sizeof_graph() != C.sizeof(GraphT):
+        raise RuntimeError("fastegnn_amd: ctypes mirror of fastegnn_layer_t/fastegnn_graph_t is out of date")
     L.fastegnn_profile_enable.argtypes = [_i32]
     L.fastegnn_profile_kernels.restype = _i32
     L.fastegnn_profile_name.restype = C.c_char_p
@@ -110,7 +114,7 @@ STAGE_FUNCS = [
 
 # every symbol include/fastegnn_hip.h declares (checked by tests/test_abi_cpu.py)
 EXPORTED = STAGE_FUNCS + [
-    "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_csr_tmp_bytes",
+    "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes",
     "fastegnn_build_csr", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_wgrad",

@@ -78,6 +78,8 @@ const char *fastegnn_last_error(void) { return g_last_error.c_str(); }
 int fastegnn_version(void) { return 100; }
 size_t fastegnn_wpack_floats(int32_t C) { return wpack_floats(C); }
 size_t fastegnn_wg_slab_floats(void) { return wg_slab_floats(); }
+size_t fastegnn_sizeof_layer(void) { return sizeof(fastegnn_layer_t); }
+size_t fastegnn_sizeof_graph(void) { return sizeof(fastegnn_graph_t); }
 
 STAGE(fastegnn_pack_weights, pack_weights)
 STAGE(fastegnn_node_pre_forward, node_pre_forward)

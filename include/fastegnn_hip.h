@@ -183,6 +183,9 @@ int fastegnn_version(void);
 size_t fastegnn_wpack_floats(int32_t C);
 /* floats of the weight-gradient slab workspace (independent of the problem size) */
 size_t fastegnn_wg_slab_floats(void);
+/* struct sizes, so that a foreign-language binding can verify its mirror of the descriptors */
+size_t fastegnn_sizeof_layer(void);
+size_t fastegnn_sizeof_graph(void);
 
 /* ---- graph preprocessing (COO int64, any order -> row-sorted CSR + col-keyed index) ----
  * edge_index: device int64 [2,E] as the reference passes it (models/FastEGNN.py:204).
