@@ -125,12 +125,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
     import fastegnn_amd
     from fastegnn_amd import _lib as K
+    from fastegnn_amd.dist import allreduce_gradients, init_from_env, max_over_ranks
+    init_from_env("nccl")
     N, C, L = args.nodes, args.channels, args.layers
     torch.manual_seed(43)
     model = fastegnn_amd.FastEGNN(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=C,
@@ -146,9 +144,8 @@ def main():
         loc, vloc = model(**frame)
         loss = loss_fn(loc, vloc, target)
         loss.backward()
-        if world > 1:   # data-parallel gradient exchange (one flat bucket, 2.2 MB)
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat)
+        if world > 1:   # data-parallel gradient exchange (one flat bucket, 2.2 MB, RCCL over xGMI)
+            allreduce_gradients(params)
         return loss
 
     def sync():
@@ -168,10 +165,7 @@ def main():
     dt = time.perf_counter() - t0
     K.lib().fastegnn_profile_enable(0)
     prof = K.profile_collect()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = max_over_ranks(dt, dev)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -218,7 +212,7 @@ def main():
                                    + ("cached" if args.cache_graph else "inside the step"),
                        "nodes": N, "edges": E, "virtual_channels": C, "layers": L, "graphs_per_step_per_gpu": 1,
                        "parallelism": f"dp{world} (one frame per GPU, RCCL gradient all-reduce)" if world > 1 else "1 GPU",
-                       "loss": float(loss)},
+                       "loss": float(loss.detach())},
             "roofline": roof,
             "edge_scatter": edge_scatter,
             "kernels": kernels,
