@@ -114,6 +114,26 @@ __device__ __forceinline__ float vdot(const Vec &v, const Vec &w) {
   return qsum(p);
 }
 
+// ---- in-kernel phase stamps (diagnostic builds only: -DFE_STAMP; never in the shipped library) ----
+#ifdef FE_STAMP
+__device__ unsigned long long g_stamps[16];
+struct Stamp {
+  unsigned long long prev, acc[8];
+};
+#define FE_TP , Stamp &_st
+#define FE_TA , _st
+#define FE_T0() Stamp _st; for (int _k = 0; _k < 8; ++_k) _st.acc[_k] = 0; _st.prev = __builtin_amdgcn_s_memtime();
+#define FE_T(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+                  _st.acc[i] += _t - _st.prev; _st.prev = _t; __builtin_amdgcn_sched_barrier(0); }
+#define FE_TEND() if (lane_id() == 0) { for (int _k = 0; _k < 8; ++_k) atomicAdd(&g_stamps[_k], _st.acc[_k]); }
+#else
+#define FE_TP
+#define FE_TA
+#define FE_T0()
+#define FE_T(i)
+#define FE_TEND()
+#endif
+
 // ---- weight images ----
 // Image of A[o][k] (64x64) for gemm64: float index ((t*4+tp)*64 + lane)*4 + r holds
 // A[16t + (lane&15)][16tp + 4(lane>>4) + r].

@@ -40,7 +40,7 @@ struct ProfScope {
 //   dW[o*lddw + c0 + k*ks] += sum_m G[m*ldg + o] * T[m*ldt + k]   (o < 64, k < kmax),  db[o] += sum_m G[m*ldg+o]
 //   batched over `nb` with strides (sG, sT, sW) in floats.  Jobs are queued and run by finish().
 constexpr int WG_MAX_JOBS = 12;
-constexpr int WG_SLABS = 4608;   // 64x64 partial slabs in the wg_slab workspace (+ 64-float bias slabs)
+constexpr int WG_SLABS = 6400;   // 64x64 partial slabs in the wg_slab workspace (+ 64-float bias slabs)
 struct WgJob {
   const float *G, *T;
   float *dW, *db;

@@ -490,7 +490,7 @@ struct EdgeBwdArgs {
   float *d_wx2, *d_attw, *d_attb, *d_w1tail;   // d_w1tail: edge_mlp.0.weight grad at column 2H (row stride ld)
   int ld_e0;
 };
-constexpr int XT = 12;  // per-edge scalar row in LDS: g_d[3] | radial | edge_attr[<=7]
+constexpr int XT = 4;   // per-edge scalar row in LDS: g_d[3] | pad
 
 __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -511,6 +511,7 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
              norm_on = a.flags & FASTEGNN_F_NORMALIZE;
   Vec acc_wx2 = vzero(), acc_att = vzero();
   float acc_attb = 0.f;
+  FE_T0()
   for (int ch = wave; ch < a.n_chunks; ch += nwaves) {
     const int r0 = a.chunk_row[ch], r1 = a.chunk_row[ch + 1];
     if (r0 >= r1) continue;
@@ -519,16 +520,18 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
     float acc = 0.f, accx = 0.f;
     auto flush = [&]() {
       A.g_P[(size_t)cur * H + l] = acc;
-      if (l < 3) A.g_xrow[(size_t)cur * 3 + l] = accx;
+      if (l < 3) A.g_xrow[(size_t)cur * 3 + l] = accx;   // lanes 0..2 hold x,y,z (lane 3: pad)
     };
     for (int base = e0; base < e1; base += 16) {
-      asm volatile("" ::: "memory");  // no LICM of LDS weight reads (register pressure)
+      asm volatile("" ::: "memory");
       const int nvalid = min(16, e1 - base);
       const bool valid = j < nvalid;
       const int e = min(base + j, e1 - 1);
+      EdgeIdx cur_i;
+      edge_load_idx(a, e, cur_i);
       EdgeFwdState S;
       Vec pre;
-      edge_tile_forward(a, img, vec, e, q, S, pre);
+      edge_tile_forward(a, img, vec, cur_i, q, S, pre FE_TA);
       const int dg = a.rowptr[S.row + 1] - a.rowptr[S.row];
       const float inv = valid ? 1.0f / (float)(dg > 1 ? dg : 1) : 0.f;
       const float invx = valid ? (mean ? inv : 1.f) : 0.f;
@@ -576,12 +579,14 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
       }
       // row-side segment sums: g_P[row] = sum g_pre, g_xrow[row] = sum g_d
       tile_store(pt, j, q, g_pre);
-      if (q == 0) {
-        *reinterpret_cast<f32x4 *>(xt + j * XT) = f32x4{g_d[0], g_d[1], g_d[2], S.r};
-        *reinterpret_cast<f32x4 *>(xt + j * XT + 4) = f32x4{S.eav[0], S.eav[1], S.eav[2], S.eav[3]};
-        *reinterpret_cast<f32x4 *>(xt + j * XT + 8) = f32x4{S.eav[4], S.eav[5], S.eav[6], 0.f};
-      }
+      if (q == 0) *reinterpret_cast<f32x4 *>(xt + j * XT) = f32x4{g_d[0], g_d[1], g_d[2], 0.f};
       __builtin_amdgcn_wave_barrier();
+      float mv[16], xv[16];
+#pragma unroll
+      for (int ee = 0; ee < 16; ++ee) {   // all LDS reads up front; the walk below runs on registers
+        mv[ee] = pt[ee * TS + l];
+        xv[ee] = xt[ee * XT + (l & 3)];
+      }
       const int rowv = S.row;
 #pragma unroll
       for (int ee = 0; ee < 16; ++ee) {
@@ -593,13 +598,16 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
             acc = 0.f;
             accx = 0.f;
           }
-          const float gp = pt[ee * TS + l];
+          const float gp = mv[ee];
           acc += gp;
-          if (l < 3) accx += xt[ee * XT + l];
-          // d edge_mlp.0.weight[:, 2H + k] += g_pre * [radial | edge_attr][k]   (lane = output row)
+          accx += xv[ee];
+          // d edge_mlp.0.weight[:, 2H + k] += g_pre * [radial | edge_attr][k]   (lane = output row);
+          // the per-edge scalars come from the owning lane's registers (v_readlane), not from LDS
+          accW[0] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.r), ee));
 #pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (k <= a.ea_dim) accW[k] += gp * xt[ee * XT + 3 + k];
+          for (int k = 0; k < 7; ++k)
+            if (k < a.ea_dim)
+              accW[1 + k] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.eav[k]), ee));
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -671,7 +679,17 @@ __global__ __launch_bounds__(256) void edge_col_reduce_kernel(const float *g_QXe
   for (int n = wave; n < n_src; n += nwaves) {
     const int s = cscptr[n], e = cscptr[n + 1];
     float acc = 0.f, accx = 0.f;
-    for (int k = s; k < e; ++k) {
+    int k = s;
+    for (; k + 4 <= e; k += 4) {   // four indexed rows in flight
+      const float *r0 = g_QXe + (size_t)csc_eid[k] * QXLD, *r1 = g_QXe + (size_t)csc_eid[k + 1] * QXLD;
+      const float *r2 = g_QXe + (size_t)csc_eid[k + 2] * QXLD, *r3 = g_QXe + (size_t)csc_eid[k + 3] * QXLD;
+      const float a0 = r0[l], a1 = r1[l], a2 = r2[l], a3 = r3[l];
+      float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+      if (l < 4) { x0 = r0[H + l]; x1 = r1[H + l]; x2 = r2[H + l]; x3 = r3[H + l]; }
+      acc += a0; acc += a1; acc += a2; acc += a3;        // fixed order: deterministic
+      accx += x0; accx += x1; accx += x2; accx += x3;
+    }
+    for (; k < e; ++k) {
       const float *row = g_QXe + (size_t)csc_eid[k] * QXLD;
       acc += row[l];
       if (l < 4) accx += row[H + l];

@@ -205,24 +205,30 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_fwd_kernel(EdgeArgs a) {
   float *xt = mt + 16 * TS;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);
+  FE_T0()
   for (int ch = wave; ch < a.n_chunks; ch += nwaves) {
     const int r0 = a.chunk_row[ch], r1 = a.chunk_row[ch + 1];
     if (r0 >= r1) continue;
     const int e0 = a.rowptr[r0], e1 = a.rowptr[r1];
     int cur = -1;
     float acc = 0.f, accx = 0.f;
+    FE_T(7)   // chunk bookkeeping
+    int cnt = 0;   // edges of the current row seen so far == its in-degree at flush time (rows never straddle chunks)
     auto flush = [&]() {
-      const int dg = a.rowptr[cur + 1] - a.rowptr[cur];
-      const float inv = 1.0f / (float)(dg > 1 ? dg : 1);
+      const float inv = 1.0f / (float)cnt;
       a.aggm[(size_t)cur * H + l] = acc * inv;
       if (l < 3) a.aggx[(size_t)cur * 3 + l] = mean ? accx * inv : accx;
     };
+    EdgeIdx cur_i, nxt_i;
+    edge_load_idx(a, min(e0 + j, e1 - 1), cur_i);
     for (int base = e0; base < e1; base += 16) {
       const int nvalid = min(16, e1 - base);
-      const int e = min(base + j, e1 - 1);
+      nxt_i = cur_i;
+      if (base + 16 < e1) edge_load_idx(a, min(base + 16 + j, e1 - 1), nxt_i);   // next tile's indices in flight
       EdgeFwdState S;
       Vec pre;
-      edge_tile_forward(a, img, vec, e, q, S, pre);
+      edge_tile_forward(a, img, vec, cur_i, q, S, pre FE_TA);
+      cur_i = nxt_i;
       tile_store(mt, j, q, S.m);
       if (q == 0) {
         xt[j * 4 + 0] = S.dn[0] * S.s;
@@ -230,6 +236,15 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_fwd_kernel(EdgeArgs a) {
         xt[j * 4 + 2] = S.dn[2] * S.s;
       }
       __builtin_amdgcn_wave_barrier();
+      FE_T(5)   // transpose tile to LDS
+      // hidden-on-lane column of the tile: all 16 LDS reads issued up front, the row-boundary walk
+      // below then runs on registers and scalar compares only
+      float mv[16], xv[16];
+#pragma unroll
+      for (int ee = 0; ee < 16; ++ee) {
+        mv[ee] = mt[ee * TS + l];
+        xv[ee] = xt[ee * 4 + (l & 3)];
+      }
       const int rowv = S.row;
 #pragma unroll
       for (int ee = 0; ee < 16; ++ee) {
@@ -240,15 +255,19 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_fwd_kernel(EdgeArgs a) {
             cur = rw;
             acc = 0.f;
             accx = 0.f;
+            cnt = 0;
           }
-          acc += mt[ee * TS + l];
-          if (l < 3) accx += xt[ee * 4 + l];
+          acc += mv[ee];
+          accx += xv[ee];
+          ++cnt;
         }
       }
       __builtin_amdgcn_wave_barrier();
+      FE_T(6)   // row-segmented reduction
     }
     if (cur >= 0) flush();
   }
+  FE_TEND()
 }
 
 int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
@@ -460,3 +479,14 @@ int graph_post_forward(const fastegnn_layer_t *L, hipStream_t st) {
 }
 
 }  // namespace fe
+
+#ifdef FE_STAMP
+extern "C" int fastegnn_debug_read_stamps(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(fe::g_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif

@@ -68,9 +68,10 @@ __global__ void build_batch_kernel(const int64_t *b64, int N, int B, int32_t *ba
 constexpr int WTS = 80;  // LDS row stride of the staged operand tiles (conflict-free b32 column reads)
 
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
-  __shared__ __attribute__((aligned(16))) float stage[4][2][16 * WTS];
-  __shared__ float red[IMG];
+  // 40 KB of staging tiles; the 64x64 reduction buffer aliases them after the main loop
+  __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 16 * WTS];
   __shared__ float redb[H];
+  float *red = smem;
   // locate the job of this workgroup
   int jb = 0;
 #pragma unroll 1
@@ -85,9 +86,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
   const long m0 = (long)split * a.rows_per_wg;
   long m1 = m0 + a.rows_per_wg;
   if (m1 > a.M) m1 = a.M;
-  for (int k = threadIdx.x; k < IMG; k += 256) red[k] = 0.f;
   if (threadIdx.x < H) redb[threadIdx.x] = 0.f;
-  float *gt = stage[w][0], *tt = stage[w][1];
+  float *gt = smem + (w * 2 + 0) * 16 * WTS, *tt = smem + (w * 2 + 1) * 16 * WTS;
   f32x4 acc[4][4];
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
       const long row = m + 4 * s + q;
       const bool ok = row < m1;
       const long rc = ok ? row : m0;
-      const f32x4 g4 = *reinterpret_cast<const f32x4 *>(G + (size_t)rc * a.ldg + 4 * i);
-      const f32x4 t4 = *reinterpret_cast<const f32x4 *>(T + (size_t)rc * a.ldt + 4 * i);
-      gv[s] = ok ? g4 : f32x4{0.f, 0.f, 0.f, 0.f};
-      tv[s] = ok ? t4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      // raw loads only: masking happens when the tile is written to LDS one iteration later, so
+      // nothing consumes the load results while the current tile's MFMAs run
+      gv[s] = *reinterpret_cast<const f32x4 *>(G + (size_t)rc * a.ldg + 4 * i);
+      tv[s] = *reinterpret_cast<const f32x4 *>(T + (size_t)rc * a.ldt + 4 * i);
     }
   };
   long m = m0 + 16 * w;
@@ -114,8 +114,9 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      *reinterpret_cast<f32x4 *>(gt + (4 * s + q) * WTS + 4 * i) = gv[s];
-      *reinterpret_cast<f32x4 *>(tt + (4 * s + q) * WTS + 4 * i) = tv[s];
+      const bool ok = m + 4 * s + q < m1;
+      *reinterpret_cast<f32x4 *>(gt + (4 * s + q) * WTS + 4 * i) = ok ? gv[s] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4 *>(tt + (4 * s + q) * WTS + 4 * i) = ok ? tv[s] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __builtin_amdgcn_wave_barrier();
     if (m + 64 < m1) issue(m + 64);
@@ -136,6 +137,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
       }
     }
   }
+  __syncthreads();   // all waves are done with their staging tiles
+  for (int k = threadIdx.x; k < IMG; k += 256) red[k] = 0.f;
   __syncthreads();
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti)
@@ -211,7 +214,7 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   FE_REQUIRE(tab.n_jobs < WG_MAX_JOBS, "wgrad: too many jobs in one batch");
   FE_REQUIRE((ldg % 4) == 0 && (ldt % 4) == 0, "wgrad: operand rows must be 16-byte aligned");
   long nsplit = (M + 1023) / 1024;            // >= 1024 rows per workgroup
-  long cap = 512 / nb;
+  long cap = 768 / nb;
   if (cap < 4) cap = 4;
   if (nsplit > cap) nsplit = cap;
   long rows = (M + nsplit - 1) / nsplit;

@@ -37,11 +37,32 @@ struct EdgeFwdState {
   int row, col;
 };
 
+// per-edge indices and scalar attributes; loaded one tile ahead of their use so that only one
+// level of the (index -> gathered row) dependent-load chain is exposed per tile
+struct EdgeIdx {
+  int row, col;
+  float eav[8];
+};
+__device__ __forceinline__ void edge_load_idx(const EdgeArgs &a, int e, EdgeIdx &I) {
+  I.row = a.erow[e];
+  I.col = a.col[e];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) I.eav[k] = 0.f;
+  if (a.ea_dim > 0) {
+    const float *er = a.ea + (size_t)e * a.ea_dim;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // unconditional (clamped) loads: no branch + wait per attribute
+      const float v = er[k < a.ea_dim ? k : 0];
+      I.eav[k] = k < a.ea_dim ? v : 0.f;
+    }
+  }
+}
+
 // forward math of one 16-edge tile (shared with the backward kernel for recomputation)
-__device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float *img, const float *vec, int e, int q,
-                                                  EdgeFwdState &S, Vec &pre) {
-  S.row = a.erow[e];
-  S.col = a.col[e];
+__device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float *img, const float *vec,
+                                                  const EdgeIdx &I, int q, EdgeFwdState &S, Vec &pre FE_TP) {
+  S.row = I.row;
+  S.col = I.col;
   const float *qrow = a.QXs + (size_t)S.col * QXLD;
   const f32x4 xc = *reinterpret_cast<const f32x4 *>(qrow + H);
   const f32x4 xr = *reinterpret_cast<const f32x4 *>(a.QX + (size_t)S.row * QXLD + H);
@@ -56,20 +77,21 @@ __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float
   } else {
     S.dn[0] = S.d[0]; S.dn[1] = S.d[1]; S.dn[2] = S.d[2];
   }
+  FE_T(0)   // indices + coordinates arrived
   pre = vload_row(a.P + (size_t)S.row * H, q);
   vadd(pre, vload_row(qrow, q));
   vaxpy(pre, S.r, vload_vec(vec + EV_WR * H, q));
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    S.eav[k] = 0.f;
-    if (k < a.ea_dim) {
-      S.eav[k] = a.ea[(size_t)e * a.ea_dim + k];
-      vaxpy(pre, S.eav[k], vload_vec(vec + (EV_WE + k) * H, q));
-    }
+    S.eav[k] = I.eav[k];
+    if (k < a.ea_dim) vaxpy(pre, S.eav[k], vload_vec(vec + (EV_WE + k) * H, q));
   }
+  FE_T(1)   // gathered rows arrived, pre-activation formed
   S.t = vsilu(pre);
+  FE_T(2)   // silu 1
   S.mp = vload_vec(vec + EV_B2 * H, q);
   gemm64(img + 0 * IMG, S.t, S.mp);
+  FE_T(3)   // gemm 1
   S.m0 = vsilu(S.mp);
   if (a.flags & FASTEGNN_F_ATTENTION) {
     S.att = sigmoid_f(vdot(S.m0, vload_vec(vec + EV_ATT * H, q)) + a.attb[0]);
@@ -78,11 +100,14 @@ __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float
     S.att = 1.f;
     S.m = S.m0;
   }
+  FE_T(2)
   S.up = vload_vec(vec + EV_BX1 * H, q);
   gemm64(img + 1 * IMG, S.m, S.up);
+  FE_T(3)
   S.u = vsilu(S.up);
   const float sraw = vdot(S.u, vload_vec(vec + EV_WX2 * H, q));
   S.s = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sraw) : sraw;
+  FE_T(4)   // silu 3 + head dot
 }
 
 inline EdgeArgs make_edge_args(const fastegnn_layer_t *L) {
