@@ -90,6 +90,25 @@ __device__ __forceinline__ void vstore_row(float *row, int q, const Vec &v) {
   for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(row + 16 * t + 4 * q) = v.t[t];
 }
 
+// Same with a wave-uniform base pointer and a 32-bit per-lane element offset: the compiler can then
+// use the SGPR-base + VGPR-offset addressing form, so a lane carries ONE offset register for
+// several arrays instead of a 64-bit pointer per array (register pressure of the fused kernels).
+// (`off` counts floats and must stay below 2^30: the byte offset is formed in 32 bits.)
+__device__ __forceinline__ Vec vload_u(const float *base, unsigned off) {
+  Vec v;
+  const unsigned bo = off * 4u;
+  const char *p = reinterpret_cast<const char *>(base);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v.t[t] = *reinterpret_cast<const f32x4 *>(p + (bo + 64u * t));
+  return v;
+}
+__device__ __forceinline__ void vstore_u(float *base, unsigned off, const Vec &v) {
+  const unsigned bo = off * 4u;
+  char *p = reinterpret_cast<char *>(base);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(p + (bo + 64u * t)) = v.t[t];
+}
+
 // sum over the four q-lanes of an item (xor 16, xor 32)
 __device__ __forceinline__ float qsum(float p) {
   p += __shfl_xor(p, 16);

@@ -109,14 +109,14 @@ struct VirtBwdArgs {
   int ld_v0;
 };
 
-__global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A) {
+__global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VirtArgs &a = A.f;
   const int C = a.C;
   float *img = lds;                              // V2 WXV0 WXX0 V2T WXV0T WXX0T
   float *vec = lds + 6 * IMG;
   float *tiles = vec + 16 * H;
-  float *gBc_l = tiles + VIRT_WAVES * 16 * TS;   // [C][64]
+  float *gBc_l = tiles + VIRT_BWD_WAVES * 16 * TS;   // [C][64]
   float *gZ_l = gBc_l + C * H;                   // [3][C]
   load_images(img, a.wpack + (size_t)I_V2 * IMG, 6);
   virt_load_vecs(vec, a);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
   float *tile = tiles + wv * 16 * TS;
-  constexpr int GROUP = 16 * VIRT_WAVES;
+  constexpr int GROUP = 16 * VIRT_BWD_WAVES;
   const int ntg = (a.N + GROUP - 1) / GROUP;
   const float invC = 1.0f / (float)C;
   const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION;
@@ -158,16 +158,37 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A
       const bool valid = n < nend;
       const int nc = valid ? n : nend - 1;
       const int b = a.batch[nc];
+      // wave-uniform bases of this 128-node group + one 32-bit lane offset per array family
+      const size_t g0 = (size_t)n0;
+      const unsigned offN = (unsigned)(nc - n0) * H + 4u * q;            // [N,64] arrays
+      const unsigned offNC = (unsigned)(nc - n0) * C * H + 4u * q;       // [N*C,64] arrays (+ c*H)
+      const unsigned offB = (unsigned)b * C * H + 4u * q;                // [B,C,64] arrays (+ c*H)
+      const float *b_gho = A.g_h_out + g0 * H, *b_npre = A.npre_in + g0 * H, *b_A = a.A + g0 * H;
+      float *b_t3 = A.wg_t3 + g0 * H, *b_gnp = A.wg_gnp + g0 * H, *b_gh = A.g_h + g0 * H, *b_gam = A.g_aggm + g0 * H;
+      float *b_gA = A.g_A + g0 * H;
+      float *b_v = A.wg_v + g0 * C * H, *b_t = A.wg_t + g0 * C * H, *b_gux = A.wg_gux + g0 * C * H;
+      float *b_guX = A.wg_guX + g0 * C * H, *b_gvp = A.wg_gvp + g0 * C * H;
       // ---- node MLP adjoint (node_model, :153-166)
-      const Vec g_out = vmask(vload_row(A.g_h_out + (size_t)nc * H, q), valid);
-      const Vec npre = vload_row(A.npre_in + (size_t)nc * H, q);
-      Vec g_t3 = vzero();
-      gemm64(a.wpack + (size_t)I_W4T * IMG, g_out, g_t3);
-      const Vec g_np = vdsilu_mul(g_t3, npre);
-      Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
-      gemm64(a.wpack + (size_t)I_W3AT * IMG, g_np, g_h);
-      Vec g_am = vzero();
-      gemm64(a.wpack + (size_t)I_W3BT * IMG, g_np, g_am);
+      const Vec g_out = vmask(vload_u(b_gho, offN), valid);
+      Vec g_np;
+      {
+        const Vec npre = vload_u(b_npre, offN);
+        Vec g_t3 = vzero();
+        gemm64(a.wpack + (size_t)I_W4T * IMG, g_out, g_t3);
+        g_np = vdsilu_mul(g_t3, npre);
+        if (valid) vstore_u(b_t3, offN, vsilu(npre));
+      }
+      if (valid) vstore_u(b_gnp, offN, g_np);
+      {
+        Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
+        gemm64(a.wpack + (size_t)I_W3AT * IMG, g_np, g_h);
+        if (valid) vstore_u(b_gh, offN, g_h);
+      }
+      {
+        Vec g_am = vzero();
+        gemm64(a.wpack + (size_t)I_W3BT * IMG, g_np, g_am);
+        if (valid) vstore_u(b_gam, offN, g_am);
+      }
       float gxn[3], xi[3], gx[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -175,45 +196,39 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A
         xi[k] = a.x[(size_t)nc * 3 + k];
         gx[k] = gxn[k];
       }
-      if (valid) {
-        vstore_row(A.wg_t3 + (size_t)n * H, q, vsilu(npre));
-        vstore_row(A.wg_gnp + (size_t)n * H, q, g_np);
-        vstore_row(A.g_h + (size_t)n * H, q, g_h);
-        vstore_row(A.g_aggm + (size_t)n * H, q, g_am);
-        if (q == 0) {
-          float sv = 0.f, sg = 0.f;
+      if (valid && q == 0) {
+        float sv = 0.f, sg = 0.f;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            A.g_aggx[(size_t)n * 3 + k] = gxn[k];
-            sv += gxn[k] * a.vel[(size_t)n * 3 + k];
-            sg += gxn[k] * a.g[k];
-          }
-          A.g_svel[n] = sv;
-          if (a.flags & FASTEGNN_F_GRAVITY) A.g_sgrav[n] = sg;
+        for (int k = 0; k < 3; ++k) {
+          A.g_aggx[(size_t)n * 3 + k] = gxn[k];
+          sv += gxn[k] * a.vel[(size_t)n * 3 + k];
+          sg += gxn[k] * a.g[k];
         }
+        A.g_svel[n] = sv;
+        if (a.flags & FASTEGNN_F_GRAVITY) A.g_sgrav[n] = sg;
       }
       Vec g_A = vzero();
       const float *Zb = a.Z + (size_t)b * 3 * C;
       for (int c = 0; c < C; ++c) {
         // Recompute the forward of (tile, c) interleaved with its adjoint so that each activation is
-        // dead as soon as its gradient is formed (register pressure: 2 waves/SIMD without spills).
-        asm volatile("" ::: "memory");  // keep loop-invariant LDS weight reads inside the loop (no LICM -> no spills)
-        const size_t rc = (size_t)nc * C + c;
+        // dead as soon as its gradient is formed.
+        asm volatile("" ::: "memory");
+        const unsigned oc = offNC + (unsigned)c * H, ob = offB + (unsigned)c * H;
         float vd[3];
         vd[0] = Zb[c] - xi[0];
         vd[1] = Zb[C + c] - xi[1];
         vd[2] = Zb[2 * C + c] - xi[2];
         const float vr = sqrtf(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
         auto make_pre = [&]() {
-          Vec p = vload_row(a.A + (size_t)nc * H, q);
-          vadd(p, vload_row(a.Bc + ((size_t)b * C + c) * H, q));
+          Vec p = vload_u(b_A, offN);
+          vadd(p, vload_u(a.Bc, ob));
           vaxpy(p, vr, vload_vec(vec + VV_WVR * H, q));
           return p;
         };
         Vec vp = vload_vec(vec + VV_C2 * H, q);
         {
           const Vec t = vsilu(make_pre());
-          if (valid) vstore_row(A.wg_t + rc * H, q, t);
+          if (valid) vstore_u(b_t, oc, t);
           gemm64(img + 0 * IMG, t, vp);
         }
         const Vec v0 = vsilu(vp);
@@ -223,10 +238,10 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A
           att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + a.attb[0]);
           v = vscale(v0, att);
         }
-        if (valid) vstore_row(A.wg_v + rc * H, q, v);
+        if (valid) vstore_u(b_v, oc, v);
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
-        Vec g_v = vmask(vload_row(A.g_poolV + ((size_t)b * C + c) * H, q), valid);
-        gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, vmask(vload_row(A.wg_gnp + (size_t)nc * H, q), valid), g_v);
+        Vec g_v = vmask(vload_u(A.g_poolV, ob), valid);
+        gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, vmask(vload_u(b_gnp, offN), valid), g_v);
         float gpX[3], g_vd[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) gpX[k] = valid ? A.g_poolX[((size_t)b * 3 + k) * C + c] : 0.f;
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A
           const float g_sr = tanh_on ? g_sx * (1.f - sx * sx) : g_sx;
           vaxpy(acc_wxv2, g_sr, ux);
           const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
-          if (valid) vstore_row(A.wg_gux + rc * H, q, g_up);
+          if (valid) vstore_u(b_gux, oc, g_up);
           gemm64(img + 4 * IMG, g_up, g_v);
         }
         {  // coord_mlp_v_virtual head
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A
           const float g_sr = tanh_on ? g_sX * (1.f - sX * sX) : g_sX;
           vaxpy(acc_wxx2, g_sr, uX);
           const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
-          if (valid) vstore_row(A.wg_guX + rc * H, q, g_up);
+          if (valid) vstore_u(b_guX, oc, g_up);
           gemm64(img + 5 * IMG, g_up, g_v);
         }
 #pragma unroll
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A
         Vec g_t = vzero();
         {
           const Vec g_vp = vdsilu_mul(g_v0, vp);
-          if (valid) vstore_row(A.wg_gvp + rc * H, q, g_vp);
+          if (valid) vstore_u(b_gvp, oc, g_vp);
           gemm64(img + 3 * IMG, g_vp, g_t);
         }
         const Vec g_pre = vdsilu_mul(g_t, make_pre());
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_bwd_kernel(VirtBwdArgs A
         }
       }
       if (valid) {
-        vstore_row(A.g_A + (size_t)n * H, q, g_A);
+        vstore_u(b_gA, offN, g_A);
         if (q == 0) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) A.g_x[(size_t)n * 3 + k] = gx[k];
@@ -381,9 +396,9 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   A.d_attw = g[FASTEGNN_P_ATTV_W]; A.d_attb = g[FASTEGNN_P_ATTV_B];
   FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (A.d_attw && A.d_attb), "virt_backward: attention grads null");
   FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
-  const int ntg = cdiv(N, 16 * VIRT_WAVES);
+  const int ntg = cdiv(N, 16 * VIRT_BWD_WAVES);
   int grid = ntg < 256 ? ntg : 256;
-  { ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st); hipLaunchKernelGGL(virt_bwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(C, 6), st, A); }
+  { ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st); hipLaunchKernelGGL(virt_bwd_kernel, dim3(grid), dim3(64 * VIRT_BWD_WAVES), virt_lds_bytes(C, 6, VIRT_BWD_WAVES), st, A); }
   int rc = check_launch("virt_bwd_kernel");
   if (rc) return rc;
   const int ld_n0 = 2 * H + H * C + L->na;

@@ -7,6 +7,7 @@ namespace fe {
 
 constexpr int EDGE_WAVES = 8;
 constexpr int VIRT_WAVES = 8;
+constexpr int VIRT_BWD_WAVES = 4;   // 1 wave/SIMD: the adjoint of the virtual block needs > 256 registers
 
 struct EdgeArgs {
   const float *P, *QX, *QXs, *ea, *wpack;
@@ -194,8 +195,8 @@ inline VirtArgs make_virt_args(const fastegnn_layer_t *L) {
              {L->gravity[0], L->gravity[1], L->gravity[2]}};
   return a;
 }
-inline size_t virt_lds_bytes(int C, int n_img) {
-  return (size_t)(n_img * IMG + 16 * H + VIRT_WAVES * 16 * TS + C * H + 4 * C) * sizeof(float);
+inline size_t virt_lds_bytes(int C, int n_img, int waves = VIRT_WAVES) {
+  return (size_t)(n_img * IMG + 16 * H + waves * 16 * TS + C * H + 4 * C) * sizeof(float);
 }
 
 
