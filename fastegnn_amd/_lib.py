@@ -86,6 +86,8 @@ def lib():
     L.fastegnn_virtual_init.argtypes = [_vp, _i32, _i32, _vp, _vp]
     L.fastegnn_virtual_init_backward.argtypes = [_vp, _i32, _i32, _vp, _vp]
     L.fastegnn_selftest_gemm.argtypes = [_vp, _vp, _vp, _i32, _vp]
+    L.fastegnn_selftest_chain.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _vp]
+    L.fastegnn_selftest_chain_bf3.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
     L.fastegnn_selftest_wgrad.argtypes = [_vp, _vp, _i32, _vp, _vp, _vp, _vp]
     L.fastegnn_wg_slab_floats.restype = C.c_size_t
     L.fastegnn_sizeof_layer.restype = C.c_size_t
@@ -117,7 +119,7 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes",
     "fastegnn_build_csr", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
-    "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_wgrad",
+    "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_wgrad", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
     "fastegnn_profile_enable", "fastegnn_profile_kernels", "fastegnn_profile_name", "fastegnn_profile_collect",
 ]
 

@@ -177,6 +177,100 @@ __device__ __forceinline__ void gemm64(const float *img, const Vec &in, Vec &acc
   }
 }
 
+// ---- 3-way bf16 split ("bf16x3") variant of gemm64 ------------------------------------------
+// fp32-input MFMA shares the vector ALUs with every other VALU instruction and runs at 1/16 of the
+// bf16 matrix rate.  x = h + m + l with h, m, l bf16 values (8+8+8 mantissa bits, by truncation: the
+// residuals are exact, so the three parts reproduce x exactly) turns one fp32 product into six bf16
+// products (hh, hm, mh, hl, lh, mm; the dropped ml, lm, ll terms are <= 2^-24 relative, i.e. below
+// fp32 rounding) accumulated in fp32 by v_mfma_f32_16x16x32_bf16 on the matrix pipe, which runs
+// beside the VALU.  Same D layout as gemm64, so the chained-MLP property is unchanged.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int IMG3 = 3 * 2048;   // u32 words of a split image: 3 parts x (64x64 bf16)
+
+struct Split {
+  u32x4 p[3][2];   // [part h|m|l][k-step] : 8 bf16 per lane
+};
+__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float trunc_bf(float x) { return __builtin_bit_cast(float, f2u(x) & 0xffff0000u); }
+// {bf16(x0) in the low half, bf16(x1) in the high half}, by truncation
+__device__ __forceinline__ unsigned pack_hi(float x0, float x1) {
+  return __builtin_amdgcn_perm(f2u(x1), f2u(x0), 0x07060302u);
+}
+// k index held by element e of lane quarter q in k-step s (matches the chained D layout)
+__host__ __device__ __forceinline__ int bf3_k(int s, int q, int e) { return 16 * (2 * s + (e >> 2)) + 4 * q + (e & 3); }
+// u32 index of (part, out o, k) in a split image; pairs (e, e+1) share a word
+__host__ __device__ __forceinline__ int img3_index(int part, int o, int k) {
+  const int t = o >> 4, i = o & 15, tile = k >> 4, q = (k >> 2) & 3, r = k & 3;
+  const int s = tile >> 1, e = ((tile & 1) << 2) | r;
+  return part * 2048 + ((t * 2 + s) * 64 + q * 16 + i) * 4 + (e >> 1);
+}
+// word (two bf16) of the split image: elements k0 (low half) and k0+1 (high half) of part `part`
+__device__ __forceinline__ unsigned split_word(float w0, float w1, int part) {
+  float a0 = w0, a1 = w1;
+  for (int p = 0; p < part; ++p) {
+    a0 -= trunc_bf(a0);
+    a1 -= trunc_bf(a1);
+  }
+  return pack_hi(a0, a1);
+}
+__device__ __forceinline__ Split vsplit(const Vec &v) {
+  Split S;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float x[8], r1[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      x[e] = v.t[2 * s + (e >> 2)][e & 3];
+      r1[e] = x[e] - trunc_bf(x[e]);
+      r2[e] = r1[e] - trunc_bf(r1[e]);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      S.p[0][s][w] = pack_hi(x[2 * w], x[2 * w + 1]);
+      S.p[1][s][w] = pack_hi(r1[2 * w], r1[2 * w + 1]);
+      S.p[2][s][w] = pack_hi(r2[2 * w], r2[2 * w + 1]);
+    }
+  }
+  return S;
+}
+// hm: parts h and m of the split image (4096 words, normally LDS resident); lp: part l (2048 words,
+// read from global/L2: it feeds only one of the six products, so keeping it out of LDS makes a
+// split image cost the same 16 KB of LDS as an fp32 image).
+__device__ __forceinline__ void gemm64_bf3(const unsigned *hm, const unsigned *lp, const Split &in, Vec &acc) {
+  const u32x4 *ih = reinterpret_cast<const u32x4 *>(hm) + lane_id();
+  const u32x4 *il = reinterpret_cast<const u32x4 *>(lp) + lane_id();
+  u32x4 al[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) al[f] = il[f * 64];          // issue the global fetch first
+  // smallest terms first: (weight part, activation part) = (h,l) (m,m) | (l,h) | (h,m) (m,h) (h,h)
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, ih[(t * 2 + s) * 64]);
+      const bf16x8 am = __builtin_bit_cast(bf16x8, ih[512 + (t * 2 + s) * 64]);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, in.p[2][s]), acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8, in.p[1][s]), acc.t[t], 0, 0, 0);
+    }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[t * 2 + s]),
+                                                         __builtin_bit_cast(bf16x8, in.p[0][s]), acc.t[t], 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, ih[(t * 2 + s) * 64]);
+      const bf16x8 am = __builtin_bit_cast(bf16x8, ih[512 + (t * 2 + s) * 64]);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, in.p[1][s]), acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8, in.p[0][s]), acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, in.p[0][s]), acc.t[t], 0, 0, 0);
+    }
+}
+
 // cooperative copy of n_img consecutive images global -> LDS (16-byte moves)
 __device__ __forceinline__ void load_images(float *dst, const float *src, int n_img) {
   const f32x4 *s = reinterpret_cast<const f32x4 *>(src);
@@ -206,6 +300,10 @@ enum ImgId {
 };
 __host__ __device__ inline int img_w3c(int c) { return I_FIXED + c; }
 __host__ __device__ inline int img_w3ct(int C, int c) { return I_FIXED + C + c; }
-__host__ __device__ inline size_t wpack_floats(int C) { return (size_t)(I_FIXED + 2 * C) * IMG; }
+// wpack = [fp32 images n x 4096][hm split images n x 4096 words][l split images n x 2048 words]
+__host__ __device__ inline size_t wpack_images(int C) { return (size_t)(I_FIXED + 2 * C); }
+__host__ __device__ inline size_t wpack_floats(int C) { return wpack_images(C) * (IMG + IMG + IMG / 2); }
+__host__ __device__ inline size_t wpack_hm_off(int C) { return wpack_images(C) * IMG; }
+__host__ __device__ inline size_t wpack_l_off(int C) { return wpack_images(C) * 2 * IMG; }
 
 }  // namespace fe

@@ -311,6 +311,58 @@ __global__ __launch_bounds__(64) void selftest_gemm_kernel(const float *W, const
   vstore_row(Y + j * H, q, acc);
 }
 
+// bf16x3 counterpart of chain_kernel (mode bit0: SiLU, bit2: single layer written to out for checks)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void chain_bf3_kernel(const float *W, const float *X, float *out, int iters,
+                                                               int mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds3[];
+  for (int idx = threadIdx.x; idx < 3 * 2048; idx += blockDim.x) lds3[idx] = 0u;
+  __syncthreads();
+  // split the fp32 weights W[o][k] into the three bf16 images (what pack.hip would do once per step)
+  for (int idx = threadIdx.x; idx < IMG; idx += blockDim.x) {
+    const int o = idx >> 6, k = idx & 63;
+    const float w = W[idx];
+    const float r1 = w - trunc_bf(w), r2 = r1 - trunc_bf(r1);
+    const float parts[3] = {w, r1, r2};
+    const int tile = k >> 4, r = k & 3, e = ((tile & 1) << 2) | r;
+    for (int p = 0; p < 3; ++p) {
+      const unsigned hb = f2u(parts[p]) >> 16;
+      atomicOr(&lds3[img3_index(p, o, k)], (e & 1) ? (hb << 16) : hb);
+    }
+  }
+  __syncthreads();
+  const int l = lane_id(), j = l & 15, q = l >> 4;
+  Vec x = vload_row(X + j * H, q);
+  for (int it = 0; it < iters; ++it) {
+    Vec acc = vzero();
+    gemm64_bf3(lds3, lds3 + 4096, vsplit(x), acc);
+    x = (mode & 1) ? vsilu(acc) : vscale(acc, 0.125f);
+    if (mode & 4) x = acc;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) vstore_row(out + j * H, q, x);
+}
+
+// MFMA-chain micro-benchmark: `iters` dependent 64x64 layers per wave (optionally with SiLU), the
+// weight image in LDS or read from global memory.  Used to calibrate what the gemm64 building block
+// can reach on its own (tests/bench only).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void chain_kernel(const float *wimg, float *out, int iters, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  load_images(lds, wimg, 1);
+  __syncthreads();
+  const int l = lane_id(), q = l >> 4;
+  const float *img = (mode & 2) ? wimg : lds;
+  Vec x;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) x.t[t] = f32x4{0.01f * l, 0.02f, -0.01f * t, 0.03f};
+  for (int it = 0; it < iters; ++it) {
+    Vec acc = vzero();
+    gemm64(img, x, acc);
+    x = (mode & 1) ? vsilu(acc) : vscale(acc, 0.125f);
+  }
+  if (out) vstore_row(out + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64 * 64 * 0, q, x);
+}
+
 }  // namespace fe
 
 using namespace fe;
@@ -375,6 +427,30 @@ int fastegnn_selftest_gemm(const float *W, const float *X, float *Y, int32_t tra
   FE_REQUIRE(W && X && Y, "selftest_gemm: null pointer");
   hipLaunchKernelGGL(selftest_gemm_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, W, X, Y, transposed);
   return check_launch("selftest_gemm_kernel");
+}
+
+int fastegnn_selftest_chain(const float *wimg, float *out, int32_t iters, int32_t mode, int32_t waves, int32_t grid,
+                            void *stream) {
+  FE_REQUIRE(wimg && out, "selftest_chain: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = IMG * sizeof(float);
+  if (waves == 4) hipLaunchKernelGGL(chain_kernel<4>, dim3(grid), dim3(256), lds, st, wimg, out, iters, mode);
+  else if (waves == 8) hipLaunchKernelGGL(chain_kernel<8>, dim3(grid), dim3(512), lds, st, wimg, out, iters, mode);
+  else if (waves == 16) hipLaunchKernelGGL(chain_kernel<16>, dim3(grid), dim3(1024), lds, st, wimg, out, iters, mode);
+  else { set_error("selftest_chain: waves must be 4, 8 or 16"); return FASTEGNN_E_INVALID; }
+  return check_launch("chain_kernel");
+}
+
+int fastegnn_selftest_chain_bf3(const float *W, const float *X, float *out, int32_t iters, int32_t mode, int32_t waves,
+                                int32_t grid, void *stream) {
+  FE_REQUIRE(W && X && out, "selftest_chain_bf3: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = 3 * 2048 * sizeof(unsigned);
+  if (waves == 4) hipLaunchKernelGGL(chain_bf3_kernel<4>, dim3(grid), dim3(256), lds, st, W, X, out, iters, mode);
+  else if (waves == 8) hipLaunchKernelGGL(chain_bf3_kernel<8>, dim3(grid), dim3(512), lds, st, W, X, out, iters, mode);
+  else if (waves == 16) hipLaunchKernelGGL(chain_bf3_kernel<16>, dim3(grid), dim3(1024), lds, st, W, X, out, iters, mode);
+  else { set_error("selftest_chain_bf3: waves must be 4, 8 or 16"); return FASTEGNN_E_INVALID; }
+  return check_launch("chain_bf3_kernel");
 }
 
 int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, float *slab,

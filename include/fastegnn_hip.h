@@ -250,6 +250,14 @@ int fastegnn_profile_collect(double *total_ms, int64_t *launches);
  * Y[j][o] = sum_k A[o][k] X[j][k] for one 16-row tile through the MFMA image path (A = W or W^T,
  * W 64x64 row-major);  dW += G^T T, db += colsum(G) over M rows of 64. */
 int fastegnn_selftest_gemm(const float *W, const float *X, float *Y, int32_t transposed, void *stream);
+/* `iters` dependent 64x64 MFMA layers per wave (mode bit0: SiLU between layers, bit1: image from
+ * global memory instead of LDS); out receives one 16x64 tile.  Calibrates the MFMA building block. */
+int fastegnn_selftest_chain(const float *wimg, float *out, int32_t iters, int32_t mode, int32_t waves, int32_t grid,
+                            void *stream);
+/* same chain on the 3-way bf16 split path (W 64x64 row-major fp32, X one 16x64 tile); mode bit2: one
+ * layer, raw output (accuracy check against fp64). */
+int fastegnn_selftest_chain_bf3(const float *W, const float *X, float *out, int32_t iters, int32_t mode, int32_t waves,
+                                int32_t grid, void *stream);
 int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, float *slab,
                             void *stream);
 

@@ -35,7 +35,7 @@ def test_struct_mirrors_and_sizes():
     assert L.fastegnn_sizeof_layer() == C.sizeof(K.LayerT)
     assert L.fastegnn_sizeof_graph() == C.sizeof(K.GraphT)
     assert L.fastegnn_version() >= 100
-    assert L.fastegnn_wpack_floats(16) == (34 + 32) * 4096
+    assert L.fastegnn_wpack_floats(16) == (34 + 32) * (4096 + 4096 + 2048)   # fp32 + split [h|m] + split l
     assert L.fastegnn_profile_kernels() >= 15
 
 

@@ -64,3 +64,21 @@ def test_build_csr_matches_oracle(N, E):
     for k in range(sg.n_chunks):   # chunk k owns the rows whose first edge lies in [256k, 256(k+1))
         for r in range(int(cr[k]), int(cr[k + 1])):
             assert 256 * k <= int(rp[r]) and (int(rp[r]) < 256 * (k + 1) or k == sg.n_chunks - 1)
+
+
+def test_bf16x3_split_gemm_is_fp32_accurate():
+    """The 3-way bf16 split path (common.h: vsplit / gemm64_bf3) reproduces an fp32 GEMM to fp32
+    rounding: error vs fp64 no larger than the exact-fp32 MFMA path's."""
+    g = torch.Generator().manual_seed(3)
+    W = (torch.randn(64, 64, generator=g) * 0.3).cuda()
+    X = torch.randn(16, 64, generator=g).cuda()
+    out = torch.zeros(16, 64, device="cuda")
+    ref = torch.zeros(16, 64, device="cuda")
+    K.check(K.lib().fastegnn_selftest_chain_bf3(K.ptr(W), K.ptr(X), K.ptr(out), 1, 4, 4, 1, _st()), "chain_bf3")
+    K.check(K.lib().fastegnn_selftest_gemm(K.ptr(W), K.ptr(X), K.ptr(ref), 0, _st()), "gemm")
+    torch.cuda.synchronize()
+    exact = X.double().cpu() @ W.double().cpu().T
+    den = exact.abs().max()
+    e_bf3 = (out.cpu().double() - exact).abs().max() / den
+    e_f32 = (ref.cpu().double() - exact).abs().max() / den
+    assert e_bf3 < 5e-7 and e_bf3 < 3 * e_f32 + 1e-7
