@@ -195,8 +195,10 @@ def graph_pre_bwd(w: LayerW, cfg: Config, G, L: str, x, gptr, Z, HvT, g_Bc):
 # --------------------------------------------------------------------------
 # S3 edge  (gather -> edge MLP -> coordinate head -> row-segmented mean)
 # --------------------------------------------------------------------------
-def _edge_recompute(w: LayerW, cfg: Config, csr: Csr, P, Q, x, ea):
-    d = x[csr.row] - x[csr.col]
+def _edge_recompute(w: LayerW, cfg: Config, csr: Csr, P, Q, x, ea, x_src=None):
+    """x_src/Q may be a larger *source table* addressed by csr.col (sharded graphs); x/P are the
+    tables of the aggregation rows."""
+    d = x[csr.row] - (x if x_src is None else x_src)[csr.col]
     r = (d * d).sum(1)
     nrm = r.sqrt()
     dn = d / (nrm + cfg.epsilon).unsqueeze(1) if cfg.normalize else d
@@ -216,9 +218,9 @@ def _edge_recompute(w: LayerW, cfg: Config, csr: Csr, P, Q, x, ea):
     return dict(d=d, r=r, nrm=nrm, dn=dn, pre=pre, t=t, mp=mp, m0=m0, a=a, m=m, up=up, u=u, s=s)
 
 
-def edge_fwd(w: LayerW, cfg: Config, csr: Csr, P, Q, x, ea):
+def edge_fwd(w: LayerW, cfg: Config, csr: Csr, P, Q, x, ea, x_src=None):
     """ea is in sorted-edge order.  returns aggm [N,H] (mean), aggx [N,3] (mean|sum)."""
-    k = _edge_recompute(w, cfg, csr, P, Q, x, ea)
+    k = _edge_recompute(w, cfg, csr, P, Q, x, ea, x_src)
     N = csr.n
     aggm = torch.zeros(N, H, dtype=x.dtype).index_add_(0, csr.row, k["m"]) * csr.inv_deg.unsqueeze(1)
     aggx = torch.zeros(N, 3, dtype=x.dtype).index_add_(0, csr.row, k["dn"] * k["s"].unsqueeze(1))
@@ -227,9 +229,10 @@ def edge_fwd(w: LayerW, cfg: Config, csr: Csr, P, Q, x, ea):
     return aggm, aggx
 
 
-def edge_bwd(w: LayerW, cfg: Config, G, L: str, csr: Csr, P, Q, x, ea, g_aggm, g_aggx):
-    """returns g_P [N,H], g_Q [N,H], g_x [N,3] (row side + col side)."""
-    k = _edge_recompute(w, cfg, csr, P, Q, x, ea)
+def edge_bwd(w: LayerW, cfg: Config, G, L: str, csr: Csr, P, Q, x, ea, g_aggm, g_aggx, x_src=None):
+    """returns g_P [N,H], g_Q [N,H], g_x [N,3] (row side + col side); with a source table (x_src given)
+    returns g_P, g_Q [n_src,H], (g_x_row [N,3], g_x_src [n_src,3])."""
+    k = _edge_recompute(w, cfg, csr, P, Q, x, ea, x_src)
     N = csr.n
     idg = csr.inv_deg[csr.row]
     g_m = g_aggm[csr.row] * idg.unsqueeze(1)
@@ -261,6 +264,12 @@ def edge_bwd(w: LayerW, cfg: Config, G, L: str, csr: Csr, P, Q, x, ea, g_aggm, g
     g_r = g_pre @ w.w_r
     g_d = (g_dn / (k["nrm"] + cfg.epsilon).unsqueeze(1) if cfg.normalize else g_dn) + 2 * g_r.unsqueeze(1) * k["d"]
     g_P = torch.zeros(N, H, dtype=x.dtype).index_add_(0, csr.row, g_pre)
+    if x_src is not None:
+        ns = x_src.size(0)
+        g_Q = torch.zeros(ns, H, dtype=x.dtype).index_add_(0, csr.col, g_pre)
+        g_xr = torch.zeros(N, 3, dtype=x.dtype).index_add_(0, csr.row, g_d)
+        g_xs = torch.zeros(ns, 3, dtype=x.dtype).index_add_(0, csr.col, -g_d)
+        return g_P, g_Q, (g_xr, g_xs)
     g_Q = torch.zeros(N, H, dtype=x.dtype).index_add_(0, csr.col, g_pre)
     g_x = torch.zeros(N, 3, dtype=x.dtype).index_add_(0, csr.row, g_d).index_add_(0, csr.col, -g_d)
     return g_P, g_Q, g_x

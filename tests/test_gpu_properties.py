@@ -199,3 +199,31 @@ def test_cfg4_full_size_properties():
     assert torch.allclose(outs[0][0] + 0.25, outs[1][0], atol=2e-5)
     assert torch.allclose(outs[0][1] + 0.25, outs[1][1], atol=2e-5)
     assert rel_err(outs[1][2], outs[0][2]) < 1e-3
+
+
+def test_stage_level_api_world1_matches_whole_layer_path():
+    """The staged C entry points (what a sharded caller uses, fastegnn_amd/sharded.py) chained on one
+    GPU with a 1-rank process group give the same outputs and gradients as fastegnn_layer_forward /
+    _backward."""
+    import os
+    import torch.distributed as dist
+    from fastegnn_amd.sharded import ShardedFastEGNN
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    cfg = R.Config(2, 0, 2, 64, 8, n_layers=2, gravity=[0, -1, 0], attention=True)
+    _, m = _models(cfg, 21)
+    inp = {k: v.cuda() for k, v in _batch([150, 90], 8, 8, seed=21).items()}
+    tgt = inp["node_loc"] + 0.3
+    outs = []
+    for wrap in (lambda mod: mod, lambda mod: ShardedFastEGNN(mod)):
+        for p in m.parameters():
+            p.grad = None
+        loc, vloc = wrap(m)(**inp)
+        _loss(loc, vloc, tgt).backward()
+        outs.append((loc.detach().clone(), vloc.detach().clone(),
+                     torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in m.parameters()])))
+    assert rel_err(outs[1][0], outs[0][0]) < 1e-6 and rel_err(outs[1][1], outs[0][1]) < 1e-6
+    assert rel_err(outs[1][2], outs[0][2]) < 1e-5
+    dist.destroy_process_group()

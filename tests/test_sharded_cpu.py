@@ -1,0 +1,127 @@
+"""CPU, world_size 2 over gloo: the graph-sharded path (fastegnn_amd/sharded.py) -- row-owner
+partition, all-gather of the source table, all-reduce of centroid sums / virtual-node pools and
+their adjoints, reduce-scatter of the source-table gradient, rank-0-only gradients of the replicated
+per-graph stages -- driven on CPU with the oracle's stage functions as the compute backend
+(tests/cpu_stage_backend.py).  Every rank's outputs and the all-reduced parameter gradients must
+equal the single-process oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import fastegnn_amd
+from fastegnn_amd.dist import allreduce_gradients, init_from_env
+from fastegnn_amd.sharded import ShardedFastEGNN, ShardPlan
+from oracle import fastegnn_ref as R
+from tests.cpu_stage_backend import CpuOracleBackend
+from tests.helpers import rel_err
+
+CFG = dict(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=4, n_layers=2)
+SIZES = [9, 6, 8]     # 23 nodes: graph 1 straddles the rank boundary (Npad = 12)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(11)
+    rows, cols, batch, off = [], [], [], 0
+    for b, n in enumerate(SIZES):
+        e = 5 * n
+        rows.append(torch.randint(0, n, (e,), generator=g) + off)
+        cols.append(torch.randint(0, n, (e,), generator=g) + off)
+        batch += [b] * n
+        off += n
+    ei = torch.stack([torch.cat(rows), torch.cat(cols)])
+    ei = ei[:, torch.randperm(ei.size(1), generator=g)]
+    batch = torch.tensor(batch)
+    N, B, C = off, len(SIZES), CFG["virtual_channels"]
+    loc = torch.randn(N, 3, generator=g)
+    cm = torch.zeros(B, 3).index_add_(0, batch, loc) / torch.bincount(batch).unsqueeze(1)
+    inp = dict(node_feat=torch.rand(N, 2, generator=g), node_loc=loc, node_vel=torch.randn(N, 3, generator=g) * 0.3,
+               edge_index=ei, data_batch=batch, loc_mean=cm.unsqueeze(-1).repeat(1, 1, C),
+               edge_attr=torch.rand(ei.size(1), 2, generator=g))
+    target = loc + torch.randn(N, 3, generator=g) * 0.2
+    return inp, target
+
+
+def _model(gravity):
+    torch.manual_seed(7)
+    m = fastegnn_amd.FastEGNN(CFG["node_feat_nf"], 0, CFG["edge_attr_nf"], 64, CFG["virtual_channels"],
+                              n_layers=CFG["n_layers"], gravity=gravity)
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if k.endswith((".coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
+                v.mul_(100.0)
+    return m
+
+
+def _loss(loc_rows, vloc, target_rows, n_total):
+    return ((loc_rows - target_rows) ** 2).sum() / (3 * n_total) + 0.1 * vloc.pow(2).mean()
+
+
+def _worker(rank, world, port, gravity, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    init_from_env("gloo")
+    inp, target = _inputs()
+    m = _model(gravity)
+    cfg = R.Config(**CFG, gravity=gravity)
+    spec_names = None
+    be = CpuOracleBackend(spec_names, CFG["n_layers"], cfg)
+    sm = ShardedFastEGNN(m, backend=be)
+    loc, vloc = sm(**inp)
+    plan = sm.plan
+    _loss(loc, vloc, target[plan.n0:plan.n1], target.size(0)).backward()
+    allreduce_gradients(m.parameters())
+    grads = {k: (p.grad.numpy().copy() if p.grad is not None else None) for k, p in m.named_parameters()}
+    q.put((rank, plan.n0, plan.n1, loc.detach().numpy().copy(), vloc.detach().numpy().copy(), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gravity", [None, [0, -1, 0]])
+def test_two_rank_sharded_graph_matches_single_process_oracle(gravity):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, gravity, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    # single-process oracle
+    inp, target = _inputs()
+    m = _model(gravity)
+    cfg = R.Config(**CFG, gravity=gravity)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in m.named_parameters()}
+    loc, vloc = R.forward(p, cfg, **inp)
+    _loss(loc, vloc, target, target.size(0)).backward()
+    for rank, n0, n1, loc_r, vloc_r, grads in res:
+        assert rel_err(loc_r, loc.detach()[n0:n1]) < 1e-5
+        assert rel_err(vloc_r, vloc.detach()) < 1e-5
+        for k, v in p.items():
+            want = v.grad if v.grad is not None else torch.zeros_like(v)
+            assert grads[k] is not None, k
+            assert rel_err(grads[k], want) < 2e-4, (rank, k, rel_err(grads[k], want))
+
+
+def test_shard_plan():
+    for n, w in ((23, 2), (100, 8), (8, 8), (10, 4)):
+        plans = [ShardPlan(n, w, r) for r in range(w)]
+        assert plans[0].n0 == 0 and plans[-1].n1 == n
+        assert all(a.n1 == b.n0 for a, b in zip(plans[:-1], plans[1:]))
+        assert all(p.n_src == w * plans[0].Npad >= n for p in plans)
+    with pytest.raises(ValueError):
+        ShardPlan(9, 4, 3)       # ceil(9/4)=3 rows per rank: the last rank would own nothing
