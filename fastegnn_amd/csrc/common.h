@@ -36,6 +36,14 @@ __device__ __forceinline__ float dsilu_f(float z) {
   float s = sigmoid_f(z);
   return s * (1.0f + z * (1.0f - s));
 }
+// silu(z) and its derivative from ONE sigmoid: d = s*(1 + z*(1-s)) = s + y*(1-s) with y = z*s
+__device__ __forceinline__ void silu_both(float z, float &y, float &d) {
+  const float s = sigmoid_f(z);
+  y = z * s;
+  d = s + y * (1.0f - s);
+}
+__device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrt_f(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float tanh_f(float z) {
   // tanh(z) = 2*sigmoid(2z) - 1
   return 2.0f * sigmoid_f(2.0f * z) - 1.0f;
@@ -66,6 +74,23 @@ __device__ __forceinline__ Vec vmap2(const Vec &a, const Vec &b, F f) {
   return o;
 }
 __device__ __forceinline__ Vec vsilu(const Vec &a) { return vmap(a, [](float z) { return silu_f(z); }); }
+// y = silu(z); z is overwritten by silu'(z)  (the backward keeps the derivative instead of the pre-activation)
+__device__ __forceinline__ Vec vsilu_keep_d(Vec &z) {
+  Vec y;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float yy, dd;
+      silu_both(z.t[t][r], yy, dd);
+      y.t[t][r] = yy;
+      z.t[t][r] = dd;
+    }
+  return y;
+}
+__device__ __forceinline__ Vec vmul(const Vec &a, const Vec &b) {
+  return vmap2(a, b, [](float x, float y) { return x * y; });
+}
 __device__ __forceinline__ Vec vscale(const Vec &a, float s) { return vmap(a, [s](float z) { return z * s; }); }
 __device__ __forceinline__ void vaxpy(Vec &acc, float s, const Vec &a) {
 #pragma unroll

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         vd[0] = Zb[c] - xi[0];
         vd[1] = Zb[C + c] - xi[1];
         vd[2] = Zb[2 * C + c] - xi[2];
-        const float vr = sqrtf(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
+        const float vr = sqrt_f(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
         auto make_pre = [&]() {
           Vec p = vload_u(b_A, offN);
           vadd(p, vload_u(a.Bc, ob));
@@ -226,12 +226,13 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           return p;
         };
         Vec vp = vload_vec(vec + VV_C2 * H, q);
+        Vec d_pre = make_pre();
         {
-          const Vec t = vsilu(make_pre());
+          const Vec t = vsilu_keep_d(d_pre);      // d_pre <- silu'(pre)
           if (valid) vstore_u(b_t, oc, t);
           gemm64(img + 0 * IMG, t, vp);
         }
-        const Vec v0 = vsilu(vp);
+        const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
         float att = 1.f;
         Vec v = v0;
         if (att_on) {
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {  // coord_mlp_r_virtual head: forward, then its adjoint
           Vec uxp = vload_vec(vec + VV_BXV0 * H, q);
           gemm64(img + 1 * IMG, v, uxp);
-          const Vec ux = vsilu(uxp);
+          const Vec ux = vsilu_keep_d(uxp);       // uxp <- silu'(uxp)
           const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
           sx = tanh_on ? tanh_f(sr) : sr;
           float g_sx = 0.f;
@@ -257,14 +258,14 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           for (int k = 0; k < 3; ++k) g_sx -= vd[k] * invC * gxn[k];
           const float g_sr = tanh_on ? g_sx * (1.f - sx * sx) : g_sx;
           vaxpy(acc_wxv2, g_sr, ux);
-          const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
+          const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
           if (valid) vstore_u(b_gux, oc, g_up);
           gemm64(img + 4 * IMG, g_up, g_v);
         }
         {  // coord_mlp_v_virtual head
           Vec uXp = vload_vec(vec + VV_BXX0 * H, q);
           gemm64(img + 2 * IMG, v, uXp);
-          const Vec uX = vsilu(uXp);
+          const Vec uX = vsilu_keep_d(uXp);
           const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
           sX = tanh_on ? tanh_f(sr) : sr;
           float g_sX = 0.f;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           for (int k = 0; k < 3; ++k) g_sX += vd[k] * gpX[k];
           const float g_sr = tanh_on ? g_sX * (1.f - sX * sX) : g_sX;
           vaxpy(acc_wxx2, g_sr, uX);
-          const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
+          const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
           if (valid) vstore_u(b_guX, oc, g_up);
           gemm64(img + 5 * IMG, g_up, g_v);
         }
@@ -289,15 +290,15 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         }
         Vec g_t = vzero();
         {
-          const Vec g_vp = vdsilu_mul(g_v0, vp);
+          const Vec g_vp = vmul(g_v0, vp);
           if (valid) vstore_u(b_gvp, oc, g_vp);
           gemm64(img + 3 * IMG, g_vp, g_t);
         }
-        const Vec g_pre = vdsilu_mul(g_t, make_pre());
+        const Vec g_pre = vmul(g_t, d_pre);
         vadd(g_A, g_pre);
         vaxpy(acc_wvr, vr, g_pre);
         const float g_vr = vdot(g_pre, vload_vec(vec + VV_WVR * H, q));
-        const float ivr = vr > 0.f ? g_vr / vr : 0.f;
+        const float ivr = vr > 0.f ? g_vr * rcp_f(vr) : 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           g_vd[k] += ivr * vd[k];
@@ -546,9 +547,9 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
       edge_load_idx(a, e, cur_i);
       EdgeFwdState S;
       Vec pre;
-      edge_tile_forward(a, img, vec, cur_i, q, S, pre FE_TA);
+      edge_tile_forward<true>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
       const int dg = a.rowptr[S.row + 1] - a.rowptr[S.row];
-      const float inv = valid ? 1.0f / (float)(dg > 1 ? dg : 1) : 0.f;
+      const float inv = valid ? rcp_f((float)(dg > 1 ? dg : 1)) : 0.f;
       const float invx = valid ? (mean ? inv : 1.f) : 0.f;
       if (valid) {
         vstore_row(A.wg_t + (size_t)e * H, q, S.t);
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
       }
       const float g_sr = tanh_on ? g_s * (1.f - S.s * S.s) : g_s;
       vaxpy(acc_wx2, g_sr, S.u);
-      const Vec g_up = vdsilu_mul(vscale(vload_vec(vec + EV_WX2 * H, q), g_sr), S.up);
+      const Vec g_up = vmul(vscale(vload_vec(vec + EV_WX2 * H, q), g_sr), S.up);
       if (valid) vstore_row(A.wg_gup + (size_t)e * H, q, g_up);
       Vec g_m = vscale(vload_row(A.g_aggm + (size_t)S.row * H, q), inv);
       gemm64(img + 3 * IMG, g_up, g_m);
@@ -577,14 +578,14 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
         g_m0 = vscale(g_m, S.att);
         vaxpy(g_m0, g_z, vload_vec(vec + EV_ATT * H, q));
       }
-      const Vec g_mp = vdsilu_mul(g_m0, S.mp);
+      const Vec g_mp = vmul(g_m0, S.mp);
       if (valid) vstore_row(A.wg_gmp + (size_t)e * H, q, g_mp);
       Vec g_t = vzero();
       gemm64(img + 2 * IMG, g_mp, g_t);
-      const Vec g_pre = vdsilu_mul(g_t, pre);
+      const Vec g_pre = vmul(g_t, pre);
       const float g_r = vdot(g_pre, vload_vec(vec + EV_WR * H, q));
       float g_d[3];
-      const float invn = norm_on ? 1.0f / (S.nrm + a.eps) : 1.f;
+      const float invn = norm_on ? rcp_f(S.nrm + a.eps) : 1.f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) g_d[k] = g_dn[k] * invn + 2.f * g_r * S.d[k];
       if (valid) {

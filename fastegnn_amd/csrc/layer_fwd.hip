@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_fwd_kernel(EdgeArgs a) {
     FE_T(7)   // chunk bookkeeping
     int cnt = 0;   // edges of the current row seen so far == its in-degree at flush time (rows never straddle chunks)
     auto flush = [&]() {
-      const float inv = 1.0f / (float)cnt;
+      const float inv = rcp_f((float)cnt);
       a.aggm[(size_t)cur * H + l] = acc * inv;
       if (l < 3) a.aggx[(size_t)cur * 3 + l] = mean ? accx * inv : accx;
     };
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_fwd_kernel(EdgeArgs a) {
       if (base + 16 < e1) edge_load_idx(a, min(base + 16 + j, e1 - 1), nxt_i);   // next tile's indices in flight
       EdgeFwdState S;
       Vec pre;
-      edge_tile_forward(a, img, vec, cur_i, q, S, pre FE_TA);
+      edge_tile_forward<false>(a, img, vec, cur_i, q, S, pre FE_TA);
       cur_i = nxt_i;
       tile_store(mt, j, q, S.m);
       if (q == 0) {

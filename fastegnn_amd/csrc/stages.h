@@ -59,7 +59,10 @@ __device__ __forceinline__ void edge_load_idx(const EdgeArgs &a, int e, EdgeIdx 
   }
 }
 
-// forward math of one 16-edge tile (shared with the backward kernel for recomputation)
+// forward math of one 16-edge tile (shared with the backward kernel for recomputation).
+// KEEP_D: pre, S.mp and S.up return silu'(.) of the pre-activations instead of the pre-activations
+// (the adjoint needs only the derivatives; one sigmoid serves both).
+template <bool KEEP_D>
 __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float *img, const float *vec,
                                                   const EdgeIdx &I, int q, EdgeFwdState &S, Vec &pre FE_TP) {
   S.row = I.row;
@@ -71,9 +74,9 @@ __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float
   S.d[1] = xr[1] - xc[1];
   S.d[2] = xr[2] - xc[2];
   S.r = S.d[0] * S.d[0] + S.d[1] * S.d[1] + S.d[2] * S.d[2];
-  S.nrm = sqrtf(S.r);
+  S.nrm = sqrt_f(S.r);
   if (a.flags & FASTEGNN_F_NORMALIZE) {
-    const float inv = 1.0f / (S.nrm + a.eps);
+    const float inv = rcp_f(S.nrm + a.eps);
     S.dn[0] = S.d[0] * inv; S.dn[1] = S.d[1] * inv; S.dn[2] = S.d[2] * inv;
   } else {
     S.dn[0] = S.d[0]; S.dn[1] = S.d[1]; S.dn[2] = S.d[2];
@@ -88,12 +91,12 @@ __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float
     if (k < a.ea_dim) vaxpy(pre, S.eav[k], vload_vec(vec + (EV_WE + k) * H, q));
   }
   FE_T(1)   // gathered rows arrived, pre-activation formed
-  S.t = vsilu(pre);
+  S.t = KEEP_D ? vsilu_keep_d(pre) : vsilu(pre);
   FE_T(2)   // silu 1
   S.mp = vload_vec(vec + EV_B2 * H, q);
   gemm64(img + 0 * IMG, S.t, S.mp);
   FE_T(3)   // gemm 1
-  S.m0 = vsilu(S.mp);
+  S.m0 = KEEP_D ? vsilu_keep_d(S.mp) : vsilu(S.mp);
   if (a.flags & FASTEGNN_F_ATTENTION) {
     S.att = sigmoid_f(vdot(S.m0, vload_vec(vec + EV_ATT * H, q)) + a.attb[0]);
     S.m = vscale(S.m0, S.att);
@@ -105,7 +108,7 @@ __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float
   S.up = vload_vec(vec + EV_BX1 * H, q);
   gemm64(img + 1 * IMG, S.m, S.up);
   FE_T(3)
-  S.u = vsilu(S.up);
+  S.u = KEEP_D ? vsilu_keep_d(S.up) : vsilu(S.up);
   const float sraw = vdot(S.u, vload_vec(vec + EV_WX2 * H, q));
   S.s = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sraw) : sraw;
   FE_T(4)   // silu 3 + head dot
@@ -160,7 +163,7 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const float
   S.vd[0] = Zb[c] - xi[0];
   S.vd[1] = Zb[C + c] - xi[1];
   S.vd[2] = Zb[2 * C + c] - xi[2];
-  S.vr = sqrtf(S.vd[0] * S.vd[0] + S.vd[1] * S.vd[1] + S.vd[2] * S.vd[2]);
+  S.vr = sqrt_f(S.vd[0] * S.vd[0] + S.vd[1] * S.vd[1] + S.vd[2] * S.vd[2]);
   S.pre = Ai;
   vadd(S.pre, vload_row(a.Bc + ((size_t)b * C + c) * H, q));
   vaxpy(S.pre, S.vr, vload_vec(vec + VV_WVR * H, q));
