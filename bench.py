@@ -83,10 +83,14 @@ def kernel_model(N, E, B, C, L, gravity=True):
     return f
 
 
+CPU_THREADS = 8   # fastest of {8,16,32,64,128} torch threads for this op mix on the GPU box's host CPU
+
+
 def cpu_baseline(C, seed, steps=2, n_sample=10000):
     """Oracle (op-for-op CPU restatement of the reference) timed on the host cores on a bounded
     sample: a frame of the same density with n_sample nodes; cost is linear in N and E at fixed C."""
     from oracle import fastegnn_ref as R
+    torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or CPU_THREADS))
     frame, target = make_frame(n_sample, C, seed, "cpu")
     cfg = R.Config(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=C,
                    n_layers=4, gravity=[0, -1, 0])
@@ -200,8 +204,8 @@ def main():
         t_mfma, t_hbm = fl / (PEAK_MFMA_F32_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom)
+        if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes (tools_gpu_traffic.sh)
+            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
         if t_mfma >= t_hbm:
             roof = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": PEAK_MFMA_F32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / PEAK_MFMA_F32_TFLOPS, 4),
@@ -233,13 +237,14 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             ns = 10000
-            t_cpu, e_cpu = cpu_baseline(C, 43, steps=2, n_sample=ns)
+            t_cpu, e_cpu = cpu_baseline(C, 43, steps=3, n_sample=ns)
             scale = N / ns
             out["cpu_baseline"] = {
                 "value": round(1.0 / (t_cpu * scale), 5), "unit": "graphs/s", "cores": torch.get_num_threads(),
                 "kind": "port",
                 "sample": f"oracle/fastegnn_ref.py (torch CPU, op-for-op) fwd+bwd on a {ns}-node frame of the same "
-                          f"density (E={e_cpu}), median of 2 steps = {t_cpu:.2f} s, scaled x{scale:.0f} to the "
+                          f"density (E={e_cpu}), {torch.get_num_threads()} torch threads (fastest setting measured on this host), "
+                          f"median of 3 steps = {t_cpu:.2f} s, scaled x{scale:.0f} to the "
                           f"{N}-node frame (cost is linear in N and E at fixed C)"}
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
