@@ -94,29 +94,51 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
   for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
     for (int tk = 0; tk < 4; ++tk) acc[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // lane l loads 16 bytes of row (4s + q), columns 4i..4i+3: full 256-byte lines per row
+  // lane l loads 16 bytes of row (4s + q), columns 4i..4i+3: full 256-byte lines per row.  Addresses
+  // are a wave-uniform base (row m) plus loop-invariant 32-bit lane offsets: no per-load VALU math.
   f32x4 gv[4], tv[4];
-  auto issue = [&](long m) {
+  unsigned og[4], ot[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const long row = m + 4 * s + q;
-      const bool ok = row < m1;
-      const long rc = ok ? row : m0;
-      // raw loads only: masking happens when the tile is written to LDS one iteration later, so
-      // nothing consumes the load results while the current tile's MFMAs run
-      gv[s] = *reinterpret_cast<const f32x4 *>(G + (size_t)rc * a.ldg + 4 * i);
-      tv[s] = *reinterpret_cast<const f32x4 *>(T + (size_t)rc * a.ldt + 4 * i);
+  for (int s = 0; s < 4; ++s) {
+    og[s] = ((unsigned)(4 * s + q) * (unsigned)a.ldg + 4u * i) * 4u;
+    ot[s] = ((unsigned)(4 * s + q) * (unsigned)a.ldt + 4u * i) * 4u;
+  }
+  const bool want_bias = a.db != nullptr;
+  auto issue = [&](long m) {
+    const char *gb = reinterpret_cast<const char *>(G + (size_t)m * a.ldg);
+    const char *tb = reinterpret_cast<const char *>(T + (size_t)m * a.ldt);
+    if (m + 16 <= m1) {   // full tile (wave-uniform): unmasked loads
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        gv[s] = *reinterpret_cast<const f32x4 *>(gb + og[s]);
+        tv[s] = *reinterpret_cast<const f32x4 *>(tb + ot[s]);
+      }
+    } else {              // ragged tail: rows beyond m1 read row m (always valid) and are zeroed below
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bool ok = m + 4 * s + q < m1;
+        gv[s] = *reinterpret_cast<const f32x4 *>(gb + (ok ? og[s] : 4u * i * 4u));
+        tv[s] = *reinterpret_cast<const f32x4 *>(tb + (ok ? ot[s] : 4u * i * 4u));
+      }
     }
   };
   long m = m0 + 16 * w;
   if (m < m1) issue(m);
   for (; m < m1; m += 64) {
     __builtin_amdgcn_wave_barrier();
+    if (m + 16 <= m1) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bool ok = m + 4 * s + q < m1;
-      *reinterpret_cast<f32x4 *>(gt + (4 * s + q) * WTS + 4 * i) = ok ? gv[s] : f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4 *>(tt + (4 * s + q) * WTS + 4 * i) = ok ? tv[s] : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < 4; ++s) {
+        *reinterpret_cast<f32x4 *>(gt + (4 * s + q) * WTS + 4 * i) = gv[s];
+        *reinterpret_cast<f32x4 *>(tt + (4 * s + q) * WTS + 4 * i) = tv[s];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bool ok = m + 4 * s + q < m1;
+        *reinterpret_cast<f32x4 *>(gt + (4 * s + q) * WTS + 4 * i) = ok ? gv[s] : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(tt + (4 * s + q) * WTS + 4 * i) = ok ? tv[s] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
     __builtin_amdgcn_wave_barrier();
     if (m + 64 < m1) issue(m + 64);
@@ -130,7 +152,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
       }
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        bsum[ti] += av[ti];
+        if (want_bias) bsum[ti] += av[ti];
 #pragma unroll
         for (int tk = 0; tk < 4; ++tk)
           acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti], bv[tk], acc[ti][tk], 0, 0, 0);
