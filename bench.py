@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache-graph", action="store_true", help="reuse the sorted graph across steps")
+    ap.add_argument("--train-step", action="store_true",
+                    help="time a full training iteration instead (edge_attr augmentation, MSE+MMD loss, Adam: "
+                         "fastegnn_amd.train.train_step); the default step is fwd+loss+bwd, the BASELINE metric")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,7 +145,18 @@ def main():
     E = frame["edge_index"].size(1)
     params = [p for p in model.parameters()]
 
+    if args.train_step:
+        from fastegnn_amd.train import FusedAdam, train_step
+        opt = FusedAdam(params, lr=5e-4, weight_decay=1e-12)
+        gsel = torch.Generator().manual_seed(7)
+        samp = torch.randperm(N, generator=gsel)[: 3 * C].view(1, -1).to(dev)
+        data = dict(loc_0=frame["node_loc"], vel_0=frame["node_vel"], loc_t=target, node_feat=frame["node_feat"],
+                    edge_index=frame["edge_index"], edge_attr=frame["edge_attr"][:, :1].contiguous(),
+                    batch=frame["data_batch"], loc_mean=frame["loc_mean"])
+
     def step():
+        if args.train_step:   # utils/train.py:30-170 on device (single-GPU only)
+            return train_step(model, opt, data, samp, 1.0, 0.01)[0]
         for p in params:
             p.grad = None
         loc, vloc = model(**frame)
@@ -226,7 +240,9 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg4 Water-3D-like frame (SURVEY 8d): uniform points, radius graph r=0.035, "
-                                   "4-layer FastEGNN H=64, gravity on, fwd+loss+bwd, CSR build "
+                                   "4-layer FastEGNN H=64, gravity on, "
+                                   + ("full training iteration (augment+fwd+MSE/MMD+bwd+Adam)" if args.train_step else "fwd+loss+bwd")
+                                   + ", CSR build "
                                    + ("cached" if args.cache_graph else "inside the step"),
                        "nodes": N, "edges": E, "virtual_channels": C, "layers": L, "graphs_per_step_per_gpu": 1,
                        "parallelism": f"dp{world} (one frame per GPU, RCCL gradient all-reduce)" if world > 1 else "1 GPU",

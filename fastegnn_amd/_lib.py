@@ -85,6 +85,10 @@ def lib():
     L.fastegnn_embed_backward.argtypes = [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]
     L.fastegnn_virtual_init.argtypes = [_vp, _i32, _i32, _vp, _vp]
     L.fastegnn_virtual_init_backward.argtypes = [_vp, _i32, _i32, _vp, _vp]
+    L.fastegnn_augment_edge_attr.argtypes = [_vp, _vp, _vp, _i32, _i32, _vp, _vp]
+    L.fastegnn_loss_mse_mmd.argtypes = [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _vp, _vp, _vp, _vp]
+    L.fastegnn_adam_step.argtypes = [_vp, _vp, _vp, _vp, C.POINTER(C.c_int64), _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, _vp]
     L.fastegnn_selftest_gemm.argtypes = [_vp, _vp, _vp, _i32, _vp]
     L.fastegnn_selftest_chain.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _vp]
     L.fastegnn_selftest_chain_bf3.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
@@ -120,6 +124,7 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_build_csr", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_wgrad", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
+    "fastegnn_augment_edge_attr", "fastegnn_loss_mse_mmd", "fastegnn_adam_step",
     "fastegnn_profile_enable", "fastegnn_profile_kernels", "fastegnn_profile_name", "fastegnn_profile_collect",
 ]
 

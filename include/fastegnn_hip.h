@@ -237,6 +237,22 @@ int fastegnn_node_pre_backward(const fastegnn_layer_t *L, void *stream);   /* B1
 int fastegnn_layer_forward(const fastegnn_layer_t *L, void *stream);
 int fastegnn_layer_backward(const fastegnn_layer_t *L, void *stream);
 
+/* ---- training-step closure (the harness code that brackets the hot path, utils/train.py) ----
+ * out[e,:] = [edge_attr[e,:k] | ||loc[row_e]-loc[col_e]||]                      (utils/train.py:41-43) */
+int fastegnn_augment_edge_attr(const int64_t *edge_index, const float *loc, const float *edge_attr, int32_t E,
+                               int32_t k, float *out, void *stream);
+/* loss2[0] = MSE(loc_pred,loc_t) + weight*(l_vv - l_rv), loss2[1] = MSE      (utils/train.py:104-165, kernel :17-20);
+ * sample_nodes int32 [B,S]: absolute ids of the sampled real nodes of each graph; writes d loss / d loc_pred into
+ * g_loc [N,3] and d loss / d virtual_node_loc into g_vloc [B,3,C]. */
+int fastegnn_loss_mse_mmd(const float *loc_pred, const float *loc_t, const float *vloc, const int32_t *sample_nodes,
+                          int32_t N, int32_t B, int32_t C, int32_t S, float sigma, float weight, float *loss2,
+                          float *g_loc, float *g_vloc, void *stream);
+/* torch.optim.Adam step (no amsgrad, L2 weight decay; main_nbody.py:137) over n_tensors tensors given as HOST arrays
+ * of device pointers; grads[i] may be null (treated as zero); step counts from 1. */
+int fastegnn_adam_step(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                       const int64_t *numel, int32_t n_tensors, int32_t step, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, void *stream);
+
 /* ---- per-kernel timing with HIP events recorded on the launch stream (bench.py) ----
  * enable(1) brackets every kernel launch of this library with two events; collect() waits for
  * them and returns, per kernel id in [0, fastegnn_profile_kernels()), the summed duration in ms

@@ -272,3 +272,33 @@ def loss_mse_mmd(loc_pred, vloc, loc_t, sample_idx, sigma, weight):
     l_vv = mmd_kernel(V, V, sigma).sum() / B / C / C
     l_rv = 2 * mmd_kernel(R, V, sigma).sum() / B / R.size(1) / C
     return mse + weight * (l_vv - l_rv), mse
+
+
+def loss_mse_mmd_nodes(loc_pred, vloc, loc_t, sample_nodes, sigma, weight):
+    """Both branches of utils/train.py:104-165 in one form: `sample_nodes` [B,S] are the absolute
+    indices of the sampled real nodes of each graph (equal-sized branch :144-160: b*n + idx[s];
+    'Simulation' branch :118-142: per-graph draws).  Returns (loss, mse)."""
+    mse = F.mse_loss(loc_pred, loc_t)
+    V = vloc.permute(0, 2, 1)                      # [B,C,3]
+    B, C, _ = V.shape
+    S = sample_nodes.size(1)
+    R = loc_pred[sample_nodes.reshape(-1)].reshape(B, S, 3)
+    l_vv = mmd_kernel(V, V, sigma).sum() / B / C / C
+    l_rv = 2 * mmd_kernel(R, V, sigma).sum() / B / S / C
+    return mse + weight * (l_vv - l_rv), mse
+
+
+def adam_step(params, grads, state, step, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-12):
+    """torch.optim.Adam (non-amsgrad, L2 weight decay folded into the gradient), as constructed at
+    main_nbody.py:137.  `state` maps name -> (exp_avg, exp_avg_sq); updated in place."""
+    b1, b2 = betas
+    for k, p in params.items():
+        g = grads.get(k)
+        if g is None:
+            continue
+        g = g + weight_decay * p
+        m, v = state.setdefault(k, (torch.zeros_like(p), torch.zeros_like(p)))
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(1 - b2 ** step)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / (1 - b1 ** step))

@@ -222,8 +222,106 @@ def nbody_case(n_systems=6, n_balls=5, C=3, cutoff_rate=0.5, seed=43):
                 edge_attr=ea2)
 
 
+def train_case(FastEGNN, name, nb, *, C=3, L=2, seed=43, sigma=1.5, weight=0.01, sample=3, lr=5e-4, wd=1e-12,
+               ragged_sizes=None):
+    """Row H of SURVEY 8a: the harness's loss (utils/train.py:104-165, MSE + MMD through the reference's
+    own `kernel`, :17-20) with the sampled indices fixed, and Adam (main_nbody.py:137) for 3 steps.
+    `ragged_sizes` selects the per-graph ('Simulation') branch (:118-142)."""
+    stub = types.ModuleType("datasets.protein.dataset")   # utils/train.py:7 imports MDAnalysis through this
+    stub.MDAnalysisDataset = object
+    sys.modules["datasets.protein.dataset"] = stub
+    from utils.train import kernel
+    torch.manual_seed(seed)
+    model = FastEGNN(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=C, device="cpu",
+                     n_layers=L)
+    with torch.no_grad():
+        for k, v in model.named_parameters():
+            if k.endswith(("coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
+                v.mul_(100.0)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
+    gen = torch.Generator().manual_seed(seed + 5)
+    N = nb["node_loc"].size(0)
+    B = nb["loc_mean"].size(0)
+    batch = nb["data_batch"]
+    loc_t = nb["node_loc"] + 0.3 * torch.randn(N, 3, generator=gen)
+    if ragged_sizes is None:
+        n = N // B
+        S = min(sample * C, n)
+        idx = torch.randperm(n, generator=gen)[:S]
+        sample_nodes = (torch.arange(B).unsqueeze(1) * n + idx.unsqueeze(0))          # [B,S] global node ids
+    else:
+        S = min(sample * C, N)
+        rows, off = [], 0
+        for nb_ in ragged_sizes:
+            rows.append(off + torch.randperm(nb_, generator=gen)[:S])
+            off += nb_
+        assert all(r.numel() == S for r in rows)
+        sample_nodes = torch.stack(rows)
+
+    def loss_of(loc_pred, vloc):
+        mse = torch.nn.functional.mse_loss(loc_pred, loc_t)
+        V = vloc.permute(0, 2, 1)                                                      # [B,C,3]
+        if ragged_sizes is None:   # utils/train.py:144-160
+            R_ = loc_pred.reshape(B, -1, 3)[:, idx, :]
+            l_vv = torch.sum(kernel(V, V, sigma)) / B / C / C
+            l_rv = 2 * torch.sum(kernel(R_, V, sigma)) / B / S / C
+        else:                      # utils/train.py:118-142
+            l_vv, l_rv = 0.0, 0.0
+            for i in range(B):
+                Ri = loc_pred[sample_nodes[i]]
+                l_vv = l_vv + torch.sum(kernel(V[i], V[i], sigma))
+                l_rv = l_rv + torch.sum(kernel(Ri, V[i], sigma))
+            l_vv = l_vv / B / C / C
+            l_rv = 2 * l_rv / B / S / C
+        return mse + weight * (l_vv - l_rv), mse
+
+    rec = {}
+    for k, v in nb.items():
+        rec[f"in/{k}"] = v.numpy()
+    rec["in/loc_t"] = loc_t.numpy()
+    rec["in/sample_nodes"] = sample_nodes.numpy().astype(np.int64)
+    for k, v in model.state_dict().items():
+        rec[f"p0/{k}"] = v.detach().numpy().copy()
+    losses = []
+    for step in range(1, 4):
+        opt.zero_grad()
+        loc_pred, vloc = model(node_loc=nb["node_loc"], node_vel=nb["node_vel"], node_attr=None,
+                               node_feat=nb["node_feat"], edge_index=nb["edge_index"], loc_mean=nb["loc_mean"],
+                               data_batch=batch, edge_attr=nb["edge_attr"])
+        loss, mse = loss_of(loc_pred, vloc)
+        loss.backward()
+        if step == 1:
+            rec["out/loc"] = loc_pred.detach().numpy().copy()
+            rec["out/vloc"] = vloc.detach().numpy().copy()
+            for k, v in model.named_parameters():
+                rec[f"g1/{k}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy().copy()
+        losses.append([loss.item(), mse.item()])
+        opt.step()
+        if step in (1, 3):
+            for k, v in model.state_dict().items():
+                rec[f"p{step}/{k}"] = v.detach().numpy().copy()
+    rec["out/losses"] = np.array(losses)
+    for k, v in dict(C=C, L=L, sigma=sigma, weight=weight, lr=lr, wd=wd, S=S, ragged=int(ragged_sizes is not None)).items():
+        rec[f"meta/{k}"] = np.array(v)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: N={N} B={B} S={S} losses={losses} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
     FastEGNN = _import_reference()
+    if "--train-only" in sys.argv:
+        nb = nbody_case()
+        train_case(FastEGNN, "train_nbody5", nb)
+        gen = torch.Generator().manual_seed(77)
+        sizes = [11, 14, 12]
+        ei, batch = _rand_graph_batch(gen, sizes, [40, 50, 45])
+        loc = torch.randn(sum(sizes), 3, generator=gen)
+        rg = dict(node_feat=torch.rand(sum(sizes), 2, generator=gen), node_loc=loc,
+                  node_vel=torch.randn(sum(sizes), 3, generator=gen) * 0.3, edge_index=ei, data_batch=batch,
+                  loc_mean=_loc_mean(loc, batch, 3), edge_attr=torch.rand(ei.size(1), 2, generator=gen))
+        train_case(FastEGNN, "train_ragged_simulation", rg, sigma=1.0, ragged_sizes=sizes)
+        return
     # equivariant_test.py shape: 10 nodes, 20 random directed edges, nf=1, ea=1, C=3
     run_case(FastEGNN, "equiv10", sizes=[10], edges=[20], nf=1, na=0, ea=1, C=3, seed=1,
              loc_scale=5.0)
