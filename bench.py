@@ -34,18 +34,25 @@ UNIT = 2 * H * H               # FLOPs of one 64x64 mat-vec
 def make_frame(N, C, seed, device, radius=0.035):
     """N points uniform in a box of the density of [0,0.965]^3 @ 100k (mean degree
     ~20 at r=0.035), vel ~ N(0,0.003^2), node_feat=[|vel|,1], edge_attr=[dist,dist], target=loc+20 vel."""
-    from scipy.spatial import cKDTree
     g = torch.Generator().manual_seed(seed)
     box = 0.965 * (N / 100000.0) ** (1.0 / 3.0)
     loc = torch.rand(N, 3, generator=g) * box
     vel = torch.randn(N, 3, generator=g) * 0.003
-    pairs = cKDTree(loc.numpy().astype(np.float64)).query_pairs(radius, output_type="ndarray")
-    pairs = torch.from_numpy(pairs.astype(np.int64))
-    ei = torch.cat([pairs.t(), pairs.t().flip(0)], dim=1)              # both directions
-    # datasets emit edges sorted by length (datasets/simulation/dataset.py:96-101)
-    dist = (loc[ei[0]] - loc[ei[1]]).norm(dim=1)
-    order = torch.argsort(dist)
-    ei, dist = ei[:, order].contiguous(), dist[order]
+    if str(device) != "cpu":
+        # radius graph + length ordering on the GPU (fastegnn_amd/graphs.py; identical edge set, tests/test_gpu_graphs.py)
+        from fastegnn_amd.graphs import cutoff_edges, radius_graph
+        ei, dist = radius_graph(loc.to(device), radius)
+        ei, dist = cutoff_edges(ei, dist, 0.0)                          # datasets emit edges sorted by length
+        ei, dist = ei.cpu(), dist.cpu()
+    else:
+        from scipy.spatial import cKDTree
+        pairs = cKDTree(loc.numpy().astype(np.float64)).query_pairs(radius, output_type="ndarray")
+        pairs = torch.from_numpy(pairs.astype(np.int64))
+        ei = torch.cat([pairs.t(), pairs.t().flip(0)], dim=1)              # both directions
+        # datasets emit edges sorted by length (datasets/simulation/dataset.py:96-101)
+        dist = (loc[ei[0]] - loc[ei[1]]).norm(dim=1)
+        order = torch.argsort(dist)
+        ei, dist = ei[:, order].contiguous(), dist[order]
     frame = dict(
         node_feat=torch.stack([vel.norm(dim=1), torch.ones(N)], 1),
         node_loc=loc, node_vel=vel, edge_index=ei,

@@ -89,6 +89,13 @@ def lib():
     L.fastegnn_loss_mse_mmd.argtypes = [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _vp, _vp, _vp, _vp]
     L.fastegnn_adam_step.argtypes = [_vp, _vp, _vp, _vp, C.POINTER(C.c_int64), _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_float, _vp]
+    L.fastegnn_radius_graph_ws_bytes.restype = C.c_size_t
+    L.fastegnn_radius_graph_ws_bytes.argtypes = [_i32]
+    L.fastegnn_radius_graph_count.argtypes = [_vp, _i32, C.c_float, _vp, C.c_size_t, C.POINTER(C.c_int64), _vp]
+    L.fastegnn_radius_graph_fill.argtypes = [_vp, _i32, C.c_float, _vp, C.c_size_t, C.c_int64, _vp, _vp, _vp]
+    L.fastegnn_cutoff_tmp_bytes.restype = C.c_size_t
+    L.fastegnn_cutoff_tmp_bytes.argtypes = [C.c_int64]
+    L.fastegnn_cutoff_edges.argtypes = [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]
     L.fastegnn_selftest_gemm.argtypes = [_vp, _vp, _vp, _i32, _vp]
     L.fastegnn_selftest_chain.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _vp]
     L.fastegnn_selftest_chain_bf3.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
@@ -125,6 +132,8 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_wgrad", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
     "fastegnn_augment_edge_attr", "fastegnn_loss_mse_mmd", "fastegnn_adam_step",
+    "fastegnn_radius_graph_ws_bytes", "fastegnn_radius_graph_count", "fastegnn_radius_graph_fill",
+    "fastegnn_cutoff_tmp_bytes", "fastegnn_cutoff_edges",
     "fastegnn_profile_enable", "fastegnn_profile_kernels", "fastegnn_profile_name", "fastegnn_profile_collect",
 ]
 

@@ -253,6 +253,22 @@ int fastegnn_adam_step(float *const *params, const float *const *grads, float *c
                        const int64_t *numel, int32_t n_tensors, int32_t step, float lr, float beta1, float beta2,
                        float eps, float weight_decay, void *stream);
 
+/* ---- graph construction on device (datasets/simulation/dataset.py:80,96-101) ----
+ * radius graph without self loops: all ordered pairs (i, j != i) with |x_i - x_j|^2 <= r^2 (fp32, each
+ * operation rounded separately), grouped by i with j ascending.  Two passes so that the caller allocates:
+ * _count fills the workspace (fastegnn_radius_graph_ws_bytes(N) bytes) and returns the edge count in
+ * *n_edges (host; synchronises the stream), _fill writes edge_index int64 [2,E] and dist [E]. */
+size_t fastegnn_radius_graph_ws_bytes(int32_t N);
+int fastegnn_radius_graph_count(const float *loc, int32_t N, float r, void *ws, size_t ws_bytes, int64_t *n_edges,
+                                void *stream);
+int fastegnn_radius_graph_fill(const float *loc, int32_t N, float r, void *ws, size_t ws_bytes, int64_t n_edges,
+                               int64_t *edge_index, float *dist, void *stream);
+/* keep the `keep` shortest edges (stable: ties keep their order), in ascending length like the reference's
+ * cutoff_edge; tmp: fastegnn_cutoff_tmp_bytes(E) bytes */
+size_t fastegnn_cutoff_tmp_bytes(int64_t E);
+int fastegnn_cutoff_edges(const int64_t *edge_index, const float *dist, int64_t E, int64_t keep, int64_t *edge_index_out,
+                          float *dist_out, void *tmp, size_t tmp_bytes, void *stream);
+
 /* ---- per-kernel timing with HIP events recorded on the launch stream (bench.py) ----
  * enable(1) brackets every kernel launch of this library with two events; collect() waits for
  * them and returns, per kernel id in [0, fastegnn_profile_kernels()), the summed duration in ms

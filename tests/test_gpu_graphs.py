@@ -1,0 +1,64 @@
+"""-m gpu: device-side graph construction (fastegnn_amd/graphs.py) against the CPU restatement
+(oracle/graphs_ref.py): exact edge lists (integer parity) for the radius graph and the cutoff."""
+import numpy as np
+import pytest
+import torch
+
+from fastegnn_amd.graphs import cutoff_edges, radius_graph
+from oracle import graphs_ref as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,r,scale", [(1, 0.1, 1.0), (2, 0.5, 0.1), (300, 0.12, 1.0), (1500, 0.035, 0.3), (700, 5.0, 1.0)])
+def test_radius_graph_equals_bruteforce(N, r, scale):
+    g = np.random.RandomState(N)
+    loc = (g.rand(N, 3) * scale - 0.3 * scale).astype(np.float32)      # negative coordinates too
+    if N >= 300:
+        loc[7] = loc[3]                                               # coincident points (distance 0)
+    ei_ref, d_ref = G.radius_graph_bruteforce(loc, r)
+    ei, d = radius_graph(torch.from_numpy(loc).cuda(), r)
+    assert ei.shape[1] == ei_ref.shape[1]
+    assert np.array_equal(ei.cpu().numpy(), ei_ref)
+    assert np.allclose(d.cpu().numpy(), d_ref, rtol=1e-6, atol=1e-9)
+
+
+def test_radius_graph_water3d_size_equals_kdtree_reference():
+    # BASELINE configs[3] frame: 100k points, r = 0.035 -> ~1.9 M directed edges
+    g = torch.Generator().manual_seed(43)
+    loc = torch.rand(100000, 3, generator=g) * 0.965
+    ei_ref, d_ref = G.radius_graph_kdtree(loc.numpy(), 0.035)
+    ei, d = radius_graph(loc.cuda(), 0.035)
+    assert np.array_equal(ei.cpu().numpy(), ei_ref)
+    # symmetric, no self loops
+    a = ei.cpu().numpy()
+    assert (a[0] != a[1]).all()
+    key = a[0] * 100000 + a[1]
+    assert np.array_equal(np.sort(key), np.sort(a[1] * 100000 + a[0]))      # every (i,j) has its (j,i)
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.5, 0.9, 1.0])
+def test_cutoff_keeps_shortest_fraction(rate):
+    g = np.random.RandomState(5)
+    loc = g.rand(800, 3).astype(np.float32)
+    ei_ref, d_ref = G.radius_graph_bruteforce(loc, 0.15)
+    k_ref, kd_ref = G.cutoff_edges(ei_ref, d_ref, rate)
+    ei, d = radius_graph(torch.from_numpy(loc).cuda(), 0.15)
+    k, kd = cutoff_edges(ei, d, rate)
+    assert np.array_equal(k.cpu().numpy(), k_ref)          # stable ties: identical order
+    assert np.allclose(kd.cpu().numpy(), kd_ref, rtol=3e-7, atol=0)      # sqrt may differ by an ulp
+    assert bool((kd[1:] >= kd[:-1]).all())
+
+
+def test_device_built_graph_feeds_the_model():
+    import fastegnn_amd
+    g = torch.Generator().manual_seed(2)
+    loc = torch.rand(5000, 3, generator=g) * 0.4
+    ei, d = radius_graph(loc.cuda(), 0.035)
+    ei, d = cutoff_edges(ei, d, 0.5)
+    m = fastegnn_amd.FastEGNN(2, 0, 2, 64, 3, device="cuda", gravity=[0, -1, 0])
+    N = loc.size(0)
+    out = m(node_feat=torch.rand(N, 2).cuda(), node_loc=loc.cuda(), node_vel=torch.zeros(N, 3).cuda(), edge_index=ei,
+            data_batch=torch.zeros(N, dtype=torch.long).cuda(), loc_mean=loc.mean(0).view(1, 3, 1).repeat(1, 1, 3).cuda(),
+            edge_attr=torch.stack([d, d], 1))
+    assert torch.isfinite(out[0]).all()
