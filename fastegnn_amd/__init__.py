@@ -4,5 +4,6 @@ Only the hot path of GLAD-RUC/FastEGNN lives here: the drop-in ``FastEGNN`` modu
 (``model.py``), its ctypes binding (``_lib.py``) and the HIP sources (``csrc/``).
 """
 from .model import FastEGNN, SortedGraph  # noqa: F401
+from .egnn import EGNN  # noqa: F401
 
-__all__ = ["FastEGNN", "SortedGraph"]
+__all__ = ["FastEGNN", "EGNN", "SortedGraph"]

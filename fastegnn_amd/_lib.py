@@ -16,7 +16,7 @@ QX_LD = 68
 FEATW = 8
 
 # flags (fastegnn_hip.h)
-F_ATTENTION, F_NORMALIZE, F_TANH, F_RESIDUAL, F_GRAVITY, F_COORDS_SUM = 1, 2, 4, 8, 16, 32
+F_ATTENTION, F_NORMALIZE, F_TANH, F_RESIDUAL, F_GRAVITY, F_COORDS_SUM, F_EGNN = 1, 2, 4, 8, 16, 32, 64
 
 # per-layer parameter slots, in header order -> reference state_dict suffix (models/FastEGNN.py:28-99)
 PARAM_SLOTS = [
@@ -30,9 +30,10 @@ PARAM_SLOTS = [
     "gravity_mlp.0.weight", "gravity_mlp.0.bias", "gravity_mlp.2.weight", "gravity_mlp.2.bias",
     "node_mlp.0.weight", "node_mlp.0.bias", "node_mlp.2.weight", "node_mlp.2.bias",
     "node_mlp_virtual.0.weight", "node_mlp_virtual.0.bias", "node_mlp_virtual.2.weight", "node_mlp_virtual.2.bias",
+    "coord_mlp_r.2.bias",     # EGNN baseline only (FastEGNN's coordinate heads have no bias)
 ]
 P_COUNT = len(PARAM_SLOTS)
-assert P_COUNT == 37
+assert P_COUNT == 38
 
 _vp = C.c_void_p
 _i32 = C.c_int32

@@ -50,7 +50,7 @@ static int check_layer(const fastegnn_layer_t *L, const char *who) {
     set_error(std::string(who) + ": layer descriptor is null");
     return FASTEGNN_E_INVALID;
   }
-  if (L->N < 0 || L->B < 1 || L->C < 1 || L->ea < 0 || L->na < 0) {
+  if (L->N < 0 || L->B < 1 || L->C < ((L->flags & FASTEGNN_F_EGNN) ? 0 : 1) || L->ea < 0 || L->na < 0) {
     set_error(std::string(who) + ": bad sizes");
     return FASTEGNN_E_INVALID;
   }
@@ -125,6 +125,10 @@ int fastegnn_layer_forward(const fastegnn_layer_t *L, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if ((rc = pack_weights(L, st))) return rc;
   if ((rc = node_pre_forward(L, st))) return rc;
+  if (has(L, FASTEGNN_F_EGNN)) {   // EGNN baseline: no virtual nodes, hence no per-graph stages
+    if ((rc = edge_forward(L, st))) return rc;
+    return virt_forward(L, st);
+  }
   if ((rc = graph_xsum(L, st))) return rc;
   if ((rc = graph_pre_forward(L, st))) return rc;
   if ((rc = edge_forward(L, st))) return rc;
@@ -136,6 +140,12 @@ int fastegnn_layer_backward(const fastegnn_layer_t *L, void *stream) {
   int rc = check_layer(L, "fastegnn_layer_backward");
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (has(L, FASTEGNN_F_EGNN)) {
+    if ((rc = virt_backward(L, st))) return rc;
+    if ((rc = edge_backward(L, st))) return rc;
+    if ((rc = edge_col_reduce(L, st))) return rc;
+    return node_pre_backward(L, st);
+  }
   if ((rc = graph_post_backward(L, st))) return rc;
   if ((rc = virt_backward(L, st))) return rc;
   if ((rc = graph_pre_backward(L, st))) return rc;

@@ -126,8 +126,9 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   float *tile = tiles + wv * 16 * TS;
   constexpr int GROUP = 16 * VIRT_BWD_WAVES;
   const int ntg = (a.N + GROUP - 1) / GROUP;
-  const float invC = 1.0f / (float)C;
+  const float invC = C > 0 ? 1.0f / (float)C : 0.f;
   const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION;
+  const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;
   Vec acc_wxv2 = vzero(), acc_wxx2 = vzero(), acc_wvr = vzero(), acc_att = vzero();
   float acc_attb = 0.f;
   int cur = -1;
@@ -200,7 +201,9 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         float sv = 0.f, sg = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          A.g_aggx[(size_t)n * 3 + k] = gxn[k];
+          // clamp(tot_f, -100, 100) of the EGNN baseline passes the gradient only inside the interval
+          const bool pass = !clamp_aggx || fabsf(a.aggx[(size_t)n * 3 + k]) <= 100.f;
+          A.g_aggx[(size_t)n * 3 + k] = pass ? gxn[k] : 0.f;
           sv += gxn[k] * a.vel[(size_t)n * 3 + k];
           sg += gxn[k] * a.g[k];
         }
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
     if (l == 0) atomicAdd(&red[4 * H], s);
   }
   __syncthreads();
-  if (threadIdx.x < H) {
+  if (threadIdx.x < H && C > 0) {
     const int o = threadIdx.x;
     atomicAdd(&A.d_wxv2[o], red[o]);
     atomicAdd(&A.d_wxx2[o], red[H + o]);
@@ -372,14 +375,19 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
 }
 
 int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
-  FE_REQUIRE(L->h && L->A && L->Bc && L->x && L->vel && L->Z && L->aggm && L->npre && L->batch && L->wpack,
+  const bool egnn = has(L, FASTEGNN_F_EGNN);
+  FE_REQUIRE(L->h && L->A && L->x && L->vel && L->aggm && L->npre && L->batch && L->wpack && (!egnn || L->aggx),
              "virt_backward: null saved buffer");
-  FE_REQUIRE(L->g_h_out && L->g_x_out && L->g_poolV && L->g_poolX && L->g_h && L->g_x && L->g_A && L->g_aggm &&
-                 L->g_aggx && L->g_svel && L->g_Bc && L->g_Zp && L->wg_node && L->wg_virt && L->grads,
+  FE_REQUIRE(L->g_h_out && L->g_x_out && L->g_h && L->g_x && L->g_A && L->g_aggm && L->g_aggx && L->g_svel &&
+                 L->wg_node && L->grads,
              "virt_backward: null gradient buffer");
+  FE_REQUIRE(egnn ? L->C == 0 : (L->Bc && L->Z && L->g_poolV && L->g_poolX && L->g_Bc && L->g_Zp && L->wg_virt && L->C >= 1),
+             "virt_backward: virtual buffers null or bad C");
   const int N = L->N, C = L->C;
-  (void)hipMemsetAsync(L->g_Bc, 0, (size_t)L->B * C * H * sizeof(float), st);
-  (void)hipMemsetAsync(L->g_Zp, 0, (size_t)L->B * 3 * C * sizeof(float), st);
+  if (C > 0) {
+    (void)hipMemsetAsync(L->g_Bc, 0, (size_t)L->B * C * H * sizeof(float), st);
+    (void)hipMemsetAsync(L->g_Zp, 0, (size_t)L->B * 3 * C * sizeof(float), st);
+  }
   if (N == 0) return check_launch("virt_backward(memset)");
   float *const *g = L->grads;
   const long NC = (long)N * C;
@@ -393,7 +401,7 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   A.wg_guX = L->wg_virt + 3 * NC * H; A.wg_gvp = L->wg_virt + 4 * NC * H;
   A.ld_v0 = 2 * H + 1 + C;
   A.d_wxv2 = g[FASTEGNN_P_CRV2_W]; A.d_wxx2 = g[FASTEGNN_P_CVV2_W];
-  A.d_wvr = g[FASTEGNN_P_VIRT0_W] + 2 * H;
+  A.d_wvr = g[FASTEGNN_P_VIRT0_W] ? g[FASTEGNN_P_VIRT0_W] + 2 * H : nullptr;
   A.d_attw = g[FASTEGNN_P_ATTV_W]; A.d_attb = g[FASTEGNN_P_ATTV_B];
   FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (A.d_attw && A.d_attb), "virt_backward: attention grads null");
   FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
@@ -409,8 +417,9 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   // node_mlp.0: [h | agg | flat(v) | node_attr]
   if ((rc = wb.add(A.wg_gnp, H, L->h, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 0, 1, g[FASTEGNN_P_NODE0_B]))) return rc;
   if ((rc = wb.add(A.wg_gnp, H, L->aggm, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, H, 1, nullptr))) return rc;
-  if ((rc = wb.add(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
-  // coordinate heads and edge_mlp_virtual.2 over the N*C (node, channel) rows
+  if (C > 0)
+    if ((rc = wb.add(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
+  // coordinate heads and edge_mlp_virtual.2 over the N*C (node, channel) rows (none when C = 0)
   if ((rc = wb.add(A.wg_gux, H, A.wg_v, H, NC, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B]))) return rc;
   if ((rc = wb.add(A.wg_guX, H, A.wg_v, H, NC, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B]))) return rc;
   if ((rc = wb.add(A.wg_gvp, H, A.wg_t, H, NC, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B]))) return rc;
@@ -503,7 +512,8 @@ struct EdgeBwdArgs {
   const float *g_aggm, *g_aggx;
   float *g_P, *g_xrow, *g_QXe;
   float *wg_gmp, *wg_t, *wg_gup, *wg_m;
-  float *d_wx2, *d_attw, *d_attb, *d_w1tail;   // d_w1tail: edge_mlp.0.weight grad at column 2H (row stride ld)
+  float *d_wx2, *d_attw, *d_attb, *d_bx2;
+  float *d_wr, *d_we;   // edge_mlp.0.weight grad: radial column and first edge_attr column (row stride ld_e0)
   int ld_e0;
 };
 constexpr int XT = 4;   // per-edge scalar row in LDS: g_d[3] | pad
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
   const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION,
              norm_on = a.flags & FASTEGNN_F_NORMALIZE;
   Vec acc_wx2 = vzero(), acc_att = vzero();
-  float acc_attb = 0.f;
+  float acc_attb = 0.f, acc_bx2 = 0.f;
   FE_T0()
   for (int ch = wave; ch < a.n_chunks; ch += nwaves) {
     const int r0 = a.chunk_row[ch], r1 = a.chunk_row[ch + 1];
@@ -565,6 +575,7 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
       }
       const float g_sr = tanh_on ? g_s * (1.f - S.s * S.s) : g_s;
       vaxpy(acc_wx2, g_sr, S.u);
+      if (q == 0) acc_bx2 += g_sr;
       const Vec g_up = vmul(vscale(vload_vec(vec + EV_WX2 * H, q), g_sr), S.up);
       if (valid) vstore_row(A.wg_gup + (size_t)e * H, q, g_up);
       Vec g_m = vscale(vload_row(A.g_aggm + (size_t)S.row * H, q), inv);
@@ -643,6 +654,10 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
     float s = jsum(acc_attb);
     if (l == 0) atomicAdd(&red[2 * H], s);
   }
+  if (A.d_bx2) {
+    float s = jsum(acc_bx2);
+    if (l == 0) atomicAdd(&red[2 * H + 1], s);
+  }
   __syncthreads();
   if (threadIdx.x < H) {
     atomicAdd(&A.d_wx2[threadIdx.x], red[threadIdx.x]);
@@ -650,8 +665,10 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
       atomicAdd(&A.d_attw[threadIdx.x], red[H + threadIdx.x]);
       if (threadIdx.x == 0) atomicAdd(A.d_attb, red[2 * H]);
     }
-    for (int k = 0; k <= a.ea_dim; ++k)
-      atomicAdd(&A.d_w1tail[(size_t)threadIdx.x * A.ld_e0 + k], red[(3 + k) * H + threadIdx.x]);
+    if (A.d_bx2 && threadIdx.x == 0) atomicAdd(A.d_bx2, red[2 * H + 1]);
+    atomicAdd(&A.d_wr[(size_t)threadIdx.x * A.ld_e0], red[3 * H + threadIdx.x]);
+    for (int k = 0; k < a.ea_dim; ++k)
+      atomicAdd(&A.d_we[(size_t)threadIdx.x * A.ld_e0 + k], red[(4 + k) * H + threadIdx.x]);
   }
 }
 
@@ -671,7 +688,9 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   A.wg_gmp = L->wg_edge; A.wg_t = L->wg_edge + E * H; A.wg_gup = L->wg_edge + 2 * E * H;
   A.wg_m = L->wg_edge + 3 * E * H;
   A.ld_e0 = 2 * H + 1 + L->ea;
-  A.d_w1tail = g[FASTEGNN_P_EDGE0_W] + 2 * H;
+  A.d_wr = g[FASTEGNN_P_EDGE0_W] + (has(L, FASTEGNN_F_EGNN) ? 0 : 2 * H);   // basic.py:313: radial is column 0
+  A.d_we = g[FASTEGNN_P_EDGE0_W] + 2 * H + 1;
+  A.d_bx2 = g[FASTEGNN_P_CR2_B];
   A.d_wx2 = g[FASTEGNN_P_CR2_W]; A.d_attw = g[FASTEGNN_P_ATT_W]; A.d_attb = g[FASTEGNN_P_ATT_B];
   FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (A.d_attw && A.d_attb), "edge_backward: attention grads null");
   int grid = cdiv(gr.n_chunks, EDGE_WAVES);
@@ -738,7 +757,7 @@ struct NodePreBwdArgs {
   const int32_t *batch;
   float *g_h, *g_x, *g_vel, *wg_gzv, *wg_gzg;
   float *d_wv2, *d_bv2, *d_wg2, *d_bg2;
-  int N, gravity;
+  int N, gravity, has_vel;
 };
 __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
   const int l = lane_id(), j = l & 15, q = l >> 4;
@@ -755,7 +774,7 @@ __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
     gemm64(a.wpack + (size_t)I_W1AT * IMG, vload_row(a.g_P + (size_t)nc * H, q), g_h);
     gemm64(a.wpack + (size_t)I_W1BT * IMG, vload_row(a.g_QX + (size_t)nc * QXLD, q), g_h);
     gemm64(a.wpack + (size_t)I_V1AT * IMG, vload_row(a.g_A + (size_t)nc * H, q), g_h);
-    {  // coord_mlp_vel head (:139)
+    if (a.has_vel) {  // coord_mlp_vel head (:139)
       Vec z = vload_vec(a.bv0, q);
       gemm64(a.wpack + (size_t)I_WVEL0 * IMG, hv, z);
       const float gs = valid ? a.g_svel[nc] : 0.f;
@@ -791,9 +810,12 @@ __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
   __shared__ float red[2 * H + 2];
   for (int i = threadIdx.x; i < 2 * H + 2; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
-  vec_reduce_lds(red, acc_wv2, j, q);
-  float s = jsum(acc_bv2);
-  if (l == 0) atomicAdd(&red[2 * H], s);
+  float s = 0.f;
+  if (a.has_vel) {
+    vec_reduce_lds(red, acc_wv2, j, q);
+    s = jsum(acc_bv2);
+    if (l == 0) atomicAdd(&red[2 * H], s);
+  }
   if (a.gravity) {
     vec_reduce_lds(red + H, acc_wg2, j, q);
     s = jsum(acc_bg2);
@@ -801,8 +823,10 @@ __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
   }
   __syncthreads();
   if (threadIdx.x < H) {
-    atomicAdd(&a.d_wv2[threadIdx.x], red[threadIdx.x]);
-    if (threadIdx.x == 0) atomicAdd(a.d_bv2, red[2 * H]);
+    if (a.has_vel) {
+      atomicAdd(&a.d_wv2[threadIdx.x], red[threadIdx.x]);
+      if (threadIdx.x == 0) atomicAdd(a.d_bv2, red[2 * H]);
+    }
     if (a.gravity) {
       atomicAdd(&a.d_wg2[threadIdx.x], red[H + threadIdx.x]);
       if (threadIdx.x == 0) atomicAdd(a.d_bg2, red[2 * H + 1]);
@@ -823,7 +847,8 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   NodePreBwdArgs a{L->h, L->wpack, L->g_P, L->g_QX, L->g_A, L->g_svel, L->g_sgrav, L->g_xrow, L->g_xbar, L->g_x_out,
                    L->svel, p[FASTEGNN_P_VEL0_B], p[FASTEGNN_P_VEL2_W], p[FASTEGNN_P_GRAV0_B], p[FASTEGNN_P_GRAV2_W],
                    L->batch, L->g_h, L->g_x, L->g_vel, wg_gzv, wg_gzg,
-                   g[FASTEGNN_P_VEL2_W], g[FASTEGNN_P_VEL2_B], g[FASTEGNN_P_GRAV2_W], g[FASTEGNN_P_GRAV2_B], N, grav ? 1 : 0};
+                   g[FASTEGNN_P_VEL2_W], g[FASTEGNN_P_VEL2_B], g[FASTEGNN_P_GRAV2_W], g[FASTEGNN_P_GRAV2_B], N, grav ? 1 : 0,
+                   p[FASTEGNN_P_VEL0_W] ? 1 : 0};
   int grid = cdiv(cdiv(N, 16), 4);
   if (grid > 512) grid = 512;
   { ProfScope _ps_node_pre_bwd_kernel(K_NODE_PRE_BWD, st); hipLaunchKernelGGL(node_pre_bwd_kernel, dim3(grid), dim3(256), 0, st, a); }
@@ -832,11 +857,13 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   const int ld_e0 = 2 * H + 1 + L->ea, ld_v0 = 2 * H + 1 + L->C;
   // edge_mlp.0 columns [0,H) <- h[row] (P), [H,2H) <- h[col] (Q), bias through P
   WgradBatch wb(L->wg_slab, st);
-  if ((rc = wb.add(L->g_P, H, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, 0, 1, g[FASTEGNN_P_EDGE0_B]))) return rc;
-  if ((rc = wb.add(L->g_QX, QXLD, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, H, 1, nullptr))) return rc;
-  // edge_mlp_virtual.0 columns [0,H) <- h (A)
+  const int c0 = has(L, FASTEGNN_F_EGNN) ? 1 : 0;   // EGNN baseline: [radial | h_row | h_col | edge_attr]
+  if ((rc = wb.add(L->g_P, H, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, c0, 1, g[FASTEGNN_P_EDGE0_B]))) return rc;
+  if ((rc = wb.add(L->g_QX, QXLD, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, c0 + H, 1, nullptr))) return rc;
+  // edge_mlp_virtual.0 columns [0,H) <- h (A)   (absent for the EGNN baseline: add() skips a null dW)
   if ((rc = wb.add(L->g_A, H, L->h, H, N, g[FASTEGNN_P_VIRT0_W], ld_v0, 0, 1, nullptr))) return rc;
-  if ((rc = wb.add(wg_gzv, H, L->h, H, N, g[FASTEGNN_P_VEL0_W], H, 0, 1, g[FASTEGNN_P_VEL0_B]))) return rc;
+  if (p[FASTEGNN_P_VEL0_W])
+    if ((rc = wb.add(wg_gzv, H, L->h, H, N, g[FASTEGNN_P_VEL0_W], H, 0, 1, g[FASTEGNN_P_VEL0_B]))) return rc;
   if (grav)
     if ((rc = wb.add(wg_gzg, H, L->h, H, N, g[FASTEGNN_P_GRAV0_W], H, 0, 1, g[FASTEGNN_P_GRAV0_B]))) return rc;
   return wb.finish();

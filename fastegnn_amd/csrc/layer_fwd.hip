@@ -12,7 +12,7 @@ struct NodePreArgs {
   const float *h, *x, *wpack;
   const float *b1, *bv0, *wv2, *bv2, *bg0, *wg2, *bg2;
   float *P, *QX, *A, *svel, *sgrav;
-  int N, gravity;
+  int N, gravity, has_vel;
 };
 
 __global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
   const int l = lane_id(), j = l & 15, q = l >> 4;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const int ntiles = (a.N + 15) >> 4;
-  const float bv2 = a.bv2[0];
+  const float bv2 = a.has_vel ? a.bv2[0] : 0.f;
   const float bg2 = a.gravity ? a.bg2[0] : 0.f;
   for (int tile = wave; tile < ntiles; tile += nwaves) {
     const int n = tile * 16 + j;
@@ -52,9 +52,12 @@ __global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
     acc = vzero();
     gemm64(img + 2 * IMG, hv, acc);
     if (valid) vstore_row(a.A + (size_t)n * H, q, acc);
-    acc = vload_vec(vec + 1 * H, q);
-    gemm64(img + 3 * IMG, hv, acc);
-    float s = vdot(vsilu(acc), vload_vec(vec + 2 * H, q)) + bv2;
+    float s = 0.f;
+    if (a.has_vel) {
+      acc = vload_vec(vec + 1 * H, q);
+      gemm64(img + 3 * IMG, hv, acc);
+      s = vdot(vsilu(acc), vload_vec(vec + 2 * H, q)) + bv2;
+    }
     if (valid && q == 0) a.svel[n] = s;
     if (a.gravity) {
       acc = vload_vec(vec + 3 * H, q);
@@ -73,7 +76,7 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
   const float *const *p = L->params;
   NodePreArgs a{L->h, L->x, L->wpack, p[FASTEGNN_P_EDGE0_B], p[FASTEGNN_P_VEL0_B], p[FASTEGNN_P_VEL2_W],
                 p[FASTEGNN_P_VEL2_B], p[FASTEGNN_P_GRAV0_B], p[FASTEGNN_P_GRAV2_W], p[FASTEGNN_P_GRAV2_B],
-                L->P, L->QX, L->A, L->svel, L->sgrav, L->N, grav ? 1 : 0};
+                L->P, L->QX, L->A, L->svel, L->sgrav, L->N, grav ? 1 : 0, p[FASTEGNN_P_VEL0_W] ? 1 : 0};
   const int ntiles = (L->N + 15) / 16;
   int grid = cdiv(ntiles, 4);
   if (grid > 512) grid = 512;
@@ -311,7 +314,8 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   float *tile = tiles + wv * 16 * TS;
   constexpr int GROUP = 16 * VIRT_WAVES;
   const int ntg = (a.N + GROUP - 1) / GROUP;
-  const float invC = 1.0f / (float)C;
+  const float invC = C > 0 ? 1.0f / (float)C : 0.f;
+  const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;   // basic.py:310
   int cur = -1;  // graph the LDS pool accumulators belong to
   auto flush_pools = [&]() {
     for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
@@ -405,9 +409,11 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
           const float sv = a.svel[n];
           const float sg = (a.flags & FASTEGNN_F_GRAVITY) ? a.sgrav[n] : 0.f;
 #pragma unroll
-          for (int k = 0; k < 3; ++k)
-            a.x_out[(size_t)n * 3 + k] = xi[k] + a.aggx[(size_t)n * 3 + k] + transv[k] * invC +
-                                         sv * a.vel[(size_t)n * 3 + k] + sg * a.g[k];
+          for (int k = 0; k < 3; ++k) {
+            float ax = a.aggx[(size_t)n * 3 + k];
+            if (clamp_aggx) ax = fminf(fmaxf(ax, -100.f), 100.f);
+            a.x_out[(size_t)n * 3 + k] = xi[k] + ax + transv[k] * invC + sv * a.vel[(size_t)n * 3 + k] + sg * a.g[k];
+          }
         }
       }
     }
@@ -417,13 +423,17 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
 }
 
 int virt_forward(const fastegnn_layer_t *L, hipStream_t st) {
-  FE_REQUIRE(L->h && L->A && L->Bc && L->x && L->vel && L->Z && L->aggm && L->aggx && L->svel && L->npre &&
-                 L->h_out && L->x_out && L->poolV && L->poolX && L->batch && L->wpack,
+  const bool egnn = has(L, FASTEGNN_F_EGNN);
+  FE_REQUIRE(L->h && L->A && L->x && L->vel && L->aggm && L->aggx && L->svel && L->npre && L->h_out && L->x_out &&
+                 L->batch && L->wpack,
              "virt_forward: null buffer");
-  FE_REQUIRE(L->C >= 1 && L->C <= 64, "virt_forward: virtual_channels must be in [1,64]");
+  FE_REQUIRE(egnn ? L->C == 0 : (L->Bc && L->Z && L->poolV && L->poolX && L->C >= 1 && L->C <= 64),
+             "virt_forward: virtual_channels must be in [1,64] (0 with FASTEGNN_F_EGNN) and the virtual buffers non-null");
   FE_REQUIRE(L->na == 0 || L->node_attr, "virt_forward: node_attr null");
-  (void)hipMemsetAsync(L->poolV, 0, (size_t)L->B * L->C * H * sizeof(float), st);
-  (void)hipMemsetAsync(L->poolX, 0, (size_t)L->B * 3 * L->C * sizeof(float), st);
+  if (L->C > 0) {
+    (void)hipMemsetAsync(L->poolV, 0, (size_t)L->B * L->C * H * sizeof(float), st);
+    (void)hipMemsetAsync(L->poolX, 0, (size_t)L->B * 3 * L->C * sizeof(float), st);
+  }
   if (L->N == 0) return check_launch("virt_forward(memset)");
   VirtArgs a = make_virt_args(L);
   const int ntg = cdiv(L->N, 16 * VIRT_WAVES);

@@ -11,7 +11,7 @@ constexpr int VIRT_BWD_WAVES = 4;   // 1 wave/SIMD: the adjoint of the virtual b
 
 struct EdgeArgs {
   const float *P, *QX, *QXs, *ea, *wpack;
-  const float *E0W, *b2, *bx1, *wx2, *attw, *attb;
+  const float *E0W, *b2, *bx1, *wx2, *attw, *attb, *bx2;   // bx2: coordinate-head bias (EGNN baseline) or null
   const int32_t *rowptr, *erow, *col, *chunk_row;
   float *aggm, *aggx;
   int n_chunks, ea_dim, flags;
@@ -23,7 +23,7 @@ constexpr int EV_WR = 0, EV_WE = 1, EV_B2 = 9, EV_BX1 = 10, EV_WX2 = 11, EV_ATT 
 __device__ __forceinline__ void edge_load_vecs(float *vec, const EdgeArgs &a) {
   const int ld = 2 * H + 1 + a.ea_dim;
   for (int i = threadIdx.x; i < H; i += blockDim.x) {
-    vec[EV_WR * H + i] = a.E0W[(size_t)i * ld + 2 * H];
+    vec[EV_WR * H + i] = a.E0W[(size_t)i * ld + ((a.flags & FASTEGNN_F_EGNN) ? 0 : 2 * H)];
     for (int k = 0; k < 8; ++k) vec[(EV_WE + k) * H + i] = k < a.ea_dim ? a.E0W[(size_t)i * ld + 2 * H + 1 + k] : 0.f;
     vec[EV_B2 * H + i] = a.b2[i];
     vec[EV_BX1 * H + i] = a.bx1[i];
@@ -109,7 +109,7 @@ __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float
   gemm64(img + 1 * IMG, S.m, S.up);
   FE_T(3)
   S.u = KEEP_D ? vsilu_keep_d(S.up) : vsilu(S.up);
-  const float sraw = vdot(S.u, vload_vec(vec + EV_WX2 * H, q));
+  const float sraw = vdot(S.u, vload_vec(vec + EV_WX2 * H, q)) + (a.bx2 ? a.bx2[0] : 0.f);
   S.s = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sraw) : sraw;
   FE_T(4)   // silu 3 + head dot
 }
@@ -119,7 +119,7 @@ inline EdgeArgs make_edge_args(const fastegnn_layer_t *L) {
   const fastegnn_graph_t &g = L->graph;
   EdgeArgs a{L->P, L->QX, L->QX_src ? L->QX_src : L->QX, L->ea_sorted, L->wpack,
              p[FASTEGNN_P_EDGE0_W], p[FASTEGNN_P_EDGE2_B], p[FASTEGNN_P_CR0_B], p[FASTEGNN_P_CR2_W],
-             p[FASTEGNN_P_ATT_W], p[FASTEGNN_P_ATT_B], g.rowptr, g.erow, g.col, g.chunk_row, L->aggm, L->aggx,
+             p[FASTEGNN_P_ATT_W], p[FASTEGNN_P_ATT_B], p[FASTEGNN_P_CR2_B], g.rowptr, g.erow, g.col, g.chunk_row, L->aggm, L->aggx,
              g.n_chunks, L->ea, L->flags, L->epsilon};
   return a;
 }
@@ -143,12 +143,13 @@ struct VirtFwdState {
 __device__ __forceinline__ void virt_load_vecs(float *vec, const VirtArgs &a) {
   const int ld = 2 * H + 1 + a.C;
   for (int i = threadIdx.x; i < H; i += blockDim.x) {
-    vec[VV_WVR * H + i] = a.V0W[(size_t)i * ld + 2 * H];
-    vec[VV_C2 * H + i] = a.c2[i];
-    vec[VV_BXV0 * H + i] = a.bxv0[i];
-    vec[VV_WXV2 * H + i] = a.wxv2[i];
-    vec[VV_BXX0 * H + i] = a.bxx0[i];
-    vec[VV_WXX2 * H + i] = a.wxx2[i];
+    // the virtual-node parameters are absent (null) for the EGNN baseline (C = 0)
+    vec[VV_WVR * H + i] = a.V0W ? a.V0W[(size_t)i * ld + 2 * H] : 0.f;
+    vec[VV_C2 * H + i] = a.c2 ? a.c2[i] : 0.f;
+    vec[VV_BXV0 * H + i] = a.bxv0 ? a.bxv0[i] : 0.f;
+    vec[VV_WXV2 * H + i] = a.wxv2 ? a.wxv2[i] : 0.f;
+    vec[VV_BXX0 * H + i] = a.bxx0 ? a.bxx0[i] : 0.f;
+    vec[VV_WXX2 * H + i] = a.wxx2 ? a.wxx2[i] : 0.f;
     vec[VV_ATT * H + i] = a.attw ? a.attw[i] : 0.f;
     vec[VV_B3 * H + i] = a.b3[i];
     vec[VV_B4 * H + i] = a.b4[i];

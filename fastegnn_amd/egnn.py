@@ -1,0 +1,187 @@
+"""Drop-in ``EGNN`` baseline (reference ``models/basic.py:285-341``; built at ``main_nbody.py:107`` as
+``EGNN(n_layers, in_node_nf=2, in_edge_nf=2, hidden_nf, device, with_v=True)``) on the same HIP kernels as
+FastEGNN: it is the virtual-channel-free wiring of the stage kernels (``FASTEGNN_F_EGNN``: C = 0, radial
+first in the message MLP's input, coordinate head with bias, +-100 clamp, no residual on h).
+Same constructor / forward signature / state_dict keys as the reference class; GPU only."""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib as K
+from .model import SortedGraph, _PtrTable, _carve, _fill, _new_layer, _stream
+
+H = K.H
+
+
+def _base_mlp(i, h, o, act, last_act=False):
+    mods = [nn.Linear(i, h), act, nn.Linear(h, o)] + ([act] if last_act else [])
+    m = nn.Module()
+    m.mlp = nn.Sequential(*mods)
+    return m
+
+
+class EGNN_Layer(nn.Module):
+    """Parameter holder; construction order of models/basic.py:286-300."""
+
+    def __init__(self, in_edge_nf, hidden_nf, activation, with_v):
+        super().__init__()
+        self.edge_message_net = nn.Module()
+        self.edge_message_net.scalar_net = _base_mlp(1 + 2 * hidden_nf + in_edge_nf, hidden_nf, hidden_nf, activation, True)
+        self.coord_net = _base_mlp(hidden_nf, hidden_nf, 1, activation)
+        self.node_net = _base_mlp(2 * hidden_nf, hidden_nf, hidden_nf, activation)
+        self.node_v_net = _base_mlp(hidden_nf, hidden_nf, 1, activation) if with_v else None
+
+
+_SLOT_OF = {   # FASTEGNN_P_* slot name -> reference key suffix inside layers.<i>
+    "edge_mlp.0.weight": "edge_message_net.scalar_net.mlp.0.weight", "edge_mlp.0.bias": "edge_message_net.scalar_net.mlp.0.bias",
+    "edge_mlp.2.weight": "edge_message_net.scalar_net.mlp.2.weight", "edge_mlp.2.bias": "edge_message_net.scalar_net.mlp.2.bias",
+    "coord_mlp_r.0.weight": "coord_net.mlp.0.weight", "coord_mlp_r.0.bias": "coord_net.mlp.0.bias",
+    "coord_mlp_r.2.weight": "coord_net.mlp.2.weight", "coord_mlp_r.2.bias": "coord_net.mlp.2.bias",
+    "node_mlp.0.weight": "node_net.mlp.0.weight", "node_mlp.0.bias": "node_net.mlp.0.bias",
+    "node_mlp.2.weight": "node_net.mlp.2.weight", "node_mlp.2.bias": "node_net.mlp.2.bias",
+    "coord_mlp_vel.0.weight": "node_v_net.mlp.0.weight", "coord_mlp_vel.0.bias": "node_v_net.mlp.0.bias",
+    "coord_mlp_vel.2.weight": "node_v_net.mlp.2.weight", "coord_mlp_vel.2.bias": "node_v_net.mlp.2.bias",
+}
+
+
+class _EGNNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, graph, ea_sorted, x, h_in, v, *params):
+        lib = K.lib()
+        dev = x.device
+        st = _stream(dev)
+        N = x.size(0)
+        f32 = dict(dtype=torch.float32, device=dev)
+        params = [p.detach() for p in params]
+        x, h_in, v = x.detach().contiguous().float(), h_in.detach().contiguous().float(), v.detach().contiguous().float()
+        batch = torch.zeros(N, dtype=torch.int32, device=dev)
+        h = torch.empty(N, H, **f32)
+        K.check(lib.fastegnn_embed_forward(K.ptr(h_in), N, spec.nf, K.ptr(params[0]), K.ptr(params[1]), K.ptr(h), st),
+                "fastegnn_embed_forward")
+        nwp = lib.fastegnn_wpack_floats(0)
+        saved = []
+        for i in range(spec.n_layers):
+            tab = _PtrTable([params[s] if s is not None else None for s in spec.layer_slots[i]])
+            b = dict(h=h, x=x)
+            b.update(_carve(dev, dict(wpack=(nwp,), P=(N, H), QX=(N, K.QX_LD), A=(N, H), svel=(N,), aggm=(N, H),
+                                      aggx=(N, 3), npre=(N, H))))
+            b.update(h_out=torch.empty(N, H, **f32), x_out=torch.empty(N, 3, **f32))
+            L = _new_layer(spec, N, 1, graph)
+            _fill(L, batch=batch, vel=v, params=tab.addr(), **b)
+            L.QX_src = b["QX"].data_ptr()
+            if ea_sorted is not None:
+                L.ea_sorted = ea_sorted.data_ptr()
+            K.check(lib.fastegnn_layer_forward(C.byref(L), st), f"fastegnn_layer_forward[egnn {i}]")
+            saved.append(b)
+            h, x = b["h_out"], b["x_out"]
+            del b["h_out"], b["x_out"]
+        ctx.spec, ctx.graph, ctx.saved = spec, graph, saved
+        ctx.misc = (batch, ea_sorted, h_in, v, params)
+        return x, h
+
+    @staticmethod
+    def backward(ctx, g_x, g_h):
+        lib = K.lib()
+        spec, graph, saved = ctx.spec, ctx.graph, ctx.saved
+        batch, ea_sorted, h_in, v, params = ctx.misc
+        dev = v.device
+        st = _stream(dev)
+        N, E = v.size(0), graph.E
+        f32 = dict(dtype=torch.float32, device=dev)
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]
+        flat = torch.zeros(sum(sizes), **f32)
+        grads, off = [], 0
+        for p, s in zip(params, sizes):
+            grads.append(flat[off:off + p.numel()].view_as(p))
+            off += s
+        g_h = (g_h if g_h is not None else torch.zeros(N, H, **f32)).contiguous().float()
+        g_x = (g_x if g_x is not None else torch.zeros(N, 3, **f32)).contiguous().float()
+        g_vel = torch.zeros(N, 3, **f32)
+        sc = _carve(dev, dict(g_A=(N, H), g_P=(N, H), g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,),
+                              g_QXe=(max(E, 1), K.QX_LD), g_QX_src=(N, K.QX_LD), g_xrow=(N, 3),
+                              wg_edge=(max(E, 1) * 4 * H,), wg_node=(8 * N * H,), wg_slab=(lib.fastegnn_wg_slab_floats(),)))
+        sc["g_xbar"] = torch.zeros(1, 4, **f32)
+        for i in reversed(range(spec.n_layers)):
+            b = saved[i]
+            ptab = _PtrTable([params[s] if s is not None else None for s in spec.layer_slots[i]])
+            gtab = _PtrTable([grads[s] if s is not None else None for s in spec.layer_slots[i]])
+            out = dict(g_h=torch.empty(N, H, **f32), g_x=torch.empty(N, 3, **f32))
+            L = _new_layer(spec, N, 1, graph)
+            _fill(L, batch=batch, vel=v, params=ptab.addr(), grads=gtab.addr(), g_h_out=g_h, g_x_out=g_x, g_vel=g_vel,
+                  **b, **out, **sc)
+            L.QX_src = b["QX"].data_ptr()
+            L.g_QX = sc["g_QX_src"].data_ptr()
+            if ea_sorted is not None:
+                L.ea_sorted = ea_sorted.data_ptr()
+            K.check(lib.fastegnn_layer_backward(C.byref(L), st), f"fastegnn_layer_backward[egnn {i}]")
+            g_h, g_x = out["g_h"], out["g_x"]
+            saved[i] = None
+        g_hin = torch.empty_like(h_in) if ctx.needs_input_grad[4] else None
+        K.check(lib.fastegnn_embed_backward(K.ptr(h_in), K.ptr(g_h), N, spec.nf, K.ptr(params[0]), K.ptr(grads[0]),
+                                            K.ptr(grads[1]), K.ptr(g_hin), st), "fastegnn_embed_backward")
+        return (None, None, None, g_x, g_hin, g_vel, *grads)
+
+
+class EGNN(nn.Module):
+    """MI355X-native drop-in for the reference ``EGNN`` (models/basic.py:323-341)."""
+
+    def __init__(self, n_layers, in_node_nf, in_edge_nf, hidden_nf, activation=nn.SiLU(), device='cpu', with_v=False,
+                 flat=False, norm=False):
+        super().__init__()
+        if hidden_nf != H or flat or norm or not isinstance(activation, nn.SiLU):
+            raise NotImplementedError("fastegnn_amd.EGNN: hidden_nf=64, SiLU, flat=False, norm=False only")
+        if in_edge_nf > 7 or in_node_nf > 8:
+            raise NotImplementedError("fastegnn_amd.EGNN: in_edge_nf<=7, in_node_nf<=8")
+        self.n_layers, self.with_v = n_layers, with_v
+        self.in_node_nf, self.in_edge_nf = in_node_nf, in_edge_nf
+        self.layers = nn.ModuleList()                      # registered first, filled after the embedding (basic.py:327-335)
+        self.embedding = nn.Linear(in_node_nf, hidden_nf)
+        for _ in range(n_layers):
+            self.layers.append(EGNN_Layer(in_edge_nf, hidden_nf, activation, with_v))
+        self._spec = None
+        self._graph_cache = {}
+        self.to(device)
+
+    def _build_spec(self):
+        pidx = dict(self.named_parameters())
+        names = ["embedding.weight", "embedding.bias"]
+        layer_slots: List[List[Optional[int]]] = []
+        for i in range(self.n_layers):
+            slots = []
+            for slot in K.PARAM_SLOTS:
+                key = f"layers.{i}.{_SLOT_OF[slot]}" if slot in _SLOT_OF else None
+                if key is not None and key in pidx:
+                    slots.append(len(names))
+                    names.append(key)
+                else:
+                    slots.append(None)
+            layer_slots.append(slots)
+        self._plist = [pidx[n] for n in names]
+        self._spec = SimpleNamespace(C=0, ea=self.in_edge_nf, na=0, nf=self.in_node_nf, n_layers=self.n_layers,
+                                     flags=K.F_EGNN, gravity=[0.0, 0.0, 0.0], layer_slots=layer_slots, names=names)
+
+    def forward(self, x, h, edge_index, edge_fea, v=None):
+        if not x.is_cuda:
+            raise RuntimeError("fastegnn_amd.EGNN runs on a gfx950 GPU only (no CPU fallback)")
+        if edge_fea is not None and edge_fea.requires_grad:
+            raise NotImplementedError("fastegnn_amd: gradient w.r.t. edge_fea is not implemented")
+        if self._spec is None:
+            self._build_spec()
+        N = x.size(0)
+        key = (edge_index.data_ptr(), edge_index.size(1), edge_index._version, N)
+        graph = self._graph_cache.get(key)
+        if graph is None:
+            graph = SortedGraph(edge_index, N)
+            graph._keepalive = edge_index
+            if len(self._graph_cache) >= 8:
+                self._graph_cache.pop(next(iter(self._graph_cache)))
+            self._graph_cache[key] = graph
+        ea_sorted = graph.permute(edge_fea.detach() if edge_fea is not None else None)
+        vv = v if v is not None else torch.zeros_like(x)
+        x_out, h_out = _EGNNFunction.apply(self._spec, graph, ea_sorted, x, h, vv, *self._plist)
+        return (x_out, v, h_out) if v is not None else (x_out, h_out)

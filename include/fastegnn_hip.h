@@ -50,7 +50,11 @@ enum {
   FASTEGNN_F_TANH = 4,
   FASTEGNN_F_RESIDUAL = 8,
   FASTEGNN_F_GRAVITY = 16,
-  FASTEGNN_F_COORDS_SUM = 32 /* coords_agg='sum' (default 'mean') */
+  FASTEGNN_F_COORDS_SUM = 32, /* coords_agg='sum' (default 'mean') */
+  /* EGNN baseline layer (models/basic.py:285-320) on the same kernels: C = 0 (no virtual nodes),
+   * edge_mlp.0 columns ordered [radial | h_row | h_col | edge_attr] (:313), coordinate head with bias,
+   * aggregated coordinate message clamped to +-100 (:310), no residual on h, velocity head optional */
+  FASTEGNN_F_EGNN = 64
 };
 
 /* Per-layer parameter slots: the reference state_dict tensors of gcl_<i>, untouched
@@ -93,6 +97,7 @@ enum {
   FASTEGNN_P_NODEV0_B,
   FASTEGNN_P_NODEV2_W,    /* node_mlp_virtual.2.weight  [64,64] */
   FASTEGNN_P_NODEV2_B,
+  FASTEGNN_P_CR2_B,       /* coord head bias [1] (EGNN baseline only: coord_net.mlp.2.bias) */
   FASTEGNN_P_COUNT
 };
 

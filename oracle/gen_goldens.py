@@ -308,7 +308,65 @@ def train_case(FastEGNN, name, nb, *, C=3, L=2, seed=43, sigma=1.5, weight=0.01,
     print(f"{name}: N={N} B={B} S={S} losses={losses} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def egnn_cases():
+    """Row A13 of SURVEY 8a: the EGNN baseline (models/basic.py:285-341).  basic.py imports torch_sparse /
+    torch_scatter / torch_geometric.nn.MessagePassing at module level (:6-8); EGNN never calls them, so inert
+    stand-ins are enough."""
+    _install_pyg_stand_in()
+    sys.modules["torch_geometric.nn"].MessagePassing = type("MessagePassing", (torch.nn.Module,), {})
+    for name, attr in (("torch_sparse", "spmm"), ("torch_scatter", "scatter_add")):
+        mod = types.ModuleType(name)
+        setattr(mod, attr, lambda *a, **k: (_ for _ in ()).throw(RuntimeError("stand-in")))
+        sys.modules[name] = mod
+    sys.path.insert(0, REF)
+    from models.basic import EGNN
+
+    def case(name, seed, with_v, coord_scale=1.0, L=2, loc_scale=2.0):
+        torch.manual_seed(seed)
+        gen = torch.Generator().manual_seed(seed + 100)
+        model = EGNN(n_layers=L, in_node_nf=2, in_edge_nf=2, hidden_nf=64, device="cpu", with_v=with_v)
+        with torch.no_grad():
+            for k, v in model.named_parameters():
+                if "coord_net.mlp.2" in k:
+                    v.mul_(coord_scale)
+        sizes = [7, 4, 9]
+        ei, batch = _rand_graph_batch(gen, sizes, [25, 10, 25], isolate=(2, 3))
+        N = sum(sizes)
+        inp = dict(x=torch.randn(N, 3, generator=gen) * loc_scale, h=torch.rand(N, 2, generator=gen), edge_index=ei,
+                   edge_fea=torch.rand(ei.size(1), 2, generator=gen))
+        if with_v:
+            inp["v"] = torch.randn(N, 3, generator=gen) * 0.5
+        leaf = {k: inp[k].clone().requires_grad_(True) for k in ("x", "h") + (("v",) if with_v else ())}
+        out = model(**{**inp, **leaf})
+        x_out, h_out = out[0], out[-1]
+        target = inp["x"] + torch.randn(N, 3, generator=gen)
+        wh = torch.randn(N, 64, generator=gen)
+        loss = torch.nn.functional.mse_loss(x_out, target) + 0.05 * (h_out * wh).sum() / N
+        loss.backward()
+        rec = {f"in/{k}": v.numpy() for k, v in inp.items()}
+        rec["in/target"], rec["in/wh"] = target.numpy(), wh.numpy()
+        for k, v in model.state_dict().items():
+            rec[f"p/{k}"] = v.numpy()
+        rec["out/x"], rec["out/h"], rec["out/loss"] = x_out.detach().numpy(), h_out.detach().numpy(), np.array(loss.item())
+        for k, v in model.named_parameters():
+            rec[f"gp/{k}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
+        for k, v in leaf.items():
+            rec[f"gin/{k}"] = v.grad.numpy()
+        rec["meta/with_v"], rec["meta/L"] = np.array(int(with_v)), np.array(L)
+        path = os.path.join(OUT, f"{name}.npz")
+        np.savez_compressed(path, **rec)
+        clamped = float((x_out.detach() - inp["x"]).abs().max())
+        print(f"{name}: N={N} E={ei.size(1)} loss={loss.item():.5f} max|dx|={clamped:.2f} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+    case("egnn_with_v", 21, True)
+    case("egnn_no_v", 22, False)
+    case("egnn_clamped", 23, True, coord_scale=4000.0, loc_scale=6.0)    # tot_f hits the +-100 clamp (:310)
+
+
 def main():
+    if "--egnn" in sys.argv:
+        egnn_cases()
+        return
     FastEGNN = _import_reference()
     if "--train-only" in sys.argv:
         nb = nbody_case()
