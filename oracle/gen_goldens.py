@@ -363,7 +363,67 @@ def egnn_cases():
     case("egnn_clamped", 23, True, coord_scale=4000.0, loc_scale=6.0)    # tot_f hits the +-100 clamp (:310)
 
 
+def dataset_case(n_systems=6, n_balls=5, seed=43):
+    """Row 8f-3: a tiny on-disk N-body dataset written by the reference's own simulator in the
+    reference's file format (generate_dataset.py:84-92 -> {loc,vel,edges,charges}_<partition>_charged<name>.npy)
+    and the graphs the reference's reader builds from it (datasets/nbody/dataset.py:14-113, with a
+    plain-attribute stand-in for torch_geometric.data.Data).  The .npy files are committed as fixtures
+    (data); the expected per-graph tensors go to dataset_nbody5.npz."""
+    import pickle, tempfile
+    sys.path.insert(0, os.path.join(REF, "datasets", "nbody", "datagen"))
+    from system import System
+    np.random.seed(seed)
+    loc, vel, edges, charges, cfgs = [], [], [], [], []
+    for _ in range(n_systems):
+        s = System(n_isolated=n_balls, n_stick=0, n_hinge=0)
+        X, V = [], []
+        for t in range(4100):
+            s.simulate_one_step()
+            if t % 100 == 0:
+                X.append(s.X.copy()); V.append(s.V.copy())
+        loc.append(np.array(X)); vel.append(np.array(V)); edges.append(s.edges); charges.append(s.charges)
+        cfgs.append(s.configuration())
+    name = f"{n_balls}_0_0"
+    fix = os.path.join(OUT, "nbody_tiny")
+    os.makedirs(fix, exist_ok=True)
+    tmp = tempfile.mkdtemp()
+    for d in (fix, tmp):
+        np.save(os.path.join(d, f"loc_train_charged{name}.npy"), np.array(loc))
+        np.save(os.path.join(d, f"vel_train_charged{name}.npy"), np.array(vel))
+        np.save(os.path.join(d, f"edges_train_charged{name}.npy"), np.array(edges))
+        np.save(os.path.join(d, f"charges_train_charged{name}.npy"), np.array(charges))
+    with open(os.path.join(tmp, f"cfg_train_charged{name}.pkl"), "wb") as f:   # the reference reader opens it
+        pickle.dump(cfgs, f)
+
+    class Data:   # stand-in: attribute bag with .to()
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+        def to(self, *_a, **_k):
+            return self
+        def __repr__(self):
+            return "Data(" + ", ".join(f"{k}={list(v.shape)}" for k, v in self.__dict__.items()) + ")"
+    tg = types.ModuleType("torch_geometric"); tgd = types.ModuleType("torch_geometric.data")
+    tgd.Data = Data; tg.data = tgd
+    sys.modules["torch_geometric"] = tg; sys.modules["torch_geometric.data"] = tgd
+    sys.path.insert(0, REF)
+    from datasets.nbody.dataset import NBodySystemDataset
+    out = {}
+    for tag, rate, C, ms in (("r50", 0.5, 3, 1e8), ("r00", 0.0, 2, 4), ("r30", 0.3, 3, 1e8)):
+        ds = NBodySystemDataset(name, tmp, virtual_channels=C, partition="train", max_samples=ms, frame_0=30, frame_T=40,
+                                cutoff_rate=rate)
+        out[f"{tag}/n"] = np.array(len(ds)); out[f"{tag}/C"] = np.array(C); out[f"{tag}/rate"] = np.array(rate)
+        out[f"{tag}/max_samples"] = np.array(int(ms))
+        for i in range(len(ds)):
+            for k, v in ds[i].__dict__.items():
+                out[f"{tag}/{i}/{k}"] = v.detach().cpu().numpy()
+    np.savez_compressed(os.path.join(OUT, "dataset_nbody5.npz"), **out)
+    print("dataset_nbody5:", len(out), "arrays")
+
+
 def main():
+    if "--dataset" in sys.argv:
+        dataset_case()
+        return
     if "--egnn" in sys.argv:
         egnn_cases()
         return

@@ -62,3 +62,34 @@ def test_device_built_graph_feeds_the_model():
             data_batch=torch.zeros(N, dtype=torch.long).cuda(), loc_mean=loc.mean(0).view(1, 3, 1).repeat(1, 1, 3).cuda(),
             edge_attr=torch.stack([d, d], 1))
     assert torch.isfinite(out[0]).all()
+
+
+def test_water3d_frames_collate_and_train_on_device():
+    """Row 8f-3 on the GPU: positions -> water3d_frame (device radius graph + cutoff) -> collate -> one
+    training step, i.e. the loop body of utils/train.py:30-179 with every tensor resident on the device."""
+    import fastegnn_amd
+    from fastegnn_amd import data as D
+    from fastegnn_amd.train import FusedAdam, train_step
+    g = torch.Generator().manual_seed(3)
+    frames = []
+    for n in (1500, 2200):
+        pos = (torch.rand(n, 3, generator=g) * 0.25).cuda()
+        vel = (torch.randn(n, 3, generator=g) * 0.003).cuda()
+        kind = torch.randint(1, 4, (n, 1), generator=g).float().cuda()
+        f = D.water3d_frame(pos, vel, pos + 15 * vel, kind, virtual_channels=4, radius=0.035, cutoff_rate=0.5)
+        # the frame equals the host restatement of get_graph_step
+        ref = G.cutoff_edges(*G.radius_graph_bruteforce(pos.cpu(), 0.035), 0.5)
+        assert sorted(zip(*f.edge_index.cpu().tolist())) == sorted(zip(*ref[0].tolist()))
+        torch.testing.assert_close(f.node_feat[:, 0].cpu(), vel.cpu().norm(dim=1))
+        torch.testing.assert_close(f.node_feat[:, 1], kind[:, 0] / kind.max())
+        assert f.loc_mean.shape == (1, 3, 4)
+        frames.append(f)
+    b = D.collate(frames)
+    assert b["ptr"].tolist() == [0, 1500, 3700] and b["edge_index"].is_cuda
+    assert torch.equal(b["batch"][b["edge_index"][0]], b["batch"][b["edge_index"][1]])
+    m = fastegnn_amd.FastEGNN(2, 0, 2, 64, 4, device="cuda", n_layers=2, gravity=[0, -1, 0])
+    opt = FusedAdam(m.parameters(), lr=5e-4, weight_decay=1e-12)
+    sample = torch.stack([torch.randperm(1500, generator=g)[:12], 1500 + torch.randperm(2200, generator=g)[:12]]).cuda()
+    l0, mse0 = train_step(m, opt, b, sample_nodes=sample, sigma=1.0, weight=0.01)
+    l1, mse1 = train_step(m, opt, b, sample_nodes=sample, sigma=1.0, weight=0.01)
+    assert np.isfinite(float(l0)) and np.isfinite(float(l1)) and float(mse1) != float(mse0)
