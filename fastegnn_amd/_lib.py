@@ -78,6 +78,8 @@ def lib():
     L.fastegnn_wpack_floats.argtypes = [_i32]
     L.fastegnn_csr_tmp_bytes.restype = C.c_size_t
     L.fastegnn_csr_tmp_bytes.argtypes = [_i32, _i32, _i32]
+    L.fastegnn_chunk_rows.restype = C.c_size_t
+    L.fastegnn_chunk_rows.argtypes = [_i32]
     L.fastegnn_build_csr.argtypes = [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      C.POINTER(_i32), _vp, C.c_size_t, _vp]
     L.fastegnn_permute_rows.argtypes = [_vp, _vp, _i32, _i32, _vp, _vp]
@@ -101,6 +103,7 @@ def lib():
     L.fastegnn_selftest_chain.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _vp]
     L.fastegnn_selftest_chain_bf3.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
     L.fastegnn_selftest_wgrad.argtypes = [_vp, _vp, _i32, _vp, _vp, _vp, _vp]
+    L.fastegnn_selftest_stream.argtypes = [_vp, _vp, C.c_size_t, _i32, _vp]
     L.fastegnn_wg_slab_floats.restype = C.c_size_t
     L.fastegnn_sizeof_layer.restype = C.c_size_t
     L.fastegnn_sizeof_graph.restype = C.c_size_t
@@ -128,10 +131,10 @@ STAGE_FUNCS = [
 
 # every symbol include/fastegnn_hip.h declares (checked by tests/test_abi_cpu.py)
 EXPORTED = STAGE_FUNCS + [
-    "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes",
+    "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes", "fastegnn_chunk_rows",
     "fastegnn_build_csr", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
-    "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_wgrad", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
+    "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_wgrad", "fastegnn_selftest_stream", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
     "fastegnn_augment_edge_attr", "fastegnn_loss_mse_mmd", "fastegnn_adam_step",
     "fastegnn_radius_graph_ws_bytes", "fastegnn_radius_graph_count", "fastegnn_radius_graph_fill",
     "fastegnn_cutoff_tmp_bytes", "fastegnn_cutoff_edges",

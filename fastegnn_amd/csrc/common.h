@@ -28,6 +28,11 @@ struct Vec {
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// wave index in the workgroup / in the grid, as scalars: everything derived from them (chunk bounds,
+// row pointers, loop trip counts) then lives in SGPRs, is fetched with scalar loads and branches on scc
+// instead of exec masks
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int global_wave_id() { return (int)(blockIdx.x * (blockDim.x >> 6)) + wave_id(); }
 
 // ---- activations (fp32; v_exp_f32 / v_rcp_f32 are ~1 ulp) ----
 __device__ __forceinline__ float sigmoid_f(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
@@ -259,48 +264,40 @@ __device__ __forceinline__ Split vsplit(const Vec &v) {
   }
   return S;
 }
-// hm: parts h and m of the split image (4096 words, normally LDS resident); lp: part l (2048 words,
-// read from global/L2: it feeds only one of the six products, so keeping it out of LDS makes a
-// split image cost the same 16 KB of LDS as an fp32 image).
-__device__ __forceinline__ void gemm64_bf3(const unsigned *hm, const unsigned *lp, const Split &in, Vec &acc) {
-  const u32x4 *ih = reinterpret_cast<const u32x4 *>(hm) + lane_id();
-  const u32x4 *il = reinterpret_cast<const u32x4 *>(lp) + lane_id();
-  u32x4 al[8];
-#pragma unroll
-  for (int f = 0; f < 8; ++f) al[f] = il[f * 64];          // issue the global fetch first
-  // smallest terms first: (weight part, activation part) = (h,l) (m,m) | (l,h) | (h,m) (m,h) (h,h)
+// img3: split image, IMG3 words = parts h | m | l (2048 words each), normally LDS resident.
+__device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Split &in, Vec &acc) {
+  const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + lane_id();
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, ih[(t * 2 + s) * 64]);
-      const bf16x8 am = __builtin_bit_cast(bf16x8, ih[512 + (t * 2 + s) * 64]);
-      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, in.p[2][s]), acc.t[t], 0, 0, 0);
-      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8, in.p[1][s]), acc.t[t], 0, 0, 0);
-    }
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[t * 2 + s]),
-                                                         __builtin_bit_cast(bf16x8, in.p[0][s]), acc.t[t], 0, 0, 0);
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, ih[(t * 2 + s) * 64]);
-      const bf16x8 am = __builtin_bit_cast(bf16x8, ih[512 + (t * 2 + s) * 64]);
-      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, in.p[1][s]), acc.t[t], 0, 0, 0);
-      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(bf16x8, in.p[0][s]), acc.t[t], 0, 0, 0);
-      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, in.p[0][s]), acc.t[t], 0, 0, 0);
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, ip[(t * 2 + s) * 64]);
+      const bf16x8 am = __builtin_bit_cast(bf16x8, ip[512 + (t * 2 + s) * 64]);
+      const bf16x8 al = __builtin_bit_cast(bf16x8, ip[1024 + (t * 2 + s) * 64]);
+      const bf16x8 xh = __builtin_bit_cast(bf16x8, in.p[0][s]);
+      const bf16x8 xm = __builtin_bit_cast(bf16x8, in.p[1][s]);
+      const bf16x8 xl = __builtin_bit_cast(bf16x8, in.p[2][s]);
+      // smallest terms first: (weight part, activation part) = (l,h) (m,m) (h,l) | (m,h) (h,m) | (h,h)
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xm, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xh, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xm, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc.t[t], 0, 0, 0);
     }
 }
+__device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Vec &in, Vec &acc) { gemm64_x3(img3, vsplit(in), acc); }
 
 // cooperative copy of n_img consecutive images global -> LDS (16-byte moves)
 __device__ __forceinline__ void load_images(float *dst, const float *src, int n_img) {
   const f32x4 *s = reinterpret_cast<const f32x4 *>(src);
   f32x4 *d = reinterpret_cast<f32x4 *>(dst);
   for (int i = threadIdx.x; i < n_img * (IMG / 4); i += blockDim.x) d[i] = s[i];
+}
+__device__ __forceinline__ void load_images_x3(unsigned *dst, const unsigned *src, int n_img) {
+  const u32x4 *s = reinterpret_cast<const u32x4 *>(src);
+  u32x4 *d = reinterpret_cast<u32x4 *>(dst);
+  for (int i = threadIdx.x; i < n_img * (IMG3 / 4); i += blockDim.x) d[i] = s[i];
 }
 __device__ __forceinline__ void load_floats(float *dst, const float *src, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src ? src[i] : 0.f;
@@ -325,10 +322,11 @@ enum ImgId {
 };
 __host__ __device__ inline int img_w3c(int c) { return I_FIXED + c; }
 __host__ __device__ inline int img_w3ct(int C, int c) { return I_FIXED + C + c; }
-// wpack = [fp32 images n x 4096][hm split images n x 4096 words][l split images n x 2048 words]
+// wpack = [fp32 images n x 4096 floats][split images n x IMG3 words (h | m | l)]
 __host__ __device__ inline size_t wpack_images(int C) { return (size_t)(I_FIXED + 2 * C); }
-__host__ __device__ inline size_t wpack_floats(int C) { return wpack_images(C) * (IMG + IMG + IMG / 2); }
-__host__ __device__ inline size_t wpack_hm_off(int C) { return wpack_images(C) * IMG; }
-__host__ __device__ inline size_t wpack_l_off(int C) { return wpack_images(C) * 2 * IMG; }
+__host__ __device__ inline size_t wpack_floats(int C) { return wpack_images(C) * (IMG + IMG3); }
+__host__ __device__ inline const unsigned *wpack_x3(const float *wpack, int C, int id) {
+  return reinterpret_cast<const unsigned *>(wpack + wpack_images(C) * IMG) + (size_t)id * IMG3;
+}
 
 }  // namespace fe

@@ -8,7 +8,10 @@
 
 namespace fe {
 
-constexpr int CHUNK_EDGES = 256;
+#ifndef FE_CHUNK_EDGES
+#define FE_CHUNK_EDGES 32
+#endif
+constexpr int CHUNK_EDGES = FE_CHUNK_EDGES;   // the unit in which the edge kernels split rows among waves
 
 __global__ void csr_keys_kernel(const int64_t *ei, int E, int row_begin, int32_t *keys, int32_t *vals) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,6 +57,8 @@ static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 using namespace fe;
 
 extern "C" {
+
+size_t fastegnn_chunk_rows(int32_t E) { return (size_t)(E / CHUNK_EDGES + 2); }
 
 size_t fastegnn_csr_tmp_bytes(int32_t E, int32_t n_rows, int32_t n_src) {
   (void)n_rows; (void)n_src;

@@ -4,6 +4,11 @@
 // operands of the 64x64 weight gradients are written once ([rows,64]) and contracted by the
 // generic wgrad_tn kernel (misc.hip).
 #include "stages.h"
+#ifdef FE_DIAG_NOSTORE
+#define WG_STORE(x)
+#else
+#define WG_STORE(x) x
+#endif
 
 namespace fe {
 
@@ -35,7 +40,7 @@ struct GraphPostBwdArgs {
 };
 __global__ __launch_bounds__(256) void graph_post_bwd_kernel(GraphPostBwdArgs a) {
   const int l = lane_id(), j = l & 15, q = l >> 4;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int M = a.B * a.C, ntiles = (M + 15) >> 4;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.B * 3 * a.C; i += gridDim.x * blockDim.x) {
     const int b = i / (3 * a.C);
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) gBc_l[i] = 0.f;
   __syncthreads();
-  const int l = lane_id(), j = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
   float *tile = tiles + wv * 16 * TS;
   constexpr int GROUP = 16 * VIRT_BWD_WAVES;
   const int ntg = (a.N + GROUP - 1) / GROUP;
@@ -212,19 +217,43 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       }
       Vec g_A = vzero();
       const float *Zb = a.Z + (size_t)b * 3 * C;
+      // Channel-invariant rows stay in registers, and the per-channel rows of channel c+1 are requested
+      // at the top of channel c, ahead of that channel's operand stores: a load issued after the
+      // stores could only be waited for together with them (vmcnt counts stores too).
+      const Vec Arow = vload_u(b_A, offN);
+      const Vec g_np_m = vmask(g_np, valid);
+      Vec nBc = vload_u(a.Bc, offB), nGpv = vload_u(A.g_poolV, offB);
+      float nZ[3] = {Zb[0], Zb[C], Zb[2 * C]}, nGpx[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C];
       for (int c = 0; c < C; ++c) {
         // Recompute the forward of (tile, c) interleaved with its adjoint so that each activation is
         // dead as soon as its gradient is formed.
         asm volatile("" ::: "memory");
-        const unsigned oc = offNC + (unsigned)c * H, ob = offB + (unsigned)c * H;
-        float vd[3];
-        vd[0] = Zb[c] - xi[0];
-        vd[1] = Zb[C + c] - xi[1];
-        vd[2] = Zb[2 * C + c] - xi[2];
+        const unsigned oc = offNC + (unsigned)c * H;
+        const Vec Bc_c = nBc, gpv_c = nGpv;
+        float vd[3], gpX[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          vd[k] = nZ[k] - xi[k];
+          gpX[k] = valid ? nGpx[k] : 0.f;
+        }
+        {
+          const int cn = c + 1 < C ? c + 1 : c;
+          const unsigned obn = offB + (unsigned)cn * H;
+          nBc = vload_u(a.Bc, obn);
+          nGpv = vload_u(A.g_poolV, obn);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            nZ[k] = Zb[k * C + cn];
+            nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C + cn];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         const float vr = sqrt_f(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
         auto make_pre = [&]() {
-          Vec p = vload_u(b_A, offN);
-          vadd(p, vload_u(a.Bc, ob));
+          Vec p = Arow;
+          vadd(p, Bc_c);
           vaxpy(p, vr, vload_vec(vec + VV_WVR * H, q));
           return p;
         };
@@ -232,7 +261,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         Vec d_pre = make_pre();
         {
           const Vec t = vsilu_keep_d(d_pre);      // d_pre <- silu'(pre)
-          if (valid) vstore_u(b_t, oc, t);
+          WG_STORE(if (valid) vstore_u(b_t, oc, t);)
           gemm64(img + 0 * IMG, t, vp);
         }
         const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
@@ -242,13 +271,11 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + a.attb[0]);
           v = vscale(v0, att);
         }
-        if (valid) vstore_u(b_v, oc, v);
+        WG_STORE(if (valid) vstore_u(b_v, oc, v);)
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
-        Vec g_v = vmask(vload_u(A.g_poolV, ob), valid);
-        gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, vmask(vload_u(b_gnp, offN), valid), g_v);
-        float gpX[3], g_vd[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gpX[k] = valid ? A.g_poolX[((size_t)b * 3 + k) * C + c] : 0.f;
+        Vec g_v = vmask(gpv_c, valid);
+        gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);
+        float g_vd[3];
         float sx, sX;
         {  // coord_mlp_r_virtual head: forward, then its adjoint
           Vec uxp = vload_vec(vec + VV_BXV0 * H, q);
@@ -262,7 +289,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           const float g_sr = tanh_on ? g_sx * (1.f - sx * sx) : g_sx;
           vaxpy(acc_wxv2, g_sr, ux);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
-          if (valid) vstore_u(b_gux, oc, g_up);
+          WG_STORE(if (valid) vstore_u(b_gux, oc, g_up);)
           gemm64(img + 4 * IMG, g_up, g_v);
         }
         {  // coord_mlp_v_virtual head
@@ -277,7 +304,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           const float g_sr = tanh_on ? g_sX * (1.f - sX * sX) : g_sX;
           vaxpy(acc_wxx2, g_sr, uX);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
-          if (valid) vstore_u(b_guX, oc, g_up);
+          WG_STORE(if (valid) vstore_u(b_guX, oc, g_up);)
           gemm64(img + 5 * IMG, g_up, g_v);
         }
 #pragma unroll
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         Vec g_t = vzero();
         {
           const Vec g_vp = vmul(g_v0, vp);
-          if (valid) vstore_u(b_gvp, oc, g_vp);
+          WG_STORE(if (valid) vstore_u(b_gvp, oc, g_vp);)
           gemm64(img + 3 * IMG, g_vp, g_t);
         }
         const Vec g_pre = vmul(g_t, d_pre);
@@ -514,23 +541,25 @@ struct EdgeBwdArgs {
   float *wg_gmp, *wg_t, *wg_gup, *wg_m;
   float *d_wx2, *d_attw, *d_attb, *d_bx2;
   float *d_wr, *d_we;   // edge_mlp.0.weight grad: radial column and first edge_attr column (row stride ld_e0)
-  int ld_e0;
+  int ld_e0, C;
 };
 constexpr int XT = 4;   // per-edge scalar row in LDS: g_d[3] | pad
+constexpr int EDGE_BWD_IMG_FLOATS = BWD_X3 ? 4 * IMG3 : 4 * IMG;
 
 __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const EdgeArgs &a = A.f;
-  float *img = lds;                    // W2, WX1, W2T, WX1T
-  float *vec = lds + 4 * IMG;
+  float *img = lds;                    // W2, WX1, W2T, WX1T (fp32 or split images)
+  float *vec = lds + EDGE_BWD_IMG_FLOATS;
   float *tiles = vec + EV_COUNT * H;
-  load_images(img, a.wpack + (size_t)I_W2 * IMG, 4);
+  if constexpr (BWD_X3) load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, A.C, I_W2), 4);
+  else load_images(img, a.wpack + (size_t)I_W2 * IMG, 4);
   edge_load_vecs(vec, a);
   __syncthreads();
-  const int l = lane_id(), j = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
   float *pt = tiles + wv * (16 * TS + 16 * XT);
   float *xt = pt + 16 * TS;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);
   float accW[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // [radial | edge_attr] columns of edge_mlp.0, lane = out
   const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION,
@@ -538,9 +567,10 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
   Vec acc_wx2 = vzero(), acc_att = vzero();
   float acc_attb = 0.f, acc_bx2 = 0.f;
   FE_T0()
-  for (int ch = wave; ch < a.n_chunks; ch += nwaves) {
-    const int r0 = a.chunk_row[ch], r1 = a.chunk_row[ch + 1];
-    if (r0 >= r1) continue;
+  // this wave's share: a contiguous run of whole rows holding ~E/nwaves edges (see edge_fwd_kernel)
+  const int c0 = (int)((long)wave * a.n_chunks / nwaves), c1 = (int)((long)(wave + 1) * a.n_chunks / nwaves);
+  const int r0 = a.chunk_row[c0], r1 = a.chunk_row[c1];
+  if (r0 < r1) {
     const int e0 = a.rowptr[r0], e1 = a.rowptr[r1];
     int cur = -1;
     float acc = 0.f, accx = 0.f;
@@ -557,13 +587,13 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
       edge_load_idx(a, e, cur_i);
       EdgeFwdState S;
       Vec pre;
-      edge_tile_forward<true>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
+      edge_tile_forward<true, BWD_X3>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
       const int dg = a.rowptr[S.row + 1] - a.rowptr[S.row];
       const float inv = valid ? rcp_f((float)(dg > 1 ? dg : 1)) : 0.f;
       const float invx = valid ? (mean ? inv : 1.f) : 0.f;
       if (valid) {
-        vstore_row(A.wg_t + (size_t)e * H, q, S.t);
-        vstore_row(A.wg_m + (size_t)e * H, q, S.m);
+        WG_STORE(vstore_row(A.wg_t + (size_t)e * H, q, S.t);)
+        WG_STORE(vstore_row(A.wg_m + (size_t)e * H, q, S.m);)
       }
       // coordinate head adjoint (coord_mlp_r, :125)
       float g_tr[3], g_dn[3], g_s = 0.f;
@@ -577,9 +607,9 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
       vaxpy(acc_wx2, g_sr, S.u);
       if (q == 0) acc_bx2 += g_sr;
       const Vec g_up = vmul(vscale(vload_vec(vec + EV_WX2 * H, q), g_sr), S.up);
-      if (valid) vstore_row(A.wg_gup + (size_t)e * H, q, g_up);
+      WG_STORE(if (valid) vstore_row(A.wg_gup + (size_t)e * H, q, g_up);)
       Vec g_m = vscale(vload_row(A.g_aggm + (size_t)S.row * H, q), inv);
-      gemm64(img + 3 * IMG, g_up, g_m);
+      gemm_i<BWD_X3>(img, 3, g_up, g_m);
       Vec g_m0 = g_m;
       if (att_on) {
         const float g_a = vdot(g_m, S.m0);
@@ -590,9 +620,9 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
         vaxpy(g_m0, g_z, vload_vec(vec + EV_ATT * H, q));
       }
       const Vec g_mp = vmul(g_m0, S.mp);
-      if (valid) vstore_row(A.wg_gmp + (size_t)e * H, q, g_mp);
+      WG_STORE(if (valid) vstore_row(A.wg_gmp + (size_t)e * H, q, g_mp);)
       Vec g_t = vzero();
-      gemm64(img + 2 * IMG, g_mp, g_t);
+      gemm_i<BWD_X3>(img, 2, g_mp, g_t);
       const Vec g_pre = vmul(g_t, pre);
       const float g_r = vdot(g_pre, vload_vec(vec + EV_WR * H, q));
       float g_d[3];
@@ -693,9 +723,12 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   A.d_bx2 = g[FASTEGNN_P_CR2_B];
   A.d_wx2 = g[FASTEGNN_P_CR2_W]; A.d_attw = g[FASTEGNN_P_ATT_W]; A.d_attb = g[FASTEGNN_P_ATT_B];
   FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (A.d_attw && A.d_attb), "edge_backward: attention grads null");
-  int grid = cdiv(gr.n_chunks, EDGE_WAVES);
+  A.C = L->C;
+  FE_REQUIRE((size_t)L->N * QXLD < (1u << 30) && (size_t)gr.n_src * QXLD < (1u << 30) && (size_t)gr.n_edges * 8 < (1u << 30),
+             "edge_backward: tables exceed the 32-bit offset range of the gather path");
+  int grid = cdiv(cdiv(gr.n_edges, 256), EDGE_WAVES);
   if (grid > 256) grid = 256;
-  const size_t lds = (4 * IMG + EV_COUNT * H + EDGE_WAVES * (16 * TS + 16 * XT)) * sizeof(float);
+  const size_t lds = (EDGE_BWD_IMG_FLOATS + EV_COUNT * H + EDGE_WAVES * (16 * TS + 16 * XT)) * sizeof(float);
   { ProfScope _ps_edge_bwd_kernel(K_EDGE_BWD, st); hipLaunchKernelGGL(edge_bwd_kernel, dim3(grid), dim3(64 * EDGE_WAVES), lds, st, A); }
   int rc = check_launch("edge_bwd_kernel");
   if (rc) return rc;
@@ -710,7 +743,7 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
 __global__ __launch_bounds__(256) void edge_col_reduce_kernel(const float *g_QXe, const int32_t *cscptr,
                                                               const int32_t *csc_eid, int n_src, float *g_QXs) {
   const int l = lane_id();
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   for (int n = wave; n < n_src; n += nwaves) {
     const int s = cscptr[n], e = cscptr[n + 1];
     float acc = 0.f, accx = 0.f;
@@ -761,7 +794,7 @@ struct NodePreBwdArgs {
 };
 __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
   const int l = lane_id(), j = l & 15, q = l >> 4;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int ntiles = (a.N + 15) >> 4;
   Vec acc_wv2 = vzero(), acc_wg2 = vzero();
   float acc_bv2 = 0.f, acc_bg2 = 0.f;

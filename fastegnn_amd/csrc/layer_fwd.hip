@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
   load_floats(vec + 4 * H, a.wg2, H);
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int ntiles = (a.N + 15) >> 4;
   const float bv2 = a.has_vel ? a.bv2[0] : 0.f;
   const float bg2 = a.gravity ? a.bg2[0] : 0.f;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const i
   const int n1 = min(N, n0 + PER);
   if (n0 >= n1) return;
   const int bf = batch[n0], bl = batch[n1 - 1];
-  const int l = lane_id(), w = threadIdx.x >> 6;
+  const int l = lane_id(), w = wave_id();
   if (bf == bl) {  // whole block inside one graph: tree-reduce, one atomic set per block
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int n = n0 + threadIdx.x; n < n1; n += 256) {
@@ -195,80 +195,91 @@ int graph_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // One wave walks an edge-balanced chunk of CSR rows in 16-edge tiles; sums stay in registers
 // until the row changes, so every row is written exactly once (no atomics, deterministic).
 // =====================================================================================
-__global__ __launch_bounds__(64 * EDGE_WAVES) void edge_fwd_kernel(EdgeArgs a) {
+constexpr int EDGE_FWD_IMG_FLOATS = FWD_X3 ? 2 * IMG3 : 2 * IMG;
+__global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs a, int C) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *img = lds;                    // W2, WX1
-  float *vec = lds + 2 * IMG;          // EV_COUNT vectors
-  float *tiles = vec + EV_COUNT * H;   // per wave: [16][TS] + [16][4]
-  load_images(img, a.wpack + (size_t)I_W2 * IMG, 2);
+  float *img = lds;                              // W2, WX1 (fp32 or split images)
+  float *vec = lds + EDGE_FWD_IMG_FLOATS;        // EV_COUNT vectors
+  float *tiles = vec + EV_COUNT * H;             // per wave: [16][TS] + [16][4]
+  if constexpr (FWD_X3) load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, C, I_W2), 2);
+  else load_images(img, a.wpack + (size_t)I_W2 * IMG, 2);
   edge_load_vecs(vec, a);
   __syncthreads();
-  const int l = lane_id(), j = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
   float *mt = tiles + wv * (16 * TS + 64);
   float *xt = mt + 16 * TS;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);
   FE_T0()
+#if FE_EDGE_RANGE
+  // this wave's share: a contiguous run of whole rows holding ~E/nwaves edges (chunk_row marks the row
+  // boundary nearest to every CHUNK_EDGES-th edge)
+  const int c0 = (int)((long)wave * a.n_chunks / nwaves), c1 = (int)((long)(wave + 1) * a.n_chunks / nwaves);
+  {
+    const int r0 = a.chunk_row[c0], r1 = a.chunk_row[c1];
+#else
   for (int ch = wave; ch < a.n_chunks; ch += nwaves) {
     const int r0 = a.chunk_row[ch], r1 = a.chunk_row[ch + 1];
-    if (r0 >= r1) continue;
-    const int e0 = a.rowptr[r0], e1 = a.rowptr[r1];
-    int cur = -1;
-    float acc = 0.f, accx = 0.f;
-    FE_T(7)   // chunk bookkeeping
-    int cnt = 0;   // edges of the current row seen so far == its in-degree at flush time (rows never straddle chunks)
-    auto flush = [&]() {
-      const float inv = rcp_f((float)cnt);
-      a.aggm[(size_t)cur * H + l] = acc * inv;
-      if (l < 3) a.aggx[(size_t)cur * 3 + l] = mean ? accx * inv : accx;
-    };
-    EdgeIdx cur_i, nxt_i;
-    edge_load_idx(a, min(e0 + j, e1 - 1), cur_i);
-    for (int base = e0; base < e1; base += 16) {
-      const int nvalid = min(16, e1 - base);
-      nxt_i = cur_i;
-      if (base + 16 < e1) edge_load_idx(a, min(base + 16 + j, e1 - 1), nxt_i);   // next tile's indices in flight
-      EdgeFwdState S;
-      Vec pre;
-      edge_tile_forward<false>(a, img, vec, cur_i, q, S, pre FE_TA);
-      cur_i = nxt_i;
-      tile_store(mt, j, q, S.m);
-      if (q == 0) {
-        xt[j * 4 + 0] = S.dn[0] * S.s;
-        xt[j * 4 + 1] = S.dn[1] * S.s;
-        xt[j * 4 + 2] = S.dn[2] * S.s;
-      }
-      __builtin_amdgcn_wave_barrier();
-      FE_T(5)   // transpose tile to LDS
-      // hidden-on-lane column of the tile: all 16 LDS reads issued up front, the row-boundary walk
-      // below then runs on registers and scalar compares only
-      float mv[16], xv[16];
-#pragma unroll
-      for (int ee = 0; ee < 16; ++ee) {
-        mv[ee] = mt[ee * TS + l];
-        xv[ee] = xt[ee * 4 + (l & 3)];
-      }
-      const int rowv = S.row;
-#pragma unroll
-      for (int ee = 0; ee < 16; ++ee) {
-        if (ee < nvalid) {
-          const int rw = __builtin_amdgcn_readlane(rowv, ee);
-          if (rw != cur) {
-            if (cur >= 0) flush();
-            cur = rw;
-            acc = 0.f;
-            accx = 0.f;
-            cnt = 0;
-          }
-          acc += mv[ee];
-          accx += xv[ee];
-          ++cnt;
+#endif
+    if (r0 < r1) {
+      const int e0 = a.rowptr[r0], e1 = a.rowptr[r1];
+      int cur = -1;
+      float acc = 0.f, accx = 0.f;
+      FE_T(7)   // chunk bookkeeping
+      int cnt = 0;   // edges of the current row seen so far == its in-degree at flush time (rows never straddle waves)
+      auto flush = [&]() {
+        const float inv = rcp_f((float)cnt);
+        a.aggm[(size_t)cur * H + l] = acc * inv;
+        if (l < 3) a.aggx[(size_t)cur * 3 + l] = mean ? accx * inv : accx;
+      };
+      EdgeIdx cur_i, nxt_i;
+      if (e0 < e1) edge_load_idx(a, min(e0 + j, e1 - 1), cur_i);
+      for (int base = e0; base < e1; base += 16) {
+        const int nvalid = min(16, e1 - base);
+        nxt_i = cur_i;
+        if (base + 16 < e1) edge_load_idx(a, min(base + 16 + j, e1 - 1), nxt_i);   // next tile's indices in flight
+        EdgeFwdState S;
+        Vec pre;
+        edge_tile_forward<false, FWD_X3>(a, img, vec, cur_i, q, S, pre FE_TA);
+        cur_i = nxt_i;
+        tile_store(mt, j, q, S.m);
+        if (q == 0) {
+          xt[j * 4 + 0] = S.dn[0] * S.s;
+          xt[j * 4 + 1] = S.dn[1] * S.s;
+          xt[j * 4 + 2] = S.dn[2] * S.s;
         }
+        __builtin_amdgcn_wave_barrier();
+        FE_T(5)   // transpose tile to LDS
+        // hidden-on-lane column of the tile: all 16 LDS reads issued up front, the row-boundary walk
+        // below then runs on registers and scalar compares only
+        float mv[16], xv[16];
+#pragma unroll
+        for (int ee = 0; ee < 16; ++ee) {
+          mv[ee] = mt[ee * TS + l];
+          xv[ee] = xt[ee * 4 + (l & 3)];
+        }
+        const int rowv = S.row;
+#pragma unroll
+        for (int ee = 0; ee < 16; ++ee) {
+          if (ee < nvalid) {
+            const int rw = __builtin_amdgcn_readlane(rowv, ee);
+            if (rw != cur) {
+              if (cur >= 0) flush();
+              cur = rw;
+              acc = 0.f;
+              accx = 0.f;
+              cnt = 0;
+            }
+            acc += mv[ee];
+            accx += xv[ee];
+            ++cnt;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        FE_T(6)   // row-segmented reduction
       }
-      __builtin_amdgcn_wave_barrier();
-      FE_T(6)   // row-segmented reduction
+      if (cur >= 0) flush();
     }
-    if (cur >= 0) flush();
   }
   FE_TEND()
 }
@@ -284,10 +295,13 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
   if (g.n_edges == 0 || L->N == 0) return check_launch("edge_forward(memset)");
   FE_REQUIRE(g.rowptr && g.erow && g.col && g.chunk_row && (L->ea == 0 || L->ea_sorted), "edge_forward: null graph");
   EdgeArgs a = make_edge_args(L);
-  int grid = cdiv(g.n_chunks, EDGE_WAVES);
-  if (grid > 512) grid = 512;
-  const size_t lds = (2 * IMG + EV_COUNT * H + EDGE_WAVES * (16 * TS + 64)) * sizeof(float);
-  { ProfScope _ps_edge_fwd_kernel(K_EDGE_FWD, st); hipLaunchKernelGGL(edge_fwd_kernel, dim3(grid), dim3(64 * EDGE_WAVES), lds, st, a); }
+  FE_REQUIRE((size_t)L->N * QXLD < (1u << 30) && (size_t)g.n_src * QXLD < (1u << 30) && (size_t)g.n_edges * 8 < (1u << 30),
+             "edge_forward: tables exceed the 32-bit offset range of the gather path");
+  int grid = cdiv(cdiv(g.n_edges, 256), EDGE_FWD_WAVES);   // at least sixteen tiles per wave
+  const int max_grid = FWD_X3 ? 256 : 512;
+  if (grid > max_grid) grid = max_grid;
+  const size_t lds = (EDGE_FWD_IMG_FLOATS + EV_COUNT * H + EDGE_FWD_WAVES * (16 * TS + 64)) * sizeof(float);
+  { ProfScope _ps_edge_fwd_kernel(K_EDGE_FWD, st); hipLaunchKernelGGL(edge_fwd_kernel, dim3(grid), dim3(64 * EDGE_FWD_WAVES), lds, st, a, L->C); }
   return check_launch("edge_fwd_kernel");
 }
 
@@ -298,19 +312,23 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // contraction of node_mlp.0 accumulates in MFMA registers, v [N,C,H] never reaches HBM.
 // =====================================================================================
 
+// LDS: images V2, WXV0, WXX0 | W3c[c] stage (split mode) | vectors | per-wave transpose tiles | pools
+constexpr int VIRT_FWD_IMG_FLOATS = FWD_X3 ? 4 * IMG3 : 3 * IMG;
 __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C;
-  float *img = lds;                              // V2, WXV0, WXX0
-  float *vec = lds + 3 * IMG;                    // VV_COUNT vectors
+  float *img = lds;                              // V2, WXV0, WXX0 (fp32 or split images)
+  unsigned *stage = reinterpret_cast<unsigned *>(lds) + 3 * IMG3;   // split mode: W3c[c] of the channel in flight
+  float *vec = lds + VIRT_FWD_IMG_FLOATS;        // VV_COUNT vectors
   float *tiles = vec + VV_COUNT * H;             // per wave [16][TS]
   float *poolV_l = tiles + VIRT_WAVES * 16 * TS; // [C][64]
   float *poolX_l = poolV_l + C * H;              // [3][C]
-  load_images(img, a.wpack + (size_t)I_V2 * IMG, 3);
+  if constexpr (FWD_X3) load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, C, I_V2), 3);
+  else load_images(img, a.wpack + (size_t)I_V2 * IMG, 3);
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) poolV_l[i] = 0.f;
   __syncthreads();
-  const int l = lane_id(), j = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
   float *tile = tiles + wv * 16 * TS;
   constexpr int GROUP = 16 * VIRT_WAVES;
   const int ntg = (a.N + GROUP - 1) / GROUP;
@@ -327,6 +345,22 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       poolX_l[i] = 0.f;
     }
   };
+  // split mode: the K = H*C contraction of node_mlp.0 reads W3c[c] from an LDS stage that the whole
+  // workgroup refills once per channel (all waves walk the channels in step); the next channel's
+  // image is fetched into registers while the current one is being used.
+  constexpr int STG = IMG3 / 4 / (64 * VIRT_WAVES);   // 16-byte pieces per thread
+  static_assert(!FWD_X3 || STG * 4 * 64 * VIRT_WAVES == IMG3, "stage copy must tile the image");
+  u32x4 pre_w[FWD_X3 ? STG : 1];
+  auto fetch_w3c = [&](int c) {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_x3(a.wpack, C, img_w3c(c)));
+#pragma unroll
+    for (int i = 0; i < STG; ++i) pre_w[i] = src[threadIdx.x + i * 64 * VIRT_WAVES];
+  };
+  auto commit_w3c = [&]() {
+    u32x4 *dst = reinterpret_cast<u32x4 *>(stage);
+#pragma unroll
+    for (int i = 0; i < STG; ++i) dst[threadIdx.x + i * 64 * VIRT_WAVES] = pre_w[i];
+  };
   for (int tg = blockIdx.x; tg < ntg; tg += gridDim.x) {
     const int n0 = tg * GROUP, nend = min(a.N, n0 + GROUP);
     const int bfirst = a.batch[n0], blast = a.batch[nend - 1];
@@ -339,18 +373,30 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     }
     const int nb = n0 + wv * 16;
     const int nvalid = max(0, min(16, nend - nb));
-    if (nvalid > 0) {
-      const int n = nb + j;
-      const bool valid = n < nend;
-      const int nc = valid ? n : nend - 1;
-      const int b = a.batch[nc];
-      const Vec Ai = vload_row(a.A + (size_t)nc * H, q);
-      const float xi[3] = {a.x[(size_t)nc * 3], a.x[(size_t)nc * 3 + 1], a.x[(size_t)nc * 3 + 2]};
-      float transv[3] = {0.f, 0.f, 0.f};
-      Vec nodeacc = vload_vec(vec + VV_B3 * H, q);
-      for (int c = 0; c < C; ++c) {
+    const bool active = nvalid > 0;
+    const int n = nb + j;
+    const bool valid = n < nend;
+    const int nc = valid ? n : nend - 1;
+    const int b = a.batch[nc];
+    Vec Ai;
+    float xi[3] = {0.f, 0.f, 0.f};
+    if (active) {
+      Ai = vload_row(a.A + (size_t)nc * H, q);
+      xi[0] = a.x[(size_t)nc * 3]; xi[1] = a.x[(size_t)nc * 3 + 1]; xi[2] = a.x[(size_t)nc * 3 + 2];
+    }
+    float transv[3] = {0.f, 0.f, 0.f};
+    Vec nodeacc = vload_vec(vec + VV_B3 * H, q);
+    if constexpr (FWD_X3) { if (C > 0) fetch_w3c(0); }
+    for (int c = 0; c < C; ++c) {
+      if constexpr (FWD_X3) {
+        __syncthreads();          // every wave is done with the previous channel's stage
+        commit_w3c();
+        __syncthreads();
+        if (c + 1 < C) fetch_w3c(c + 1);
+      }
+      if (active) {
         VirtFwdState S;
-        virt_tile_forward(a, img, vec, Ai, xi, b, c, q, S);
+        virt_tile_forward<FWD_X3>(a, img, vec, Ai, xi, b, c, q, S);
         transv[0] -= S.vd[0] * S.sx;
         transv[1] -= S.vd[1] * S.sx;
         transv[2] -= S.vd[2] * S.sx;
@@ -382,8 +428,11 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
             }
           }
         }
-        gemm64(a.wpack + (size_t)img_w3c(c) * IMG, S.v, nodeacc);
+        if constexpr (FWD_X3) gemm64_x3(stage, S.vs, nodeacc);
+        else gemm64(a.wpack + (size_t)img_w3c(c) * IMG, S.v, nodeacc);
       }
+    }
+    if (active) {
       // node_model: node_mlp.0 on [h | agg | flat(v) | node_attr]  (:153-166)
       const Vec hv = vload_row(a.h + (size_t)nc * H, q);
       gemm64(a.wpack + (size_t)I_W3A * IMG, hv, nodeacc);
@@ -438,7 +487,7 @@ int virt_forward(const fastegnn_layer_t *L, hipStream_t st) {
   VirtArgs a = make_virt_args(L);
   const int ntg = cdiv(L->N, 16 * VIRT_WAVES);
   int grid = ntg < 512 ? ntg : 512;
-  { ProfScope _ps_virt_fwd_kernel(K_VIRT_FWD, st); hipLaunchKernelGGL(virt_fwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(L->C, 3), st, a); }
+  { ProfScope _ps_virt_fwd_kernel(K_VIRT_FWD, st); hipLaunchKernelGGL(virt_fwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(L->C, 3) + (VIRT_FWD_IMG_FLOATS - 3 * IMG) * sizeof(float), st, a); }
   return check_launch("virt_fwd_kernel");
 }
 
@@ -453,7 +502,7 @@ struct GraphPostArgs {
 };
 __global__ __launch_bounds__(256) void graph_post_fwd_kernel(GraphPostArgs a) {
   const int l = lane_id(), j = l & 15, q = l >> 4;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int M = a.B * a.C, ntiles = (M + 15) >> 4;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.B * 3 * a.C; i += gridDim.x * blockDim.x) {
     const int b = i / (3 * a.C);

@@ -65,6 +65,9 @@ __global__ void build_batch_kernel(const int64_t *b64, int N, int B, int32_t *ba
 // 64x64 partial as a plain 16 KB slab; a second small kernel sums the slabs in a fixed order and
 // adds them to the gradient tensors.  No float atomics: deterministic, and no same-address
 // contention (4096 atomics x hundreds of workgroups onto one 16 KB tile cost ~50 us per launch).
+// The kernel streams its operands at ~4.0 TB/s against 5.3 TB/s for a bare read loop on this part
+// (fastegnn_selftest_stream): it is HBM-bound, and a bf16x3 version of the inner product (6x fewer
+// MFMA issue cycles) measured the same 6.0 ms per step -- the fp32-input MFMA form is kept.
 constexpr int WTS = 80;  // LDS row stride of the staged operand tiles (conflict-free b32 column reads)
 
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
   const int local = blockIdx.x - a.wg_begin;
   // batch index varies fastest: co-resident workgroups read the same row range of every batch slice
   const int bidx = local % a.nb, split = local / a.nb;
-  const int l = lane_id(), i = l & 15, q = l >> 4, w = threadIdx.x >> 6;
+  const int l = lane_id(), i = l & 15, q = l >> 4, w = wave_id();
   const float *G = a.G + (size_t)bidx * a.sG;
   const float *T = a.T + (size_t)bidx * a.sT;
   const long m0 = (long)split * a.rows_per_wg;
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
   if (threadIdx.x < H) tab.slab_b[sidx * H + threadIdx.x] = redb[threadIdx.x];
 }
 
+
 // Sum the partial slabs of every (job, batch) and accumulate into the gradients.  A workgroup owns
 // 64 consecutive elements of one 64x64 tile; its 8 waves sum interleaved subsets of the splits
 // (8 independent loads in flight per thread) and the 8 partials are added in a fixed order.
@@ -256,7 +260,7 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
 
 int WgradBatch::finish() {
   if (tab.n_jobs == 0) return FASTEGNN_OK;
-  { ProfScope _ps(K_WGRAD_TN, st); hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, tab); }
+    { ProfScope _ps(K_WGRAD_TN, st); hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, tab); }
   int rc = check_launch("wgrad_tn_kernel");
   if (rc) return rc;
   { ProfScope _ps(K_WGRAD_REDUCE, st); hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tab.n_jobs, (unsigned)max_nb, IMG / H + 1), dim3(512), 0, st, tab); }
@@ -272,7 +276,7 @@ struct WgsArgs {
   int ldg, ldf, kf, lddw, c0, rows_per_wg;
 };
 __global__ __launch_bounds__(256) void wgrad_small_kernel(WgsArgs a) {
-  const int o = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int o = threadIdx.x & 63, w = wave_id();
   const long m0 = (long)blockIdx.x * a.rows_per_wg;
   long m1 = m0 + a.rows_per_wg;
   if (m1 > a.M) m1 = a.M;
@@ -316,6 +320,25 @@ int launch_wgrad_small(const float *G, int ldg, const float *F, int ldf, int kf,
   return launch_wgrad_small_b(G, ldg, F, ldf, kf, M, dW, lddw, c0, nullptr, st);
 }
 
+// HBM streaming calibration (bench/tests only): mode 0 read + reduce, 1 copy, 2 write
+__global__ __launch_bounds__(256) void stream_kernel(const f32x4 *src, f32x4 *dst, size_t n, int mode) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (mode == 0) {
+    for (; k + 3 * stride < n; k += 4 * stride) {
+      const f32x4 a = src[k], b = src[k + stride], c = src[k + 2 * stride], d = src[k + 3 * stride];
+      acc += (a + b) + (c + d);
+    }
+    for (; k < n; k += stride) acc += src[k];
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) dst[0] = acc;   // keep the loads alive
+  } else if (mode == 1) {
+    for (; k < n; k += stride) dst[k] = src[k];
+  } else {
+    for (; k < n; k += stride) dst[k] = acc;
+  }
+}
+
 // ---------------------------------------------------------------- toolkit self-test
 // Y[j][o] = sum_k A[o][k] X[j][k] for one 16-item tile, A = W or W^T (64x64 row-major).
 __global__ __launch_bounds__(64) void selftest_gemm_kernel(const float *W, const float *X, float *Y, int transposed) {
@@ -357,7 +380,7 @@ __global__ __launch_bounds__(64 * WAVES) void chain_bf3_kernel(const float *W, c
   Vec x = vload_row(X + j * H, q);
   for (int it = 0; it < iters; ++it) {
     Vec acc = vzero();
-    gemm64_bf3(lds3, lds3 + 4096, vsplit(x), acc);
+    gemm64_x3(lds3, vsplit(x), acc);
     x = (mode & 1) ? vsilu(acc) : vscale(acc, 0.125f);
     if (mode & 4) x = acc;
   }
@@ -473,6 +496,13 @@ int fastegnn_selftest_chain_bf3(const float *W, const float *X, float *out, int3
   else if (waves == 16) hipLaunchKernelGGL(chain_bf3_kernel<16>, dim3(grid), dim3(1024), lds, st, W, X, out, iters, mode);
   else { set_error("selftest_chain_bf3: waves must be 4, 8 or 16"); return FASTEGNN_E_INVALID; }
   return check_launch("chain_bf3_kernel");
+}
+
+int fastegnn_selftest_stream(const float *src, float *dst, size_t n_floats, int32_t mode, void *stream) {
+  FE_REQUIRE(src && dst && n_floats % 4 == 0, "selftest_stream: bad arguments");
+  hipLaunchKernelGGL(stream_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4 *>(src),
+                     reinterpret_cast<f32x4 *>(dst), n_floats / 4, mode);
+  return check_launch("stream_kernel");
 }
 
 int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, float *slab,

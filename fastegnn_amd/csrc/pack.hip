@@ -75,8 +75,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
   const int id = blockIdx.x;
   const PackDesc d = pack_desc(a, id);
   float *dst = a.wpack + (size_t)id * IMG;
-  unsigned *dhm = reinterpret_cast<unsigned *>(a.wpack + wpack_hm_off(a.C)) + (size_t)id * IMG;
-  unsigned *dl = reinterpret_cast<unsigned *>(a.wpack + wpack_l_off(a.C)) + (size_t)id * (IMG / 2);
+  unsigned *d3 = const_cast<unsigned *>(wpack_x3(a.wpack, a.C, id));
   auto at = [&](int o, int k) -> float {
     if (!d.src) return 0.f;
     return d.transposed ? d.src[(size_t)k * d.ld + d.c0 + o * d.ks] : d.src[(size_t)o * d.ld + d.c0 + k * d.ks];
@@ -89,9 +88,9 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
   for (int idx = threadIdx.x; idx < IMG / 2; idx += 256) {
     int o = idx >> 5, k = (idx & 31) * 2;
     const float w0 = at(o, k), w1 = at(o, k + 1);
-    dhm[img3_index(0, o, k)] = split_word(w0, w1, 0);
-    dhm[img3_index(1, o, k)] = split_word(w0, w1, 1);
-    dl[img3_index(0, o, k)] = split_word(w0, w1, 2);
+    d3[img3_index(0, o, k)] = split_word(w0, w1, 0);
+    d3[img3_index(1, o, k)] = split_word(w0, w1, 1);
+    d3[img3_index(2, o, k)] = split_word(w0, w1, 2);
   }
 }
 

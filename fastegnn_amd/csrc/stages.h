@@ -5,7 +5,24 @@
 
 namespace fe {
 
+// FE_FWD_X3: the 64x64 layers of the forward edge / virtual kernels run as bf16x3 products on the
+// matrix pipe (common.h, gemm64_x3) instead of fp32-input MFMA on the vector ALUs.
+#ifndef FE_FWD_X3
+#define FE_FWD_X3 1
+#endif
+constexpr bool FWD_X3 = FE_FWD_X3;
+#ifndef FE_BWD_X3
+#define FE_BWD_X3 1   // same for the backward edge kernel (recompute + the two transposed layers)
+#endif
+constexpr bool BWD_X3 = FE_BWD_X3;
 constexpr int EDGE_WAVES = 8;
+#ifndef FE_EDGE_RANGE
+#define FE_EDGE_RANGE 1   // waves own contiguous row ranges (else: round-robin over the row chunks)
+#endif
+#ifndef FE_EDGE_FWD_WAVES
+#define FE_EDGE_FWD_WAVES (FE_FWD_X3 ? 16 : 8)
+#endif
+constexpr int EDGE_FWD_WAVES = FE_EDGE_FWD_WAVES;   // 48 KB of split images are shared by more waves
 constexpr int VIRT_WAVES = 8;
 constexpr int VIRT_BWD_WAVES = 4;   // 1 wave/SIMD: the adjoint of the virtual block needs > 256 registers
 
@@ -45,34 +62,54 @@ struct EdgeIdx {
   float eav[8];
 };
 __device__ __forceinline__ void edge_load_idx(const EdgeArgs &a, int e, EdgeIdx &I) {
-  I.row = a.erow[e];
-  I.col = a.col[e];
+  const unsigned eo = (unsigned)e * 4u;
+  I.row = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(a.erow) + eo);
+  I.col = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(a.col) + eo);
+  // ea_dim is wave-uniform: scalar branches, and no select on a loaded value (a select would make the
+  // load wait at issue).  Slots k >= ea_dim stay unset; every use is guarded by k < ea_dim.
+  if (a.ea_dim == 2) {
+    const float2 v = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(a.ea) + 2u * eo);
+    I.eav[0] = v.x;
+    I.eav[1] = v.y;
+  } else {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) I.eav[k] = 0.f;
-  if (a.ea_dim > 0) {
-    const float *er = a.ea + (size_t)e * a.ea_dim;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {   // unconditional (clamped) loads: no branch + wait per attribute
-      const float v = er[k < a.ea_dim ? k : 0];
-      I.eav[k] = k < a.ea_dim ? v : 0.f;
-    }
+    for (int k = 0; k < 8; ++k)
+      if (k < a.ea_dim) I.eav[k] = a.ea[(size_t)e * a.ea_dim + k];
   }
+}
+
+// gathered operands of one 16-edge tile: issued one tile ahead of their use by the forward kernel, so
+// the (index -> gathered row) latency is covered by the previous tile's arithmetic
+struct EdgeRows {
+  Vec p, qv;        // P[row], Q[col] in D layout
+  f32x4 xr, xc;     // coordinates of the two end points
+};
+// (32-bit element offsets from wave-uniform bases: the launchers require the tables to stay below 2^30 floats)
+__device__ __forceinline__ void edge_gather(const EdgeArgs &a, const EdgeIdx &I, int q, EdgeRows &G) {
+  const unsigned qoff = (unsigned)I.col * QXLD, roff = (unsigned)I.row * QXLD;
+  G.xc = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(a.QXs) + (qoff + H) * 4u);
+  G.xr = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(a.QX) + (roff + H) * 4u);
+  G.p = vload_u(a.P, (unsigned)I.row * H + 4 * q);
+  G.qv = vload_u(a.QXs, qoff + 4 * q);
 }
 
 // forward math of one 16-edge tile (shared with the backward kernel for recomputation).
 // KEEP_D: pre, S.mp and S.up return silu'(.) of the pre-activations instead of the pre-activations
 // (the adjoint needs only the derivatives; one sigmoid serves both).
-template <bool KEEP_D>
-__device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float *img, const float *vec,
-                                                  const EdgeIdx &I, int q, EdgeFwdState &S, Vec &pre FE_TP) {
+// X3: img holds split (bf16x3) images and the two 64x64 layers run on the bf16 matrix pipe (gemm64_x3).
+template <bool X3>
+__device__ __forceinline__ void gemm_i(const void *img, int i, const Vec &in, Vec &acc) {
+  if constexpr (X3) gemm64_x3(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
+  else gemm64(reinterpret_cast<const float *>(img) + i * IMG, in, acc);
+}
+// part 1: consumes the gathered operands (geometry + first-layer pre-activation)
+__device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *vec, const EdgeIdx &I, const EdgeRows &G,
+                                              int q, EdgeFwdState &S, Vec &pre FE_TP) {
   S.row = I.row;
   S.col = I.col;
-  const float *qrow = a.QXs + (size_t)S.col * QXLD;
-  const f32x4 xc = *reinterpret_cast<const f32x4 *>(qrow + H);
-  const f32x4 xr = *reinterpret_cast<const f32x4 *>(a.QX + (size_t)S.row * QXLD + H);
-  S.d[0] = xr[0] - xc[0];
-  S.d[1] = xr[1] - xc[1];
-  S.d[2] = xr[2] - xc[2];
+  S.d[0] = G.xr[0] - G.xc[0];
+  S.d[1] = G.xr[1] - G.xc[1];
+  S.d[2] = G.xr[2] - G.xc[2];
   S.r = S.d[0] * S.d[0] + S.d[1] * S.d[1] + S.d[2] * S.d[2];
   S.nrm = sqrt_f(S.r);
   if (a.flags & FASTEGNN_F_NORMALIZE) {
@@ -82,8 +119,8 @@ __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float
     S.dn[0] = S.d[0]; S.dn[1] = S.d[1]; S.dn[2] = S.d[2];
   }
   FE_T(0)   // indices + coordinates arrived
-  pre = vload_row(a.P + (size_t)S.row * H, q);
-  vadd(pre, vload_row(qrow, q));
+  pre = G.p;
+  vadd(pre, G.qv);
   vaxpy(pre, S.r, vload_vec(vec + EV_WR * H, q));
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -91,10 +128,15 @@ __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float
     if (k < a.ea_dim) vaxpy(pre, S.eav[k], vload_vec(vec + (EV_WE + k) * H, q));
   }
   FE_T(1)   // gathered rows arrived, pre-activation formed
+}
+// part 2: the two 64x64 layers and the coordinate head
+template <bool KEEP_D, bool X3 = false>
+__device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img, const float *vec, int q, EdgeFwdState &S,
+                                              Vec &pre FE_TP) {
   S.t = KEEP_D ? vsilu_keep_d(pre) : vsilu(pre);
   FE_T(2)   // silu 1
   S.mp = vload_vec(vec + EV_B2 * H, q);
-  gemm64(img + 0 * IMG, S.t, S.mp);
+  gemm_i<X3>(img, 0, S.t, S.mp);
   FE_T(3)   // gemm 1
   S.m0 = KEEP_D ? vsilu_keep_d(S.mp) : vsilu(S.mp);
   if (a.flags & FASTEGNN_F_ATTENTION) {
@@ -106,12 +148,20 @@ __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const float
   }
   FE_T(2)
   S.up = vload_vec(vec + EV_BX1 * H, q);
-  gemm64(img + 1 * IMG, S.m, S.up);
+  gemm_i<X3>(img, 1, S.m, S.up);
   FE_T(3)
   S.u = KEEP_D ? vsilu_keep_d(S.up) : vsilu(S.up);
   const float sraw = vdot(S.u, vload_vec(vec + EV_WX2 * H, q)) + (a.bx2 ? a.bx2[0] : 0.f);
   S.s = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sraw) : sraw;
   FE_T(4)   // silu 3 + head dot
+}
+template <bool KEEP_D, bool X3 = false>
+__device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const void *img, const float *vec,
+                                                  const EdgeIdx &I, int q, EdgeFwdState &S, Vec &pre FE_TP) {
+  EdgeRows G;
+  edge_gather(a, I, q, G);
+  edge_tile_pre(a, vec, I, G, q, S, pre FE_TA);
+  edge_tile_mlp<KEEP_D, X3>(a, img, vec, q, S, pre FE_TA);
 }
 
 inline EdgeArgs make_edge_args(const fastegnn_layer_t *L) {
@@ -137,6 +187,7 @@ constexpr int VV_WVR = 0, VV_C2 = 1, VV_BXV0 = 2, VV_WXV2 = 3, VV_BXX0 = 4, VV_W
 
 struct VirtFwdState {
   Vec pre, t, vp, v0, v, uxp, uXp;
+  Split vs;
   float vd[3], vr, att, sx, sX;
 };
 
@@ -157,7 +208,8 @@ __device__ __forceinline__ void virt_load_vecs(float *vec, const VirtArgs &a) {
 }
 
 // forward math of one (16-node tile, channel c); img = resident V2, WXV0, WXX0
-__device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const float *img, const float *vec, const Vec &Ai,
+template <bool X3 = false>
+__device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void *img, const float *vec, const Vec &Ai,
                                                   const float xi[3], int b, int c, int q, VirtFwdState &S) {
   const int C = a.C;
   const float *Zb = a.Z + (size_t)b * 3 * C;
@@ -170,7 +222,7 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const float
   vaxpy(S.pre, S.vr, vload_vec(vec + VV_WVR * H, q));
   S.t = vsilu(S.pre);
   S.vp = vload_vec(vec + VV_C2 * H, q);
-  gemm64(img + 0 * IMG, S.t, S.vp);
+  gemm_i<X3>(img, 0, S.t, S.vp);
   S.v0 = vsilu(S.vp);
   if (a.flags & FASTEGNN_F_ATTENTION) {
     S.att = sigmoid_f(vdot(S.v0, vload_vec(vec + VV_ATT * H, q)) + a.attb[0]);
@@ -180,11 +232,17 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const float
     S.v = S.v0;
   }
   S.uxp = vload_vec(vec + VV_BXV0 * H, q);
-  gemm64(img + 1 * IMG, S.v, S.uxp);
+  if constexpr (X3) {
+    S.vs = vsplit(S.v);   // one split feeds both coordinate heads and the node MLP
+    gemm64_x3(reinterpret_cast<const unsigned *>(img) + 1 * IMG3, S.vs, S.uxp);
+  } else {
+    gemm64(reinterpret_cast<const float *>(img) + 1 * IMG, S.v, S.uxp);
+  }
   float sr = vdot(vsilu(S.uxp), vload_vec(vec + VV_WXV2 * H, q));
   S.sx = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;
   S.uXp = vload_vec(vec + VV_BXX0 * H, q);
-  gemm64(img + 2 * IMG, S.v, S.uXp);
+  if constexpr (X3) gemm64_x3(reinterpret_cast<const unsigned *>(img) + 2 * IMG3, S.vs, S.uXp);
+  else gemm64(reinterpret_cast<const float *>(img) + 2 * IMG, S.v, S.uXp);
   sr = vdot(vsilu(S.uXp), vload_vec(vec + VV_WXX2 * H, q));
   S.sX = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;
 }

@@ -76,8 +76,8 @@ class SortedGraph:
         self.perm = torch.empty(max(E, 1), **i32)
         self.cscptr = torch.empty(n_src + 1, **i32)
         self.csc_eid = torch.empty(max(E, 1), **i32)
-        self.chunk_row = torch.empty(E // 256 + 2, **i32)
         L = K.lib()
+        self.chunk_row = torch.empty(L.fastegnn_chunk_rows(E), **i32)
         nbytes = L.fastegnn_csr_tmp_bytes(E, n_rows, n_src)
         tmp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         nch = C.c_int32(0)

@@ -196,9 +196,11 @@ size_t fastegnn_sizeof_graph(void);
  * edge_index: device int64 [2,E] as the reference passes it (models/FastEGNN.py:204).
  * Rows must lie in [row_begin, row_begin+n_rows) and are stored relative to row_begin; cols
  * address the source table [0,n_src).  All outputs caller-allocated:
- * rowptr[n_rows+1], erow/col/perm/csc_eid[E], cscptr[n_src+1], chunk_row[E/256+2];
+ * rowptr[n_rows+1], erow/col/perm/csc_eid[E], cscptr[n_src+1], chunk_row[fastegnn_chunk_rows(E)]
+ * (row boundaries nearest to every 32nd edge: the edge kernels give each wave a contiguous run of them);
  * tmp: fastegnn_csr_tmp_bytes(E, n_rows, n_src) bytes.  *n_chunks is a host int. */
 size_t fastegnn_csr_tmp_bytes(int32_t E, int32_t n_rows, int32_t n_src);
+size_t fastegnn_chunk_rows(int32_t E);
 int fastegnn_build_csr(const int64_t *edge_index, int32_t E, int32_t row_begin, int32_t n_rows,
                        int32_t n_src, int32_t *rowptr, int32_t *erow, int32_t *col, int32_t *perm,
                        int32_t *cscptr, int32_t *csc_eid, int32_t *chunk_row, int32_t *n_chunks,
@@ -297,6 +299,8 @@ int fastegnn_selftest_chain_bf3(const float *W, const float *X, float *out, int3
                                 int32_t grid, void *stream);
 int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, float *slab,
                             void *stream);
+/* HBM streaming calibration: mode 0 reads src (n_floats, multiple of 4), 1 copies src -> dst, 2 writes dst */
+int fastegnn_selftest_stream(const float *src, float *dst, size_t n_floats, int32_t mode, void *stream);
 
 #ifdef __cplusplus
 }

@@ -78,7 +78,7 @@ def test_water3d_frames_collate_and_train_on_device():
         kind = torch.randint(1, 4, (n, 1), generator=g).float().cuda()
         f = D.water3d_frame(pos, vel, pos + 15 * vel, kind, virtual_channels=4, radius=0.035, cutoff_rate=0.5)
         # the frame equals the host restatement of get_graph_step
-        ref = G.cutoff_edges(*G.radius_graph_bruteforce(pos.cpu(), 0.035), 0.5)
+        ref = G.cutoff_edges(*G.radius_graph_bruteforce(pos.cpu().numpy(), 0.035), 0.5)
         assert sorted(zip(*f.edge_index.cpu().tolist())) == sorted(zip(*ref[0].tolist()))
         torch.testing.assert_close(f.node_feat[:, 0].cpu(), vel.cpu().norm(dim=1))
         torch.testing.assert_close(f.node_feat[:, 1], kind[:, 0] / kind.max())
