@@ -59,6 +59,7 @@ using namespace fe;
 extern "C" {
 
 size_t fastegnn_chunk_rows(int32_t E) { return (size_t)(E / CHUNK_EDGES + 2); }
+int32_t fastegnn_chunk_edges(void) { return CHUNK_EDGES; }
 
 size_t fastegnn_csr_tmp_bytes(int32_t E, int32_t n_rows, int32_t n_src) {
   (void)n_rows; (void)n_src;

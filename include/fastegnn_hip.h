@@ -201,6 +201,7 @@ size_t fastegnn_sizeof_graph(void);
  * tmp: fastegnn_csr_tmp_bytes(E, n_rows, n_src) bytes.  *n_chunks is a host int. */
 size_t fastegnn_csr_tmp_bytes(int32_t E, int32_t n_rows, int32_t n_src);
 size_t fastegnn_chunk_rows(int32_t E);
+int32_t fastegnn_chunk_edges(void);   /* edges per row chunk: chunk k owns the rows whose first edge lies in [k*T, (k+1)*T) */
 int fastegnn_build_csr(const int64_t *edge_index, int32_t E, int32_t row_begin, int32_t n_rows,
                        int32_t n_src, int32_t *rowptr, int32_t *erow, int32_t *col, int32_t *perm,
                        int32_t *cscptr, int32_t *csc_eid, int32_t *chunk_row, int32_t *n_chunks,

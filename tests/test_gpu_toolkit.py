@@ -61,9 +61,10 @@ def test_build_csr_matches_oracle(N, E):
     cr = sg.chunk_row.cpu()[: sg.n_chunks + 1]
     assert cr[0] == 0 and cr[-1] == N and bool((cr[1:] >= cr[:-1]).all())
     rp = sg.rowptr.cpu()
-    for k in range(sg.n_chunks):   # chunk k owns the rows whose first edge lies in [256k, 256(k+1))
+    T = K.lib().fastegnn_chunk_edges()
+    for k in range(sg.n_chunks):   # chunk k owns the rows whose first edge lies in [T k, T (k+1))
         for r in range(int(cr[k]), int(cr[k + 1])):
-            assert 256 * k <= int(rp[r]) and (int(rp[r]) < 256 * (k + 1) or k == sg.n_chunks - 1)
+            assert T * k <= int(rp[r]) and (int(rp[r]) < T * (k + 1) or k == sg.n_chunks - 1)
 
 
 def test_bf16x3_split_gemm_is_fp32_accurate():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick GPU check: parity tests + bench kernel table
-python -m pytest tests -m gpu -q -x 2>&1 | tail -4 | tee gpurun_out/pytest_tail.txt
+python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|FAILED|^E " | head -8 | tee gpurun_out/pytest_tail.txt
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bq.json 2>gpurun_out/bq.err || tail -5 gpurun_out/bq.err
 python - <<'PY'
 import json
