@@ -5,5 +5,6 @@ Only the hot path of GLAD-RUC/FastEGNN lives here: the drop-in ``FastEGNN`` modu
 """
 from .model import FastEGNN, SortedGraph  # noqa: F401
 from .egnn import EGNN  # noqa: F401
+from .fastrf import FastRF  # noqa: F401
 
-__all__ = ["FastEGNN", "EGNN", "SortedGraph"]
+__all__ = ["FastEGNN", "FastRF", "EGNN", "SortedGraph"]

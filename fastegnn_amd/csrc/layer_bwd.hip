@@ -48,6 +48,13 @@ __global__ __launch_bounds__(256) void graph_post_bwd_kernel(GraphPostBwdArgs a)
     a.g_Z[i] = g;
     a.g_poolX[i] = g / fmaxf(a.xsum[b * 4 + 3], 1.f);
   }
+  if (a.flags & FASTEGNN_F_RF) {   // identity on the virtual features: no pooled-message gradient
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * H; i += gridDim.x * blockDim.x) {
+      a.g_HvT[i] = a.g_HvT_out[i];
+      a.g_poolV[i] = 0.f;
+    }
+    return;
+  }
   for (int tile = wave; tile < ntiles; tile += nwaves) {
     const int m = tile * 16 + j;
     const bool valid = m < M;
@@ -91,6 +98,7 @@ int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st) {
   { ProfScope _ps_graph_post_bwd_kernel(K_GRAPH_POST_BWD, st); hipLaunchKernelGGL(graph_post_bwd_kernel, dim3(grid), dim3(256), 0, st, a); }
   int rc = check_launch("graph_post_bwd_kernel");
   if (rc) return rc;
+  if (has(L, FASTEGNN_F_RF)) return FASTEGNN_OK;   // no node_mlp_virtual
   float *const *g = L->grads;
   WgradBatch wb(L->wg_slab, st);
   // node_mlp_virtual.2: dW6 += g_out^T u, db6 += colsum g_out
@@ -134,6 +142,8 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   const float invC = C > 0 ? 1.0f / (float)C : 0.f;
   const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION;
   const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;
+  const bool rf = a.flags & FASTEGNN_F_RF;
+  const float *gpv_base = rf ? a.Bc : A.g_poolV;   // FastRF: no pooled-message gradient (the rows are ignored)
   Vec acc_wxv2 = vzero(), acc_wxx2 = vzero(), acc_wvr = vzero(), acc_att = vzero();
   float acc_attb = 0.f;
   int cur = -1;
@@ -174,26 +184,33 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       float *b_gA = A.g_A + g0 * H;
       float *b_v = A.wg_v + g0 * C * H, *b_t = A.wg_t + g0 * C * H, *b_gux = A.wg_gux + g0 * C * H;
       float *b_guX = A.wg_guX + g0 * C * H, *b_gvp = A.wg_gvp + g0 * C * H;
-      // ---- node MLP adjoint (node_model, :153-166)
+      // ---- node MLP adjoint (node_model, :153-166); FastRF: h passes through, no segment-mean message
       const Vec g_out = vmask(vload_u(b_gho, offN), valid);
-      Vec g_np;
-      {
-        const Vec npre = vload_u(b_npre, offN);
-        Vec g_t3 = vzero();
-        gemm64(a.wpack + (size_t)I_W4T * IMG, g_out, g_t3);
-        g_np = vdsilu_mul(g_t3, npre);
-        if (valid) vstore_u(b_t3, offN, vsilu(npre));
-      }
-      if (valid) vstore_u(b_gnp, offN, g_np);
-      {
-        Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
-        gemm64(a.wpack + (size_t)I_W3AT * IMG, g_np, g_h);
-        if (valid) vstore_u(b_gh, offN, g_h);
-      }
-      {
-        Vec g_am = vzero();
-        gemm64(a.wpack + (size_t)I_W3BT * IMG, g_np, g_am);
-        if (valid) vstore_u(b_gam, offN, g_am);
+      Vec g_np = vzero();
+      if (rf) {
+        if (valid) {
+          vstore_u(b_gh, offN, g_out);
+          vstore_u(b_gam, offN, vzero());
+        }
+      } else {
+        {
+          const Vec npre = vload_u(b_npre, offN);
+          Vec g_t3 = vzero();
+          gemm64(a.wpack + (size_t)I_W4T * IMG, g_out, g_t3);
+          g_np = vdsilu_mul(g_t3, npre);
+          if (valid) vstore_u(b_t3, offN, vsilu(npre));
+        }
+        if (valid) vstore_u(b_gnp, offN, g_np);
+        {
+          Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
+          gemm64(a.wpack + (size_t)I_W3AT * IMG, g_np, g_h);
+          if (valid) vstore_u(b_gh, offN, g_h);
+        }
+        {
+          Vec g_am = vzero();
+          gemm64(a.wpack + (size_t)I_W3BT * IMG, g_np, g_am);
+          if (valid) vstore_u(b_gam, offN, g_am);
+        }
       }
       float gxn[3], xi[3], gx[3];
 #pragma unroll
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       // stores could only be waited for together with them (vmcnt counts stores too).
       const Vec Arow = vload_u(b_A, offN);
       const Vec g_np_m = vmask(g_np, valid);
-      Vec nBc = vload_u(a.Bc, offB), nGpv = vload_u(A.g_poolV, offB);
+      Vec nBc = vload_u(a.Bc, offB), nGpv = vload_u(gpv_base, offB);
       float nZ[3] = {Zb[0], Zb[C], Zb[2 * C]}, nGpx[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C];
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           const int cn = c + 1 < C ? c + 1 : c;
           const unsigned obn = offB + (unsigned)cn * H;
           nBc = vload_u(a.Bc, obn);
-          nGpv = vload_u(A.g_poolV, obn);
+          nGpv = vload_u(gpv_base, obn);
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             nZ[k] = Zb[k * C + cn];
@@ -273,8 +290,8 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         }
         WG_STORE(if (valid) vstore_u(b_v, oc, v);)
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
-        Vec g_v = vmask(gpv_c, valid);
-        gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);
+        Vec g_v = rf ? vzero() : vmask(gpv_c, valid);
+        if (!rf) gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);
         float g_vd[3];
         float sx, sX;
         {  // coord_mlp_r_virtual head: forward, then its adjoint
@@ -791,12 +808,14 @@ struct NodePreBwdArgs {
   float *g_h, *g_x, *g_vel, *wg_gzv, *wg_gzg;
   float *d_wv2, *d_bv2, *d_wg2, *d_bg2;
   int N, gravity, has_vel;
+  const float *vel, *wv0;   // FastRF velocity head: coord_mlp_vel(||vel||), wv0 = coord_mlp_vel.0.weight [H,1]
+  float *d_wv0, *d_bv0;
 };
 __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
   const int l = lane_id(), j = l & 15, q = l >> 4;
   const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int ntiles = (a.N + 15) >> 4;
-  Vec acc_wv2 = vzero(), acc_wg2 = vzero();
+  Vec acc_wv2 = vzero(), acc_wg2 = vzero(), acc_wv0 = vzero(), acc_bv0 = vzero();
   float acc_bv2 = 0.f, acc_bg2 = 0.f;
   for (int tile = wave; tile < ntiles; tile += nwaves) {
     const int n = tile * 16 + j;
@@ -816,6 +835,18 @@ __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
       const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z);
       if (valid) vstore_row(a.wg_gzv + (size_t)n * H, q, g_z);
       gemm64(a.wpack + (size_t)I_WVEL0T * IMG, g_z, g_h);
+    }
+    if (a.wv0) {  // FastRF.py:139: only parameter gradients (the norm of the velocity is detached)
+      const float vx = a.vel[(size_t)nc * 3], vy = a.vel[(size_t)nc * 3 + 1], vz = a.vel[(size_t)nc * 3 + 2];
+      const float vn = sqrt_f(vx * vx + vy * vy + vz * vz);
+      Vec z = vload_vec(a.bv0, q);
+      vaxpy(z, vn, vload_vec(a.wv0, q));
+      const float gs = valid ? a.g_svel[nc] : 0.f;
+      vaxpy(acc_wv2, gs, vsilu(z));
+      if (q == 0) acc_bv2 += gs;
+      const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z);
+      vadd(acc_bv0, g_z);
+      vaxpy(acc_wv0, vn, g_z);
     }
     if (a.gravity) {  // gravity_mlp head (:142)
       Vec z = vload_vec(a.bg0, q);
@@ -840,14 +871,18 @@ __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
       }
     }
   }
-  __shared__ float red[2 * H + 2];
-  for (int i = threadIdx.x; i < 2 * H + 2; i += blockDim.x) red[i] = 0.f;
+  __shared__ float red[4 * H + 2];
+  for (int i = threadIdx.x; i < 4 * H + 2; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
   float s = 0.f;
-  if (a.has_vel) {
+  if (a.has_vel || a.wv0) {
     vec_reduce_lds(red, acc_wv2, j, q);
     s = jsum(acc_bv2);
     if (l == 0) atomicAdd(&red[2 * H], s);
+  }
+  if (a.wv0) {
+    vec_reduce_lds(red + 2 * H + 2, acc_wv0, j, q);
+    vec_reduce_lds(red + 3 * H + 2, acc_bv0, j, q);
   }
   if (a.gravity) {
     vec_reduce_lds(red + H, acc_wg2, j, q);
@@ -856,9 +891,13 @@ __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
   }
   __syncthreads();
   if (threadIdx.x < H) {
-    if (a.has_vel) {
+    if (a.has_vel || a.wv0) {
       atomicAdd(&a.d_wv2[threadIdx.x], red[threadIdx.x]);
       if (threadIdx.x == 0) atomicAdd(a.d_bv2, red[2 * H]);
+    }
+    if (a.wv0) {
+      atomicAdd(&a.d_wv0[threadIdx.x], red[2 * H + 2 + threadIdx.x]);
+      atomicAdd(&a.d_bv0[threadIdx.x], red[3 * H + 2 + threadIdx.x]);
     }
     if (a.gravity) {
       atomicAdd(&a.d_wg2[threadIdx.x], red[H + threadIdx.x]);
@@ -872,7 +911,7 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
                  L->svel && L->g_h && L->g_x && L->wg_node && L->grads && L->batch,
              "node_pre_backward: null buffer");
   if (L->N == 0) return FASTEGNN_OK;
-  const bool grav = has(L, FASTEGNN_F_GRAVITY);
+  const bool grav = has(L, FASTEGNN_F_GRAVITY), rf = has(L, FASTEGNN_F_RF);
   const float *const *p = L->params;
   float *const *g = L->grads;
   const int N = L->N;
@@ -881,7 +920,11 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
                    L->svel, p[FASTEGNN_P_VEL0_B], p[FASTEGNN_P_VEL2_W], p[FASTEGNN_P_GRAV0_B], p[FASTEGNN_P_GRAV2_W],
                    L->batch, L->g_h, L->g_x, L->g_vel, wg_gzv, wg_gzg,
                    g[FASTEGNN_P_VEL2_W], g[FASTEGNN_P_VEL2_B], g[FASTEGNN_P_GRAV2_W], g[FASTEGNN_P_GRAV2_B], N, grav ? 1 : 0,
-                   p[FASTEGNN_P_VEL0_W] ? 1 : 0};
+                   (p[FASTEGNN_P_VEL0_W] && !rf) ? 1 : 0, L->vel, rf ? p[FASTEGNN_P_VEL0_W] : nullptr,
+                   g[FASTEGNN_P_VEL0_W], g[FASTEGNN_P_VEL0_B]};
+  FE_REQUIRE(!rf || (L->vel && p[FASTEGNN_P_VEL0_W] && g[FASTEGNN_P_VEL0_W] && g[FASTEGNN_P_VEL0_B] && g[FASTEGNN_P_VEL2_W] &&
+                     g[FASTEGNN_P_VEL2_B]),
+             "node_pre_backward: FastRF needs vel and the coord_mlp_vel parameters / gradients");
   int grid = cdiv(cdiv(N, 16), 4);
   if (grid > 512) grid = 512;
   { ProfScope _ps_node_pre_bwd_kernel(K_NODE_PRE_BWD, st); hipLaunchKernelGGL(node_pre_bwd_kernel, dim3(grid), dim3(256), 0, st, a); }
@@ -895,7 +938,7 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   if ((rc = wb.add(L->g_QX, QXLD, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, c0 + H, 1, nullptr))) return rc;
   // edge_mlp_virtual.0 columns [0,H) <- h (A)   (absent for the EGNN baseline: add() skips a null dW)
   if ((rc = wb.add(L->g_A, H, L->h, H, N, g[FASTEGNN_P_VIRT0_W], ld_v0, 0, 1, nullptr))) return rc;
-  if (p[FASTEGNN_P_VEL0_W])
+  if (p[FASTEGNN_P_VEL0_W] && !rf)
     if ((rc = wb.add(wg_gzv, H, L->h, H, N, g[FASTEGNN_P_VEL0_W], H, 0, 1, g[FASTEGNN_P_VEL0_B]))) return rc;
   if (grav)
     if ((rc = wb.add(wg_gzg, H, L->h, H, N, g[FASTEGNN_P_GRAV0_W], H, 0, 1, g[FASTEGNN_P_GRAV0_B]))) return rc;

@@ -13,6 +13,7 @@ struct NodePreArgs {
   const float *b1, *bv0, *wv2, *bv2, *bg0, *wg2, *bg2;
   float *P, *QX, *A, *svel, *sgrav;
   int N, gravity, has_vel;
+  const float *vel, *wv0;   // FastRF: velocity scale from ||vel|| through coord_mlp_vel.0.weight [H,1]
 };
 
 __global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
@@ -26,11 +27,12 @@ __global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
   load_floats(vec + 2 * H, a.wv2, H);
   load_floats(vec + 3 * H, a.bg0, H);
   load_floats(vec + 4 * H, a.wg2, H);
+  load_floats(vec + 5 * H, a.wv0, H);
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4;
   const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int ntiles = (a.N + 15) >> 4;
-  const float bv2 = a.has_vel ? a.bv2[0] : 0.f;
+  const float bv2 = (a.has_vel || a.wv0) ? a.bv2[0] : 0.f;
   const float bg2 = a.gravity ? a.bg2[0] : 0.f;
   for (int tile = wave; tile < ntiles; tile += nwaves) {
     const int n = tile * 16 + j;
@@ -57,6 +59,11 @@ __global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
       acc = vload_vec(vec + 1 * H, q);
       gemm64(img + 3 * IMG, hv, acc);
       s = vdot(vsilu(acc), vload_vec(vec + 2 * H, q)) + bv2;
+    } else if (a.wv0) {   // FastRF.py:139: coord_mlp_vel(||vel||), the norm is detached (:169)
+      const float vx = a.vel[(size_t)nc * 3], vy = a.vel[(size_t)nc * 3 + 1], vz = a.vel[(size_t)nc * 3 + 2];
+      acc = vload_vec(vec + 1 * H, q);
+      vaxpy(acc, sqrt_f(vx * vx + vy * vy + vz * vz), vload_vec(vec + 5 * H, q));
+      s = vdot(vsilu(acc), vload_vec(vec + 2 * H, q)) + bv2;
     }
     if (valid && q == 0) a.svel[n] = s;
     if (a.gravity) {
@@ -76,11 +83,16 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
   const float *const *p = L->params;
   NodePreArgs a{L->h, L->x, L->wpack, p[FASTEGNN_P_EDGE0_B], p[FASTEGNN_P_VEL0_B], p[FASTEGNN_P_VEL2_W],
                 p[FASTEGNN_P_VEL2_B], p[FASTEGNN_P_GRAV0_B], p[FASTEGNN_P_GRAV2_W], p[FASTEGNN_P_GRAV2_B],
-                L->P, L->QX, L->A, L->svel, L->sgrav, L->N, grav ? 1 : 0, p[FASTEGNN_P_VEL0_W] ? 1 : 0};
+                L->P, L->QX, L->A, L->svel, L->sgrav, L->N, grav ? 1 : 0,
+                (p[FASTEGNN_P_VEL0_W] && !has(L, FASTEGNN_F_RF)) ? 1 : 0,
+                L->vel, has(L, FASTEGNN_F_RF) ? p[FASTEGNN_P_VEL0_W] : nullptr};
+  FE_REQUIRE(!has(L, FASTEGNN_F_RF) || (L->vel && p[FASTEGNN_P_VEL0_W] && p[FASTEGNN_P_VEL0_B] && p[FASTEGNN_P_VEL2_W] &&
+                                         p[FASTEGNN_P_VEL2_B]),
+             "node_pre_forward: FastRF needs vel and the coord_mlp_vel parameters");
   const int ntiles = (L->N + 15) / 16;
   int grid = cdiv(ntiles, 4);
   if (grid > 512) grid = 512;
-  const size_t lds = (5 * IMG + 5 * H) * sizeof(float);
+  const size_t lds = (5 * IMG + 6 * H) * sizeof(float);
   { ProfScope _ps_node_pre_fwd_kernel(K_NODE_PRE_FWD, st); hipLaunchKernelGGL(node_pre_fwd_kernel, dim3(grid), dim3(256), lds, st, a); }
   return check_launch("node_pre_fwd_kernel");
 }
@@ -334,12 +346,14 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   const int ntg = (a.N + GROUP - 1) / GROUP;
   const float invC = C > 0 ? 1.0f / (float)C : 0.f;
   const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;   // basic.py:310
+  const bool rf = a.flags & FASTEGNN_F_RF;             // FastRF.py:155-186: no node_model / node_model_virtual
   int cur = -1;  // graph the LDS pool accumulators belong to
   auto flush_pools = [&]() {
-    for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
-      atomicAdd(&a.poolV[(size_t)cur * C * H + i], poolV_l[i]);
-      poolV_l[i] = 0.f;
-    }
+    if (!rf)
+      for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
+        atomicAdd(&a.poolV[(size_t)cur * C * H + i], poolV_l[i]);
+        poolV_l[i] = 0.f;
+      }
     for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
       atomicAdd(&a.poolX[(size_t)cur * 3 * C + i], poolX_l[i]);
       poolX_l[i] = 0.f;
@@ -386,13 +400,15 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     }
     float transv[3] = {0.f, 0.f, 0.f};
     Vec nodeacc = vload_vec(vec + VV_B3 * H, q);
-    if constexpr (FWD_X3) { if (C > 0) fetch_w3c(0); }
+    if constexpr (FWD_X3) { if (C > 0 && !rf) fetch_w3c(0); }
     for (int c = 0; c < C; ++c) {
       if constexpr (FWD_X3) {
-        __syncthreads();          // every wave is done with the previous channel's stage
-        commit_w3c();
-        __syncthreads();
-        if (c + 1 < C) fetch_w3c(c + 1);
+        if (!rf) {
+          __syncthreads();          // every wave is done with the previous channel's stage
+          commit_w3c();
+          __syncthreads();
+          if (c + 1 < C) fetch_w3c(c + 1);
+        }
       }
       if (active) {
         VirtFwdState S;
@@ -401,9 +417,11 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
         transv[1] -= S.vd[1] * S.sx;
         transv[2] -= S.vd[2] * S.sx;
         // pools: sum over the nodes of the tile
-        __builtin_amdgcn_wave_barrier();
-        tile_store(tile, j, q, valid ? S.v : vzero());
-        __builtin_amdgcn_wave_barrier();
+        if (!rf) {
+          __builtin_amdgcn_wave_barrier();
+          tile_store(tile, j, q, valid ? S.v : vzero());
+          __builtin_amdgcn_wave_barrier();
+        }
         if (fast) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
@@ -411,28 +429,37 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
             pv = jsum(pv);
             if (l == 0) atomicAdd(&poolX_l[k * C + c], pv);
           }
-          float s = 0.f;
+          if (!rf) {
+            float s = 0.f;
 #pragma unroll
-          for (int ee = 0; ee < 16; ++ee) s += tile[ee * TS + l];
-          atomicAdd(&poolV_l[c * H + l], s);
+            for (int ee = 0; ee < 16; ++ee) s += tile[ee * TS + l];
+            atomicAdd(&poolV_l[c * H + l], s);
+          }
         } else {
           if (valid && q == 0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) atomicAdd(&a.poolX[((size_t)b * 3 + k) * C + c], S.vd[k] * S.sX);
           }
+          if (!rf) {
 #pragma unroll
-          for (int ee = 0; ee < 16; ++ee) {
-            if (ee < nvalid) {
-              const int be = __builtin_amdgcn_readlane(b, ee);
-              atomicAdd(&a.poolV[((size_t)be * C + c) * H + l], tile[ee * TS + l]);
+            for (int ee = 0; ee < 16; ++ee) {
+              if (ee < nvalid) {
+                const int be = __builtin_amdgcn_readlane(b, ee);
+                atomicAdd(&a.poolV[((size_t)be * C + c) * H + l], tile[ee * TS + l]);
+              }
             }
           }
         }
-        if constexpr (FWD_X3) gemm64_x3(stage, S.vs, nodeacc);
-        else gemm64(a.wpack + (size_t)img_w3c(c) * IMG, S.v, nodeacc);
+        if (!rf) {
+          if constexpr (FWD_X3) gemm64_x3(stage, S.vs, nodeacc);
+          else gemm64(a.wpack + (size_t)img_w3c(c) * IMG, S.v, nodeacc);
+        }
       }
     }
-    if (active) {
+    if (active && rf) {   // the node features pass through unchanged (FastRF.py:186)
+      if (valid) vstore_row(a.h_out + (size_t)n * H, q, vload_row(a.h + (size_t)nc * H, q));
+    }
+    if (active && !rf) {
       // node_model: node_mlp.0 on [h | agg | flat(v) | node_attr]  (:153-166)
       const Vec hv = vload_row(a.h + (size_t)nc * H, q);
       gemm64(a.wpack + (size_t)I_W3A * IMG, hv, nodeacc);
@@ -452,8 +479,10 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       Vec out = vload_vec(vec + VV_B4 * H, q);
       gemm64(a.wpack + (size_t)I_W4 * IMG, vsilu(nodeacc), out);
       if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
+      if (valid) vstore_row(a.h_out + (size_t)n * H, q, out);
+    }
+    if (active) {
       if (valid) {
-        vstore_row(a.h_out + (size_t)n * H, q, out);
         if (q == 0) {
           const float sv = a.svel[n];
           const float sg = (a.flags & FASTEGNN_F_GRAVITY) ? a.sgrav[n] : 0.f;
@@ -507,6 +536,10 @@ __global__ __launch_bounds__(256) void graph_post_fwd_kernel(GraphPostArgs a) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.B * 3 * a.C; i += gridDim.x * blockDim.x) {
     const int b = i / (3 * a.C);
     a.Z_out[i] = a.Z[i] + a.poolX[i] / fmaxf(a.xsum[b * 4 + 3], 1.f);
+  }
+  if (a.flags & FASTEGNN_F_RF) {   // FastRF.py:186: the virtual node features pass through
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * H; i += gridDim.x * blockDim.x) a.HvT_out[i] = a.HvT[i];
+    return;
   }
   for (int tile = wave; tile < ntiles; tile += nwaves) {
     const int m = tile * 16 + j;

@@ -12,7 +12,7 @@ struct PackDesc {
 struct PackArgs {
   const float *p[FASTEGNN_P_COUNT];
   float *wpack;
-  int C, ea, na, egnn;
+  int C, ea, na, egnn, rf;
 };
 
 __device__ __forceinline__ PackDesc pack_desc(const PackArgs &a, int id) {
@@ -39,12 +39,12 @@ __device__ __forceinline__ PackDesc pack_desc(const PackArgs &a, int id) {
     case I_W1A: set(FASTEGNN_P_EDGE0_W, ld_e0, a.egnn, 0); break;       // EGNN: column 0 is the radial
     case I_W1B: set(FASTEGNN_P_EDGE0_W, ld_e0, H + a.egnn, 0); break;
     case I_V1A: set(FASTEGNN_P_VIRT0_W, ld_v0, 0, 0); break;
-    case I_WVEL0: set(FASTEGNN_P_VEL0_W, H, 0, 0); break;
+    case I_WVEL0: if (!a.rf) set(FASTEGNN_P_VEL0_W, H, 0, 0); break;   // FastRF: [H,1] weight, no image
     case I_WG0: set(FASTEGNN_P_GRAV0_W, H, 0, 0); break;
     case I_W1AT: set(FASTEGNN_P_EDGE0_W, ld_e0, a.egnn, 1); break;
     case I_W1BT: set(FASTEGNN_P_EDGE0_W, ld_e0, H + a.egnn, 1); break;
     case I_V1AT: set(FASTEGNN_P_VIRT0_W, ld_v0, 0, 1); break;
-    case I_WVEL0T: set(FASTEGNN_P_VEL0_W, H, 0, 1); break;
+    case I_WVEL0T: if (!a.rf) set(FASTEGNN_P_VEL0_W, H, 0, 1); break;
     case I_WG0T: set(FASTEGNN_P_GRAV0_W, H, 0, 1); break;
     case I_W5A: set(FASTEGNN_P_NODEV0_W, 2 * H, 0, 0); break;
     case I_W5B: set(FASTEGNN_P_NODEV0_W, 2 * H, H, 0); break;
@@ -103,6 +103,7 @@ int pack_weights(const fastegnn_layer_t *L, hipStream_t st) {
   a.ea = L->ea;
   a.na = L->na;
   a.egnn = has(L, FASTEGNN_F_EGNN) ? 1 : 0;
+  a.rf = has(L, FASTEGNN_F_RF) ? 1 : 0;
   { ProfScope _ps_pack_kernel(K_PACK, st); hipLaunchKernelGGL(pack_kernel, dim3(I_FIXED + 2 * L->C), dim3(256), 0, st, a); }
   return check_launch("pack_kernel");
 }

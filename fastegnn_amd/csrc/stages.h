@@ -202,8 +202,8 @@ __device__ __forceinline__ void virt_load_vecs(float *vec, const VirtArgs &a) {
     vec[VV_BXX0 * H + i] = a.bxx0 ? a.bxx0[i] : 0.f;
     vec[VV_WXX2 * H + i] = a.wxx2 ? a.wxx2[i] : 0.f;
     vec[VV_ATT * H + i] = a.attw ? a.attw[i] : 0.f;
-    vec[VV_B3 * H + i] = a.b3[i];
-    vec[VV_B4 * H + i] = a.b4[i];
+    vec[VV_B3 * H + i] = a.b3 ? a.b3[i] : 0.f;   // node_mlp is absent in the FastRF layer
+    vec[VV_B4 * H + i] = a.b4 ? a.b4[i] : 0.f;
   }
 }
 

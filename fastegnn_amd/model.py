@@ -164,7 +164,7 @@ class _Spec:
         flags |= K.F_TANH if model.tanh else 0
         flags |= K.F_RESIDUAL if model.residual else 0
         flags |= K.F_GRAVITY if model.gravity is not None else 0
-        self.flags = flags
+        self.flags = flags | model._extra_flags
         self.gravity = [float(v) for v in model.gravity] if model.gravity is not None else [0.0, 0.0, 0.0]
         # parameter order handed to the autograd function
         self.names = ["virtual_node_feat", "embedding_in.weight", "embedding_in.bias"]
@@ -304,6 +304,9 @@ class _FastEGNNFunction(torch.autograd.Function):
 class FastEGNN(nn.Module):
     """MI355X-native drop-in for the reference ``FastEGNN`` (models/FastEGNN.py:226-276)."""
 
+    _layer_cls = E_GCL_vel   # parameter holder of one layer
+    _extra_flags = 0         # FASTEGNN_F_* bits a sibling model adds (fastrf.py)
+
     def __init__(self, node_feat_nf, node_attr_nf, edge_attr_nf, hidden_nf, virtual_channels, device='cpu',
                  act_fn=nn.SiLU(), n_layers=4, residual=True, attention=False, normalize=False, tanh=False,
                  gravity=None):
@@ -326,8 +329,8 @@ class FastEGNN(nn.Module):
                                               requires_grad=True)
         self.embedding_in = nn.Linear(node_feat_nf, self.hidden_nf)
         for i in range(n_layers):
-            self.add_module("gcl_%d" % i, E_GCL_vel(hidden_nf, node_attr_nf, edge_attr_nf, virtual_channels, act_fn,
-                                                    attention, tanh, gravity))
+            self.add_module("gcl_%d" % i, self._layer_cls(hidden_nf, node_attr_nf, edge_attr_nf, virtual_channels, act_fn,
+                                                          attention, tanh, gravity))
         self._graph_cache: Dict[tuple, SortedGraph] = {}
         self.cache_graphs = True
         self._spec = None      # built lazily (after .to(device) / load_state_dict), parameters are fixed objects

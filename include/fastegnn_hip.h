@@ -54,7 +54,11 @@ enum {
   /* EGNN baseline layer (models/basic.py:285-320) on the same kernels: C = 0 (no virtual nodes),
    * edge_mlp.0 columns ordered [radial | h_row | h_col | edge_attr] (:313), coordinate head with bias,
    * aggregated coordinate message clamped to +-100 (:310), no residual on h, velocity head optional */
-  FASTEGNN_F_EGNN = 64
+  FASTEGNN_F_EGNN = 64,
+  /* FastRF reduced layer (models/FastRF.py:155-186) on the same kernels: node_mlp / node_mlp_virtual are
+   * absent (h and the virtual features pass through unchanged, their parameter slots are null) and the
+   * velocity scale is coord_mlp_vel(||vel||) with coord_mlp_vel.0.weight of shape [H,1] (:76-80,:139) */
+  FASTEGNN_F_RF = 128
 };
 
 /* Per-layer parameter slots: the reference state_dict tensors of gcl_<i>, untouched

@@ -420,7 +420,59 @@ def dataset_case(n_systems=6, n_balls=5, seed=43):
     print("dataset_nbody5:", len(out), "arrays")
 
 
+def fastrf_cases():
+    """Row 8f-4: the reference's FastRF class (models/FastRF.py) on small ragged batches: outputs and all
+    gradients, same file layout as the FastEGNN cases."""
+    _install_pyg_stand_in()
+    sys.path.insert(0, REF)
+    from models.FastRF import FastRF
+
+    def case(name, seed, L=2, C=4, coord_scale=300.0, **flags):
+        torch.manual_seed(seed); random.seed(seed); np.random.seed(seed)
+        gen = torch.Generator().manual_seed(seed)
+        sizes, edges = [7, 4, 9], [25, 10, 25]
+        ei, batch = _rand_graph_batch(gen, sizes, edges, isolate=(2, 3))
+        N = sum(sizes)
+        model = FastRF(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=C, n_layers=L, **flags)
+        with torch.no_grad():
+            for k, prm in model.named_parameters():
+                if k.endswith(("coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
+                    prm.mul_(coord_scale)
+        inp = dict(node_feat=torch.rand(N, 2, generator=gen), node_loc=torch.randn(N, 3, generator=gen) * 2.0,
+                   node_vel=torch.randn(N, 3, generator=gen) * 0.5, edge_index=ei, data_batch=batch,
+                   edge_attr=torch.rand(ei.size(1), 2, generator=gen))
+        inp["loc_mean"] = _loc_mean(inp["node_loc"], batch, C)
+        target = torch.randn(N, 3, generator=gen); wv = torch.randn(len(sizes), 3, C, generator=gen)
+        leaf = {k: inp[k].clone().requires_grad_(True) for k in ("node_feat", "node_loc", "node_vel", "loc_mean")}
+        loc, vloc = model(**{**inp, **leaf})
+        loss = torch.nn.functional.mse_loss(loc, target) + 0.3 * (vloc * wv).sum() / vloc.numel()
+        loss.backward()
+        out = {f"in/{k}": v.numpy() for k, v in inp.items()}
+        out["in/target"], out["in/wv"] = target.numpy(), wv.numpy()
+        for k, prm in model.named_parameters():
+            out[f"p/{k}"] = prm.detach().numpy()
+            out[f"gp/{k}"] = (prm.grad if prm.grad is not None else torch.zeros_like(prm)).numpy()
+        for k, v in leaf.items():
+            out[f"gin/{k}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
+        out["out/loc"], out["out/vloc"] = loc.detach().numpy(), vloc.detach().numpy()
+        g = flags.get("gravity")
+        meta = dict(nf=2, na=0, ea=2, H=64, C=C, L=L, residual=1, attention=int(flags.get("attention", False)),
+                    normalize=int(flags.get("normalize", False)), tanh=int(flags.get("tanh", False)),
+                    has_gravity=int(g is not None), gravity=np.array(g if g is not None else [0, 0, 0], dtype=np.float32))
+        for k, v in meta.items():
+            out[f"meta/{k}"] = np.asarray(v)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(name, "loss", float(loss))
+
+    case("fastrf_plain", 21)
+    case("fastrf_allflags", 22, attention=True, normalize=True, tanh=True, gravity=[0, -1, 0])
+    case("fastrf_c16", 23, C=16, coord_scale=100.0, gravity=[0, -1, 0])
+
+
 def main():
+    if "--fastrf" in sys.argv:
+        fastrf_cases()
+        return
     if "--dataset" in sys.argv:
         dataset_case()
         return

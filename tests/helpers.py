@@ -12,7 +12,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def golden_names(include_fp64=False):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    names = [n for n in names if not n.startswith(("train_", "egnn_", "dataset_"))]   # other fixture families have their own tests
+    names = [n for n in names if not n.startswith(("train_", "egnn_", "dataset_", "fastrf_"))]   # other fixture families have their own tests
     if not include_fp64:
         names = [n for n in names if not n.endswith("_fp64")]
     return names
