@@ -122,6 +122,9 @@ struct VirtBwdArgs {
   int ld_v0;
 };
 
+// RF (FastRF reduced layer) is a compile-time switch: as a run-time flag it cost the FastEGNN path 10 %
+// (register allocation of the channel loop)
+template <bool RF>
 __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VirtArgs &a = A.f;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   const float invC = C > 0 ? 1.0f / (float)C : 0.f;
   const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION;
   const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;
-  const bool rf = a.flags & FASTEGNN_F_RF;
+  constexpr bool rf = RF;
   const float *gpv_base = rf ? a.Bc : A.g_poolV;   // FastRF: no pooled-message gradient (the rows are ignored)
   Vec acc_wxv2 = vzero(), acc_wxx2 = vzero(), acc_wvr = vzero(), acc_att = vzero();
   float acc_attb = 0.f;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       // ---- node MLP adjoint (node_model, :153-166); FastRF: h passes through, no segment-mean message
       const Vec g_out = vmask(vload_u(b_gho, offN), valid);
       Vec g_np = vzero();
-      if (rf) {
+      if constexpr (rf) {
         if (valid) {
           vstore_u(b_gh, offN, g_out);
           vstore_u(b_gam, offN, vzero());
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         WG_STORE(if (valid) vstore_u(b_v, oc, v);)
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
         Vec g_v = rf ? vzero() : vmask(gpv_c, valid);
-        if (!rf) gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);
+        if constexpr (!rf) gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);
         float g_vd[3];
         float sx, sX;
         {  // coord_mlp_r_virtual head: forward, then its adjoint
@@ -451,7 +454,12 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
   const int ntg = cdiv(N, 16 * VIRT_BWD_WAVES);
   int grid = ntg < 256 ? ntg : 256;
-  { ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st); hipLaunchKernelGGL(virt_bwd_kernel, dim3(grid), dim3(64 * VIRT_BWD_WAVES), virt_lds_bytes(C, 6, VIRT_BWD_WAVES), st, A); }
+  {
+    ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st);
+    const size_t lds = virt_lds_bytes(C, 6, VIRT_BWD_WAVES);
+    if (has(L, FASTEGNN_F_RF)) hipLaunchKernelGGL(virt_bwd_kernel<true>, dim3(grid), dim3(64 * VIRT_BWD_WAVES), lds, st, A);
+    else hipLaunchKernelGGL(virt_bwd_kernel<false>, dim3(grid), dim3(64 * VIRT_BWD_WAVES), lds, st, A);
+  }
   int rc = check_launch("virt_bwd_kernel");
   if (rc) return rc;
   const int ld_n0 = 2 * H + H * C + L->na;
