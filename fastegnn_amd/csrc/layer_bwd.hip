@@ -819,7 +819,19 @@ struct NodePreBwdArgs {
   const float *vel, *wv0;   // FastRF velocity head: coord_mlp_vel(||vel||), wv0 = coord_mlp_vel.0.weight [H,1]
   float *d_wv0, *d_bv0;
 };
-__global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
+__global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodePreBwdArgs a) {
+  // images WVEL0 WG0 | W1AT W1BT V1AT WVEL0T WG0T (consecutive ids) resident in LDS
+  extern __shared__ __attribute__((aligned(16))) float limg[];
+  load_images(limg, a.wpack + (size_t)I_WVEL0 * IMG, 7);
+  __syncthreads();
+  auto im = [&](int id) { return limg + (id - I_WVEL0) * IMG; };
+  // one GEMM's operand reads at a time: without the fences the scheduler hoists the LDS reads of all seven
+  // GEMMs of a tile (448 registers) and spills
+  auto gemm_f = [&](const float *img, const Vec &in, Vec &acc) {
+    __builtin_amdgcn_sched_barrier(0);
+    gemm64(img, in, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   const int l = lane_id(), j = l & 15, q = l >> 4;
   const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int ntiles = (a.N + 15) >> 4;
@@ -831,18 +843,18 @@ __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
     const int nc = valid ? n : a.N - 1;
     const Vec hv = vload_row(a.h + (size_t)nc * H, q);
     Vec g_h = vload_row(a.g_h + (size_t)nc * H, q);
-    gemm64(a.wpack + (size_t)I_W1AT * IMG, vload_row(a.g_P + (size_t)nc * H, q), g_h);
-    gemm64(a.wpack + (size_t)I_W1BT * IMG, vload_row(a.g_QX + (size_t)nc * QXLD, q), g_h);
-    gemm64(a.wpack + (size_t)I_V1AT * IMG, vload_row(a.g_A + (size_t)nc * H, q), g_h);
+    gemm_f(im(I_W1AT), vload_row(a.g_P + (size_t)nc * H, q), g_h);
+    gemm_f(im(I_W1BT), vload_row(a.g_QX + (size_t)nc * QXLD, q), g_h);
+    gemm_f(im(I_V1AT), vload_row(a.g_A + (size_t)nc * H, q), g_h);
     if (a.has_vel) {  // coord_mlp_vel head (:139)
       Vec z = vload_vec(a.bv0, q);
-      gemm64(a.wpack + (size_t)I_WVEL0 * IMG, hv, z);
+      gemm_f(im(I_WVEL0), hv, z);
       const float gs = valid ? a.g_svel[nc] : 0.f;
       vaxpy(acc_wv2, gs, vsilu(z));
       if (q == 0) acc_bv2 += gs;
       const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z);
       if (valid) vstore_row(a.wg_gzv + (size_t)n * H, q, g_z);
-      gemm64(a.wpack + (size_t)I_WVEL0T * IMG, g_z, g_h);
+      gemm_f(im(I_WVEL0T), g_z, g_h);
     }
     if (a.wv0) {  // FastRF.py:139: only parameter gradients (the norm of the velocity is detached)
       const float vx = a.vel[(size_t)nc * 3], vy = a.vel[(size_t)nc * 3 + 1], vz = a.vel[(size_t)nc * 3 + 2];
@@ -858,13 +870,13 @@ __global__ __launch_bounds__(256) void node_pre_bwd_kernel(NodePreBwdArgs a) {
     }
     if (a.gravity) {  // gravity_mlp head (:142)
       Vec z = vload_vec(a.bg0, q);
-      gemm64(a.wpack + (size_t)I_WG0 * IMG, hv, z);
+      gemm_f(im(I_WG0), hv, z);
       const float gs = valid ? a.g_sgrav[nc] : 0.f;
       vaxpy(acc_wg2, gs, vsilu(z));
       if (q == 0) acc_bg2 += gs;
       const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wg2, q), gs), z);
       if (valid) vstore_row(a.wg_gzg + (size_t)n * H, q, g_z);
-      gemm64(a.wpack + (size_t)I_WG0T * IMG, g_z, g_h);
+      gemm_f(im(I_WG0T), g_z, g_h);
     }
     if (valid) {
       vstore_row(a.g_h + (size_t)n * H, q, g_h);
@@ -933,9 +945,9 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(!rf || (L->vel && p[FASTEGNN_P_VEL0_W] && g[FASTEGNN_P_VEL0_W] && g[FASTEGNN_P_VEL0_B] && g[FASTEGNN_P_VEL2_W] &&
                      g[FASTEGNN_P_VEL2_B]),
              "node_pre_backward: FastRF needs vel and the coord_mlp_vel parameters / gradients");
-  int grid = cdiv(cdiv(N, 16), 4);
-  if (grid > 512) grid = 512;
-  { ProfScope _ps_node_pre_bwd_kernel(K_NODE_PRE_BWD, st); hipLaunchKernelGGL(node_pre_bwd_kernel, dim3(grid), dim3(256), 0, st, a); }
+  int grid = cdiv(cdiv(N, 16), NODE_PRE_WAVES);
+  if (grid > 256) grid = 256;
+  { ProfScope _ps_node_pre_bwd_kernel(K_NODE_PRE_BWD, st); hipLaunchKernelGGL(node_pre_bwd_kernel, dim3(grid), dim3(64 * NODE_PRE_WAVES), 7 * IMG * sizeof(float), st, a); }
   int rc = check_launch("node_pre_bwd_kernel");
   if (rc) return rc;
   const int ld_e0 = 2 * H + 1 + L->ea, ld_v0 = 2 * H + 1 + L->C;

@@ -16,7 +16,7 @@ struct NodePreArgs {
   const float *vel, *wv0;   // FastRF: velocity scale from ||vel|| through coord_mlp_vel.0.weight [H,1]
 };
 
-__global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
+__global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodePreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *img = lds;            // 5 images: W1A W1B V1A WVEL0 WG0
   float *vec = lds + 5 * IMG;  // b1 bv0 wv2 bg0 wg2
@@ -40,10 +40,10 @@ __global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
     const int nc = valid ? n : a.N - 1;
     const Vec hv = vload_row(a.h + (size_t)nc * H, q);
     Vec acc = vload_vec(vec, q);
-    gemm64(img + 0 * IMG, hv, acc);
+    gemm64_f(img + 0 * IMG, hv, acc);
     if (valid) vstore_row(a.P + (size_t)n * H, q, acc);
     acc = vzero();
-    gemm64(img + 1 * IMG, hv, acc);
+    gemm64_f(img + 1 * IMG, hv, acc);
     if (valid) {
       vstore_row(a.QX + (size_t)n * QXLD, q, acc);
       if (q == 0) {
@@ -52,12 +52,12 @@ __global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
       }
     }
     acc = vzero();
-    gemm64(img + 2 * IMG, hv, acc);
+    gemm64_f(img + 2 * IMG, hv, acc);
     if (valid) vstore_row(a.A + (size_t)n * H, q, acc);
     float s = 0.f;
     if (a.has_vel) {
       acc = vload_vec(vec + 1 * H, q);
-      gemm64(img + 3 * IMG, hv, acc);
+      gemm64_f(img + 3 * IMG, hv, acc);
       s = vdot(vsilu(acc), vload_vec(vec + 2 * H, q)) + bv2;
     } else if (a.wv0) {   // FastRF.py:139: coord_mlp_vel(||vel||), the norm is detached (:169)
       const float vx = a.vel[(size_t)nc * 3], vy = a.vel[(size_t)nc * 3 + 1], vz = a.vel[(size_t)nc * 3 + 2];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void node_pre_fwd_kernel(NodePreArgs a) {
     if (valid && q == 0) a.svel[n] = s;
     if (a.gravity) {
       acc = vload_vec(vec + 3 * H, q);
-      gemm64(img + 4 * IMG, hv, acc);
+      gemm64_f(img + 4 * IMG, hv, acc);
       s = vdot(vsilu(acc), vload_vec(vec + 4 * H, q)) + bg2;
       if (valid && q == 0) a.sgrav[n] = s;
     }
@@ -90,10 +90,10 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
                                          p[FASTEGNN_P_VEL2_B]),
              "node_pre_forward: FastRF needs vel and the coord_mlp_vel parameters");
   const int ntiles = (L->N + 15) / 16;
-  int grid = cdiv(ntiles, 4);
-  if (grid > 512) grid = 512;
+  int grid = cdiv(ntiles, NODE_PRE_WAVES);
+  if (grid > 256) grid = 256;
   const size_t lds = (5 * IMG + 6 * H) * sizeof(float);
-  { ProfScope _ps_node_pre_fwd_kernel(K_NODE_PRE_FWD, st); hipLaunchKernelGGL(node_pre_fwd_kernel, dim3(grid), dim3(256), lds, st, a); }
+  { ProfScope _ps_node_pre_fwd_kernel(K_NODE_PRE_FWD, st); hipLaunchKernelGGL(node_pre_fwd_kernel, dim3(grid), dim3(64 * NODE_PRE_WAVES), lds, st, a); }
   return check_launch("node_pre_fwd_kernel");
 }
 

@@ -23,8 +23,15 @@ constexpr int EDGE_WAVES = 8;
 #define FE_EDGE_FWD_WAVES (FE_FWD_X3 ? 16 : 8)
 #endif
 constexpr int EDGE_FWD_WAVES = FE_EDGE_FWD_WAVES;   // 48 KB of split images are shared by more waves
+#ifndef FE_NODE_PRE_WAVES
+#define FE_NODE_PRE_WAVES 8
+#endif
+constexpr int NODE_PRE_WAVES = FE_NODE_PRE_WAVES;   // 8: two waves per SIMD (<= 256 registers each)
 constexpr int VIRT_WAVES = 8;
-constexpr int VIRT_BWD_WAVES = 4;   // 1 wave/SIMD: the adjoint of the virtual block needs > 256 registers
+#ifndef FE_VIRT_BWD_WAVES
+#define FE_VIRT_BWD_WAVES 4
+#endif
+constexpr int VIRT_BWD_WAVES = FE_VIRT_BWD_WAVES;   // 1 wave/SIMD: the adjoint of the virtual block needs > 256 registers
 
 struct EdgeArgs {
   const float *P, *QX, *QXs, *ea, *wpack;
