@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   float *tiles = vec + 16 * H;
   float *gBc_l = tiles + VIRT_BWD_WAVES * 16 * TS;   // [C][64]
   float *gZ_l = gBc_l + C * H;                   // [3][C]
+  float *w3ct_l = gZ_l + ((3 * C + 3) & ~3);     // W3cT[c] of the channel in flight (fp32 image)
   load_images(img, a.wpack + (size_t)I_V2 * IMG, 6);
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) gBc_l[i] = 0.f;
@@ -172,7 +173,8 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
     }
     const int nb = n0 + wv * 16;
     const int nvalid = max(0, min(16, nend - nb));
-    if (nvalid > 0) {
+    {   // a wave without valid nodes runs the body on masked lanes (every contribution is zero): the
+        // workgroup walks the channels in step for the W3cT stage below
       const int n = nb + j;
       const bool valid = n < nend;
       const int nc = valid ? n : nend - 1;
@@ -246,10 +248,28 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       float nZ[3] = {Zb[0], Zb[C], Zb[2 * C]}, nGpx[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C];
+      // W3cT[c] goes through an LDS stage refilled once per workgroup and channel; the image of channel
+      // c+1 is fetched into registers at the top of channel c (ahead of that channel's stores)
+      constexpr int STG = IMG / 4 / (64 * VIRT_BWD_WAVES);
+      f32x4 pre_w[STG];
+      auto fetch_w3ct = [&](int c) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (size_t)img_w3ct(C, c) * IMG);
+#pragma unroll
+        for (int i = 0; i < STG; ++i) pre_w[i] = src[threadIdx.x + i * 64 * VIRT_BWD_WAVES];
+      };
+      if constexpr (!rf) { if (C > 0) fetch_w3ct(0); }
       for (int c = 0; c < C; ++c) {
         // Recompute the forward of (tile, c) interleaved with its adjoint so that each activation is
         // dead as soon as its gradient is formed.
         asm volatile("" ::: "memory");
+        if constexpr (!rf) {
+          __syncthreads();          // every wave is done with the previous channel's stage
+          f32x4 *dst = reinterpret_cast<f32x4 *>(w3ct_l);
+#pragma unroll
+          for (int i = 0; i < STG; ++i) dst[threadIdx.x + i * 64 * VIRT_BWD_WAVES] = pre_w[i];
+          __syncthreads();
+          fetch_w3ct(c + 1 < C ? c + 1 : c);
+        }
         const unsigned oc = offNC + (unsigned)c * H;
         const Vec Bc_c = nBc, gpv_c = nGpv;
         float vd[3], gpX[3];
@@ -294,7 +314,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         WG_STORE(if (valid) vstore_u(b_v, oc, v);)
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
         Vec g_v = rf ? vzero() : vmask(gpv_c, valid);
-        if constexpr (!rf) gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);
+        if constexpr (!rf) gemm64(w3ct_l, g_np_m, g_v);
         float g_vd[3];
         float sx, sX;
         {  // coord_mlp_r_virtual head: forward, then its adjoint
@@ -456,7 +476,7 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   int grid = ntg < 256 ? ntg : 256;
   {
     ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st);
-    const size_t lds = virt_lds_bytes(C, 6, VIRT_BWD_WAVES);
+    const size_t lds = virt_lds_bytes(C, 6, VIRT_BWD_WAVES) + (IMG + 4) * sizeof(float);
     if (has(L, FASTEGNN_F_RF)) hipLaunchKernelGGL(virt_bwd_kernel<true>, dim3(grid), dim3(64 * VIRT_BWD_WAVES), lds, st, A);
     else hipLaunchKernelGGL(virt_bwd_kernel<false>, dim3(grid), dim3(64 * VIRT_BWD_WAVES), lds, st, A);
   }
