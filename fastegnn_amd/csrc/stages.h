@@ -27,7 +27,10 @@ constexpr int EDGE_FWD_WAVES = FE_EDGE_FWD_WAVES;   // 48 KB of split images are
 #define FE_NODE_PRE_WAVES 8
 #endif
 constexpr int NODE_PRE_WAVES = FE_NODE_PRE_WAVES;   // 8: two waves per SIMD (<= 256 registers each)
-constexpr int VIRT_WAVES = 8;
+#ifndef FE_VIRT_WAVES
+#define FE_VIRT_WAVES 8
+#endif
+constexpr int VIRT_WAVES = FE_VIRT_WAVES;
 #ifndef FE_VIRT_BWD_WAVES
 #define FE_VIRT_BWD_WAVES 4
 #endif
