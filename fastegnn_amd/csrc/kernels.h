@@ -59,6 +59,9 @@ struct WgradBatch {
   WgradBatch(float *slab, hipStream_t st);
   int add(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks, float *db,
           int nb = 1, long sG = 0, long sT = 0, long sW = 0, int kmax = 64);
+  // a job whose partial slabs (nsplit of them, [64][64] + [64] bias each) are written by the caller's own kernel:
+  // only the fixed-order reduction into dW / db runs here.  *slab_begin receives the first slab index.
+  int add_slabs(float *dW, int lddw, int c0, int ks, float *db, int nsplit, int *slab_begin);
   int finish();
 };
 inline size_t wg_slab_floats() { return (size_t)WG_SLABS * (IMG + H); }

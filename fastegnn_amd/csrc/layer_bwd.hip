@@ -244,10 +244,17 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       // stores could only be waited for together with them (vmcnt counts stores too).
       const Vec Arow = vload_u(b_A, offN);
       const Vec g_np_m = vmask(g_np, valid);
-      Vec nBc = vload_u(a.Bc, offB), nGpv = vload_u(gpv_base, offB);
-      float nZ[3] = {Zb[0], Zb[C], Zb[2 * C]}, nGpx[3];
+      Vec nBc = vzero(), nGpv = vzero();
+      float nZ[3] = {0.f, 0.f, 0.f}, nGpx[3] = {0.f, 0.f, 0.f};
+      if (C > 0) {   // the virtual-node buffers are null for the EGNN baseline (C = 0)
+        nBc = vload_u(a.Bc, offB);
+        nGpv = vload_u(gpv_base, offB);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C];
+        for (int k = 0; k < 3; ++k) {
+          nZ[k] = Zb[k * C];
+          nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C];
+        }
+      }
       // W3cT[c] goes through an LDS stage refilled once per workgroup and channel; the image of channel
       // c+1 is fetched into registers at the top of channel c (ahead of that channel's stores)
       constexpr int STG = IMG / 4 / (64 * VIRT_BWD_WAVES);
@@ -587,7 +594,15 @@ struct EdgeBwdArgs {
   float *d_wx2, *d_attw, *d_attb, *d_bx2;
   float *d_wr, *d_we;   // edge_mlp.0.weight grad: radial column and first edge_attr column (row stride ld_e0)
   int ld_e0, C;
+  float *slab, *slab_b;   // producer/consumer variant: partial slabs of the two in-kernel weight gradients
+  int slab_w2, slab_wx1;
 };
+#ifndef FE_EDGE_BWD_PC
+#define FE_EDGE_BWD_PC 1
+#endif
+#ifndef FE_PC_PRIO
+#define FE_PC_PRIO 3
+#endif
 constexpr int XT = 4;   // per-edge scalar row in LDS: g_d[3] | pad
 constexpr int EDGE_BWD_IMG_FLOATS = BWD_X3 ? 4 * IMG3 : 4 * IMG;
 
@@ -747,6 +762,345 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A
   }
 }
 
+// ---- producer/consumer variant: the two 64x64 weight gradients of the edge stage are contracted inside the
+// workgroup.  Waves 0..6 run the tile adjoint (producers) and hand each operand pair (g_mp,t) / (g_up,m) as two
+// 16x64 tiles to wave 7 (consumer) through a ring of LDS slots; the consumer owns the two 64x64 accumulators and
+// writes one partial slab per workgroup and weight (summed by wgrad_reduce_kernel in a fixed order).  The
+// operands never reach HBM.  The consumer contracts two slots of a ring at a time (K = 32 edges) as bf16x3
+// products on the matrix pipe.  Slot protocol (tickets taken from an LDS counter per ring, consumed in order):
+// producer waits drained[s] == round, writes, sets filled[s] = round + 1; consumer waits filled[s] == round + 1,
+// contracts, sets drained[s] = round + 1.
+#ifndef FE_PC_WAVES
+#define FE_PC_WAVES 7
+#endif
+constexpr int PC_WAVES = FE_PC_WAVES;       // 8: consumer shares its SIMD with a producer; 7: wave 3 (consumer) has SIMD 3 alone
+constexpr int PC_CONS = PC_WAVES == 7 ? 3 : PC_WAVES - 1;
+constexpr int PC_PROD = PC_WAVES - 1;       // producer waves
+#ifndef FE_PC_RING
+#define FE_PC_RING 2
+#endif
+constexpr int PC_RING = FE_PC_RING;                  // slots per ring; one ring per weight (kind 0: edge_mlp.2, kind 1: coord_mlp_r.0)
+constexpr int PC_RS = 68;                   // row stride of a slot tile
+constexpr int PC_SLOT = 2 * 16 * PC_RS;     // floats per slot: G tile | T tile
+constexpr int PC_IMG_FLOATS = BWD_X3 ? 4 * IMG3 : 4 * IMG;
+enum { PC_HEAD = 0, PC_TOTAL = 2, PC_FILLED = 4, PC_DRAINED = 4 + 2 * PC_RING, PC_CTRL = 4 + 4 * PC_RING };
+struct Split8 {
+  u32x4 h, m, l;
+};
+// eight fp32 values -> their three bf16 parts, packed as one k-block of v_mfma_f32_16x16x32_bf16
+__device__ __forceinline__ Split8 split8(const float (&x)[8]) {
+  float r1[8], r2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    r1[e] = x[e] - trunc_bf(x[e]);
+    r2[e] = r1[e] - trunc_bf(r1[e]);
+  }
+  Split8 S;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    S.h[w] = pack_hi(x[2 * w], x[2 * w + 1]);
+    S.m[w] = pack_hi(r1[2 * w], r1[2 * w + 1]);
+    S.l[w] = pack_hi(r2[2 * w], r2[2 * w + 1]);
+  }
+  return S;
+}
+__device__ __forceinline__ int lds_ld(const int *p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void lds_st(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void pc_tile_store(float *tile, int j, int q, const Vec &v) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(tile + j * PC_RS + 16 * t + 4 * q) = v.t[t];
+}
+__global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const EdgeArgs &a = A.f;
+  float *img = lds;                    // W2, WX1, W2T, WX1T (split images)
+  float *vec = lds + PC_IMG_FLOATS;
+  float *tiles = vec + EV_COUNT * H;   // per producer [16][TS]; the 4 pad columns of a row hold its g_d scalars
+  float *ring = tiles + PC_PROD * 16 * TS;
+  int *ctrl = reinterpret_cast<int *>(ring + 2 * PC_RING * PC_SLOT);
+  if constexpr (BWD_X3) load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, A.C, I_W2), 4);
+  else load_images(img, a.wpack + (size_t)I_W2 * IMG, 4);
+  edge_load_vecs(vec, a);
+  if (threadIdx.x < PC_CTRL) ctrl[threadIdx.x] = 0;
+  __syncthreads();
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
+  const bool consumer = wv == PC_CONS;
+  const int pw = wv > PC_CONS ? wv - 1 : wv;   // producer index
+  float *pt = tiles + (consumer ? 0 : pw) * 16 * TS;
+  const int wave = (int)blockIdx.x * PC_PROD + pw, nwaves = (int)gridDim.x * PC_PROD;
+  const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);
+  float accW[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // [radial | edge_attr] columns of edge_mlp.0, lane = out
+  const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION,
+             norm_on = a.flags & FASTEGNN_F_NORMALIZE;
+  Vec acc_wx2 = vzero(), acc_att = vzero();
+  float acc_attb = 0.f, acc_bx2 = 0.f;
+  FE_T0()
+  // this wave's share: a contiguous run of whole rows holding ~E/nwaves edges (see edge_fwd_kernel)
+  int r0 = 0, r1 = 0, e0 = 0, e1 = 0;
+  if (!consumer) {
+    const int c0 = (int)((long)wave * a.n_chunks / nwaves), c1 = (int)((long)(wave + 1) * a.n_chunks / nwaves);
+    r0 = a.chunk_row[c0];
+    r1 = a.chunk_row[c1];
+    if (r0 < r1) {
+      e0 = a.rowptr[r0];
+      e1 = a.rowptr[r1];
+      if (l == 0) atomicAdd(&ctrl[PC_TOTAL], (e1 - e0 + 15) >> 4);   // tiles = tickets per ring
+    }
+  }
+  __syncthreads();
+  // hand one operand pair to the consumer
+  auto publish = [&](int kind, const Vec &Gv, const Vec &Tv) {
+    int tk = 0;
+    if (l == 0) tk = atomicAdd(&ctrl[PC_HEAD + kind], 1);
+    tk = __builtin_amdgcn_readfirstlane(tk);
+    const int sl = tk % PC_RING, round = tk / PC_RING;
+    while (lds_ld(&ctrl[PC_DRAINED + kind * PC_RING + sl]) != round) __builtin_amdgcn_s_sleep(2);
+    float *slot = ring + (kind * PC_RING + sl) * PC_SLOT;
+    pc_tile_store(slot, j, q, Gv);
+    pc_tile_store(slot + 16 * PC_RS, j, q, Tv);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is in LDS before the flag
+    if (l == 0) lds_st(&ctrl[PC_FILLED + kind * PC_RING + sl], round + 1);
+  };
+  if (consumer) {
+#if FE_PC_PRIO
+    __builtin_amdgcn_s_setprio(FE_PC_PRIO);   // the consumer must never be the slower side: it wins issue arbitration on its SIMD
+#endif
+    const int total = lds_ld(&ctrl[PC_TOTAL]);   // tiles of this workgroup = tickets per ring
+    f32x4 accA[4][4], accB[4][4];
+    float bsA[4] = {0.f, 0.f, 0.f, 0.f}, bsB[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk) accA[ti][tk] = accB[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K = 32 edges per step: tickets tk, tk+1 of one ring; lane (q,i) takes feature i of the rows 4e+q
+    // (e < 4: first slot, e >= 4: second slot), the same map for both operands
+    auto contract = [&](int kind, int tk, f32x4 (&acc)[4][4], float (&bs)[4]) {
+      const int s0 = tk % PC_RING, r0w = tk / PC_RING;
+      const bool two = tk + 1 < total;
+      const int s1 = (tk + 1) % PC_RING, r1w = (tk + 1) / PC_RING;
+      while (lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s0]) != r0w + 1) __builtin_amdgcn_s_sleep(2);
+      if (two)
+        while (lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s1]) != r1w + 1) __builtin_amdgcn_s_sleep(2);
+      const float *g0 = ring + (kind * PC_RING + s0) * PC_SLOT, *g1 = ring + (kind * PC_RING + s1) * PC_SLOT;
+      Split8 B[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[e] = g0[16 * PC_RS + (4 * e + q) * PC_RS + 16 * t + j];
+          x[4 + e] = two ? g1[16 * PC_RS + (4 * e + q) * PC_RS + 16 * t + j] : 0.f;
+        }
+        B[t] = split8(x);
+      }
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[e] = g0[(4 * e + q) * PC_RS + 16 * ti + j];
+          x[4 + e] = two ? g1[(4 * e + q) * PC_RS + 16 * ti + j] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[ti] += x[e];
+        const Split8 Aop = split8(x);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, Aop.h), am = __builtin_bit_cast(bf16x8, Aop.m),
+                     al = __builtin_bit_cast(bf16x8, Aop.l);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, B[t].h), bm = __builtin_bit_cast(bf16x8, B[t].m),
+                       bl = __builtin_bit_cast(bf16x8, B[t].l);
+          f32x4 c = acc[ti][t];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+          acc[ti][t] = c;
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // every read of the slots has returned
+      if (l == 0) {
+        lds_st(&ctrl[PC_DRAINED + kind * PC_RING + s0], r0w + 1);
+        if (two) lds_st(&ctrl[PC_DRAINED + kind * PC_RING + s1], r1w + 1);
+      }
+    };
+    // work-conserving service: whichever ring has its next K-step complete (two filled slots, or the last
+    // single one) is contracted; a full ring always has a complete step, so no producer waits on an idle consumer
+    auto ready = [&](int kind, int done) {
+      const int s0 = done % PC_RING, s1 = (done + 1) % PC_RING;
+      if (lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s0]) != done / PC_RING + 1) return false;
+      return done + 1 >= total || lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s1]) == (done + 1) / PC_RING + 1;
+    };
+    int done0 = 0, done1 = 0;
+    while (done0 < total || done1 < total) {
+      bool progress = false;
+      if (done1 < total && ready(1, done1)) {
+        contract(1, done1, accB, bsB);
+        done1 += 2;
+        progress = true;
+      }
+      if (done0 < total && ready(0, done0)) {
+        contract(0, done0, accA, bsA);
+        done0 += 2;
+        progress = true;
+      }
+      if (!progress) __builtin_amdgcn_s_sleep(1);
+    }
+    // one partial slab per workgroup and weight: [o][k] row-major, o = G feature, k = T feature
+    float *sa = A.slab + ((size_t)A.slab_w2 + blockIdx.x) * IMG, *sb = A.slab + ((size_t)A.slab_wx1 + blockIdx.x) * IMG;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tk2 = 0; tk2 < 4; ++tk2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sa[(16 * ti + 4 * q + r) * H + 16 * tk2 + j] = accA[ti][tk2][r];
+          sb[(16 * ti + 4 * q + r) * H + 16 * tk2 + j] = accB[ti][tk2][r];
+        }
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const float s0 = qsum(bsA[ti]), s1 = qsum(bsB[ti]);
+      if (q == 0) {
+        A.slab_b[((size_t)A.slab_w2 + blockIdx.x) * H + 16 * ti + j] = s0;
+        A.slab_b[((size_t)A.slab_wx1 + blockIdx.x) * H + 16 * ti + j] = s1;
+      }
+    }
+  }
+  if (!consumer && r0 < r1) {
+    int cur = -1;
+    float acc = 0.f, accx = 0.f;
+    auto flush = [&]() {
+      A.g_P[(size_t)cur * H + l] = acc;
+      if (l < 3) A.g_xrow[(size_t)cur * 3 + l] = accx;   // lanes 0..2 hold x,y,z (lane 3: pad)
+    };
+    for (int base = e0; base < e1; base += 16) {
+      asm volatile("" ::: "memory");
+      const int nvalid = min(16, e1 - base);
+      const bool valid = j < nvalid;
+      const int e = min(base + j, e1 - 1);
+      EdgeIdx cur_i;
+      edge_load_idx(a, e, cur_i);
+      EdgeFwdState S;
+      Vec pre;
+      edge_tile_forward<true, BWD_X3>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
+      const int dg = a.rowptr[S.row + 1] - a.rowptr[S.row];
+      const float inv = valid ? rcp_f((float)(dg > 1 ? dg : 1)) : 0.f;
+      const float invx = valid ? (mean ? inv : 1.f) : 0.f;
+      tile_store(pt, j, q, S.t);   // parked until its partner g_mp exists (the tile is free until the row walk)
+      // coordinate head adjoint (coord_mlp_r, :125)
+      float g_tr[3], g_dn[3], g_s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        g_tr[k] = A.g_aggx[(size_t)S.row * 3 + k] * invx;
+        g_s += S.dn[k] * g_tr[k];
+        g_dn[k] = S.s * g_tr[k];
+      }
+      const float g_sr = tanh_on ? g_s * (1.f - S.s * S.s) : g_s;
+      vaxpy(acc_wx2, g_sr, S.u);
+      if (q == 0) acc_bx2 += g_sr;
+      const Vec g_up = vmul(vscale(vload_vec(vec + EV_WX2 * H, q), g_sr), S.up);
+      publish(1, g_up, S.m);
+      Vec g_m = vscale(vload_row(A.g_aggm + (size_t)S.row * H, q), inv);
+      gemm_i<BWD_X3>(img, 3, g_up, g_m);
+      Vec g_m0 = g_m;
+      if (att_on) {
+        const float g_a = vdot(g_m, S.m0);
+        const float g_z = g_a * S.att * (1.f - S.att);
+        vaxpy(acc_att, g_z, S.m0);
+        if (q == 0) acc_attb += g_z;
+        g_m0 = vscale(g_m, S.att);
+        vaxpy(g_m0, g_z, vload_vec(vec + EV_ATT * H, q));
+      }
+      const Vec g_mp = vmul(g_m0, S.mp);
+      {
+        Vec tpark;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) tpark.t[t] = *reinterpret_cast<const f32x4 *>(pt + j * TS + 16 * t + 4 * q);
+        publish(0, g_mp, tpark);
+      }
+      Vec g_t = vzero();
+      gemm_i<BWD_X3>(img, 2, g_mp, g_t);
+      const Vec g_pre = vmul(g_t, pre);
+      const float g_r = vdot(g_pre, vload_vec(vec + EV_WR * H, q));
+      float g_d[3];
+      const float invn = norm_on ? rcp_f(S.nrm + a.eps) : 1.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g_d[k] = g_dn[k] * invn + 2.f * g_r * S.d[k];
+      if (valid) {
+        float *qe = A.g_QXe + (size_t)e * QXLD;
+        vstore_row(qe, q, g_pre);
+        if (q == 0) *reinterpret_cast<f32x4 *>(qe + H) = f32x4{-g_d[0], -g_d[1], -g_d[2], 0.f};
+      }
+      // row-side segment sums: g_P[row] = sum g_pre, g_xrow[row] = sum g_d
+      tile_store(pt, j, q, g_pre);
+      if (q == 0) *reinterpret_cast<f32x4 *>(pt + j * TS + H) = f32x4{g_d[0], g_d[1], g_d[2], 0.f};
+      __builtin_amdgcn_wave_barrier();
+      float mv[16], xv[16];
+#pragma unroll
+      for (int ee = 0; ee < 16; ++ee) {   // all LDS reads up front; the walk below runs on registers
+        mv[ee] = pt[ee * TS + l];
+        xv[ee] = pt[ee * TS + H + (l & 3)];
+      }
+      const int rowv = S.row;
+#pragma unroll
+      for (int ee = 0; ee < 16; ++ee) {
+        if (ee < nvalid) {
+          const int rw = __builtin_amdgcn_readlane(rowv, ee);
+          if (rw != cur) {
+            if (cur >= 0) flush();
+            cur = rw;
+            acc = 0.f;
+            accx = 0.f;
+          }
+          const float gp = mv[ee];
+          acc += gp;
+          accx += xv[ee];
+          // d edge_mlp.0.weight[:, 2H + k] += g_pre * [radial | edge_attr][k]   (lane = output row);
+          // the per-edge scalars come from the owning lane's registers (v_readlane), not from LDS
+          accW[0] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.r), ee));
+#pragma unroll
+          for (int k = 0; k < 7; ++k)
+            if (k < a.ea_dim)
+              accW[1 + k] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.eav[k]), ee));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (cur >= 0) flush();
+  }
+  float *red = vec;   // [3 + 8][64]; the weight vectors are dead now
+  __syncthreads();
+  for (int i = threadIdx.x; i < 11 * H; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k <= a.ea_dim) atomicAdd(&red[(3 + k) * H + l], accW[k]);
+  vec_reduce_lds(red, acc_wx2, j, q);
+  if (att_on) {
+    vec_reduce_lds(red + H, acc_att, j, q);
+    float s = jsum(acc_attb);
+    if (l == 0) atomicAdd(&red[2 * H], s);
+  }
+  if (A.d_bx2) {
+    float s = jsum(acc_bx2);
+    if (l == 0) atomicAdd(&red[2 * H + 1], s);
+  }
+  __syncthreads();
+  if (threadIdx.x < H) {
+    atomicAdd(&A.d_wx2[threadIdx.x], red[threadIdx.x]);
+    if (att_on) {
+      atomicAdd(&A.d_attw[threadIdx.x], red[H + threadIdx.x]);
+      if (threadIdx.x == 0) atomicAdd(A.d_attb, red[2 * H]);
+    }
+    if (A.d_bx2 && threadIdx.x == 0) atomicAdd(A.d_bx2, red[2 * H + 1]);
+    atomicAdd(&A.d_wr[(size_t)threadIdx.x * A.ld_e0], red[3 * H + threadIdx.x]);
+    for (int k = 0; k < a.ea_dim; ++k)
+      atomicAdd(&A.d_we[(size_t)threadIdx.x * A.ld_e0 + k], red[(4 + k) * H + threadIdx.x]);
+  }
+}
+
 int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(L->P && L->QX && L->g_aggm && L->g_aggx && L->g_P && L->g_xrow && L->g_QXe && L->wg_edge && L->grads &&
                  L->wpack,
@@ -771,6 +1125,22 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   A.C = L->C;
   FE_REQUIRE((size_t)L->N * QXLD < (1u << 30) && (size_t)gr.n_src * QXLD < (1u << 30) && (size_t)gr.n_edges * 8 < (1u << 30),
              "edge_backward: tables exceed the 32-bit offset range of the gather path");
+#if FE_EDGE_BWD_PC
+  {
+    int grid = cdiv(cdiv(gr.n_edges, 256), PC_PROD);
+    if (grid > 256) grid = 256;
+    WgradBatch wb(L->wg_slab, st);
+    int rc;
+    if ((rc = wb.add_slabs(g[FASTEGNN_P_EDGE2_W], H, 0, 1, g[FASTEGNN_P_EDGE2_B], grid, &A.slab_w2))) return rc;
+    if ((rc = wb.add_slabs(g[FASTEGNN_P_CR0_W], H, 0, 1, g[FASTEGNN_P_CR0_B], grid, &A.slab_wx1))) return rc;
+    A.slab = wb.tab.slab;
+    A.slab_b = wb.tab.slab_b;
+    const size_t lds = (PC_IMG_FLOATS + EV_COUNT * H + PC_PROD * 16 * TS + 2 * PC_RING * PC_SLOT + PC_CTRL) * sizeof(float);
+    { ProfScope _ps_edge_bwd_kernel(K_EDGE_BWD, st); hipLaunchKernelGGL(edge_bwd_pc_kernel, dim3(grid), dim3(64 * PC_WAVES), lds, st, A); }
+    if ((rc = check_launch("edge_bwd_pc_kernel"))) return rc;
+    return wb.finish();
+  }
+#else
   int grid = cdiv(cdiv(gr.n_edges, 256), EDGE_WAVES);
   if (grid > 256) grid = 256;
   const size_t lds = (EDGE_BWD_IMG_FLOATS + EV_COUNT * H + EDGE_WAVES * (16 * TS + 16 * XT)) * sizeof(float);
@@ -782,6 +1152,7 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   if ((rc = wb.add(A.wg_gmp, H, A.wg_t, H, E, g[FASTEGNN_P_EDGE2_W], H, 0, 1, g[FASTEGNN_P_EDGE2_B]))) return rc;
   if ((rc = wb.add(A.wg_gup, H, A.wg_m, H, E, g[FASTEGNN_P_CR0_W], H, 0, 1, g[FASTEGNN_P_CR0_B]))) return rc;
   return wb.finish();
+#endif
 }
 
 // B2b: col-keyed reduction of the per-edge d/d(Q|x) rows into the source table

@@ -258,11 +258,29 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   return FASTEGNN_OK;
 }
 
+int WgradBatch::add_slabs(float *dW, int lddw, int c0, int ks, float *db, int nsplit, int *slab_begin) {
+  FE_REQUIRE(dW && slab_begin && nsplit > 0, "wgrad: add_slabs arguments");
+  FE_REQUIRE(tab.slab, "wgrad: wg_slab workspace is null");
+  FE_REQUIRE(tab.n_jobs < WG_MAX_JOBS, "wgrad: too many jobs in one batch");
+  FE_REQUIRE(n_slab + nsplit <= WG_SLABS, "wgrad: slab workspace exhausted");
+  WgJob &j = tab.job[tab.n_jobs++];
+  j.G = nullptr; j.T = nullptr; j.dW = dW; j.db = db; j.M = 0; j.sG = j.sT = j.sW = 0;
+  j.ldg = j.ldt = H; j.lddw = lddw; j.c0 = c0; j.ks = ks; j.kmax = 64;
+  j.rows_per_wg = 0; j.nsplit = nsplit; j.nb = 1;
+  j.wg_begin = n_wg; j.slab_begin = n_slab;   // contributes no workgroups to wgrad_tn_kernel
+  *slab_begin = n_slab;
+  n_slab += nsplit;
+  return FASTEGNN_OK;
+}
+
 int WgradBatch::finish() {
   if (tab.n_jobs == 0) return FASTEGNN_OK;
+  int rc = FASTEGNN_OK;
+  if (n_wg > 0) {
     { ProfScope _ps(K_WGRAD_TN, st); hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, tab); }
-  int rc = check_launch("wgrad_tn_kernel");
-  if (rc) return rc;
+    rc = check_launch("wgrad_tn_kernel");
+    if (rc) return rc;
+  }
   { ProfScope _ps(K_WGRAD_REDUCE, st); hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tab.n_jobs, (unsigned)max_nb, IMG / H + 1), dim3(512), 0, st, tab); }
   tab.n_jobs = 0;
   return check_launch("wgrad_reduce_kernel");
