@@ -76,14 +76,15 @@ def kernel_model(N, E, B, C, L, gravity=True):
     heads = 2 if gravity else 1
     f = {}
     f["edge_fwd_kernel"] = (L * E * 2 * UNIT, L * (280 * E + 540 * N))
-    f["edge_bwd_kernel"] = (L * E * 4 * UNIT, L * (E * (8 + 8 + 272 + 12 + 4 * 256 + 272 + 32) + N * (256 * 2 + 12 * 2 + 268)))
+    # edge backward: 2 recomputed + 2 transposed layers + the two in-workgroup weight-gradient contractions per edge
+    f["edge_bwd_kernel"] = (L * E * 6 * UNIT, L * (E * (8 + 8 + 272 + 12 + 272 + 32) + N * (256 * 2 + 12 * 2 + 268)))
     f["virt_fwd_kernel"] = (L * (NC * 4 + N * 3) * UNIT, L * N * (5 * 256 + 60))
     f["virt_bwd_kernel"] = (L * (NC * 7 + N * 3) * UNIT, L * (NC * 5 * 256 + N * (8 * 256 + 60)))
     f["node_pre_fwd_kernel"] = (L * N * (3 + heads) * UNIT, L * N * (256 + 12 + 256 + 272 + 256 + 8))
     f["node_pre_bwd_kernel"] = (L * N * (3 + 2 * heads) * UNIT, L * N * (256 * 6 + 272 + 48))
-    # wgrad launches per layer: edge (2 x E), virt (3 x NC + C x N for the per-channel node_mlp block),
-    # node-level (N x (3 + 3 + heads)), graph-level (B*C x 5)
-    m_rows = L * (2 * E + 3 * NC + C * N + (6 + heads) * N + 5 * B * C)
+    # wgrad launches per layer: virt (3 x NC + C x N for the per-channel node_mlp block),
+    # node-level (N x (3 + 3 + heads)), graph-level (B*C x 5); the edge stage contracts in edge_bwd
+    m_rows = L * (3 * NC + C * N + (6 + heads) * N + 5 * B * C)
     f["wgrad_tn_kernel"] = (m_rows * UNIT, m_rows * 512)
     f["wgrad_small_kernel"] = (L * E * 2 * 64 * 3, L * E * (272 + 32))
     f["edge_col_reduce_kernel"] = (0, L * (E * (272 + 4) + N * 272))
