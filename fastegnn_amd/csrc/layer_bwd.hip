@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
 }
 
 int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
-  FE_REQUIRE(L->P && L->QX && L->g_aggm && L->g_aggx && L->g_P && L->g_xrow && L->g_QXe && L->wg_edge && L->grads &&
+  FE_REQUIRE(L->P && L->QX && L->g_aggm && L->g_aggx && L->g_P && L->g_xrow && L->g_QXe && (FE_EDGE_BWD_PC || L->wg_edge) && L->grads &&
                  L->wpack,
              "edge_backward: null buffer");
   const fastegnn_graph_t &gr = L->graph;
@@ -1154,6 +1154,10 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   return wb.finish();
 #endif
 }
+
+}  // namespace fe
+extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { return FE_EDGE_BWD_PC ? 4 : (size_t)(E > 0 ? E : 1) * 4 * fe::H; }
+namespace fe {
 
 // B2b: col-keyed reduction of the per-edge d/d(Q|x) rows into the source table
 __global__ __launch_bounds__(256) void edge_col_reduce_kernel(const float *g_QXe, const int32_t *cscptr,

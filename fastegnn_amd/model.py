@@ -59,6 +59,9 @@ class E_GCL_vel(nn.Module):
 # ------------------------------------------------------------------------------------------
 # sorted graph handle
 # ------------------------------------------------------------------------------------------
+_CSR_TMP: Dict[torch.device, torch.Tensor] = {}
+
+
 class SortedGraph:
     """Device-side CSR + col-keyed index of a COO ``edge_index`` (fastegnn_build_csr)."""
 
@@ -79,7 +82,12 @@ class SortedGraph:
         L = K.lib()
         self.chunk_row = torch.empty(L.fastegnn_chunk_rows(E), **i32)
         nbytes = L.fastegnn_csr_tmp_bytes(E, n_rows, n_src)
-        tmp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        # the radix-sort workspace (28 B per edge) is kept per device and reused by later builds on the same
+        # stream: at 20 M edges a fresh 0.6 GB block per step sporadically costs a device malloc (~1 s)
+        tmp = _CSR_TMP.get(dev)
+        if tmp is None or tmp.numel() < nbytes:
+            tmp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _CSR_TMP[dev] = tmp
         nch = C.c_int32(0)
         st = torch.cuda.current_stream(dev).cuda_stream
         K.check(L.fastegnn_build_csr(K.ptr(edge_index), E, row_begin, n_rows, n_src, K.ptr(self.rowptr),
@@ -269,7 +277,7 @@ class _FastEGNNFunction(torch.autograd.Function):
             g_poolV=(B, Cn, H), g_poolX=(B, 3, Cn), g_Bc=(B, Cn, H), g_Zp=(B, 3, Cn), g_xbar=(B, 4),
             g_A=(N, H), g_P=(N, H), g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,),
             g_QXe=(max(E, 1), K.QX_LD), g_QX_src=(N, K.QX_LD), g_xrow=(N, 3),
-            wg_edge=(max(E, 1) * 4 * H,), wg_virt=(5 * N * Cn * H,), wg_node=(8 * M * H,),
+            wg_edge=(lib.fastegnn_wg_edge_floats(E),), wg_virt=(5 * N * Cn * H,), wg_node=(8 * M * H,),
             wg_slab=(lib.fastegnn_wg_slab_floats(),)))
         for i in reversed(range(spec.n_layers)):
             b = saved[i]

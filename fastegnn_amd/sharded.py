@@ -55,6 +55,9 @@ class HipBackend:
     def wg_slab_floats(self):
         return self.lib.fastegnn_wg_slab_floats()
 
+    def wg_edge_floats(self, E):
+        return self.lib.fastegnn_wg_edge_floats(E)
+
     def build_graph(self, edge_index, n_rows, n_src, row_begin):
         return SortedGraph(edge_index, n_rows, n_src, row_begin)
 
@@ -184,7 +187,7 @@ class _ShardedFunction(torch.autograd.Function):
         M = max(N, B * Cn)
         sc = be.carve(dict(g_poolV=(B, Cn, H), g_poolX=(B, 3, Cn), g_xbar=(B, 4), g_A=(N, H), g_P=(N, H),
                            g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,), g_QXe=(max(E, 1), K.QX_LD),
-                           g_xrow=(N, 3), wg_edge=(max(E, 1) * 4 * H,), wg_virt=(5 * N * Cn * H,),
+                           g_xrow=(N, 3), wg_edge=(be.wg_edge_floats(E),), wg_virt=(5 * N * Cn * H,),
                            wg_node=(8 * M * H,), wg_slab=(be.wg_slab_floats(),)))
         nV = B * Cn * H
         gpools = be.empty(nV + B * 3 * Cn)                                 # g_Bc | g_Zp adjacent: one all-reduce

@@ -179,7 +179,8 @@ typedef struct {
   float *g_QX_src;            /* [n_src,68] col-keyed sums (sharded: reduce-scattered) */
   float *g_QX;                /* [N,68]  this rank's slice of g_QX_src (== g_QX_src on one GPU) */
   float *g_xrow;              /* [N,3]   row-side d/dx of the edge stage */
-  float *wg_edge;             /* [4*E*64 + E*8] weight-gradient operands of the edge stage */
+  float *wg_edge;             /* [fastegnn_wg_edge_floats(E)] weight-gradient operands of the edge stage (none when the
+                               * edge backward contracts them inside the workgroup: 4 floats then) */
   float *wg_virt;             /* [5*N*C*64]     weight-gradient operands of the virtual stage */
   float *wg_node;             /* [8*max(N,B*C)*64] node-level weight-gradient operands */
   float *wg_slab;             /* [fastegnn_wg_slab_floats()] partial 64x64 slabs of the weight-gradient GEMMs */
@@ -192,6 +193,7 @@ int fastegnn_version(void);
 size_t fastegnn_wpack_floats(int32_t C);
 /* floats of the weight-gradient slab workspace (independent of the problem size) */
 size_t fastegnn_wg_slab_floats(void);
+size_t fastegnn_wg_edge_floats(int32_t E);
 /* struct sizes, so that a foreign-language binding can verify its mirror of the descriptors */
 size_t fastegnn_sizeof_layer(void);
 size_t fastegnn_sizeof_graph(void);

@@ -44,6 +44,9 @@ class CpuOracleBackend:
     def wg_slab_floats(self):
         return 4
 
+    def wg_edge_floats(self, E):
+        return 4
+
     # ---- prologue / epilogue ----
     def build_graph(self, ei, n_rows, n_src, row_begin):
         return CpuGraph(ei, n_rows, n_src, row_begin)
