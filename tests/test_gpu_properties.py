@@ -158,6 +158,29 @@ def test_cfg2_shape_vs_oracle():
     _check_vs_oracle(cfg, _batch([100] * 4, 0, 3, seed=2, fully_connected=True), seed=2)
 
 
+def test_cfg3_shape_vs_oracle():
+    """BASELINE configs[2] (protein MD) in fp32: 3 341 points uniform in a 36 A cube, contacts
+    within 10 A minus the longest 50 %, coordinates translated by +50 A (large-magnitude inputs), C=8; two graphs."""
+    from fastegnn_amd.graphs import cutoff_edges, radius_graph
+    g = torch.Generator().manual_seed(43)
+    n, C, B = 3341, 8, 2
+    locs, eis, eas, off = [], [], [], 0
+    for b in range(B):
+        loc = torch.rand(n, 3, generator=g) * 36.0 + 50.0
+        ei, d = radius_graph(loc.cuda(), 10.0)
+        ei, d = cutoff_edges(ei, d, 0.5)
+        locs.append(loc); eis.append(ei.cpu() + off); eas.append(d.cpu()); off += n
+    loc = torch.cat(locs)
+    ei, dist = torch.cat(eis, 1), torch.cat(eas)
+    assert 400_000 < ei.size(1) < 900_000
+    batch = torch.arange(B).repeat_interleave(n)
+    cm = torch.stack([l.mean(0) for l in locs])
+    inp = dict(node_feat=torch.rand(B * n, 2, generator=g), node_loc=loc, node_vel=torch.randn(B * n, 3, generator=g) * 0.3,
+               edge_index=ei, data_batch=batch, loc_mean=cm.unsqueeze(-1).repeat(1, 1, C),
+               edge_attr=torch.stack([dist, dist], 1))
+    _check_vs_oracle(R.Config(2, 0, 2, 64, C, n_layers=2), inp, seed=8)
+
+
 def test_ragged_c16_gravity_vs_oracle():
     cfg = R.Config(2, 0, 2, 64, 16, n_layers=2, gravity=[0, -1, 0])
     _check_vs_oracle(cfg, _batch([1, 130, 17, 300], 9, 16, seed=4), seed=4)
