@@ -122,20 +122,31 @@ struct VirtBwdArgs {
   int ld_v0;
 };
 
+constexpr int virt_bwd_img_floats(bool x3h) { return x3h ? 4 * IMG + 2 * IMG3 : 6 * IMG; }
 // RF (FastRF reduced layer) is a compile-time switch: as a run-time flag it cost the FastEGNN path 10 %
 // (register allocation of the channel loop)
-template <bool RF>
+template <bool RF, bool X3H>
 __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VirtArgs &a = A.f;
   const int C = a.C;
-  float *img = lds;                              // V2 WXV0 WXX0 V2T WXV0T WXX0T
-  float *vec = lds + 6 * IMG;
+  // fp32 images V2 WXV0 WXX0 V2T WXV0T WXX0T; X3H: the two head layers WXV0, WXX0 (they share one operand
+  // split) as split images for the bf16 matrix pipe instead: V2 V2T WXV0T WXX0T | WXV0 WXX0 (LDS permitting: C <= 32)
+  float *img = lds;
+  const unsigned *img3 = reinterpret_cast<const unsigned *>(lds + 4 * IMG);   // WXV0, WXX0 split
+  constexpr int S_V2 = 0, S_V2T = X3H ? 1 : 3, S_WXV0T = X3H ? 2 : 4, S_WXX0T = X3H ? 3 : 5;
+  float *vec = lds + virt_bwd_img_floats(X3H);
   float *tiles = vec + 16 * H;
   float *gBc_l = tiles + VIRT_BWD_WAVES * 16 * TS;   // [C][64]
   float *gZ_l = gBc_l + C * H;                   // [3][C]
   float *w3ct_l = gZ_l + ((3 * C + 3) & ~3);     // W3cT[c] of the channel in flight (fp32 image)
-  load_images(img, a.wpack + (size_t)I_V2 * IMG, 6);
+  if constexpr (X3H) {
+    load_images(img, a.wpack + (size_t)I_V2 * IMG, 1);
+    load_images(img + IMG, a.wpack + (size_t)I_V2T * IMG, 3);
+    load_images_x3(reinterpret_cast<unsigned *>(lds + 4 * IMG), wpack_x3(a.wpack, C, I_WXV0), 2);
+  } else {
+    load_images(img, a.wpack + (size_t)I_V2 * IMG, 6);
+  }
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) gBc_l[i] = 0.f;
   __syncthreads();
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {
           const Vec t = vsilu_keep_d(d_pre);      // d_pre <- silu'(pre)
           WG_STORE(if (valid) vstore_u(b_t, oc, t);)
-          gemm64(img + 0 * IMG, t, vp);
+          gemm64(img + S_V2 * IMG, t, vp);
         }
         const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
         float att = 1.f;
@@ -319,6 +330,8 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           v = vscale(v0, att);
         }
         WG_STORE(if (valid) vstore_u(b_v, oc, v);)
+        Split vs;
+        if constexpr (X3H) vs = vsplit(v);   // feeds both coordinate heads
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
         Vec g_v = rf ? vzero() : vmask(gpv_c, valid);
         if constexpr (!rf) gemm64(w3ct_l, g_np_m, g_v);
@@ -326,7 +339,8 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         float sx, sX;
         {  // coord_mlp_r_virtual head: forward, then its adjoint
           Vec uxp = vload_vec(vec + VV_BXV0 * H, q);
-          gemm64(img + 1 * IMG, v, uxp);
+          if constexpr (X3H) gemm64_x3(img3 + 0 * IMG3, vs, uxp);
+          else gemm64(img + 1 * IMG, v, uxp);
           const Vec ux = vsilu_keep_d(uxp);       // uxp <- silu'(uxp)
           const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
           sx = tanh_on ? tanh_f(sr) : sr;
@@ -337,11 +351,12 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           vaxpy(acc_wxv2, g_sr, ux);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
           WG_STORE(if (valid) vstore_u(b_gux, oc, g_up);)
-          gemm64(img + 4 * IMG, g_up, g_v);
+          gemm64(img + S_WXV0T * IMG, g_up, g_v);
         }
         {  // coord_mlp_v_virtual head
           Vec uXp = vload_vec(vec + VV_BXX0 * H, q);
-          gemm64(img + 2 * IMG, v, uXp);
+          if constexpr (X3H) gemm64_x3(img3 + 1 * IMG3, vs, uXp);
+          else gemm64(img + 2 * IMG, v, uXp);
           const Vec uX = vsilu_keep_d(uXp);
           const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
           sX = tanh_on ? tanh_f(sr) : sr;
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           vaxpy(acc_wxx2, g_sr, uX);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
           WG_STORE(if (valid) vstore_u(b_guX, oc, g_up);)
-          gemm64(img + 5 * IMG, g_up, g_v);
+          gemm64(img + S_WXX0T * IMG, g_up, g_v);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) g_vd[k] = -sx * invC * gxn[k] + sX * gpX[k];
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {
           const Vec g_vp = vmul(g_v0, vp);
           WG_STORE(if (valid) vstore_u(b_gvp, oc, g_vp);)
-          gemm64(img + 3 * IMG, g_vp, g_t);
+          gemm64(img + S_V2T * IMG, g_vp, g_t);
         }
         const Vec g_pre = vmul(g_t, d_pre);
         vadd(g_A, g_pre);
@@ -483,9 +498,16 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   int grid = ntg < 256 ? ntg : 256;
   {
     ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st);
-    const size_t lds = virt_lds_bytes(C, 6, VIRT_BWD_WAVES) + (IMG + 4) * sizeof(float);
-    if (has(L, FASTEGNN_F_RF)) hipLaunchKernelGGL(virt_bwd_kernel<true>, dim3(grid), dim3(64 * VIRT_BWD_WAVES), lds, st, A);
-    else hipLaunchKernelGGL(virt_bwd_kernel<false>, dim3(grid), dim3(64 * VIRT_BWD_WAVES), lds, st, A);
+    const bool x3h = BWD_X3 && C <= 32;
+    const size_t lds = virt_lds_bytes(C, 0, VIRT_BWD_WAVES) + (virt_bwd_img_floats(x3h) + IMG + 4) * sizeof(float);
+    const dim3 g3(grid), b3(64 * VIRT_BWD_WAVES);
+    if (has(L, FASTEGNN_F_RF)) {
+      if (x3h) hipLaunchKernelGGL((virt_bwd_kernel<true, true>), g3, b3, lds, st, A);
+      else hipLaunchKernelGGL((virt_bwd_kernel<true, false>), g3, b3, lds, st, A);
+    } else {
+      if (x3h) hipLaunchKernelGGL((virt_bwd_kernel<false, true>), g3, b3, lds, st, A);
+      else hipLaunchKernelGGL((virt_bwd_kernel<false, false>), g3, b3, lds, st, A);
+    }
   }
   int rc = check_launch("virt_bwd_kernel");
   if (rc) return rc;
