@@ -54,6 +54,19 @@ def _worker(rank, world, port, q):
     nbytes = allreduce_gradients(params)
     t = max_over_ranks(1.0 + rank, "cpu")
     q.put((rank, [None if prm.grad is None else prm.grad.numpy().copy() for prm in params], nbytes, t))
+    # the layout the HIP backward produces: every .grad a slice of ONE flat buffer (16-byte aligned slots)
+    sizes = [(v.numel() + 3) // 4 * 4 for v in pp.values()]
+    flat = torch.zeros(sum(sizes))
+    off = 0
+    for prm, v, n in zip(params, pp.values(), sizes):
+        prm.grad = flat[off:off + v.numel()].view_as(v)
+        if v.grad is not None:
+            prm.grad.copy_(v.grad)
+        off += n
+    before = flat.data_ptr()
+    nb2 = allreduce_gradients(params)
+    assert nb2 == flat.numel() * 4 and all(prm.grad.untyped_storage().data_ptr() == before for prm in params)
+    q.put((rank + 100, [prm.grad.numpy().copy() for prm in params], nb2, 0.0))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,7 +79,7 @@ def test_two_rank_gradient_allreduce_matches_two_frame_sum():
     for pr in procs:
         pr.start()
     out = dict()
-    for _ in range(world):
+    for _ in range(2 * world):
         rank, grads, nbytes, t = q.get(timeout=120)
         out[rank] = (grads, nbytes, t)
     for pr in procs:
@@ -83,6 +96,8 @@ def test_two_rank_gradient_allreduce_matches_two_frame_sum():
         for k, g in zip(keys, grads):
             want = sum((ref[r][k].grad if ref[r][k].grad is not None else torch.zeros_like(p[k])) for r in range(world))
             assert g is not None and torch.allclose(torch.from_numpy(g), want, rtol=1e-6, atol=1e-7), k
+            g2 = out[rank + 100][0][keys.index(k)]   # in-place reduction of the shared flat buffer
+            assert torch.allclose(torch.from_numpy(g2), want, rtol=1e-6, atol=1e-7), k
 
 
 def test_shard_units_partitions():
