@@ -50,7 +50,7 @@ def _worker(rank, world, port, q):
     pp = _grads(cfg, p, _frame(100 + mine[0], 3))
     params = [torch.nn.Parameter(v.detach()) for v in pp.values()]
     for prm, v in zip(params, pp.values()):
-        prm.grad = v.grad          # None for the last layer's unused heads
+        prm.grad = None if v.grad is None else v.grad.clone()   # None for the last layer's unused heads
     nbytes = allreduce_gradients(params)
     t = max_over_ranks(1.0 + rank, "cpu")
     q.put((rank, [None if prm.grad is None else prm.grad.numpy().copy() for prm in params], nbytes, t))
