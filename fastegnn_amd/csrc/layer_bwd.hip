@@ -894,8 +894,9 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
       for (int tk = 0; tk < 4; ++tk) accA[ti][tk] = accB[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // K = 32 edges per step: tickets tk, tk+1 of one ring; lane (q,i) takes feature i of the rows 4e+q
-    // (e < 4: first slot, e >= 4: second slot), the same map for both operands
+    // K = 32 edges per step: tickets tk, tk+1 of one ring; lane (q,i) takes feature i of the rows 4q+e of the first
+    // (e < 4) and of the second slot (e >= 4), the same map for both operands.  With the 68-float row stride the
+    // rows of the two quarter-waves read together sit 16 banks apart: conflict-free b32 reads
     auto contract = [&](int kind, int tk, f32x4 (&acc)[4][4], float (&bs)[4]) {
       const int s0 = tk % PC_RING, r0w = tk / PC_RING;
       const bool two = tk + 1 < total;
@@ -910,8 +911,8 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         float x[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          x[e] = g0[16 * PC_RS + (4 * e + q) * PC_RS + 16 * t + j];
-          x[4 + e] = two ? g1[16 * PC_RS + (4 * e + q) * PC_RS + 16 * t + j] : 0.f;
+          x[e] = g0[16 * PC_RS + (4 * q + e) * PC_RS + 16 * t + j];
+          x[4 + e] = two ? g1[16 * PC_RS + (4 * q + e) * PC_RS + 16 * t + j] : 0.f;
         }
         B[t] = split8(x);
       }
@@ -920,8 +921,8 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         float x[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          x[e] = g0[(4 * e + q) * PC_RS + 16 * ti + j];
-          x[4 + e] = two ? g1[(4 * e + q) * PC_RS + 16 * ti + j] : 0.f;
+          x[e] = g0[(4 * q + e) * PC_RS + 16 * ti + j];
+          x[4 + e] = two ? g1[(4 * q + e) * PC_RS + 16 * ti + j] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs[ti] += x[e];

@@ -17,7 +17,7 @@ for n in ("p1","p2"):
     if not fs: print(n,"no file"); continue
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(set)
     for r in csv.DictReader(open(fs[0])):
-        k=r["Kernel_Name"].split("(")[0]
+        k=r["Kernel_Name"].split("(")[0].replace("void ","").split("<")[0].replace("_pc_kernel","_kernel")
         if not k.startswith("fe::"): continue
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
     print("==",n)
