@@ -153,6 +153,14 @@ __device__ __forceinline__ float jsum(float p) {
   p += __shfl_xor(p, 8);
   return p;
 }
+// same sum by DPP row rotations (no LDS crossbar traffic): every lane of the 16-lane row gets the total
+__device__ __forceinline__ float jsum_dpp(float p) {
+  p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x128, 0xf, 0xf, false));  // row_ror:8
+  p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x124, 0xf, 0xf, false));  // row_ror:4
+  p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x122, 0xf, 0xf, false));  // row_ror:2
+  p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return p;
+}
 // <v, w> over the hidden dimension; every q-lane of the item gets the full dot product
 __device__ __forceinline__ float vdot(const Vec &v, const Vec &w) {
   float p = 0.f;

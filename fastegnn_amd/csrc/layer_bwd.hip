@@ -122,7 +122,7 @@ struct VirtBwdArgs {
   int ld_v0;
 };
 
-constexpr int virt_bwd_img_floats(bool x3h) { return x3h ? 4 * IMG + 2 * IMG3 : 6 * IMG; }
+constexpr int virt_bwd_img_floats(bool x3h) { return x3h ? 2 * IMG + 4 * IMG3 : 6 * IMG; }
 // RF (FastRF reduced layer) is a compile-time switch: as a run-time flag it cost the FastEGNN path 10 %
 // (register allocation of the channel loop)
 template <bool RF, bool X3H>
@@ -130,20 +130,18 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VirtArgs &a = A.f;
   const int C = a.C;
-  // fp32 images V2 WXV0 WXX0 V2T WXV0T WXX0T; X3H: the two head layers WXV0, WXX0 (they share one operand
-  // split) as split images for the bf16 matrix pipe instead: V2 V2T WXV0T WXX0T | WXV0 WXX0 (LDS permitting: C <= 32)
+  // fp32 images V2 WXV0 WXX0 V2T WXV0T WXX0T; X3H (LDS permitting: C <= 32): V2, WXV0, WXX0 and V2T as split
+  // images for the bf16 matrix pipe, only the two transposed head layers stay fp32: WXV0T WXX0T | V2 WXV0 WXX0 V2T
   float *img = lds;
-  const unsigned *img3 = reinterpret_cast<const unsigned *>(lds + 4 * IMG);   // WXV0, WXX0 split
-  constexpr int S_V2 = 0, S_V2T = X3H ? 1 : 3, S_WXV0T = X3H ? 2 : 4, S_WXX0T = X3H ? 3 : 5;
+  const unsigned *img3 = reinterpret_cast<const unsigned *>(lds + 2 * IMG);   // split images (X3H)
+  constexpr int S_V2 = 0, S_V2T = 3, S_WXV0T = X3H ? 0 : 4, S_WXX0T = X3H ? 1 : 5;
   float *vec = lds + virt_bwd_img_floats(X3H);
-  float *tiles = vec + 16 * H;
-  float *gBc_l = tiles + VIRT_BWD_WAVES * 16 * TS;   // [C][64]
+  float *gBc_l = vec + 16 * H;                   // [C][64]
   float *gZ_l = gBc_l + C * H;                   // [3][C]
   float *w3ct_l = gZ_l + ((3 * C + 3) & ~3);     // W3cT[c] of the channel in flight (fp32 image)
   if constexpr (X3H) {
-    load_images(img, a.wpack + (size_t)I_V2 * IMG, 1);
-    load_images(img + IMG, a.wpack + (size_t)I_V2T * IMG, 3);
-    load_images_x3(reinterpret_cast<unsigned *>(lds + 4 * IMG), wpack_x3(a.wpack, C, I_WXV0), 2);
+    load_images(img, a.wpack + (size_t)I_WXV0T * IMG, 2);
+    load_images_x3(reinterpret_cast<unsigned *>(lds + 2 * IMG), wpack_x3(a.wpack, C, I_V2), 4);   // ids V2..V2T are consecutive
   } else {
     load_images(img, a.wpack + (size_t)I_V2 * IMG, 6);
   }
@@ -151,7 +149,6 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) gBc_l[i] = 0.f;
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
-  float *tile = tiles + wv * 16 * TS;
   constexpr int GROUP = 16 * VIRT_BWD_WAVES;
   const int ntg = (a.N + GROUP - 1) / GROUP;
   const float invC = C > 0 ? 1.0f / (float)C : 0.f;
@@ -320,7 +317,8 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {
           const Vec t = vsilu_keep_d(d_pre);      // d_pre <- silu'(pre)
           WG_STORE(if (valid) vstore_u(b_t, oc, t);)
-          gemm64(img + S_V2 * IMG, t, vp);
+          if constexpr (X3H) gemm64_x3(img3 + S_V2 * IMG3, t, vp);
+          else gemm64(img + S_V2 * IMG, t, vp);
         }
         const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
         float att = 1.f;
@@ -339,7 +337,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         float sx, sX;
         {  // coord_mlp_r_virtual head: forward, then its adjoint
           Vec uxp = vload_vec(vec + VV_BXV0 * H, q);
-          if constexpr (X3H) gemm64_x3(img3 + 0 * IMG3, vs, uxp);
+          if constexpr (X3H) gemm64_x3(img3 + 1 * IMG3, vs, uxp);
           else gemm64(img + 1 * IMG, v, uxp);
           const Vec ux = vsilu_keep_d(uxp);       // uxp <- silu'(uxp)
           const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
@@ -355,7 +353,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         }
         {  // coord_mlp_v_virtual head
           Vec uXp = vload_vec(vec + VV_BXX0 * H, q);
-          if constexpr (X3H) gemm64_x3(img3 + 1 * IMG3, vs, uXp);
+          if constexpr (X3H) gemm64_x3(img3 + 2 * IMG3, vs, uXp);
           else gemm64(img + 2 * IMG, v, uXp);
           const Vec uX = vsilu_keep_d(uXp);
           const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
@@ -384,7 +382,8 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {
           const Vec g_vp = vmul(g_v0, vp);
           WG_STORE(if (valid) vstore_u(b_gvp, oc, g_vp);)
-          gemm64(img + S_V2T * IMG, g_vp, g_t);
+          if constexpr (X3H) gemm64_x3(img3 + S_V2T * IMG3, g_vp, g_t);
+          else gemm64(img + S_V2T * IMG, g_vp, g_t);
         }
         const Vec g_pre = vmul(g_t, d_pre);
         vadd(g_A, g_pre);
@@ -396,10 +395,9 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           g_vd[k] += ivr * vd[k];
           gx[k] -= g_vd[k];
         }
-        // pools over the nodes of the tile: g_Bc[b,c,:] += g_pre, g_Zp[b,:,c] += g_vd
-        __builtin_amdgcn_wave_barrier();
-        tile_store(tile, j, q, g_pre);
-        __builtin_amdgcn_wave_barrier();
+        // pools over the nodes of the tile: g_Bc[b,c,:] += g_pre, g_Zp[b,:,c] += g_vd.  The sum over the 16 items
+        // of the tile runs on DPP row rotations in the D layout (no transpose tile in LDS: that space holds
+        // split images instead); g_pre of a masked lane is zero.
         if (fast) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
@@ -407,21 +405,24 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
             pv = jsum(pv);
             if (l == 0) atomicAdd(&gZ_l[k * C + c], pv);
           }
-          float s = 0.f;
 #pragma unroll
-          for (int ee = 0; ee < 16; ++ee) s += tile[ee * TS + l];
-          atomicAdd(&gBc_l[c * H + l], s);
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float sr = jsum_dpp(g_pre.t[t][r]);
+              if (j == 0) atomicAdd(&gBc_l[c * H + 16 * t + 4 * q + r], sr);
+            }
         } else {
           if (valid && q == 0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) atomicAdd(&A.g_Zp[((size_t)b * 3 + k) * C + c], g_vd[k]);
           }
+          if (valid) {
 #pragma unroll
-          for (int ee = 0; ee < 16; ++ee) {
-            if (ee < nvalid) {
-              const int be = __builtin_amdgcn_readlane(b, ee);
-              atomicAdd(&A.g_Bc[((size_t)be * C + c) * H + l], tile[ee * TS + l]);
-            }
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                atomicAdd(&A.g_Bc[((size_t)b * C + c) * H + 16 * t + 4 * q + r], g_pre.t[t][r]);
           }
         }
       }
@@ -499,7 +500,7 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   {
     ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st);
     const bool x3h = BWD_X3 && C <= 32;
-    const size_t lds = virt_lds_bytes(C, 0, VIRT_BWD_WAVES) + (virt_bwd_img_floats(x3h) + IMG + 4) * sizeof(float);
+    const size_t lds = virt_lds_bytes(C, 0, 0) + (virt_bwd_img_floats(x3h) + IMG + 4) * sizeof(float);
     const dim3 g3(grid), b3(64 * VIRT_BWD_WAVES);
     if (has(L, FASTEGNN_F_RF)) {
       if (x3h) hipLaunchKernelGGL((virt_bwd_kernel<true, true>), g3, b3, lds, st, A);
