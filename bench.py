@@ -226,7 +226,7 @@ def main():
         t_mfma, t_hbm = fl / (PEAK_MFMA_F32_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes (tools_gpu_traffic.sh)
+        if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes (tools/gpu_traffic.sh)
             traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
         if t_mfma >= t_hbm:
             roof = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": PEAK_MFMA_F32_TFLOPS,

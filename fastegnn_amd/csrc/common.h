@@ -200,13 +200,7 @@ __host__ __device__ __forceinline__ int img_index(int o, int k) {
 }
 
 // acc[o][item] += sum_k A[o][k] * in[k][item].  img may live in LDS or global memory.
-#ifndef FE_GEMM_FENCE
-#define FE_GEMM_FENCE 0
-#endif
 __device__ __forceinline__ void gemm64(const float *img, const Vec &in, Vec &acc) {
-#if FE_GEMM_FENCE
-  __builtin_amdgcn_sched_barrier(0);
-#endif
   const f32x4 *ip = reinterpret_cast<const f32x4 *>(img) + lane_id();
 #pragma unroll
   for (int tp = 0; tp < 4; ++tp) {
@@ -219,9 +213,6 @@ __device__ __forceinline__ void gemm64(const float *img, const Vec &in, Vec &acc
       for (int t = 0; t < 4; ++t)
         acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][r], in.t[tp][r], acc.t[t], 0, 0, 0);
   }
-#if FE_GEMM_FENCE
-  __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 
 // gemm64 between scheduling fences: the operand reads of ONE layer are in flight at a time.  Without the
@@ -291,9 +282,6 @@ __device__ __forceinline__ Split vsplit(const Vec &v) {
 }
 // img3: split image, IMG3 words = parts h | m | l (2048 words each), normally LDS resident.
 __device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Split &in, Vec &acc) {
-#if FE_GEMM_FENCE
-  __builtin_amdgcn_sched_barrier(0);
-#endif
   const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + lane_id();
 #pragma unroll
   for (int s = 0; s < 2; ++s)
@@ -313,9 +301,6 @@ __device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Split &in,
       acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xm, acc.t[t], 0, 0, 0);
       acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc.t[t], 0, 0, 0);
     }
-#if FE_GEMM_FENCE
-  __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 __device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Vec &in, Vec &acc) { gemm64_x3(img3, vsplit(in), acc); }
 

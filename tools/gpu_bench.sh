@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage on the GPU box: bash tools_gpu_bench.sh <tag>
+# usage on the GPU box: bash tools/gpu_bench.sh <tag>
 set -x
 tag=${1:-r01}
 mkdir -p gpurun_out/$tag

@@ -1,5 +1,5 @@
 import ctypes as C, sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root
 from fastegnn_amd import _lib as K
 L = K.lib()
 w = (torch.randn(4096, device="cuda") * 0.1)

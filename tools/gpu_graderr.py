@@ -1,6 +1,6 @@
 """diagnostic: per-tensor gradient error of the build vs the fp64 oracle, beside the fp32 reference's own"""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root
 from tests.gpu_util import model_from_golden
 from tests.helpers import Golden, golden_loss, fp64_truth, rel_err
 for name in sys.argv[1:]:

@@ -1,5 +1,5 @@
 import ctypes as C, json, torch, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root
 import fastegnn_amd
 from fastegnn_amd import _lib as K
 from bench import make_frame, loss_fn

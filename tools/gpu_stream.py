@@ -1,6 +1,6 @@
 """diagnostic: achievable HBM streaming rates and the stand-alone rate of the weight-gradient contraction"""
 import ctypes as C, sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root
 from fastegnn_amd import _lib as K
 L = K.lib()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,6 +1,6 @@
 #!/bin/bash
 tag=${1:-t}
-bash tools_gpu_quick.sh
+bash tools/gpu_quick.sh
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/$tag.log 2>&1
 cd $GRAFT_REPO_ROOT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # diagnostic: rebuild given sources with extra -D flags (on the GPU box's scratch copy) and print kernel times
-# usage: tools_gpu_variants.sh "<files>" "<flags variant 1>" "<flags variant 2>" ...
+# usage: tools/gpu_variants.sh "<files>" "<flags variant 1>" "<flags variant 2>" ...
 files=$1; shift
 for extra in "$@"; do
   ( cd fastegnn_amd/csrc && for f in $files; do rm -f $f.o; done && make -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include $extra" > /dev/null 2>&1 ) || { echo "build failed: $extra"; continue; }
