@@ -191,6 +191,24 @@ def test_c32_vs_oracle():
     _check_vs_oracle(cfg, _batch([257], 15, 32, seed=6), seed=6)
 
 
+def test_hub_rows_and_skewed_degrees_vs_oracle():
+    """Rows far longer than a wave's share of the edges (a 4000-edge hub, a 700-edge hub) beside hundreds of rows
+    with 0-2 edges: whole rows stay with one wave, the in-workgroup gradient rings see very uneven producers."""
+    g = torch.Generator().manual_seed(11)
+    N, C = 1500, 4
+    src = torch.randint(1, N, (4000,), generator=g)
+    rows = [torch.zeros(4000, dtype=torch.long), torch.full((700,), 7, dtype=torch.long),
+            torch.randint(0, N, (1200,), generator=g)]
+    cols = [src, torch.randint(0, N, (700,), generator=g), torch.randint(0, N, (1200,), generator=g)]
+    ei = torch.stack([torch.cat(rows), torch.cat(cols)])
+    ei = ei[:, torch.randperm(ei.size(1), generator=g)]
+    loc = torch.randn(N, 3, generator=g) * 2.0
+    inp = dict(node_feat=torch.rand(N, 2, generator=g), node_loc=loc, node_vel=torch.randn(N, 3, generator=g) * 0.3,
+               edge_index=ei, data_batch=torch.zeros(N, dtype=torch.long),
+               loc_mean=loc.mean(0).view(1, 3, 1).repeat(1, 1, C), edge_attr=torch.rand(ei.size(1), 2, generator=g))
+    _check_vs_oracle(R.Config(2, 0, 2, 64, C, n_layers=2), inp, seed=12)
+
+
 def test_no_edges_and_isolated_nodes():
     cfg = R.Config(2, 0, 2, 64, 4, n_layers=2)
     inp = _batch([40, 23], 3, 4, seed=8)
