@@ -342,8 +342,10 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
   float *tile = tiles + wv * 16 * TS;
-  constexpr int GROUP = 16 * VIRT_WAVES;
-  const int ntg = (a.N + GROUP - 1) / GROUP;
+  // a workgroup owns a contiguous run of 16-node tiles and walks it VIRT_WAVES tiles at a time; the runs differ by
+  // at most one tile, so the last, partial step of a workgroup is a single wave that has its SIMD to itself
+  const int ntiles = (a.N + 15) >> 4;
+  const int t_lo = (int)((long)blockIdx.x * ntiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   const float invC = C > 0 ? 1.0f / (float)C : 0.f;
   const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;   // basic.py:310
   const bool rf = a.flags & FASTEGNN_F_RF;             // FastRF.py:155-186: no node_model / node_model_virtual
@@ -375,8 +377,8 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
 #pragma unroll
     for (int i = 0; i < STG; ++i) dst[threadIdx.x + i * 64 * VIRT_WAVES] = pre_w[i];
   };
-  for (int tg = blockIdx.x; tg < ntg; tg += gridDim.x) {
-    const int n0 = tg * GROUP, nend = min(a.N, n0 + GROUP);
+  for (int tb = t_lo; tb < t_hi; tb += VIRT_WAVES) {
+    const int n0 = tb * 16, nend = min(a.N, min(t_hi, tb + VIRT_WAVES) * 16);
     const int bfirst = a.batch[n0], blast = a.batch[nend - 1];
     const bool fast = bfirst == blast;
     if (fast && bfirst != cur) {
@@ -515,7 +517,7 @@ int virt_forward(const fastegnn_layer_t *L, hipStream_t st) {
   if (L->N == 0) return check_launch("virt_forward(memset)");
   VirtArgs a = make_virt_args(L);
   const int ntg = cdiv(L->N, 16 * VIRT_WAVES);
-  int grid = ntg < 512 ? ntg : 512;
+  int grid = ntg < 256 ? ntg : 256;   // one workgroup per CU (LDS), each with an equal share of the tiles
   { ProfScope _ps_virt_fwd_kernel(K_VIRT_FWD, st); hipLaunchKernelGGL(virt_fwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(L->C, 3) + (VIRT_FWD_IMG_FLOATS - 3 * IMG) * sizeof(float), st, a); }
   return check_launch("virt_fwd_kernel");
 }
