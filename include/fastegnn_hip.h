@@ -204,7 +204,10 @@ size_t fastegnn_sizeof_graph(void);
  * address the source table [0,n_src).  All outputs caller-allocated:
  * rowptr[n_rows+1], erow/col/perm/csc_eid[E], cscptr[n_src+1], chunk_row[fastegnn_chunk_rows(E)]
  * (row boundaries nearest to every 32nd edge: the edge kernels give each wave a contiguous run of them);
- * tmp: fastegnn_csr_tmp_bytes(E, n_rows, n_src) bytes.  *n_chunks is a host int. */
+ * tmp: fastegnn_csr_tmp_bytes(E, n_rows, n_src) bytes.  *n_chunks is a host int.
+ * The edge stages address their tables with 32-bit offsets: n_rows * 68 and n_src * 68 must stay below 2^30
+ * (15.7 M nodes) and E * 8 below 2^30 (134 M edges); fastegnn_edge_forward / _backward return
+ * FASTEGNN_E_INVALID beyond that. */
 size_t fastegnn_csr_tmp_bytes(int32_t E, int32_t n_rows, int32_t n_src);
 size_t fastegnn_chunk_rows(int32_t E);
 int32_t fastegnn_chunk_edges(void);   /* edges per row chunk: chunk k owns the rows whose first edge lies in [k*T, (k+1)*T) */
