@@ -183,7 +183,9 @@ def main():
     # the per-kernel HIP-event profiler is on during warm-up too, so that its event pool exists
     # before the timed region (hipEventCreate is slow on a cold driver)
     K.lib().fastegnn_profile_enable(1)
-    for _ in range(max(args.warmup, 1)):
+    # two extra untimed steps ahead of the W warm-up steps: on a freshly booted box the first pass still pages
+    # the Python / torch / HIP code in from the image, which showed up as sporadic 100 ms host stalls
+    for _ in range(2 + max(args.warmup, 1)):
         step()
     sync()
     K.profile_collect()
