@@ -3,7 +3,7 @@
 set -x
 tag=${1:-r01}
 mkdir -p gpurun_out/$tag
-python bench.py --steps 5 --warmup 2 > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
+python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
 tail -c 3000 gpurun_out/$tag/bench.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/$tag/prof.log 2>&1
