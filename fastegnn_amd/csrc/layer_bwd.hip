@@ -149,8 +149,11 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) gBc_l[i] = 0.f;
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
-  constexpr int GROUP = 16 * VIRT_BWD_WAVES;
-  const int ntg = (a.N + GROUP - 1) / GROUP;
+  // a workgroup owns a contiguous run of 16-node tiles and walks it VIRT_BWD_WAVES tiles at a time.  When exactly
+  // one tile is left for the last step, its channels are dealt to the four waves (wave w takes c = w, w+4, ...)
+  // instead of leaving three SIMDs idle for a whole tile; the channel sums are combined through LDS.
+  const int ntiles = (a.N + 15) >> 4;
+  const int t_lo = (int)((long)blockIdx.x * ntiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   const float invC = C > 0 ? 1.0f / (float)C : 0.f;
   const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION;
   const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;
@@ -169,8 +172,10 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       gZ_l[i] = 0.f;
     }
   };
-  for (int tg = blockIdx.x; tg < ntg; tg += gridDim.x) {
-    const int n0 = tg * GROUP, nend = min(a.N, n0 + GROUP);
+  for (int tb = t_lo; tb < t_hi; tb += VIRT_BWD_WAVES) {
+    const bool split = t_hi - tb == 1 && C >= VIRT_BWD_WAVES;
+    const bool own = !split || wv == 0;   // split: every wave recomputes the tile prologue, wave 0 stores it
+    const int n0 = tb * 16, nend = min(a.N, min(t_hi, tb + VIRT_BWD_WAVES) * 16);
     const int bfirst = a.batch[n0], blast = a.batch[nend - 1];
     const bool fast = bfirst == blast;
     if (fast && bfirst != cur) {
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       __syncthreads();
       cur = bfirst;
     }
-    const int nb = n0 + wv * 16;
+    const int nb = split ? n0 : n0 + wv * 16;
     const int nvalid = max(0, min(16, nend - nb));
     {   // a wave without valid nodes runs the body on masked lanes (every contribution is zero): the
         // workgroup walks the channels in step for the W3cT stage below
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       const Vec g_out = vmask(vload_u(b_gho, offN), valid);
       Vec g_np = vzero();
       if constexpr (rf) {
-        if (valid) {
+        if (valid && own) {
           vstore_u(b_gh, offN, g_out);
           vstore_u(b_gam, offN, vzero());
         }
@@ -211,18 +216,18 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           Vec g_t3 = vzero();
           gemm64(a.wpack + (size_t)I_W4T * IMG, g_out, g_t3);
           g_np = vdsilu_mul(g_t3, npre);
-          if (valid) vstore_u(b_t3, offN, vsilu(npre));
+          if (valid && own) vstore_u(b_t3, offN, vsilu(npre));
         }
-        if (valid) vstore_u(b_gnp, offN, g_np);
+        if (valid && own) vstore_u(b_gnp, offN, g_np);
         {
           Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
           gemm64(a.wpack + (size_t)I_W3AT * IMG, g_np, g_h);
-          if (valid) vstore_u(b_gh, offN, g_h);
+          if (valid && own) vstore_u(b_gh, offN, g_h);
         }
         {
           Vec g_am = vzero();
           gemm64(a.wpack + (size_t)I_W3BT * IMG, g_np, g_am);
-          if (valid) vstore_u(b_gam, offN, g_am);
+          if (valid && own) vstore_u(b_gam, offN, g_am);
         }
       }
       float gxn[3], xi[3], gx[3];
@@ -230,9 +235,9 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       for (int k = 0; k < 3; ++k) {
         gxn[k] = valid ? A.g_x_out[(size_t)nc * 3 + k] : 0.f;
         xi[k] = a.x[(size_t)nc * 3 + k];
-        gx[k] = gxn[k];
+        gx[k] = own ? gxn[k] : 0.f;
       }
-      if (valid && q == 0) {
+      if (valid && q == 0 && own) {
         float sv = 0.f, sg = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -254,13 +259,14 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       const Vec g_np_m = vmask(g_np, valid);
       Vec nBc = vzero(), nGpv = vzero();
       float nZ[3] = {0.f, 0.f, 0.f}, nGpx[3] = {0.f, 0.f, 0.f};
-      if (C > 0) {   // the virtual-node buffers are null for the EGNN baseline (C = 0)
-        nBc = vload_u(a.Bc, offB);
-        nGpv = vload_u(gpv_base, offB);
+      const int c_first = split ? wv : 0, c_step = split ? VIRT_BWD_WAVES : 1;
+      if (c_first < C) {   // the virtual-node buffers are null for the EGNN baseline (C = 0)
+        nBc = vload_u(a.Bc, offB + (unsigned)c_first * H);
+        nGpv = vload_u(gpv_base, offB + (unsigned)c_first * H);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          nZ[k] = Zb[k * C];
-          nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C];
+          nZ[k] = Zb[k * C + c_first];
+          nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C + c_first];
         }
       }
       // W3cT[c] goes through an LDS stage refilled once per workgroup and channel; the image of channel
@@ -272,12 +278,12 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
 #pragma unroll
         for (int i = 0; i < STG; ++i) pre_w[i] = src[threadIdx.x + i * 64 * VIRT_BWD_WAVES];
       };
-      if constexpr (!rf) { if (C > 0) fetch_w3ct(0); }
-      for (int c = 0; c < C; ++c) {
+      if constexpr (!rf) { if (C > 0 && !split) fetch_w3ct(0); }
+      for (int c = c_first; c < C; c += c_step) {
         // Recompute the forward of (tile, c) interleaved with its adjoint so that each activation is
         // dead as soon as its gradient is formed.
         asm volatile("" ::: "memory");
-        if constexpr (!rf) {
+        if constexpr (!rf) if (!split) {
           __syncthreads();          // every wave is done with the previous channel's stage
           f32x4 *dst = reinterpret_cast<f32x4 *>(w3ct_l);
 #pragma unroll
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           gpX[k] = valid ? nGpx[k] : 0.f;
         }
         {
-          const int cn = c + 1 < C ? c + 1 : c;
+          const int cn = c + c_step < C ? c + c_step : c;
           const unsigned obn = offB + (unsigned)cn * H;
           nBc = vload_u(a.Bc, obn);
           nGpv = vload_u(gpv_base, obn);
@@ -332,7 +338,10 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         if constexpr (X3H) vs = vsplit(v);   // feeds both coordinate heads
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
         Vec g_v = rf ? vzero() : vmask(gpv_c, valid);
-        if constexpr (!rf) gemm64(w3ct_l, g_np_m, g_v);
+        if constexpr (!rf) {
+          if (split) gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);   // the stage serves one channel at a time
+          else gemm64(w3ct_l, g_np_m, g_v);
+        }
         float g_vd[3];
         float sx, sX;
         {  // coord_mlp_r_virtual head: forward, then its adjoint
@@ -426,7 +435,29 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           }
         }
       }
-      if (valid) {
+      if (split) {   // sum the four waves' channel shares of g_A and g_x ([16][68] floats in the idle W3cT stage)
+        float *comb = w3ct_l;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * TS; i += blockDim.x) comb[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(&comb[j * TS + 16 * t + 4 * q + r], g_A.t[t][r]);
+        if (q == 0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) atomicAdd(&comb[j * TS + H + k], gx[k]);
+        }
+        __syncthreads();
+        if (own) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) g_A.t[t] = *reinterpret_cast<const f32x4 *>(comb + j * TS + 16 * t + 4 * q);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) gx[k] = comb[j * TS + H + k];
+        }
+        __syncthreads();   // comb is the W3cT stage of the next workgroup step
+      }
+      if (valid && own) {
         vstore_u(b_gA, offN, g_A);
         if (q == 0) {
 #pragma unroll
@@ -496,7 +527,7 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (A.d_attw && A.d_attb), "virt_backward: attention grads null");
   FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
   const int ntg = cdiv(N, 16 * VIRT_BWD_WAVES);
-  int grid = ntg < 256 ? ntg : 256;
+  int grid = ntg < 256 ? ntg : 256;   // one workgroup per CU, each with an equal share of the tiles
   {
     ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st);
     const bool x3h = BWD_X3 && C <= 32;

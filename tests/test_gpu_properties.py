@@ -209,6 +209,13 @@ def test_hub_rows_and_skewed_degrees_vs_oracle():
     _check_vs_oracle(R.Config(2, 0, 2, 64, C, n_layers=2), inp, seed=12)
 
 
+def test_many_tiles_per_workgroup_vs_oracle():
+    """N large enough that the virtual kernels' workgroups own five tiles each (four at a time plus a last one that
+    the backward kernel deals to its waves by channel), three graphs, C=8."""
+    cfg = R.Config(2, 0, 2, 64, 8, n_layers=2, gravity=[0, -1, 0])
+    _check_vs_oracle(cfg, _batch([9000, 7000, 4321], 2, 8, seed=13), seed=13)
+
+
 def test_no_edges_and_isolated_nodes():
     cfg = R.Config(2, 0, 2, 64, 4, n_layers=2)
     inp = _batch([40, 23], 3, 4, seed=8)
