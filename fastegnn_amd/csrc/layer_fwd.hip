@@ -378,6 +378,10 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     for (int i = 0; i < STG; ++i) dst[threadIdx.x + i * 64 * VIRT_WAVES] = pre_w[i];
   };
   for (int tb = t_lo; tb < t_hi; tb += VIRT_WAVES) {
+    // a single left-over tile is dealt to the waves by channel (wave w takes c = w, w + VIRT_WAVES, ...); the
+    // channel sums of the node-MLP accumulator and of the coordinate update are combined through LDS
+    const bool split = FWD_X3 && t_hi - tb == 1 && C >= VIRT_WAVES;
+    const bool own = !split || wv == 0;
     const int n0 = tb * 16, nend = min(a.N, min(t_hi, tb + VIRT_WAVES) * 16);
     const int bfirst = a.batch[n0], blast = a.batch[nend - 1];
     const bool fast = bfirst == blast;
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       __syncthreads();
       cur = bfirst;
     }
-    const int nb = n0 + wv * 16;
+    const int nb = split ? n0 : n0 + wv * 16;
     const int nvalid = max(0, min(16, nend - nb));
     const bool active = nvalid > 0;
     const int n = nb + j;
@@ -401,11 +405,12 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       xi[0] = a.x[(size_t)nc * 3]; xi[1] = a.x[(size_t)nc * 3 + 1]; xi[2] = a.x[(size_t)nc * 3 + 2];
     }
     float transv[3] = {0.f, 0.f, 0.f};
-    Vec nodeacc = vload_vec(vec + VV_B3 * H, q);
-    if constexpr (FWD_X3) { if (C > 0 && !rf) fetch_w3c(0); }
-    for (int c = 0; c < C; ++c) {
+    Vec nodeacc = own ? vload_vec(vec + VV_B3 * H, q) : vzero();
+    if constexpr (FWD_X3) { if (C > 0 && !rf && !split) fetch_w3c(0); }
+    const int c_step = split ? VIRT_WAVES : 1;
+    for (int c = split ? wv : 0; c < C; c += c_step) {
       if constexpr (FWD_X3) {
-        if (!rf) {
+        if (!rf && !split) {
           __syncthreads();          // every wave is done with the previous channel's stage
           commit_w3c();
           __syncthreads();
@@ -453,15 +458,41 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
           }
         }
         if (!rf) {
-          if constexpr (FWD_X3) gemm64_x3(stage, S.vs, nodeacc);
-          else gemm64(a.wpack + (size_t)img_w3c(c) * IMG, S.v, nodeacc);
+          if constexpr (FWD_X3) {
+            if (split) gemm64_x3(wpack_x3(a.wpack, C, img_w3c(c)), S.vs, nodeacc);   // the stage serves one channel at a time
+            else gemm64_x3(stage, S.vs, nodeacc);
+          } else {
+            gemm64(a.wpack + (size_t)img_w3c(c) * IMG, S.v, nodeacc);
+          }
         }
       }
     }
-    if (active && rf) {   // the node features pass through unchanged (FastRF.py:186)
+    if (split) {   // sum the waves' channel shares ([16][68] floats in the idle W3c stage)
+      float *comb = reinterpret_cast<float *>(stage);
+      __syncthreads();
+      for (int i = threadIdx.x; i < 16 * TS; i += blockDim.x) comb[i] = 0.f;
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&comb[j * TS + 16 * t + 4 * q + r], nodeacc.t[t][r]);
+      if (q == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) atomicAdd(&comb[j * TS + H + k], transv[k]);
+      }
+      __syncthreads();
+      if (own) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) nodeacc.t[t] = *reinterpret_cast<const f32x4 *>(comb + j * TS + 16 * t + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) transv[k] = comb[j * TS + H + k];
+      }
+      __syncthreads();
+    }
+    if (active && rf && own) {   // the node features pass through unchanged (FastRF.py:186)
       if (valid) vstore_row(a.h_out + (size_t)n * H, q, vload_row(a.h + (size_t)nc * H, q));
     }
-    if (active && !rf) {
+    if (active && !rf && own) {
       // node_model: node_mlp.0 on [h | agg | flat(v) | node_attr]  (:153-166)
       const Vec hv = vload_row(a.h + (size_t)nc * H, q);
       gemm64(a.wpack + (size_t)I_W3A * IMG, hv, nodeacc);
@@ -483,7 +514,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
       if (valid) vstore_row(a.h_out + (size_t)n * H, q, out);
     }
-    if (active) {
+    if (active && own) {
       if (valid) {
         if (q == 0) {
           const float sv = a.svel[n];

@@ -210,10 +210,11 @@ def test_hub_rows_and_skewed_degrees_vs_oracle():
 
 
 def test_many_tiles_per_workgroup_vs_oracle():
-    """N large enough that the virtual kernels' workgroups own five tiles each (four at a time plus a last one that
-    the backward kernel deals to its waves by channel), three graphs, C=8."""
+    """N large enough that the virtual kernels' workgroups own nine tiles each: the forward kernel walks them eight
+    at a time, the backward kernel four at a time, and both deal the single left-over tile to their waves by channel
+    (2 307 tiles on 256 workgroups); three graphs, C=8."""
     cfg = R.Config(2, 0, 2, 64, 8, n_layers=2, gravity=[0, -1, 0])
-    _check_vs_oracle(cfg, _batch([9000, 7000, 4321], 2, 8, seed=13), seed=13)
+    _check_vs_oracle(cfg, _batch([20000, 12000, 4900], 2, 8, seed=13), seed=13)
 
 
 def test_no_edges_and_isolated_nodes():
