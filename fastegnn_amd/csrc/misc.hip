@@ -282,7 +282,10 @@ int WgradBatch::finish() {
     if (rc) return rc;
   }
   { ProfScope _ps(K_WGRAD_REDUCE, st); hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tab.n_jobs, (unsigned)max_nb, IMG / H + 1), dim3(512), 0, st, tab); }
-  tab.n_jobs = 0;
+  tab.n_jobs = 0;   // the batch may be refilled: slabs and workgroup ranges start over
+  n_wg = 0;
+  n_slab = 0;
+  max_nb = 1;
   return check_launch("wgrad_reduce_kernel");
 }
 
