@@ -65,3 +65,37 @@ def test_fastrf_features_pass_through_and_velocity_scale_ignores_h():
         kwc = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in kw2.items()}; kwc.pop("node_attr")
         ref, _ = RF.forward(p, g.cfg, **kwc)
     assert rel_err(b, ref) < OUT_TOL and rel_err(a, b) > 1e-4
+
+
+def test_fastrf_many_tiles_per_workgroup_vs_oracle():
+    """Large enough that the virtual kernels take their channel-split last-tile path under FASTEGNN_F_RF too."""
+    from oracle import fastegnn_ref as R
+    from tests.test_gpu_properties import _batch
+    cfg = R.Config(2, 0, 2, 64, 8, n_layers=2, gravity=[0, -1, 0])
+    inp = _batch([20000, 16900], 2, 8, seed=21)
+    m = fastegnn_amd.FastRF(2, 0, 2, 64, 8, device="cuda", n_layers=2, gravity=[0, -1, 0])
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith(("coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
+                p.mul_(50.0)
+    p32 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    tgt = inp["node_loc"] + 0.5
+    loc, vloc = m(**{k: v.cuda() for k, v in inp.items()})
+    (torch.nn.functional.mse_loss(loc, tgt.cuda()) + 0.05 * vloc.pow(2).mean()).backward()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        pp = {k: v.to(dt).clone().requires_grad_(True) for k, v in p32.items()}
+        ii = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in inp.items()}
+        l, v = RF.forward(pp, cfg, **ii)
+        (torch.nn.functional.mse_loss(l, tgt.to(dt)) + 0.05 * v.pow(2).mean()).backward()
+        res[dt] = (l.detach(), v.detach(), {k: (t.grad if t.grad is not None else torch.zeros_like(t)) for k, t in pp.items()})
+    l32, v32, g32 = res[torch.float32]
+    _, _, g64 = res[torch.float64]
+    assert rel_err(loc, l32) < OUT_TOL and rel_err(vloc, v32) < OUT_TOL
+    bad = []
+    for k, p in m.named_parameters():
+        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(p32[k])
+        e_ref, e_got = rel_err(g32[k], g64[k]), rel_err(got, g64[k])
+        if e_got > GRAD_FACTOR * e_ref + GRAD_FLOOR:
+            bad.append(f"{k} {e_got:.2e} (ref {e_ref:.2e})")
+    assert not bad, bad
