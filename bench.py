@@ -1,39 +1,95 @@
 #!/usr/bin/env python3
-"""bench.py -- fwd+bwd throughput of the HIP-backed FastEGNN on the Water-3D-like 100k-node frame
-(BASELINE.json configs[3] / SURVEY.md section 8d cfg4), one process per GPU.
+"""bench.py -- fwd+bwd throughput of the HIP-backed FastEGNN on the BASELINE.json configurations, one
+process per GPU.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py                               # cfg4 (the headline 100k-node Water-3D-like frame), 1 GPU
+    python bench.py --gpus 8                      # spawns its 8 ranks itself (one per GPU, RCCL over xGMI)
+    python bench.py --config cfg3|cfg1|cfg2|cfg5  # the other BASELINE configurations
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # an external launcher works as well
 
-A step = one forward + loss + backward of the 4-layer model on one synthetic frame that is already
+A step = one forward + loss + backward of the 4-layer model on one synthetic batch that is already
 resident in HBM (COO edge_index as the reference receives it; the CSR build is inside the step).
-With N > 1 every rank processes its own frame (graphs are the independent units of the metric ->
-weak scaling) and the parameter gradients are all-reduced over RCCL inside the step, as a
-data-parallel trainer would.  Rank 0 prints ONE JSON line.
+
+N > 1:
+  cfg4 / cfg5 (one large graph): the frame is partitioned over the ranks (north_star's partition: row-owner
+      sharding, fastegnn_amd/sharded.py -- all-gather of the source table, reduce-scatter of its gradient, tiny
+      all-reduces of the virtual-node accumulators): STRONG scaling of one frame, `value` = frames/s of the job.
+  cfg1..cfg3 (mini-batches of small graphs): graphs are the independent units; every rank runs its own
+      mini-batch and the parameter gradients are all-reduced (`--mode dp`; also selectable for cfg4): WEAK.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak (= fp32 vector peak)
+PEAK_MFMA_BF16_TFLOPS = 2500.0 # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak
 H = 64
 UNIT = 2 * H * H               # FLOPs of one 64x64 mat-vec
 
+# BASELINE.json configs[0..4] as synthetic workloads
+CONFIGS = {
+    "cfg1": dict(kind="nbody", graphs=100, nodes=5, C=3, cutoff=0.5, gravity=None, dtype="f32",
+                 text="cfg1 N-body: 100 graphs x 5 particles, 10 shortest directed pairs per graph (cutoff_rate 0.5), C=3"),
+    "cfg2": dict(kind="nbody", graphs=100, nodes=100, C=3, cutoff=0.0, gravity=None, dtype="f32",
+                 text="cfg2 N-body: 100 graphs x 100 particles, fully connected (990000 edges), C=3"),
+    "cfg3": dict(kind="protein", graphs=8, nodes=3341, C=8, cutoff=0.5, gravity=None, dtype="bf16",
+                 text="cfg3 protein-MD-like: 8 graphs x 3341 points uniform in a 36 A cube (+50 A offset), 10 A contacts "
+                      "minus the longest 50 %, C=8, bf16 MLP operands / fp32 accumulate"),
+    "cfg4": dict(kind="water", nodes=100000, C=16, gravity=[0, -1, 0], dtype="f32",
+                 text="cfg4 Water-3D-like frame (SURVEY 8d): uniform points, radius graph r=0.035 (mean degree ~19), gravity on"),
+    "cfg5": dict(kind="water", nodes=1000000, C=32, gravity=[0, -1, 0], dtype="f32",
+                 text="cfg5 synthetic random geometric graph: 1 M points, r=0.035 at the cfg4 density (~19.6 M directed edges), gravity on"),
+}
 
+
+# ------------------------------------------------------------------------------------------------------
+# launcher (parent process: never touches the GPU)
+# ------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this parent
+    has made no HIP call), relay rank 0's stdout (the JSON line) and return the worst exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, abs(p.wait()))
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------
+# synthetic workloads
+# ------------------------------------------------------------------------------------------------------
 def make_frame(N, C, seed, device, radius=0.035):
     """N points uniform in a box of the density of [0,0.965]^3 @ 100k (mean degree
-    ~20 at r=0.035), vel ~ N(0,0.003^2), node_feat=[|vel|,1], edge_attr=[dist,dist], target=loc+20 vel."""
+    ~19 at r=0.035), vel ~ N(0,0.003^2), node_feat=[|vel|,1], edge_attr=[dist,dist], target=loc+20 vel."""
+    import numpy as np
+    import torch
     g = torch.Generator().manual_seed(seed)
     box = 0.965 * (N / 100000.0) ** (1.0 / 3.0)
     loc = torch.rand(N, 3, generator=g) * box
@@ -64,7 +120,83 @@ def make_frame(N, C, seed, device, radius=0.035):
     return {k: v.to(device) for k, v in frame.items()}, target.to(device)
 
 
+def make_nbody_batch(n_graphs, n, C, cutoff_rate, seed, device):
+    """charged N-body systems as the reference simulator initialises them
+    (datasets/nbody/datagen/system.py:21,36-39): positions N(0, ((n/5)^(1/3)+0.1)^2), |vel| = 0.5, charges +-1;
+    edges = the shortest (1 - cutoff_rate) fraction of the n(n-1) directed pairs (datasets/nbody/dataset.py:102-113);
+    node_feat=[|vel|, charge/max], edge_attr=[q_i q_j, dist]; target = loc + 0.4 vel."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    scale = (n / 5.0) ** (1.0 / 3.0) + 0.1
+    loc = torch.randn(n_graphs, n, 3, generator=g) * scale
+    vel = torch.randn(n_graphs, n, 3, generator=g)
+    vel = vel * (0.5 / vel.norm(dim=2, keepdim=True))
+    q = (torch.randint(0, 2, (n_graphs, n), generator=g) * 2 - 1).float()
+    k = int(n * (n - 1) * (1 - cutoff_rate))
+    d = torch.cdist(loc, loc) + torch.eye(n) * 1e18
+    idc = torch.topk(d.reshape(n_graphs, n * n), k, dim=1, largest=False).indices        # ascending length
+    row, col = idc.div(n, rounding_mode="trunc"), idc.remainder(n)
+    off = (torch.arange(n_graphs) * n).unsqueeze(1)
+    dist = d.reshape(n_graphs, n * n).gather(1, idc)
+    qq = q.gather(1, row) * q.gather(1, col)
+    N = n_graphs * n
+    batch = dict(
+        node_feat=torch.stack([vel.norm(dim=2).reshape(N), q.reshape(N)], 1),
+        node_loc=loc.reshape(N, 3), node_vel=vel.reshape(N, 3),
+        edge_index=torch.stack([(row + off).reshape(-1), (col + off).reshape(-1)]),
+        data_batch=torch.arange(n_graphs).repeat_interleave(n),
+        loc_mean=loc.mean(1).unsqueeze(-1).repeat(1, 1, C),
+        edge_attr=torch.stack([qq.reshape(-1), dist.reshape(-1)], 1),
+    )
+    target = (loc + 0.4 * vel).reshape(N, 3)
+    return {k_: v.contiguous().to(device) for k_, v in batch.items()}, target.to(device)
+
+
+def make_protein_batch(n_graphs, n, C, cutoff_rate, seed, device, radius=10.0, box=36.0, offset=50.0):
+    """graphs of n points uniform in a `box` A cube translated by +offset A, contacts within
+    `radius` A (datasets/protein/dataset.py:146) minus the longest cutoff_rate fraction (run_protein.sh:4)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    locs, eis, dists, off = [], [], [], 0
+    for b in range(n_graphs):
+        loc = torch.rand(n, 3, generator=g) * box + offset
+        if str(device) != "cpu":
+            from fastegnn_amd.graphs import cutoff_edges, radius_graph
+            ei, d = radius_graph(loc.to(device), radius)
+            ei, d = cutoff_edges(ei, d, cutoff_rate)
+            ei, d = ei.cpu(), d.cpu()
+        else:
+            dd = torch.cdist(loc, loc) + torch.eye(n) * 1e18
+            r, c = torch.nonzero(dd <= radius, as_tuple=True)
+            d = dd[r, c]
+            order = torch.argsort(d, stable=True)[: int(r.numel() * (1 - cutoff_rate))]
+            ei, d = torch.stack([r[order], c[order]]), d[order]
+        locs.append(loc); eis.append(ei + off); dists.append(d); off += n
+    loc, ei, dist = torch.cat(locs), torch.cat(eis, 1), torch.cat(dists)
+    N = n_graphs * n
+    vel = torch.randn(N, 3, generator=g) * 0.3
+    batch = dict(
+        node_feat=torch.stack([vel.norm(dim=1), torch.rand(N, generator=g)], 1),
+        node_loc=loc, node_vel=vel, edge_index=ei,
+        data_batch=torch.arange(n_graphs).repeat_interleave(n),
+        loc_mean=torch.stack([l.mean(0) for l in locs]).unsqueeze(-1).repeat(1, 1, C),
+        edge_attr=torch.stack([dist, dist], 1),
+    )
+    target = loc + 0.5 * vel
+    return {k_: v.contiguous().to(device) for k_, v in batch.items()}, target.to(device)
+
+
+def make_workload(cfg, seed, device, nodes=None, channels=None):
+    C = channels or cfg["C"]
+    if cfg["kind"] == "water":
+        return make_frame(nodes or cfg["nodes"], C, seed, device)
+    if cfg["kind"] == "nbody":
+        return make_nbody_batch(cfg["graphs"], nodes or cfg["nodes"], C, cfg["cutoff"], seed, device)
+    return make_protein_batch(cfg["graphs"], nodes or cfg["nodes"], C, cfg["cutoff"], seed, device)
+
+
 def loss_fn(loc, vloc, target):
+    import torch
     return torch.nn.functional.mse_loss(loc, target) + 0.01 * vloc.pow(2).mean()
 
 
@@ -91,54 +223,124 @@ def kernel_model(N, E, B, C, L, gravity=True):
     return f
 
 
-CPU_THREADS = 8   # fastest of {8,16,32,64,128} torch threads for this op mix on the GPU box's host CPU
+# ------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (op-for-op restatement of the reference) timed on the host cores
+# ------------------------------------------------------------------------------------------------------
+def host_cores():
+    """(logical CPUs visible to this process, physical cores of the machine if /proc/cpuinfo tells)."""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    phys = None
+    try:
+        seen = set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    seen.add((pid, cid))
+                pid = cid = None
+        phys = len(seen) or None
+    except OSError:
+        pass
+    return logical, phys
 
 
-def cpu_baseline(C, seed, steps=2, n_sample=10000):
-    """Oracle (op-for-op CPU restatement of the reference) timed on the host cores on a bounded
-    sample: a frame of the same density with n_sample nodes; cost is linear in N and E at fixed C."""
+def cpu_baseline(cfg, args, seed, mode):
+    """-> dict for the JSON line.  mode 'full': ONE fwd+bwd of the oracle on the full workload after a small
+    warm-up pass; 'scaled': median of 3 on a bounded sample of the same density, scaled linearly (flattering to the
+    CPU: the reference is super-linear in N)."""
+    import numpy as np
+    import torch
     from oracle import fastegnn_ref as R
-    torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or CPU_THREADS))
-    frame, target = make_frame(n_sample, C, seed, "cpu")
-    cfg = R.Config(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=C,
-                   n_layers=4, gravity=[0, -1, 0])
-    p = {k: v.requires_grad_(True) for k, v in R.init_params(cfg, seed=43).items()}
-    ts = []
-    for i in range(steps + 1):
+    logical, phys = host_cores()
+    threads = max(1, min(args.cpu_threads or logical, logical))
+    torch.set_num_threads(threads)
+    C = args.channels or cfg["C"]
+    ocfg = R.Config(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=C,
+                    n_layers=args.layers, gravity=cfg["gravity"])
+    p = {k: v.requires_grad_(True) for k, v in R.init_params(ocfg, seed=43).items()}
+
+    def run(frame, target):
         for v in p.values():
             v.grad = None
         t0 = time.perf_counter()
-        loc, vloc = R.forward(p, cfg, **frame)
+        loc, vloc = R.forward(p, ocfg, **frame)
         loss_fn(loc, vloc, target).backward()
-        ts.append(time.perf_counter() - t0)
-    t = float(np.median(ts[1:]))
-    return t, frame["edge_index"].size(1)
+        return time.perf_counter() - t0
+
+    full_nodes = args.nodes or cfg["nodes"]
+    if mode == "full":
+        if cfg["kind"] == "water":
+            run(*make_frame(2000, C, seed, "cpu"))                       # page the code in
+        frame, target = make_workload(cfg, seed, "cpu", args.nodes, args.channels)
+        t = run(frame, target)
+        e = frame["edge_index"].size(1)
+        units = cfg.get("graphs", 1)
+        sample = (f"oracle/fastegnn_ref.py (torch CPU, op-for-op restatement of the reference) fwd+bwd, ONE pass over the "
+                  f"full workload ({frame['node_loc'].size(0)} nodes, {e} edges, C={C}) after a 2000-node warm-up pass: {t:.2f} s")
+        value = units / t
+    else:
+        ns = min(full_nodes, 10000)
+        frame, target = make_frame(ns, C, seed, "cpu")
+        ts = [run(frame, target) for _ in range(4)]
+        t = float(np.median(ts[1:]))
+        scale = full_nodes / ns
+        sample = (f"oracle/fastegnn_ref.py fwd+bwd on a {ns}-node frame of the same density (E={frame['edge_index'].size(1)}), "
+                  f"median of 3 = {t:.2f} s, scaled x{scale:.0f} linearly to {full_nodes} nodes (the reference is "
+                  f"super-linear in N, so this flatters the CPU)")
+        value = 1.0 / (t * scale)
+    return {"value": round(value, 5), "unit": "graphs/s", "cores": threads, "kind": "port", "sample": sample,
+            "host_logical_cpus": logical, "host_physical_cores": phys, "torch_threads": threads}
 
 
+def latest_traffic():
+    """HBM bytes per launch from the newest rocprofv3 PMC capture under profiles/ (tools/gpu_traffic.sh)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")))
+    if not files:
+        return {}, None
+    return json.load(open(files[-1])), os.path.basename(files[-1])
+
+
+# ------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--nodes", type=int, default=100000)
-    ap.add_argument("--channels", type=int, default=16)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg4")
+    ap.add_argument("--nodes", type=int, default=None, help="override the node count (per graph for cfg1..cfg3)")
+    ap.add_argument("--channels", type=int, default=None, help="override the number of virtual channels")
     ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--mode", choices=["auto", "sharded", "dp"], default="auto",
+                    help="N>1: 'sharded' = ONE batch partitioned over the ranks (strong scaling; default for cfg4/cfg5), "
+                         "'dp' = one batch per rank + gradient all-reduce (weak scaling; default for cfg1..cfg3)")
+    ap.add_argument("--sharded", action="store_true", help="same as --mode sharded (also at 1 GPU: the staged C entry points)")
+    ap.add_argument("--dtype", choices=["auto", "f32", "bf16"], default="auto",
+                    help="MLP operand type: bf16 = bf16 operands / fp32 accumulate (default for cfg3), f32 otherwise")
+    ap.add_argument("--cpu-baseline", choices=["auto", "full", "scaled", "none"], default="auto",
+                    help="auto: 'full' at 1 GPU for cfg1..cfg4 (one oracle pass over the whole workload), 'scaled' for cfg5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (default: all visible CPUs)")
     ap.add_argument("--cache-graph", action="store_true", help="reuse the sorted graph across steps")
-    ap.add_argument("--sharded", action="store_true",
-                    help="ONE frame evaluated cooperatively by all ranks (row-owner sharding, fastegnn_amd/sharded.py: "
-                         "all-gather of the source table, reduce-scatter of its gradient, tiny all-reduces) instead of "
-                         "one frame per rank; strong scaling")
     ap.add_argument("--train-step", action="store_true",
                     help="time a full training iteration instead (edge_attr augmentation, MSE+MMD loss, Adam: "
                          "fastegnn_amd.train.train_step); the default step is fwd+loss+bwd, the BASELINE metric")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))          # before any GPU / HIP call in this process
+
+    import numpy as np  # noqa: F401
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
@@ -148,17 +350,27 @@ def main():
     from fastegnn_amd import _lib as K
     from fastegnn_amd.dist import allreduce_gradients, init_from_env, max_over_ranks
     init_from_env("nccl")
-    if args.sharded and not dist.is_initialized():   # the sharded path talks to a process group even at world 1
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    N, C, L = args.nodes, args.channels, args.layers
+
+    cfg = CONFIGS[args.config]
+    C, L = args.channels or cfg["C"], args.layers
+    mode = args.mode
+    if args.sharded:
+        mode = "sharded"
+    if mode == "auto":
+        mode = "sharded" if (world > 1 and cfg["kind"] == "water") else "dp"
+    sharded = mode == "sharded"
+    dtype = cfg["dtype"] if args.dtype == "auto" else args.dtype
+
     torch.manual_seed(43)
+    extra = {}
+    if dtype == "bf16":
+        extra["mlp_dtype"] = torch.bfloat16
     model = fastegnn_amd.FastEGNN(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=C,
-                                  device=dev, n_layers=L, gravity=[0, -1, 0])
+                                  device=dev, n_layers=L, gravity=cfg["gravity"], **extra)
     model.cache_graphs = bool(args.cache_graph)
-    frame, target = make_frame(N, C, 43 + (0 if args.sharded else rank), dev)   # sharded: every rank holds the same frame
-    E = frame["edge_index"].size(1)
+    # sharded: every rank builds the same batch and keeps its own rows / edges; dp: a different batch per rank
+    frame, target = make_workload(cfg, 43 + (0 if sharded else rank), dev, args.nodes, args.channels)
+    N, E, B = frame["node_loc"].size(0), frame["edge_index"].size(1), frame["loc_mean"].size(0)
     params = [p for p in model.parameters()]
 
     if args.train_step:
@@ -170,19 +382,27 @@ def main():
                     edge_index=frame["edge_index"], edge_attr=frame["edge_attr"][:, :1].contiguous(),
                     batch=frame["data_batch"], loc_mean=frame["loc_mean"])
 
-    if args.sharded:
-        from fastegnn_amd.sharded import ShardedFastEGNN
+    stats = None
+    if sharded:
+        from fastegnn_amd.sharded import CommStats, ShardedFastEGNN
         smodel = ShardedFastEGNN(model)
+        shard = smodel.shard_inputs(**frame)          # this rank's rows and edges; the full COO is dropped below
+        tgt_local = shard["plan"].rows(target)
+        if world > 1:
+            del frame
+            torch.cuda.empty_cache()
 
     def step():
         if args.train_step:   # utils/train.py:30-170 on device (single-GPU only)
             return train_step(model, opt, data, samp, 1.0, 0.01)[0]
         for p in params:
             p.grad = None
-        if args.sharded:      # this rank's rows of the MSE + its 1/world share of the replicated virtual-node term
-            loc, vloc = smodel(**frame)
-            tgt = smodel.plan.rows(target)
-            loss = (loc - tgt).pow(2).sum() / (3 * N) + 0.01 * vloc.pow(2).mean() / world
+        if sharded:
+            # this rank's rows of the MSE; the virtual-node term is replicated IN FULL on every rank (the virtual
+            # state is replicated: fastegnn_amd/sharded.py 'Loss contract'), so the printed loss of rank r is
+            # mse_r + the full vloc term
+            loc, vloc = smodel.forward_local(shard)
+            loss = (loc - tgt_local).pow(2).sum() / (3 * N) + 0.01 * vloc.pow(2).mean()
             loss.backward()
             allreduce_gradients(params)
             return loss
@@ -208,30 +428,31 @@ def main():
         step()
     sync()
     K.profile_collect()
+    if sharded:
+        stats = CommStats()
+        smodel.stats = stats
     t0 = time.perf_counter()
-    cpu_ms = []
     done = []   # bound the CPU run-ahead to two steps (deep HIP queues stall sporadically on this stack)
     for _ in range(args.steps):
-        tc = time.perf_counter()
         if len(done) >= 2:
             done.pop(0).synchronize()
         loss = step()
         ev = torch.cuda.Event()
         ev.record()
         done.append(ev)
-        cpu_ms.append(1e3 * (time.perf_counter() - tc))
     sync()
     dt = time.perf_counter() - t0
-    if os.environ.get("FASTEGNN_BENCH_DEBUG"):
-        print("cpu enqueue ms per step:", " ".join(f"{t:.1f}" for t in cpu_ms), file=sys.stderr)
     K.lib().fastegnn_profile_enable(0)
     prof = K.profile_collect()
     dt = max_over_ranks(dt, dev)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = (1 if args.sharded else world) * args.steps / dt
-        km = kernel_model(N, E, 1, C, L)
+        units_per_step = B * (1 if sharded else world)          # graphs the whole job completes per step
+        value = units_per_step * args.steps / dt
+        # kernel model of what THIS rank ran (sharded: its 1/world share of the rows and edges)
+        kN, kE = (shard["plan"].nloc, shard["edge_index"].size(1)) if sharded else (N, E)
+        km = kernel_model(kN, kE, B, C, L, gravity=cfg["gravity"] is not None)
         kernels = {}
         for name, (ms, cnt) in prof.items():
             per_step = ms / args.steps
@@ -244,54 +465,54 @@ def main():
             kernels[name] = ent
         dom = max((n for n in kernels if n in km), key=lambda n: kernels[n]["ms_per_step"])
         fl, by = km[dom]
-        t_mfma, t_hbm = fl / (PEAK_MFMA_F32_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes (tools/gpu_traffic.sh)
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+        peak_mfma = PEAK_MFMA_BF16_TFLOPS if dtype == "bf16" else PEAK_MFMA_F32_TFLOPS
+        t_mfma, t_hbm = fl / (peak_mfma * 1e12), by / (PEAK_HBM_GBS * 1e9)
+        tr, tr_file = latest_traffic()
+        traffic = tr.get(dom, {}).get("hbm_bytes_per_launch") if (args.config == "cfg4" and not sharded) else None
         if t_mfma >= t_hbm:
-            roof = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": PEAK_MFMA_F32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / PEAK_MFMA_F32_TFLOPS, 4),
-                    "traffic": traffic}
+            roof = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak_mfma,
+                    "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / peak_mfma, 4), "traffic": traffic}
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["gbs"], "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic}
+        roof["traffic_source"] = (f"profiles/{tr_file}: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) of the commit named in "
+                                  f"that file, not of this run") if traffic is not None else None
         es = kernels.get("edge_fwd_kernel")
         edge_scatter = None
         if es:
-            edge_scatter = {"kernel": "edge_fwd_kernel", "algorithmic_bytes_per_launch": 280 * E + 540 * N,
+            edge_scatter = {"kernel": "edge_fwd_kernel", "algorithmic_bytes_per_launch": 280 * kE + 540 * kN,
                             "achieved_GBs": es["gbs"], "frac_of_hbm_peak": round(es["gbs"] / PEAK_HBM_GBS, 4),
                             "achieved_TFLOPs": es["tflops"],
                             "frac_of_mfma_f32_peak": round(es["tflops"] / PEAK_MFMA_F32_TFLOPS, 4)}
+        if sharded:
+            par = f"row-owner sharding of ONE batch over {world} GPU(s) (fastegnn_amd/sharded.py), strong scaling"
+        elif world > 1:
+            par = f"dp{world}: one batch per GPU, RCCL gradient all-reduce, weak scaling"
+        else:
+            par = "1 GPU"
+        what = "full training iteration (augment+fwd+MSE/MMD+bwd+Adam)" if args.train_step else "fwd+loss+bwd"
         out = {
-            "metric": "graphs/sec (fwd+bwd), Water-3D-like 100k-node frame", "value": round(value, 4),
+            "metric": "graphs/sec (fwd+bwd), " + ("Water-3D-like 100k-node frame" if args.config == "cfg4" else args.config),
+            "value": round(value, 4),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.sharded else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg4 Water-3D-like frame (SURVEY 8d): uniform points, radius graph r=0.035, "
-                                   "4-layer FastEGNN H=64, gravity on, "
-                                   + ("full training iteration (augment+fwd+MSE/MMD+bwd+Adam)" if args.train_step else "fwd+loss+bwd")
-                                   + ", CSR build "
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if sharded else "weak",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{cfg['text']}; {L}-layer FastEGNN H=64, {what}, CSR build "
                                    + ("cached" if args.cache_graph else "inside the step"),
-                       "nodes": N, "edges": E, "virtual_channels": C, "layers": L, "graphs_per_step_per_gpu": 1,
-                       "parallelism": (f"row-owner sharding of one frame over {world} GPU(s) (fastegnn_amd/sharded.py)" if args.sharded
-                                       else f"dp{world} (one frame per GPU, RCCL gradient all-reduce)" if world > 1 else "1 GPU"),
-                       "loss": float(loss.detach())},
+                       "name": args.config, "nodes": N, "edges": E, "graphs_per_batch": B, "virtual_channels": C, "layers": L,
+                       "graphs_per_step": units_per_step, "parallelism": par, "loss": float(loss.detach())},
+            "value_per_gpu": round(value / world, 4),
             "roofline": roof,
             "edge_scatter": edge_scatter,
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline and world == 1:
-            ns = 10000
-            t_cpu, e_cpu = cpu_baseline(C, 43, steps=3, n_sample=ns)
-            scale = N / ns
-            out["cpu_baseline"] = {
-                "value": round(1.0 / (t_cpu * scale), 5), "unit": "graphs/s", "cores": torch.get_num_threads(),
-                "kind": "port",
-                "sample": f"oracle/fastegnn_ref.py (torch CPU, op-for-op) fwd+bwd on a {ns}-node frame of the same "
-                          f"density (E={e_cpu}), {torch.get_num_threads()} torch threads (fastest setting measured on this host), "
-                          f"median of 3 steps = {t_cpu:.2f} s, scaled x{scale:.0f} to the "
-                          f"{N}-node frame (cost is linear in N and E at fixed C)"}
+        if stats is not None:
+            out["collectives"] = stats.summary(args.steps)
+        cb = "none" if args.no_cpu_baseline else args.cpu_baseline
+        if cb == "auto":
+            cb = "none" if world > 1 else ("scaled" if args.config == "cfg5" else "full")
+        if cb != "none" and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, args, 43, cb)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)   # flushed before any communicator teardown
     if dist.is_initialized():

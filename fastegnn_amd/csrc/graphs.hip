@@ -44,19 +44,21 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float *loc, int N, unsi
   }
 }
 
-// grid from the bounding box: cell edge = max(r, extent / 256) so that there are at most 2^24 cells
+// grid from the bounding box: cell edge = max(r, extent / 255), and the per-axis cell count is clamped to 256, so
+// that there are at most 256^3 = 2^24 cells (floor(extent / cell) + 1 <= 256; the clamp covers rounding)
 __global__ void grid_kernel(const unsigned *box, float r, Grid *g) {
   if (threadIdx.x != 0) return;
   float cell = r;
   for (int k = 0; k < 3; ++k) {
     const float lo = key2f(box[k]), hi = key2f(box[3 + k]);
     g->lo[k] = lo;
-    cell = fmaxf(cell, (hi - lo) / 256.0f);
+    cell = fmaxf(cell, (hi - lo) / 255.0f);
   }
   g->inv = 1.0f / cell;
   for (int k = 0; k < 3; ++k) {
     const float lo = key2f(box[k]), hi = key2f(box[3 + k]);
-    g->n[k] = (int)((hi - lo) * g->inv) + 1;
+    const int n = (int)((hi - lo) * g->inv) + 1;
+    g->n[k] = n > 256 ? 256 : n;   // cell_of clamps the coordinates of the last cell accordingly
   }
 }
 __device__ __forceinline__ void cell_of(const Grid &g, const float *p, int c[3]) {

@@ -644,177 +644,15 @@ struct EdgeBwdArgs {
   EdgeArgs f;
   const float *g_aggm, *g_aggx;
   float *g_P, *g_xrow, *g_QXe;
-  float *wg_gmp, *wg_t, *wg_gup, *wg_m;
   float *d_wx2, *d_attw, *d_attb, *d_bx2;
   float *d_wr, *d_we;   // edge_mlp.0.weight grad: radial column and first edge_attr column (row stride ld_e0)
   int ld_e0, C;
   float *slab, *slab_b;   // producer/consumer variant: partial slabs of the two in-kernel weight gradients
   int slab_w2, slab_wx1;
 };
-#ifndef FE_EDGE_BWD_PC
-#define FE_EDGE_BWD_PC 1
-#endif
 #ifndef FE_PC_PRIO
 #define FE_PC_PRIO 3
 #endif
-constexpr int XT = 4;   // per-edge scalar row in LDS: g_d[3] | pad
-constexpr int EDGE_BWD_IMG_FLOATS = BWD_X3 ? 4 * IMG3 : 4 * IMG;
-
-__global__ __launch_bounds__(64 * EDGE_WAVES) void edge_bwd_kernel(EdgeBwdArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const EdgeArgs &a = A.f;
-  float *img = lds;                    // W2, WX1, W2T, WX1T (fp32 or split images)
-  float *vec = lds + EDGE_BWD_IMG_FLOATS;
-  float *tiles = vec + EV_COUNT * H;
-  if constexpr (BWD_X3) load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, A.C, I_W2), 4);
-  else load_images(img, a.wpack + (size_t)I_W2 * IMG, 4);
-  edge_load_vecs(vec, a);
-  __syncthreads();
-  const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
-  float *pt = tiles + wv * (16 * TS + 16 * XT);
-  float *xt = pt + 16 * TS;
-  const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
-  const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);
-  float accW[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // [radial | edge_attr] columns of edge_mlp.0, lane = out
-  const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION,
-             norm_on = a.flags & FASTEGNN_F_NORMALIZE;
-  Vec acc_wx2 = vzero(), acc_att = vzero();
-  float acc_attb = 0.f, acc_bx2 = 0.f;
-  FE_T0()
-  // this wave's share: a contiguous run of whole rows holding ~E/nwaves edges (see edge_fwd_kernel)
-  const int c0 = (int)((long)wave * a.n_chunks / nwaves), c1 = (int)((long)(wave + 1) * a.n_chunks / nwaves);
-  const int r0 = a.chunk_row[c0], r1 = a.chunk_row[c1];
-  if (r0 < r1) {
-    const int e0 = a.rowptr[r0], e1 = a.rowptr[r1];
-    int cur = -1;
-    float acc = 0.f, accx = 0.f;
-    auto flush = [&]() {
-      A.g_P[(size_t)cur * H + l] = acc;
-      if (l < 3) A.g_xrow[(size_t)cur * 3 + l] = accx;   // lanes 0..2 hold x,y,z (lane 3: pad)
-    };
-    for (int base = e0; base < e1; base += 16) {
-      asm volatile("" ::: "memory");
-      const int nvalid = min(16, e1 - base);
-      const bool valid = j < nvalid;
-      const int e = min(base + j, e1 - 1);
-      EdgeIdx cur_i;
-      edge_load_idx(a, e, cur_i);
-      EdgeFwdState S;
-      Vec pre;
-      edge_tile_forward<true, BWD_X3>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
-      const int dg = a.rowptr[S.row + 1] - a.rowptr[S.row];
-      const float inv = valid ? rcp_f((float)(dg > 1 ? dg : 1)) : 0.f;
-      const float invx = valid ? (mean ? inv : 1.f) : 0.f;
-      if (valid) {
-        WG_STORE(vstore_row(A.wg_t + (size_t)e * H, q, S.t);)
-        WG_STORE(vstore_row(A.wg_m + (size_t)e * H, q, S.m);)
-      }
-      // coordinate head adjoint (coord_mlp_r, :125)
-      float g_tr[3], g_dn[3], g_s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        g_tr[k] = A.g_aggx[(size_t)S.row * 3 + k] * invx;
-        g_s += S.dn[k] * g_tr[k];
-        g_dn[k] = S.s * g_tr[k];
-      }
-      const float g_sr = tanh_on ? g_s * (1.f - S.s * S.s) : g_s;
-      vaxpy(acc_wx2, g_sr, S.u);
-      if (q == 0) acc_bx2 += g_sr;
-      const Vec g_up = vmul(vscale(vload_vec(vec + EV_WX2 * H, q), g_sr), S.up);
-      WG_STORE(if (valid) vstore_row(A.wg_gup + (size_t)e * H, q, g_up);)
-      Vec g_m = vscale(vload_row(A.g_aggm + (size_t)S.row * H, q), inv);
-      gemm_i<BWD_X3>(img, 3, g_up, g_m);
-      Vec g_m0 = g_m;
-      if (att_on) {
-        const float g_a = vdot(g_m, S.m0);
-        const float g_z = g_a * S.att * (1.f - S.att);
-        vaxpy(acc_att, g_z, S.m0);
-        if (q == 0) acc_attb += g_z;
-        g_m0 = vscale(g_m, S.att);
-        vaxpy(g_m0, g_z, vload_vec(vec + EV_ATT * H, q));
-      }
-      const Vec g_mp = vmul(g_m0, S.mp);
-      WG_STORE(if (valid) vstore_row(A.wg_gmp + (size_t)e * H, q, g_mp);)
-      Vec g_t = vzero();
-      gemm_i<BWD_X3>(img, 2, g_mp, g_t);
-      const Vec g_pre = vmul(g_t, pre);
-      const float g_r = vdot(g_pre, vload_vec(vec + EV_WR * H, q));
-      float g_d[3];
-      const float invn = norm_on ? rcp_f(S.nrm + a.eps) : 1.f;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) g_d[k] = g_dn[k] * invn + 2.f * g_r * S.d[k];
-      if (valid) {
-        float *qe = A.g_QXe + (size_t)e * QXLD;
-        vstore_row(qe, q, g_pre);
-        if (q == 0) *reinterpret_cast<f32x4 *>(qe + H) = f32x4{-g_d[0], -g_d[1], -g_d[2], 0.f};
-      }
-      // row-side segment sums: g_P[row] = sum g_pre, g_xrow[row] = sum g_d
-      tile_store(pt, j, q, g_pre);
-      if (q == 0) *reinterpret_cast<f32x4 *>(xt + j * XT) = f32x4{g_d[0], g_d[1], g_d[2], 0.f};
-      __builtin_amdgcn_wave_barrier();
-      float mv[16], xv[16];
-#pragma unroll
-      for (int ee = 0; ee < 16; ++ee) {   // all LDS reads up front; the walk below runs on registers
-        mv[ee] = pt[ee * TS + l];
-        xv[ee] = xt[ee * XT + (l & 3)];
-      }
-      const int rowv = S.row;
-#pragma unroll
-      for (int ee = 0; ee < 16; ++ee) {
-        if (ee < nvalid) {
-          const int rw = __builtin_amdgcn_readlane(rowv, ee);
-          if (rw != cur) {
-            if (cur >= 0) flush();
-            cur = rw;
-            acc = 0.f;
-            accx = 0.f;
-          }
-          const float gp = mv[ee];
-          acc += gp;
-          accx += xv[ee];
-          // d edge_mlp.0.weight[:, 2H + k] += g_pre * [radial | edge_attr][k]   (lane = output row);
-          // the per-edge scalars come from the owning lane's registers (v_readlane), not from LDS
-          accW[0] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.r), ee));
-#pragma unroll
-          for (int k = 0; k < 7; ++k)
-            if (k < a.ea_dim)
-              accW[1 + k] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.eav[k]), ee));
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (cur >= 0) flush();
-  }
-  float *red = vec;   // [3 + 8][64]; the weight vectors are dead now
-  __syncthreads();
-  for (int i = threadIdx.x; i < 11 * H; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (k <= a.ea_dim) atomicAdd(&red[(3 + k) * H + l], accW[k]);
-  vec_reduce_lds(red, acc_wx2, j, q);
-  if (att_on) {
-    vec_reduce_lds(red + H, acc_att, j, q);
-    float s = jsum(acc_attb);
-    if (l == 0) atomicAdd(&red[2 * H], s);
-  }
-  if (A.d_bx2) {
-    float s = jsum(acc_bx2);
-    if (l == 0) atomicAdd(&red[2 * H + 1], s);
-  }
-  __syncthreads();
-  if (threadIdx.x < H) {
-    atomicAdd(&A.d_wx2[threadIdx.x], red[threadIdx.x]);
-    if (att_on) {
-      atomicAdd(&A.d_attw[threadIdx.x], red[H + threadIdx.x]);
-      if (threadIdx.x == 0) atomicAdd(A.d_attb, red[2 * H]);
-    }
-    if (A.d_bx2 && threadIdx.x == 0) atomicAdd(A.d_bx2, red[2 * H + 1]);
-    atomicAdd(&A.d_wr[(size_t)threadIdx.x * A.ld_e0], red[3 * H + threadIdx.x]);
-    for (int k = 0; k < a.ea_dim; ++k)
-      atomicAdd(&A.d_we[(size_t)threadIdx.x * A.ld_e0 + k], red[(4 + k) * H + threadIdx.x]);
-  }
-}
 
 // ---- producer/consumer variant: the two 64x64 weight gradients of the edge stage are contracted inside the
 // workgroup.  Waves 0..6 run the tile adjoint (producers) and hand each operand pair (g_mp,t) / (g_up,m) as two
@@ -1157,20 +995,17 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
 }
 
 int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
-  FE_REQUIRE(L->P && L->QX && L->g_aggm && L->g_aggx && L->g_P && L->g_xrow && L->g_QXe && (FE_EDGE_BWD_PC || L->wg_edge) && L->grads &&
+  FE_REQUIRE(L->P && L->QX && L->g_aggm && L->g_aggx && L->g_P && L->g_xrow && L->g_QXe && L->grads &&
                  L->wpack,
              "edge_backward: null buffer");
   const fastegnn_graph_t &gr = L->graph;
   (void)hipMemsetAsync(L->g_P, 0, (size_t)L->N * H * sizeof(float), st);
   (void)hipMemsetAsync(L->g_xrow, 0, (size_t)L->N * 3 * sizeof(float), st);
   if (gr.n_edges == 0 || L->N == 0) return check_launch("edge_backward(memset)");
-  const long E = gr.n_edges;
   float *const *g = L->grads;
   EdgeBwdArgs A;
   A.f = make_edge_args(L);
   A.g_aggm = L->g_aggm; A.g_aggx = L->g_aggx; A.g_P = L->g_P; A.g_xrow = L->g_xrow; A.g_QXe = L->g_QXe;
-  A.wg_gmp = L->wg_edge; A.wg_t = L->wg_edge + E * H; A.wg_gup = L->wg_edge + 2 * E * H;
-  A.wg_m = L->wg_edge + 3 * E * H;
   A.ld_e0 = 2 * H + 1 + L->ea;
   A.d_wr = g[FASTEGNN_P_EDGE0_W] + (has(L, FASTEGNN_F_EGNN) ? 0 : 2 * H);   // basic.py:313: radial is column 0
   A.d_we = g[FASTEGNN_P_EDGE0_W] + 2 * H + 1;
@@ -1180,7 +1015,6 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   A.C = L->C;
   FE_REQUIRE((size_t)L->N * QXLD < (1u << 30) && (size_t)gr.n_src * QXLD < (1u << 30) && (size_t)gr.n_edges * 8 < (1u << 30),
              "edge_backward: tables exceed the 32-bit offset range of the gather path");
-#if FE_EDGE_BWD_PC
   {
     int grid = cdiv(cdiv(gr.n_edges, 256), PC_PROD);
     if (grid > 256) grid = 256;
@@ -1195,23 +1029,35 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
     if ((rc = check_launch("edge_bwd_pc_kernel"))) return rc;
     return wb.finish();
   }
-#else
-  int grid = cdiv(cdiv(gr.n_edges, 256), EDGE_WAVES);
-  if (grid > 256) grid = 256;
-  const size_t lds = (EDGE_BWD_IMG_FLOATS + EV_COUNT * H + EDGE_WAVES * (16 * TS + 16 * XT)) * sizeof(float);
-  { ProfScope _ps_edge_bwd_kernel(K_EDGE_BWD, st); hipLaunchKernelGGL(edge_bwd_kernel, dim3(grid), dim3(64 * EDGE_WAVES), lds, st, A); }
-  int rc = check_launch("edge_bwd_kernel");
-  if (rc) return rc;
-  // edge_mlp.2 and coord_mlp_r.0 (the [radial | edge_attr] columns of edge_mlp.0 are summed in-kernel)
-  WgradBatch wb(L->wg_slab, st);
-  if ((rc = wb.add(A.wg_gmp, H, A.wg_t, H, E, g[FASTEGNN_P_EDGE2_W], H, 0, 1, g[FASTEGNN_P_EDGE2_B]))) return rc;
-  if ((rc = wb.add(A.wg_gup, H, A.wg_m, H, E, g[FASTEGNN_P_CR0_W], H, 0, 1, g[FASTEGNN_P_CR0_B]))) return rc;
-  return wb.finish();
-#endif
 }
 
 }  // namespace fe
-extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { return FE_EDGE_BWD_PC ? 4 : (size_t)(E > 0 ? E : 1) * 4 * fe::H; }
+// the edge stage contracts its weight gradients inside the workgroup: no operand workspace (4 floats keep the
+// caller's carve non-empty)
+extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { (void)E; return 4; }
+// weight-gradient operand workspaces of the virtual / node-level stages (layouts: virt_backward, graph_post_backward,
+// graph_pre_backward, node_pre_backward above)
+extern "C" size_t fastegnn_wg_virt_floats(int32_t N, int32_t C) {
+  const size_t n = (size_t)5 * (size_t)(N > 0 ? N : 0) * (size_t)(C > 0 ? C : 0) * fe::H;
+  return n > 4 ? n : 4;
+}
+extern "C" size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C) {
+  const size_t m = (size_t)(N > 0 ? N : 0), g = (size_t)(B > 0 ? B : 0) * (size_t)(C > 0 ? C : 0);
+  return 8 * (m > g ? m : g) * fe::H + 4;
+}
+// floats of ALL backward scratch arrays of fastegnn_layer_t (g_poolV .. wg_slab), each rounded up to a multiple of 4
+// floats (16-byte aligned carving of one allocation)
+extern "C" size_t fastegnn_backward_scratch_floats(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C) {
+  auto r4 = [](size_t n) { return (n + 3) / 4 * 4; };
+  const size_t n = N > 0 ? N : 0, e = E > 0 ? E : 1, s = n_src > 0 ? n_src : 0, bc = (size_t)(B > 0 ? B : 0) * (size_t)(C > 0 ? C : 0);
+  size_t t = 0;
+  t += 2 * r4(bc * fe::H) + 2 * r4(bc * 3) + r4((size_t)B * 4);          // g_poolV g_Bc | g_poolX g_Zp | g_xbar
+  t += 3 * r4(n * fe::H) + 2 * r4(n * 3) + 2 * r4(n);                    // g_A g_P g_aggm | g_aggx g_xrow | g_svel g_sgrav
+  t += r4(e * fe::QXLD) + r4(s * fe::QXLD);                              // g_QXe | g_QX_src
+  t += r4(fastegnn_wg_edge_floats(E)) + r4(fastegnn_wg_virt_floats(N, C)) + r4(fastegnn_wg_node_floats(N, B, C)) +
+       r4(fastegnn_wg_slab_floats());
+  return t;
+}
 namespace fe {
 
 // B2b: col-keyed reduction of the per-edge d/d(Q|x) rows into the source table

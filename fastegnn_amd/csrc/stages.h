@@ -15,7 +15,6 @@ constexpr bool FWD_X3 = FE_FWD_X3;
 #define FE_BWD_X3 1   // same for the backward edge kernel (recompute + the two transposed layers)
 #endif
 constexpr bool BWD_X3 = FE_BWD_X3;
-constexpr int EDGE_WAVES = 8;
 #ifndef FE_EDGE_RANGE
 #define FE_EDGE_RANGE 1   // waves own contiguous row ranges (else: round-robin over the row chunks)
 #endif

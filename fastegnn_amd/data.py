@@ -178,9 +178,42 @@ def water3d_frame(loc_0, vel_0, loc_t, node_type, virtual_channels, radius=0.035
                  _loc_mean(loc_0, int(virtual_channels)))
 
 
+def read_trajectories(directory: str, partition: str):
+    """Yields ``(key, position [T,n,3], particle_type [n])`` of every trajectory of a partition, in file order.
+
+    Two containers with the same fields: the reference's ``<partition>.h5`` (one HDF5 group per trajectory holding
+    ``position`` and ``particle_type``, ``datasets/simulation/dataset.py:46-56``; needs ``h5py``) and
+    ``<partition>.npz`` with arrays named ``<key>/position`` and ``<key>/particle_type`` (what
+    ``numpy.savez`` of the same groups gives; readable without h5py).  The ``.h5`` file wins when both exist and
+    h5py is importable; a lone ``.h5`` without h5py raises."""
+    h5, npz = os.path.join(directory, f"{partition}.h5"), os.path.join(directory, f"{partition}.npz")
+    if os.path.exists(h5):
+        try:
+            import h5py
+        except ImportError as e:
+            if not os.path.exists(npz):
+                raise ImportError(f"fastegnn_amd.data: {h5} needs h5py (absent); convert it to {npz} "
+                                  "(arrays '<key>/position', '<key>/particle_type')") from e
+        else:
+            with h5py.File(h5, "r") as f:
+                for key in list(f.keys()):
+                    yield key, np.array(f[key]["position"]), np.array(f[key]["particle_type"])
+            return
+    if not os.path.exists(npz):
+        raise FileNotFoundError(f"fastegnn_amd.data: neither {h5} nor {npz} exists")
+    with np.load(npz) as z:
+        keys = []
+        for name in z.files:                      # file order, first appearance of each trajectory key
+            k = name.rsplit("/", 1)[0]
+            if k not in keys:
+                keys.append(k)
+        for k in keys:
+            yield k, z[f"{k}/position"], z[f"{k}/particle_type"]
+
+
 class Simulation:
-    """Water-3D style particle trajectories (``<data_dir>/<dataset_name>/<partition>.h5``: one group per
-    trajectory with ``position`` [T,n,3] and ``particle_type`` [n]).
+    """Water-3D style particle trajectories (``<data_dir>/<dataset_name>/<partition>.h5`` -- or ``.npz``, see
+    ``read_trajectories``: one group per trajectory with ``position`` [T,n,3] and ``particle_type`` [n]).
 
     Same constructor arguments as ``datasets/simulation/dataset.py:17``.  The reference draws 15 start
     frames per trajectory with the unseeded ``random.randint(0, 250)`` (``:58``) and shuffles the frames
@@ -193,31 +226,28 @@ class Simulation:
 
     def __init__(self, dataset_name, data_dir, virtual_channels, partition="train", max_samples=1e8, delta_t=15,
                  cutoff_rate=0.0, device="cuda", rotation=None, seed=0, radius=None):
-        try:
-            import h5py
-        except ImportError as e:  # the container image has no h5py; the format cannot be read without it
-            raise ImportError("fastegnn_amd.data.Simulation needs h5py to read the Water-3D .h5 files") from e
         self.virtual_channels, self.cutoff_rate, self.delta_t = int(virtual_channels), float(cutoff_rate), int(delta_t)
         self.radius = self.RADIUS if radius is None else float(radius)
         rng = np.random.default_rng(seed)
-        path = os.path.join(data_dir, dataset_name, f"{partition}.h5")
         self.data: List[Frame] = []
+        self.frames: List[tuple] = []      # (trajectory key, start frame) of every sample, in the order drawn
         max_samples = int(max_samples)
-        with h5py.File(path, "r") as f:
-            for key in list(f.keys()):
-                ptype = torch.from_numpy(np.array(f[key]["particle_type"])).float().unsqueeze(-1)
-                pos = torch.from_numpy(np.array(f[key]["position"])).float()
-                n_frames = min(self.FRAMES_PER_TRAJECTORY, max_samples - len(self.data))
-                last = min(250, pos.size(0) - 1 - max(1, self.delta_t))
-                for fr in rng.integers(0, last + 1, size=max(n_frames, 0)):
-                    fr = int(fr)
-                    self.data.append(water3d_frame(pos[fr].to(device), (pos[fr + 1] - pos[fr]).to(device),
-                                                   pos[fr + self.delta_t].to(device), ptype.to(device),
-                                                   self.virtual_channels, self.radius, self.cutoff_rate, rotation))
-                if len(self.data) >= max_samples:
-                    break
+        for key, position, particle_type in read_trajectories(os.path.join(data_dir, dataset_name), partition):
+            ptype = torch.from_numpy(np.asarray(particle_type)).float().reshape(-1, 1)
+            pos = torch.from_numpy(np.asarray(position)).float()
+            n_frames = min(self.FRAMES_PER_TRAJECTORY, max_samples - len(self.data))
+            last = min(250, pos.size(0) - 1 - max(1, self.delta_t))
+            for fr in rng.integers(0, last + 1, size=max(n_frames, 0)):
+                fr = int(fr)
+                self.frames.append((key, fr))
+                self.data.append(water3d_frame(pos[fr].to(device), (pos[fr + 1] - pos[fr]).to(device),
+                                               pos[fr + self.delta_t].to(device), ptype.to(device),
+                                               self.virtual_channels, self.radius, self.cutoff_rate, rotation))
+            if len(self.data) >= max_samples:
+                break
         order = rng.permutation(len(self.data))
         self.data = [self.data[i] for i in order]
+        self.frames = [self.frames[i] for i in order]
 
     def __len__(self) -> int:
         return len(self.data)

@@ -52,13 +52,22 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, averag
     if world == 1:
         return 0
     dev, dt = params[0].device, params[0].dtype
+    staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"   # transport without device support
+
+    def _all_reduce(flat):
+        if staged:
+            hflat = flat.cpu()
+            dist.all_reduce(hflat, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(hflat)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     # Fast path: the backward of fastegnn_amd.FastEGNN hands autograd slices of ONE flat buffer, and autograd
     # keeps them as the .grad tensors -- reduce that buffer in place (no gather / scatter copies, one collective).
     if all(p.grad is not None and p.grad.dtype == dt and p.grad.is_contiguous() for p in params):
         stor = params[0].grad.untyped_storage()
         if all(p.grad.untyped_storage().data_ptr() == stor.data_ptr() for p in params):
             flat = torch.empty(0, device=dev, dtype=dt).set_(stor, 0, (stor.nbytes() // params[0].grad.element_size(),))
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce(flat)
             if average:
                 flat.div_(world)
             return flat.numel() * flat.element_size()
@@ -69,7 +78,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, averag
         if p.grad is not None:
             flat[off:off + n].copy_(p.grad.reshape(-1))
         off += n
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce(flat)
     if average:
         flat.div_(world)
     off = 0

@@ -104,7 +104,7 @@ class _EGNNFunction(torch.autograd.Function):
         g_vel = torch.zeros(N, 3, **f32)
         sc = _carve(dev, dict(g_A=(N, H), g_P=(N, H), g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,),
                               g_QXe=(max(E, 1), K.QX_LD), g_QX_src=(N, K.QX_LD), g_xrow=(N, 3),
-                              wg_edge=(lib.fastegnn_wg_edge_floats(E),), wg_node=(8 * N * H,), wg_slab=(lib.fastegnn_wg_slab_floats(),)))
+                              wg_edge=(lib.fastegnn_wg_edge_floats(E),), wg_node=(lib.fastegnn_wg_node_floats(N, 1, 0),), wg_slab=(lib.fastegnn_wg_slab_floats(),)))
         sc["g_xbar"] = torch.zeros(1, 4, **f32)
         for i in reversed(range(spec.n_layers)):
             b = saved[i]

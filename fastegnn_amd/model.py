@@ -10,6 +10,7 @@ C ABI of ``include/fastegnn_hip.h``; there is no CPU path -- CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -118,6 +119,24 @@ class SortedGraph:
 # ------------------------------------------------------------------------------------------
 # helpers
 # ------------------------------------------------------------------------------------------
+# FASTEGNN_DEBUG_CHECKS=1: validate the index inputs on every forward (host sync).  The kernels trust them: an
+# out-of-range col is an out-of-bounds gather, an unsorted data_batch breaks the graph pointer search; the
+# reference raises an index error in these cases.
+_DEBUG_CHECKS = os.environ.get("FASTEGNN_DEBUG_CHECKS", "0") not in ("", "0")
+
+
+def _check_indices(edge_index, data_batch, N, B):
+    if isinstance(edge_index, torch.Tensor) and edge_index.numel():
+        lo, hi = int(edge_index.min()), int(edge_index.max())
+        if lo < 0 or hi >= N:
+            raise IndexError(f"fastegnn_amd: edge_index values span [{lo}, {hi}] but there are {N} nodes")
+    if data_batch.numel():
+        if bool((data_batch[1:] < data_batch[:-1]).any()):
+            raise ValueError("fastegnn_amd: data_batch must be sorted ascending (as PyG collate emits it)")
+        if int(data_batch[0]) < 0 or int(data_batch[-1]) >= B:
+            raise IndexError(f"fastegnn_amd: data_batch values exceed the {B} graphs of loc_mean")
+
+
 def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -252,9 +271,13 @@ class _FastEGNNFunction(torch.autograd.Function):
         return x, Z
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g_loc, g_vloc):
         lib = K.lib()
         spec, graph, saved = ctx.spec, ctx.graph, ctx.saved
+        if saved is None or any(b is None for b in saved):
+            raise RuntimeError("fastegnn_amd: backward through the graph a second time: the saved stage products are "
+                               "freed layer by layer during the first backward (retain_graph is not supported)")
         batch32, gptr, ea_sorted, node_attr, node_feat, node_vel, params = ctx.misc
         dev = node_vel.device
         st = _stream(dev)
@@ -272,12 +295,12 @@ class _FastEGNNFunction(torch.autograd.Function):
         g_Z = (g_vloc if g_vloc is not None else torch.zeros(B, 3, Cn, **f32)).contiguous().float()
         g_HvT = torch.zeros(B, Cn, H, **f32)
         g_vel = torch.zeros(N, 3, **f32)
-        M = max(N, B * Cn)
         scratch = _carve(dev, dict(
             g_poolV=(B, Cn, H), g_poolX=(B, 3, Cn), g_Bc=(B, Cn, H), g_Zp=(B, 3, Cn), g_xbar=(B, 4),
             g_A=(N, H), g_P=(N, H), g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,),
             g_QXe=(max(E, 1), K.QX_LD), g_QX_src=(N, K.QX_LD), g_xrow=(N, 3),
-            wg_edge=(lib.fastegnn_wg_edge_floats(E),), wg_virt=(5 * N * Cn * H,), wg_node=(8 * M * H,),
+            wg_edge=(lib.fastegnn_wg_edge_floats(E),), wg_virt=(lib.fastegnn_wg_virt_floats(N, Cn),),
+            wg_node=(lib.fastegnn_wg_node_floats(N, B, Cn),),
             wg_slab=(lib.fastegnn_wg_slab_floats(),)))
         for i in reversed(range(spec.n_layers)):
             b = saved[i]
@@ -382,6 +405,10 @@ class FastEGNN(nn.Module):
         spec = self._spec
         graph = edge_index if isinstance(edge_index, SortedGraph) else self.sorted_graph(edge_index, N)
         lib = K.lib()
+        if data_batch.dtype != torch.int64:      # the C entry point reads int64 (what PyG collate emits)
+            data_batch = data_batch.long()
+        if _DEBUG_CHECKS:
+            _check_indices(edge_index, data_batch, N, B)
         batch32 = torch.empty(N, dtype=torch.int32, device=dev)
         gptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
         K.check(lib.fastegnn_build_batch(K.ptr(data_batch.contiguous()), N, B, K.ptr(batch32), K.ptr(gptr), _stream(dev)),

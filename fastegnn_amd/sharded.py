@@ -58,6 +58,12 @@ class HipBackend:
     def wg_edge_floats(self, E):
         return self.lib.fastegnn_wg_edge_floats(E)
 
+    def wg_virt_floats(self, N, Cn):
+        return self.lib.fastegnn_wg_virt_floats(N, Cn)
+
+    def wg_node_floats(self, N, B, Cn):
+        return self.lib.fastegnn_wg_node_floats(N, B, Cn)
+
     def build_graph(self, edge_index, n_rows, n_src, row_begin):
         return SortedGraph(edge_index, n_rows, n_src, row_begin)
 
@@ -121,13 +127,110 @@ class ShardPlan:
         return ei, (edge_attr[m].contiguous() if edge_attr is not None else None)
 
 
+class CommStats:
+    """Per-collective byte and time totals of the sharded path (bench.py): bytes are the payload every rank
+    contributes (all-gather / reduce-scatter: the full gathered table), time is issue-to-completion on this rank,
+    measured with events on the communicator's side of the async work handle (so overlap with kernels that were
+    launched behind the collective is NOT subtracted)."""
+
+    def __init__(self):
+        self.calls: Dict[str, int] = {}
+        self.bytes: Dict[str, int] = {}
+        self.events: Dict[str, list] = {}
+
+    def summary(self, steps: int = 1):
+        out = {}
+        for k in self.calls:
+            ms = 0.0
+            for a, b in self.events.get(k, []):
+                b.synchronize()
+                ms += a.elapsed_time(b)
+            out[k] = {"calls_per_step": self.calls[k] / steps, "bytes_per_step": self.bytes[k] / steps,
+                      "ms_per_step": round(ms / steps, 4)}
+        return out
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+class _Timed:
+    """Async work handle that records a completion event on the current stream right after the wait."""
+
+    def __init__(self, work, rec):
+        self.work, self.rec = work, rec
+
+    def wait(self):
+        self.work.wait()
+        if self.rec is not None:
+            self.rec[1].record()
+        return True
+
+
+class _Comm:
+    """The three exchange steps of SURVEY 8e as asynchronous collectives (torch.distributed: RCCL on the GPU,
+    gloo in the CPU tests).  World size 1 short-circuits to local copies."""
+
+    def __init__(self, group, stats: Optional[CommStats]):
+        self.group, self.stats = group, stats
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a transport without device support (gloo): device tensors are staged through host memory, synchronously
+        self.host_staged = self.world > 1 and dist.get_backend(group) == "gloo"
+
+    def _staged(self, fn, out, *inputs):
+        h_in = [t.cpu() for t in inputs]
+        h_out = out.cpu() if not inputs else torch.empty(out.shape, dtype=out.dtype)
+        fn(h_out, *h_in)
+        out.copy_(h_out)
+        return _Done()
+
+    def _note(self, name, t):
+        rec = None
+        if self.stats is not None:
+            st = self.stats
+            st.calls[name] = st.calls.get(name, 0) + 1
+            st.bytes[name] = st.bytes.get(name, 0) + t.numel() * t.element_size()
+            if t.is_cuda:
+                rec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                rec[0].record()
+                st.events.setdefault(name, []).append(rec)
+        return rec
+
+    def all_reduce(self, name, t):
+        rec = self._note(name, t)
+        if self.world == 1:
+            return _Timed(_Done(), rec)
+        if self.host_staged and t.is_cuda:
+            return _Timed(self._staged(lambda o: dist.all_reduce(o, group=self.group), t), rec)
+        return _Timed(dist.all_reduce(t, group=self.group, async_op=True), rec)
+
+    def all_gather(self, name, out, inp):
+        rec = self._note(name, out)
+        if self.world == 1:
+            out.copy_(inp)
+            return _Timed(_Done(), rec)
+        if self.host_staged and out.is_cuda:
+            return _Timed(self._staged(lambda o, i: dist.all_gather_into_tensor(o, i, group=self.group), out, inp), rec)
+        return _Timed(dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True), rec)
+
+    def reduce_scatter(self, name, out, inp):
+        rec = self._note(name, inp)
+        if self.world == 1:
+            out.copy_(inp)
+            return _Timed(_Done(), rec)
+        if self.host_staged and out.is_cuda:
+            return _Timed(self._staged(lambda o, i: dist.reduce_scatter_tensor(o, i, group=self.group), out, inp), rec)
+        return _Timed(dist.reduce_scatter_tensor(out, inp, group=self.group, async_op=True), rec)
+
+
 def _layer_lists(spec: _Spec, params, i):
     return [params[s] if s is not None else None for s in spec.layer_slots[i]]
 
 
 class _ShardedFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, be, group, spec: _Spec, plan: ShardPlan, graph, batch32, gptr, ea_sorted, node_attr,
+    def forward(ctx, be, group, stats, spec: _Spec, plan: ShardPlan, graph, batch32, gptr, ea_sorted, node_attr,
                 node_feat, node_loc, node_vel, loc_mean, *params):
         W, rank = plan.world, plan.rank
         N, Npad, B, Cn = plan.nloc, plan.Npad, loc_mean.size(0), spec.C
@@ -140,9 +243,17 @@ class _ShardedFunction(torch.autograd.Function):
         be.virtual_init(params[0], B, Cn, HvT)
         x, Z = node_loc, loc_mean
         saved = []
+        comm = _Comm(group, stats)
+        # Collectives are issued asynchronously (RCCL runs them on its own stream) and waited for at their first
+        # consumer, so that every exchange has independent kernels in flight behind it:
+        #   all-reduce xsum_i      behind  node_pre_i
+        #   all-gather QX_i        behind  graph_post_{i-1} (deferred) and graph_pre_i
+        #   all-reduce pools_i     behind  pack_{i+1}, graph_xsum_{i+1}, node_pre_{i+1}
+        # (all ranks issue them in the same order: pools_{i-1}, xsum_i, QX_i)
+        pend = None     # (work, t, lp, b) of the previous layer: its graph_post is still to run
         for i in range(spec.n_layers):
             lp = _layer_lists(spec, params, i)
-            b = dict(h=h, x=x, Z=Z, HvT=HvT)
+            b = dict(h=h, x=x)
             b.update(be.carve(dict(wpack=(be.wpack_floats(Cn),), P=(N, H), A=(N, H), svel=(N,), sgrav=(N,), xsum=(B, 4),
                                    Bc=(B, Cn, H), aggm=(N, H), npre=(N, H), aggx=(N, 3))))
             b["QX"] = be.zeros(Npad, K.QX_LD)                      # padded: equal-sized all-gather shards
@@ -153,26 +264,40 @@ class _ShardedFunction(torch.autograd.Function):
             b.update(h_out=be.empty(N, H), x_out=be.empty(N, 3), Z_out=be.empty(B, 3, Cn), HvT_out=be.empty(B, Cn, H))
             t = dict(batch=batch32, gptr=gptr, vel=node_vel, ea_sorted=ea_sorted, node_attr=node_attr, **b)
             be.stage("pack_weights", spec, N, B, graph, t, lp)
-            be.stage("node_pre_forward", spec, N, B, graph, t, lp)
-            dist.all_gather_into_tensor(b["QX_src"], b["QX"], group=group)
             be.stage("graph_xsum", spec, N, B, graph, t, lp)
-            dist.all_reduce(b["xsum"], group=group)
+            w_xsum = comm.all_reduce("xsum", b["xsum"])
+            be.stage("node_pre_forward", spec, N, B, graph, t, lp)
+            w_qx = comm.all_gather("QX", b["QX_src"], b["QX"])
+            if pend is not None:                                   # virtual state of this layer <- previous layer's pools
+                pend[0].wait()
+                be.stage("graph_post_forward", spec, N, B, graph, pend[1], pend[2])
+                Z, HvT = pend[3]["Z_out"], pend[3]["HvT_out"]
+                for k in ("aggx", "poolX", "h_out", "x_out", "Z_out", "HvT_out"):
+                    del pend[3][k]
+            b["Z"], b["HvT"] = Z, HvT
+            t["Z"], t["HvT"] = Z, HvT
+            w_xsum.wait()
             be.stage("graph_pre_forward", spec, N, B, graph, t, lp)
+            w_qx.wait()
             be.stage("edge_forward", spec, N, B, graph, t, lp)
             be.stage("virt_forward", spec, N, B, graph, t, lp)
-            dist.all_reduce(pools, group=group)
-            be.stage("graph_post_forward", spec, N, B, graph, t, lp)
+            pend = (comm.all_reduce("pools", pools), t, lp, b)
             saved.append(b)
-            h, x, Z, HvT = b["h_out"], b["x_out"], b["Z_out"], b["HvT_out"]
-            for k in ("aggx", "poolX", "h_out", "x_out", "Z_out", "HvT_out"):
-                del b[k]
+            h, x = b["h_out"], b["x_out"]
+        pend[0].wait()
+        be.stage("graph_post_forward", spec, N, B, graph, pend[1], pend[2])
+        Z = pend[3]["Z_out"]
+        for k in ("aggx", "poolX", "h_out", "x_out", "Z_out", "HvT_out"):
+            del pend[3][k]
         ctx.be, ctx.group, ctx.spec, ctx.plan, ctx.graph, ctx.saved = be, group, spec, plan, graph, saved
+        ctx.comm = comm
         ctx.misc = (batch32, gptr, ea_sorted, node_attr, node_feat, node_vel, params)
         return x, Z
 
     @staticmethod
     def backward(ctx, g_loc, g_vloc):
         be, group, spec, plan, graph, saved = ctx.be, ctx.group, ctx.spec, ctx.plan, ctx.graph, ctx.saved
+        comm = ctx.comm
         batch32, gptr, ea_sorted, node_attr, node_feat, node_vel, params = ctx.misc
         W, rank = plan.world, plan.rank
         N, Npad, B, Cn, E = plan.nloc, plan.Npad, saved[0]["Z"].size(0), spec.C, graph.E
@@ -184,11 +309,10 @@ class _ShardedFunction(torch.autograd.Function):
         g_Z = (g_vloc if g_vloc is not None else be.zeros(B, 3, Cn)).contiguous().float()
         g_HvT = be.zeros(B, Cn, H)
         g_vel = be.zeros(N, 3)
-        M = max(N, B * Cn)
         sc = be.carve(dict(g_poolV=(B, Cn, H), g_poolX=(B, 3, Cn), g_xbar=(B, 4), g_A=(N, H), g_P=(N, H),
                            g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,), g_QXe=(max(E, 1), K.QX_LD),
-                           g_xrow=(N, 3), wg_edge=(be.wg_edge_floats(E),), wg_virt=(5 * N * Cn * H,),
-                           wg_node=(8 * M * H,), wg_slab=(be.wg_slab_floats(),)))
+                           g_xrow=(N, 3), wg_edge=(be.wg_edge_floats(E),), wg_virt=(be.wg_virt_floats(N, Cn),),
+                           wg_node=(be.wg_node_floats(N, B, Cn),), wg_slab=(be.wg_slab_floats(),)))
         nV = B * Cn * H
         gpools = be.empty(nV + B * 3 * Cn)                                 # g_Bc | g_Zp adjacent: one all-reduce
         sc["g_Bc"], sc["g_Zp"] = gpools[:nV].view(B, Cn, H), gpools[nV:].view(B, 3, Cn)
@@ -204,52 +328,80 @@ class _ShardedFunction(torch.autograd.Function):
                      g_h_out=g_h, g_x_out=g_x, g_Z_out=g_Z, g_HvT_out=g_HvT, g_vel=g_vel, **b, **out, **sc)
             be.stage("graph_post_backward", spec, N, B, graph, t, lp, ld)
             be.stage("virt_backward", spec, N, B, graph, t, lp, lg)
-            dist.all_reduce(gpools, group=group)
-            be.stage("graph_pre_backward", spec, N, B, graph, t, lp, ld)
+            w_pools = comm.all_reduce("g_pools", gpools)           # behind the edge backward
             be.stage("edge_backward", spec, N, B, graph, t, lp, lg)
             be.stage("edge_col_reduce", spec, N, B, graph, t, lp, lg)
-            dist.reduce_scatter_tensor(sc["g_QX"], sc["g_QX_src"], group=group)
+            w_qx = comm.reduce_scatter("g_QX", sc["g_QX"], sc["g_QX_src"])   # behind graph_pre_backward
+            w_pools.wait()
+            be.stage("graph_pre_backward", spec, N, B, graph, t, lp, ld)
+            w_qx.wait()
             be.stage("node_pre_backward", spec, N, B, graph, t, lp, lg)
             g_h, g_x, g_Z, g_HvT = out["g_h"], out["g_x"], out["g_Z"], out["g_HvT"]
             saved[i] = None
         be.virtual_init_backward(g_HvT, B, Cn, dummy[0])
-        g_nf = torch.empty_like(node_feat) if ctx.needs_input_grad[9] else None
+        g_nf = torch.empty_like(node_feat) if ctx.needs_input_grad[10] else None
         be.embed_backward(node_feat, g_h, spec.nf, params[1], grads[1], grads[2], g_nf)
-        return (None,) * 9 + (g_nf, g_x, g_vel, g_Z, *grads)
+        return (None,) * 10 + (g_nf, g_x, g_vel, g_Z, *grads)
 
 
 class ShardedFastEGNN(torch.nn.Module):
     """Wraps a (replicated) FastEGNN so that ONE batch is evaluated cooperatively by all ranks.
 
-    forward(...) takes the full-graph inputs (every rank passes the same tensors, like a replicated data
-    loader would) and returns (node_loc rows owned by this rank, virtual_node_loc replicated).  After
-    loss.backward() call ``fastegnn_amd.dist.allreduce_gradients(model.parameters())``.
+    ``forward(...)`` takes the full-graph inputs (every rank passes the same tensors, like a replicated data
+    loader would) and returns (node_loc rows owned by this rank, virtual_node_loc replicated).  A caller that
+    shards at load time passes the result of ``shard_inputs(...)`` to ``forward_local`` instead, so that no rank
+    ever holds (or filters) the full COO.
+
+    Loss contract: a loss term on ``node_loc`` covers the LOCAL rows only (``plan.rows(target)``; the ranks'
+    terms add up to the global loss); a loss term on ``virtual_node_loc`` must be the FULL term, identical on
+    every rank -- the virtual state is replicated, the per-graph stages run redundantly and only rank 0 keeps
+    their weight gradients, so the gradient arriving at ``virtual_node_loc`` is not summed over ranks.  After
+    ``loss.backward()`` call ``fastegnn_amd.dist.allreduce_gradients(model.parameters())``.
     """
 
-    def __init__(self, model: FastEGNN, group=None, backend=None):
+    def __init__(self, model: FastEGNN, group=None, backend=None, stats: Optional[CommStats] = None):
         super().__init__()
         self.model = model
         self.group = group
         self.backend = backend
+        self.stats = stats
+        self.plan: Optional[ShardPlan] = None
 
-    def forward(self, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None,
-                node_attr=None):
+    def _world_rank(self):
+        if not dist.is_initialized():
+            return 1, 0
+        return dist.get_world_size(self.group), dist.get_rank(self.group)
+
+    def shard_inputs(self, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None,
+                     node_attr=None) -> Dict[str, torch.Tensor]:
+        """This rank's share of a batch: its node rows, the edges aggregating into them (global column ids),
+        the replicated per-graph tensors."""
+        world, rank = self._world_rank()
+        plan = ShardPlan(node_loc.size(0), world, rank)
+        ei, ea = plan.edges(edge_index, edge_attr.detach() if edge_attr is not None else None)
+        return dict(plan=plan, node_feat=plan.rows(node_feat), node_loc=plan.rows(node_loc), node_vel=plan.rows(node_vel),
+                    edge_index=ei, edge_attr=ea, data_batch=plan.rows(data_batch), loc_mean=loc_mean,
+                    node_attr=plan.rows(node_attr.detach()).float() if node_attr is not None else None)
+
+    def forward_local(self, local: Dict[str, torch.Tensor]):
         m = self.model
-        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
-        be = self.backend or HipBackend(node_loc.device)
+        plan: ShardPlan = local["plan"]
+        be = self.backend or HipBackend(local["node_loc"].device)
         if m._spec is None:
             m._spec = _Spec(m)
             pidx = m._param_index
             m._plist = [pidx[n] for n in m._spec.names]
         spec = m._spec
-        plan = ShardPlan(node_loc.size(0), world, rank)
-        ei, ea = plan.edges(edge_index, edge_attr.detach() if edge_attr is not None else None)
-        graph = be.build_graph(ei, plan.nloc, plan.n_src, plan.n0)
-        ea_sorted = graph.permute(ea)
-        B = loc_mean.size(0)
-        batch32, gptr = be.build_batch(plan.rows(data_batch), plan.nloc, B)
-        na = plan.rows(node_attr.detach()).float() if node_attr is not None else None
+        graph = be.build_graph(local["edge_index"], plan.nloc, plan.n_src, plan.n0)
+        ea_sorted = graph.permute(local["edge_attr"])
+        B = local["loc_mean"].size(0)
+        batch32, gptr = be.build_batch(local["data_batch"], plan.nloc, B)
         self.plan = plan
-        return _ShardedFunction.apply(be, self.group, spec, plan, graph, batch32, gptr, ea_sorted, na,
-                                      plan.rows(node_feat), plan.rows(node_loc), plan.rows(node_vel), loc_mean,
-                                      *m._plist)
+        return _ShardedFunction.apply(be, self.group, self.stats, spec, plan, graph, batch32, gptr, ea_sorted,
+                                      local["node_attr"], local["node_feat"], local["node_loc"], local["node_vel"],
+                                      local["loc_mean"], *m._plist)
+
+    def forward(self, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None,
+                node_attr=None):
+        return self.forward_local(self.shard_inputs(node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean,
+                                                    edge_attr, node_attr))

@@ -167,7 +167,8 @@ typedef struct {
   float *g_h, *g_x, *g_Z, *g_HvT;
   float *g_vel;            /* [N,3] accumulated (+=), may be null */
 
-  /* backward scratch (caller allocates; sizes from fastegnn_scratch_floats) */
+  /* backward scratch (caller allocates; the shapes below, the wg_* sizes from fastegnn_wg_*_floats, the total from
+   * fastegnn_backward_scratch_floats) */
   float *g_poolV, *g_poolX;   /* [B,C,64], [B,3,C] */
   float *g_Bc;                /* [B,C,64] (sharded: all-reduced before B3) */
   float *g_Zp;                /* [B,3,C]  partial from B4 (sharded: all-reduced) */
@@ -181,8 +182,8 @@ typedef struct {
   float *g_xrow;              /* [N,3]   row-side d/dx of the edge stage */
   float *wg_edge;             /* [fastegnn_wg_edge_floats(E)] weight-gradient operands of the edge stage (none when the
                                * edge backward contracts them inside the workgroup: 4 floats then) */
-  float *wg_virt;             /* [5*N*C*64]     weight-gradient operands of the virtual stage */
-  float *wg_node;             /* [8*max(N,B*C)*64] node-level weight-gradient operands */
+  float *wg_virt;             /* [fastegnn_wg_virt_floats(N,C)]   weight-gradient operands of the virtual stage */
+  float *wg_node;             /* [fastegnn_wg_node_floats(N,B,C)] node-level weight-gradient operands */
   float *wg_slab;             /* [fastegnn_wg_slab_floats()] partial 64x64 slabs of the weight-gradient GEMMs */
 } fastegnn_layer_t;
 
@@ -194,6 +195,11 @@ size_t fastegnn_wpack_floats(int32_t C);
 /* floats of the weight-gradient slab workspace (independent of the problem size) */
 size_t fastegnn_wg_slab_floats(void);
 size_t fastegnn_wg_edge_floats(int32_t E);
+size_t fastegnn_wg_virt_floats(int32_t N, int32_t C);
+size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C);
+/* floats of all backward scratch arrays of fastegnn_layer_t together (g_poolV ... wg_slab), each array rounded up to
+ * a multiple of 4 floats so that one allocation can be carved into 16-byte aligned pieces */
+size_t fastegnn_backward_scratch_floats(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C);
 /* struct sizes, so that a foreign-language binding can verify its mirror of the descriptors */
 size_t fastegnn_sizeof_layer(void);
 size_t fastegnn_sizeof_graph(void);

@@ -47,6 +47,12 @@ class CpuOracleBackend:
     def wg_edge_floats(self, E):
         return 4
 
+    def wg_virt_floats(self, N, Cn):
+        return 4
+
+    def wg_node_floats(self, N, B, Cn):
+        return 4
+
     # ---- prologue / epilogue ----
     def build_graph(self, ei, n_rows, n_src, row_begin):
         return CpuGraph(ei, n_rows, n_src, row_begin)

@@ -84,26 +84,70 @@ def fp64_truth(g):
 
 
 OUT_TOL = 1e-5        # north_star: outputs within 1e-5 rel fp32 of the reference
-GRAD_FACTOR = 10.0    # build's fp32 error vs fp64 may be this multiple of the reference's own
-GRAD_FLOOR = 2.5e-5   # fp32 noise of short cancelling sums: a 60-term scalar bias gradient (att_mlp.0.bias of
-                      # ragged3_attention) sits at 1.0e-5 with fp32-input MFMA and 2.0e-5 with the bf16x3 products
+
+# Gradients and the displacement are compared through the fp64 oracle (hard part 2): the
+# build's error against exact arithmetic may be GRAD_FACTOR x the fp32 reference's own error on the same tensor,
+# plus GRAD_FLOOR (both as max-error relative to max|truth| of the tensor).
+GRAD_FACTOR = 2.0
+GRAD_FLOOR = 1e-6
+# Explicit per-tensor exceptions: (case pattern, tensor pattern) -> (factor, floor).  Generated from a full -m gpu
+# run with FASTEGNN_TOL_DUMP=<file> (every comparison is logged; tools/tol_report.py prints the offenders) --
+# each entry states what was measured.  A tensor lands here when its gradient is a short or strongly cancelling
+# sum, for which two fp32 evaluations in different summation orders (the reference's ATen kernels, these HIP
+# kernels) each sit at a random point of the same rounding-noise band, so "2 x the reference's own draw" is not a
+# bound; the floor granted is the measured band, never more than 2.5e-5.
+GRAD_EXCEPTIONS = [
+    # (case regex, tensor regex, factor, floor, why)
+    (r"ragged3_(allflags|normalize)|fastrf_allflags", r".", 8.0, 1e-6,
+     "normalize=True on graphs with self loops / coincident points: d/(|d|+1e-8) at d = 0 amplifies rounding noise by "
+     "1e8, the reference's own gradients are 5e-4..3e-3 from exact arithmetic there, and a mathematically identical "
+     "fp32 re-association run on the SAME torch CPU kernels (oracle/factored.py in tests/test_factored_cpu.py) "
+     "measures 2.1-5.7x the reference's draw on 13 tensors"),
+    (r"attention|allflags", r"att_mlp(_virtual)?\.0\.(weight|bias)|coord_mlp_r\.2\.weight", 12.0, 1e-6,
+     "attention gates: scalar / 64-vector gradients that are cancelling sums over ~100 edges; the same CPU "
+     "re-association measures 2.2-10.8x the reference's draw (att_mlp.0.bias: 9.1e-6 vs 8.4e-7)"),
+]
+
+
+def grad_tolerance(case, name, e_ref):
+    import re
+    f, fl = GRAD_FACTOR, GRAD_FLOOR
+    for cre, nre, ef, efl, _why in GRAD_EXCEPTIONS:
+        if re.search(cre, case) and re.search(nre, name):
+            f, fl = max(f, ef), max(fl, efl)
+    return f * e_ref + fl
+
+
+_DUMP = os.environ.get("FASTEGNN_TOL_DUMP")
+
+
+def grad_check(case, name, got, ref32, truth, bad):
+    """Appends a message to `bad` when `got` is further from `truth` (fp64) than the calibrated tolerance allows.
+    With FASTEGNN_TOL_DUMP=<file> every comparison is logged as a JSON line and nothing fails (calibration run)."""
+    e_ref, e_got = rel_err(ref32, truth), rel_err(got, truth)
+    tol = grad_tolerance(case, name, e_ref)
+    if _DUMP:
+        import json
+        with open(_DUMP, "a") as f:
+            f.write(json.dumps({"case": case, "tensor": name, "got": e_got, "ref": e_ref, "tol": tol,
+                                "max": float(torch.as_tensor(truth).abs().max()), "numel": int(torch.as_tensor(truth).numel())}) + "\n")
+        return
+    if e_got > tol:
+        bad.append(f"{name} {e_got:.2e} (ref {e_ref:.2e}, tol {tol:.2e})")
 
 
 def check_parity(g, loc, vloc, G=None, gin=None, truth=None):
     """loc/vloc: <=1e-5 rel of the reference golden.  Displacement and gradients: the fp32
     reference itself is 1e-7..1e-3 away from exact arithmetic depending on the tensor, so the
     build's error against the fp64 oracle must stay within GRAD_FACTOR x the reference's own
-    fp32 error (+ floor)."""
+    fp32 error (+ GRAD_FLOOR), see grad_check."""
     t_loc, t_vloc, t_G, t_gin = truth if truth is not None else fp64_truth(g)
     msgs = []
     e = rel_err(loc, g.out["loc"]); msgs += [f"loc {e:.2e}"] if e >= OUT_TOL else []
     e = rel_err(vloc, g.out["vloc"]); msgs += [f"vloc {e:.2e}"] if e >= OUT_TOL else []
     x0 = torch.from_numpy(g.inp["node_loc"]).double()
-    d_t = t_loc - x0
-    e_ref = rel_err(torch.from_numpy(g.out["loc"]).double() - x0, d_t)
-    e_got = rel_err(torch.as_tensor(loc).double().cpu() - x0, d_t)
-    if e_got > GRAD_FACTOR * e_ref + GRAD_FLOOR:
-        msgs.append(f"displacement {e_got:.2e} (ref {e_ref:.2e})")
+    grad_check(g.name, "displacement", torch.as_tensor(loc).double().cpu() - x0,
+               torch.from_numpy(g.out["loc"]).double() - x0, t_loc - x0, msgs)
     for got, ref, tru, tag in ((G, g.gp, t_G, "gp"), (gin, g.gin, t_gin, "gin")):
         if got is None:
             continue
@@ -111,8 +155,5 @@ def check_parity(g, loc, vloc, G=None, gin=None, truth=None):
             if k not in got or got[k] is None:
                 msgs.append(f"{tag}/{k} missing")
                 continue
-            e_ref = rel_err(ref[k], tru[k])
-            e_got = rel_err(got[k], tru[k])
-            if e_got > GRAD_FACTOR * e_ref + GRAD_FLOOR:
-                msgs.append(f"{tag}/{k} {e_got:.2e} (ref {e_ref:.2e})")
+            grad_check(g.name, f"{tag}/{k}", got[k], ref[k], tru[k], msgs)
     return msgs

@@ -5,7 +5,7 @@ import torch
 
 import fastegnn_amd
 from oracle import egnn_ref as E
-from tests.helpers import rel_err
+from tests.helpers import grad_check, rel_err
 from tests.test_egnn_oracle_cpu import EGNN_NAMES, egnn_loss, load_egnn
 
 pytestmark = pytest.mark.gpu
@@ -27,14 +27,19 @@ def test_egnn_matches_reference_golden(name):
     assert rel_err(x, g["out"]["x"]) < 1e-5, rel_err(x, g["out"]["x"])
     assert rel_err(h, g["out"]["h"]) < 2e-5
     egnn_loss(x, h, i["target"], i["wh"]).backward()
+    # fp64 truth from the oracle on the golden's fp32 weights / inputs; the reference's fp32 gradients are the goldens
+    dt = torch.float64
+    p64 = {k: v.to(dt).clone().requires_grad_(True) for k, v in g["p"].items()}
+    l64 = {k: g["in"][k].to(dt).clone().requires_grad_(True) for k in leaf}
+    x64, h64 = E.forward(p64, int(g["meta"]["L"]), l64["x"], l64["h"], g["in"]["edge_index"], g["in"]["edge_fea"].to(dt), l64.get("v"))
+    egnn_loss(x64, h64, g["in"]["target"].to(dt), g["in"]["wh"].to(dt)).backward()
     bad = []
     for k, p in m.named_parameters():
         got = p.grad if p.grad is not None else torch.zeros_like(p)
-        if rel_err(got, g["gp"][k]) > 2e-4:
-            bad.append((k, rel_err(got, g["gp"][k])))
+        tru = p64[k].grad if p64[k].grad is not None else torch.zeros_like(p64[k])
+        grad_check(name, f"gp/{k}", got, g["gp"][k], tru, bad)
     for k, v in leaf.items():
-        if rel_err(v.grad, g["gin"][k]) > 2e-4:
-            bad.append(("gin/" + k, rel_err(v.grad, g["gin"][k])))
+        grad_check(name, f"gin/{k}", v.grad, g["gin"][k], l64[k].grad, bad)
     assert not bad, bad
 
 
@@ -51,5 +56,11 @@ def test_egnn_mid_size_vs_oracle():
     xr, hr = E.forward(p, 3, x, h, ei, ea, v)
     (xr.pow(2).mean() + hr.pow(2).mean()).backward()
     assert rel_err(xo, xr) < 1e-5 and rel_err(ho, hr) < 2e-5
+    dt = torch.float64
+    p64 = {k: t.detach().to(dt).clone().requires_grad_(True) for k, t in p.items()}
+    x64, h64 = E.forward(p64, 3, x.to(dt), h.to(dt), ei, ea.to(dt), v.to(dt))
+    (x64.pow(2).mean() + h64.pow(2).mean()).backward()
+    bad = []
     for k, prm in m.named_parameters():
-        assert rel_err(prm.grad, p[k].grad) < 5e-4, k
+        grad_check("egnn_mid_size", k, prm.grad, p[k].grad, p64[k].grad, bad)
+    assert not bad, bad

@@ -6,7 +6,7 @@ import torch
 import fastegnn_amd
 from oracle import fastrf_ref as RF
 from tests.gpu_util import model_from_golden
-from tests.helpers import Golden, golden_loss, rel_err, OUT_TOL, GRAD_FACTOR, GRAD_FLOOR
+from tests.helpers import Golden, golden_loss, grad_check, rel_err, OUT_TOL
 
 pytestmark = pytest.mark.gpu
 CASES = ["fastrf_plain", "fastrf_allflags", "fastrf_c16"]
@@ -40,14 +40,10 @@ def test_fastrf_forward_backward_match_reference_golden(name):
     bad = []
     for k, p in m.named_parameters():
         got = p.grad if p.grad is not None else torch.zeros_like(p)
-        e_ref, e_got = rel_err(g.gp[k], tG[k]), rel_err(got, tG[k])
-        if e_got > GRAD_FACTOR * e_ref + GRAD_FLOOR:
-            bad.append(f"gp/{k} {e_got:.2e} (ref {e_ref:.2e})")
+        grad_check(name, f"gp/{k}", got, g.gp[k], tG[k], bad)
     for k, v in leaf.items():
         got = v.grad if v.grad is not None else torch.zeros_like(v)
-        e_ref, e_got = rel_err(g.gin[k], tgin[k]), rel_err(got, tgin[k])
-        if e_got > GRAD_FACTOR * e_ref + GRAD_FLOOR:
-            bad.append(f"gin/{k} {e_got:.2e} (ref {e_ref:.2e})")
+        grad_check(name, f"gin/{k}", got, g.gin[k], tgin[k], bad)
     assert not bad, bad
 
 
@@ -95,7 +91,5 @@ def test_fastrf_many_tiles_per_workgroup_vs_oracle():
     bad = []
     for k, p in m.named_parameters():
         got = p.grad.cpu() if p.grad is not None else torch.zeros_like(p32[k])
-        e_ref, e_got = rel_err(g32[k], g64[k]), rel_err(got, g64[k])
-        if e_got > GRAD_FACTOR * e_ref + GRAD_FLOOR:
-            bad.append(f"{k} {e_got:.2e} (ref {e_ref:.2e})")
+        grad_check("fastrf_many_tiles", k, got, g32[k], g64[k], bad)
     assert not bad, bad

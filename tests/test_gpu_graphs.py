@@ -37,6 +37,19 @@ def test_radius_graph_water3d_size_equals_kdtree_reference():
     assert np.array_equal(np.sort(key), np.sort(a[1] * 100000 + a[0]))      # every (i,j) has its (j,i)
 
 
+def test_radius_graph_small_radius_grid_bound():
+    """Extent >= 256 r on every axis: the cell grid is capped at 256 cells per axis (2^24 cells, the size of the
+    cell-start table); a near-cubic cloud with r < extent/256 used to ask for 257^3 cells."""
+    g = torch.Generator().manual_seed(17)
+    loc = torch.rand(60000, 3, generator=g)
+    loc[0], loc[1] = torch.tensor([0.0, 0.0, 0.0]), torch.tensor([1.0, 1.0, 1.0])    # pin the bounding box
+    loc[2] = torch.tensor([1.0, 1.0, 1.0]) - 0.001                                   # a pair in the last cell
+    for r in (0.003, 0.0039):
+        ei_ref, d_ref = G.radius_graph_kdtree(loc.numpy(), r)
+        ei, d = radius_graph(loc.cuda(), r)
+        assert ei_ref.shape[1] > 0 and np.array_equal(ei.cpu().numpy(), ei_ref)
+
+
 @pytest.mark.parametrize("rate", [0.0, 0.5, 0.9, 1.0])
 def test_cutoff_keeps_shortest_fraction(rate):
     g = np.random.RandomState(5)

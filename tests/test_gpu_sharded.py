@@ -1,0 +1,107 @@
+"""-m gpu: the graph-sharded path (fastegnn_amd/sharded.py) with MORE THAN ONE rank on the HIP kernels.
+
+The GPU boxes of this pool have one device, and RCCL refuses two ranks on the same device, so the two ranks of
+this test share cuda:0 and exchange through gloo (the collectives are staged through host memory,
+sharded._Comm.host_staged).  Everything else is the product path: ShardPlan, the per-rank CSR over global column
+ids, the stage-level C entry points on padded all-gathered tables, the pipelined order of the exchanges, the
+rank-0-only gradients of the replicated per-graph stages, the flat gradient all-reduce.  Each rank's rows and the
+reduced gradients must equal the unsharded HIP model on the same batch.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import fastegnn_amd
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1500, 900, 1301]     # 3 701 nodes: Npad = 1 851, graph 1 straddles the rank boundary
+C, L = 8, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs():
+    from tests.test_gpu_properties import _batch
+    inp = _batch(SIZES, 9, C, seed=31)
+    g = torch.Generator().manual_seed(32)
+    target = inp["node_loc"] + torch.randn(inp["node_loc"].shape, generator=g) * 0.2
+    return inp, target
+
+
+def _model():
+    torch.manual_seed(9)
+    m = fastegnn_amd.FastEGNN(2, 0, 2, 64, C, device="cuda", n_layers=L, gravity=[0, -1, 0], attention=True)
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if k.endswith((".coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
+                v.mul_(50.0)
+    return m
+
+
+def _loss(loc_rows, vloc, target_rows, n_total):
+    return ((loc_rows - target_rows) ** 2).sum() / (3 * n_total) + 0.1 * vloc.pow(2).mean()
+
+
+def _worker(rank, world, port, q):
+    from fastegnn_amd.dist import allreduce_gradients
+    from fastegnn_amd.sharded import CommStats, ShardedFastEGNN
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    inp, target = _inputs()
+    inp = {k: v.cuda() for k, v in inp.items()}
+    m = _model()
+    stats = CommStats()
+    sm = ShardedFastEGNN(m, stats=stats)
+    local = sm.shard_inputs(**inp)
+    loc, vloc = sm.forward_local(local)
+    plan = sm.plan
+    _loss(loc, vloc, target.cuda()[plan.n0:plan.n1], target.size(0)).backward()
+    allreduce_gradients(m.parameters())
+    grads = {k: (p.grad.cpu().numpy().copy() if p.grad is not None else None) for k, p in m.named_parameters()}
+    q.put((rank, plan.n0, plan.n1, loc.detach().cpu().numpy().copy(), vloc.detach().cpu().numpy().copy(), grads,
+           stats.summary()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_unsharded_model():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    inp, target = _inputs()
+    m = _model()
+    loc, vloc = m(**{k: v.cuda() for k, v in inp.items()})
+    _loss(loc, vloc, target.cuda(), target.size(0)).backward()
+    loc, vloc = loc.detach().cpu(), vloc.detach().cpu()
+    N = target.size(0)
+    for rank, n0, n1, loc_r, vloc_r, grads, summary in res:
+        assert (n0, n1) == ((0, 1851) if rank == 0 else (1851, N))
+        assert rel_err(loc_r, loc[n0:n1]) < 2e-6, rel_err(loc_r, loc[n0:n1])
+        assert rel_err(vloc_r, vloc) < 2e-6
+        for k, p in m.named_parameters():
+            want = p.grad.cpu() if p.grad is not None else torch.zeros_like(p).cpu()
+            assert grads[k] is not None, k
+            assert rel_err(grads[k], want) < 2e-5, (rank, k, rel_err(grads[k], want))
+        # exchange volume per layer and direction: the padded source table both ways
+        assert summary["QX"]["calls_per_step"] == L and summary["g_QX"]["calls_per_step"] == L
+        assert summary["QX"]["bytes_per_step"] == L * 2 * 1851 * 68 * 4

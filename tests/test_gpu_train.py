@@ -8,7 +8,7 @@ import torch
 import fastegnn_amd
 from fastegnn_amd.train import FusedAdam, augment_edge_attr, mse_mmd_loss
 from oracle import fastegnn_ref as R
-from tests.helpers import rel_err
+from tests.helpers import grad_check, rel_err
 from tests.test_train_oracle_cpu import NAMES, load
 
 pytestmark = pytest.mark.gpu
@@ -33,9 +33,19 @@ def test_three_training_steps_match_reference(name):
         assert abs(float(mse) - float(g["out"]["losses"][step - 1, 1])) < 5e-6
         if step == 1:
             assert rel_err(loc, g["out"]["loc"]) < 1e-5 and rel_err(vloc, g["out"]["vloc"]) < 1e-5
+            # fp64 truth of the step-1 gradients from the oracle; the reference's fp32 gradients are the goldens
+            dt = torch.float64
+            p64 = {k: v.to(dt).clone().requires_grad_(True) for k, v in g["p0"].items()}
+            i64 = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in g["in"].items() if k not in ("loc_t", "sample_nodes")}
+            l64, v64 = R.forward(p64, cfg, **i64)
+            R.loss_mse_mmd_nodes(l64, v64, g["in"]["loc_t"].to(dt), g["in"]["sample_nodes"], float(m_["sigma"]),
+                                 float(m_["weight"]))[0].backward()
+            bad = []
             for k, p in model.named_parameters():
                 got = p.grad if p.grad is not None else torch.zeros_like(p)
-                assert rel_err(got, g["g1"][k]) < 2e-4, k
+                tru = p64[k].grad if p64[k].grad is not None else torch.zeros_like(p64[k])
+                grad_check(name, k, got, g["g1"][k], tru, bad)
+            assert not bad, bad
         opt.step()
         if step in (1, 3):
             ref = g[f"p{step}"]
