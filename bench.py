@@ -256,8 +256,6 @@ def cpu_baseline(cfg, args, seed, mode):
     import torch
     from oracle import fastegnn_ref as R
     logical, phys = host_cores()
-    threads = max(1, min(args.cpu_threads or logical, logical))
-    torch.set_num_threads(threads)
     C = args.channels or cfg["C"]
     ocfg = R.Config(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=C,
                     n_layers=args.layers, gravity=cfg["gravity"])
@@ -271,6 +269,21 @@ def cpu_baseline(cfg, args, seed, mode):
         loss_fn(loc, vloc, target).backward()
         return time.perf_counter() - t0
 
+    # thread count: --cpu-threads, else the fastest of {8,16,32,64,all} on a 4000-node frame (this op mix -- gathers,
+    # scatter_add_, small GEMMs -- does not scale with threads: measured 3.2 s at 8 vs 20 s at 256 threads on a 10 k frame)
+    cal = None
+    if args.cpu_threads:
+        threads = max(1, min(args.cpu_threads, logical))
+    else:
+        cand = sorted({t for t in (8, 16, 32, 64, logical) if t <= logical})
+        fr = make_frame(4000, C, seed, "cpu")
+        cal = {}
+        for t in cand:
+            torch.set_num_threads(t)
+            run(*fr)
+            cal[t] = round(min(run(*fr), run(*fr)), 3)
+        threads = min(cal, key=cal.get)
+    torch.set_num_threads(threads)
     full_nodes = args.nodes or cfg["nodes"]
     if mode == "full":
         if cfg["kind"] == "water":
@@ -293,7 +306,8 @@ def cpu_baseline(cfg, args, seed, mode):
                   f"super-linear in N, so this flatters the CPU)")
         value = 1.0 / (t * scale)
     return {"value": round(value, 5), "unit": "graphs/s", "cores": threads, "kind": "port", "sample": sample,
-            "host_logical_cpus": logical, "host_physical_cores": phys, "torch_threads": threads}
+            "host_logical_cpus": logical, "host_physical_cores": phys, "torch_threads": threads,
+            "thread_calibration_s_4000_nodes": cal}
 
 
 def latest_traffic():

@@ -304,6 +304,74 @@ __device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Split &in,
 }
 __device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Vec &in, Vec &acc) { gemm64_x3(img3, vsplit(in), acc); }
 
+// ---- bf16 operand mode (FASTEGNN_F_BF16): both operands rounded to bf16 (RNE), ONE bf16 product, fp32 accumulate ----
+// The weights are rounded by pack_kernel, so the `h` part of a split image IS the bf16 weight matrix (m = l = 0) and
+// the fp32 images hold bf16-representable values; activations are rounded here (v_cvt_pk_bf16_f32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_rne(float x0, float x1) {   // {bf16(x0) low half, bf16(x1) high half}
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+}
+__device__ __forceinline__ float round_bf(float x) { return (float)(__bf16)x; }
+__host__ __device__ __forceinline__ float round_bf_host(float x) {   // same rounding by integer arithmetic (finite x)
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+  return __builtin_bit_cast(float, u);
+}
+struct BfOp {
+  u32x4 p[2];   // [k-step] : 8 bf16 per lane, the k order of the split images (bf3_k)
+};
+__device__ __forceinline__ BfOp vpack_bf(const Vec &v) {
+  BfOp B;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int e = 2 * w;
+      B.p[s][w] = pack_rne(v.t[2 * s + (e >> 2)][e & 3], v.t[2 * s + ((e + 1) >> 2)][(e + 1) & 3]);
+    }
+  return B;
+}
+__device__ __forceinline__ Vec vround(const Vec &v) { return vmap(v, [](float z) { return round_bf(z); }); }
+// img3: split image whose h part (first 2048 words) holds the bf16 weights
+__device__ __forceinline__ void gemm64_b1(const unsigned *img3, const BfOp &in, Vec &acc) {
+  const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + lane_id();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const bf16x8 x = __builtin_bit_cast(bf16x8, in.p[s]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ip[(t * 2 + s) * 64]), x, acc.t[t], 0, 0, 0);
+  }
+}
+
+// Arithmetic form of the 64x64 layers of a kernel (template parameter of the stage kernels)
+enum GemmMode { GM_F32 = 0, GM_X3 = 1, GM_BF16 = 2 };
+// the B operand of one or several products in the chosen form: made once, used by every layer that reads it
+template <int MODE> struct OperandOf { typedef Vec type; };
+template <> struct OperandOf<GM_X3> { typedef Split type; };
+template <> struct OperandOf<GM_BF16> { typedef BfOp type; };
+template <int MODE>
+__device__ __forceinline__ typename OperandOf<MODE>::type make_operand(const Vec &v) {
+  if constexpr (MODE == GM_X3) return vsplit(v);
+  else if constexpr (MODE == GM_BF16) return vpack_bf(v);
+  else return v;
+}
+// image i of a resident image array (fp32 images for GM_F32, split images otherwise)
+template <int MODE>
+__device__ __forceinline__ void gemm_op(const void *img, int i, const typename OperandOf<MODE>::type &in, Vec &acc) {
+  if constexpr (MODE == GM_X3) gemm64_x3(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
+  else if constexpr (MODE == GM_BF16) gemm64_b1(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
+  else gemm64(reinterpret_cast<const float *>(img) + i * IMG, in, acc);
+}
+// a product on an fp32 image (fp32-input MFMA) inside a kernel of form MODE: in bf16 mode the activation is rounded
+// (the image already holds bf16-representable weights), so the product has the bf16-mode semantics exactly
+template <int MODE>
+__device__ __forceinline__ void gemm64_m(const float *img, const Vec &in, Vec &acc) {
+  if constexpr (MODE == GM_BF16) gemm64(img, vround(in), acc);
+  else gemm64(img, in, acc);
+}
+
 // cooperative copy of n_img consecutive images global -> LDS (16-byte moves)
 __device__ __forceinline__ void load_images(float *dst, const float *src, int n_img) {
   const f32x4 *s = reinterpret_cast<const f32x4 *>(src);

@@ -46,6 +46,7 @@ struct WgJob {
   float *dW, *db;
   long M, sG, sT, sW;
   int ldg, ldt, lddw, c0, ks, kmax, rows_per_wg, nsplit, nb, wg_begin, slab_begin;
+  int round;   // bf16 operand mode: both operands are rounded to bf16 before the product
 };
 struct WgTable {
   WgJob job[WG_MAX_JOBS];
@@ -56,7 +57,8 @@ struct WgradBatch {
   WgTable tab;
   hipStream_t st;
   int n_wg, n_slab, max_nb;
-  WgradBatch(float *slab, hipStream_t st);
+  bool round;   // applied to the jobs added from now on
+  WgradBatch(float *slab, hipStream_t st, bool round_bf16 = false);
   int add(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks, float *db,
           int nb = 1, long sG = 0, long sT = 0, long sW = 0, int kmax = 64);
   // a job whose partial slabs (nsplit of them, [64][64] + [64] bias each) are written by the caller's own kernel:

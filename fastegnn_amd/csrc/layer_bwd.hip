@@ -39,6 +39,8 @@ struct GraphPostBwdArgs {
   int B, C, flags;
 };
 __global__ __launch_bounds__(256) void graph_post_bwd_kernel(GraphPostBwdArgs a) {
+  const bool bf = a.flags & FASTEGNN_F_BF16;   // bf16 operand mode: the B operand of every product is rounded
+  auto rb = [&](const Vec &v) { return bf ? vround(v) : v; };
   const int l = lane_id(), j = l & 15, q = l >> 4;
   const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int M = a.B * a.C, ntiles = (M + 15) >> 4;
@@ -64,16 +66,16 @@ __global__ __launch_bounds__(256) void graph_post_bwd_kernel(GraphPostBwdArgs a)
     const Vec hv = vload_row(a.HvT + (size_t)mc * H, q);
     const Vec pm = vscale(vload_row(a.poolV + (size_t)mc * H, q), inv);
     Vec z5 = vload_vec(a.b5, q);
-    gemm64(a.wpack + (size_t)I_W5A * IMG, hv, z5);
-    gemm64(a.wpack + (size_t)I_W5B * IMG, pm, z5);
+    gemm64(a.wpack + (size_t)I_W5A * IMG, rb(hv), z5);
+    gemm64(a.wpack + (size_t)I_W5B * IMG, rb(pm), z5);
     const Vec g_out = vload_row(a.g_HvT_out + (size_t)mc * H, q);
     Vec g_u = vzero();
-    gemm64(a.wpack + (size_t)I_W6T * IMG, g_out, g_u);
+    gemm64(a.wpack + (size_t)I_W6T * IMG, rb(g_out), g_u);
     const Vec g_z5 = vdsilu_mul(g_u, z5);
     Vec g_hv = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
-    gemm64(a.wpack + (size_t)I_W5AT * IMG, g_z5, g_hv);
+    gemm64(a.wpack + (size_t)I_W5AT * IMG, rb(g_z5), g_hv);
     Vec g_pm = vzero();
-    gemm64(a.wpack + (size_t)I_W5BT * IMG, g_z5, g_pm);
+    gemm64(a.wpack + (size_t)I_W5BT * IMG, rb(g_z5), g_pm);
     if (valid) {
       vstore_row(a.wg_u + (size_t)m * H, q, vsilu(z5));
       vstore_row(a.wg_gz5 + (size_t)m * H, q, g_z5);
@@ -100,7 +102,7 @@ int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st) {
   if (rc) return rc;
   if (has(L, FASTEGNN_F_RF)) return FASTEGNN_OK;   // no node_mlp_virtual
   float *const *g = L->grads;
-  WgradBatch wb(L->wg_slab, st);
+  WgradBatch wb(L->wg_slab, st, has(L, FASTEGNN_F_BF16));
   // node_mlp_virtual.2: dW6 += g_out^T u, db6 += colsum g_out
   if ((rc = wb.add(L->g_HvT_out, H, wg_u, H, M, g[FASTEGNN_P_NODEV2_W], H, 0, 1, g[FASTEGNN_P_NODEV2_B]))) return rc;
   // node_mlp_virtual.0: [Hv | pooled v]
@@ -125,8 +127,14 @@ struct VirtBwdArgs {
 constexpr int virt_bwd_img_floats(bool x3h) { return x3h ? 2 * IMG + 4 * IMG3 : 6 * IMG; }
 // RF (FastRF reduced layer) is a compile-time switch: as a run-time flag it cost the FastEGNN path 10 %
 // (register allocation of the channel loop)
-template <bool RF, bool X3H>
+// BF: bf16 operand mode (FASTEGNN_F_BF16): split-image sites run one bf16 product of the rounded activation, fp32-image
+// sites round their activation (every image holds bf16-rounded weights then).
+template <bool RF, bool X3H, bool BF>
 __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdArgs A) {
+  constexpr int SM = X3H ? (BF ? GM_BF16 : GM_X3) : GM_F32;    // arithmetic form of the split-image sites
+  constexpr int FM = BF ? GM_BF16 : GM_F32;                    // fp32-image sites: gemm64_m<FM> rounds in bf16 mode
+  typedef typename OperandOf<SM>::type SOp;
+  auto sop = [](const Vec &v) -> SOp { return make_operand<SM>((BF && !X3H) ? vround(v) : v); };
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VirtArgs &a = A.f;
   const int C = a.C;
@@ -135,6 +143,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   float *img = lds;
   const unsigned *img3 = reinterpret_cast<const unsigned *>(lds + 2 * IMG);   // split images (X3H)
   constexpr int S_V2 = 0, S_V2T = 3, S_WXV0T = X3H ? 0 : 4, S_WXX0T = X3H ? 1 : 5;
+  const void *simg = X3H ? static_cast<const void *>(img3) : static_cast<const void *>(img);   // images of the split-image sites
   float *vec = lds + virt_bwd_img_floats(X3H);
   float *gBc_l = vec + 16 * H;                   // [C][64]
   float *gZ_l = gBc_l + C * H;                   // [3][C]
@@ -214,19 +223,19 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {
           const Vec npre = vload_u(b_npre, offN);
           Vec g_t3 = vzero();
-          gemm64(a.wpack + (size_t)I_W4T * IMG, g_out, g_t3);
+          gemm64_m<FM>(a.wpack + (size_t)I_W4T * IMG, g_out, g_t3);
           g_np = vdsilu_mul(g_t3, npre);
           if (valid && own) vstore_u(b_t3, offN, vsilu(npre));
         }
         if (valid && own) vstore_u(b_gnp, offN, g_np);
         {
           Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
-          gemm64(a.wpack + (size_t)I_W3AT * IMG, g_np, g_h);
+          gemm64_m<FM>(a.wpack + (size_t)I_W3AT * IMG, g_np, g_h);
           if (valid && own) vstore_u(b_gh, offN, g_h);
         }
         {
           Vec g_am = vzero();
-          gemm64(a.wpack + (size_t)I_W3BT * IMG, g_np, g_am);
+          gemm64_m<FM>(a.wpack + (size_t)I_W3BT * IMG, g_np, g_am);
           if (valid && own) vstore_u(b_gam, offN, g_am);
         }
       }
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       // at the top of channel c, ahead of that channel's operand stores: a load issued after the
       // stores could only be waited for together with them (vmcnt counts stores too).
       const Vec Arow = vload_u(b_A, offN);
-      const Vec g_np_m = vmask(g_np, valid);
+      const Vec g_np_m = BF ? vround(vmask(g_np, valid)) : vmask(g_np, valid);   // B operand of every W3cT product
       Vec nBc = vzero(), nGpv = vzero();
       float nZ[3] = {0.f, 0.f, 0.f}, nGpx[3] = {0.f, 0.f, 0.f};
       const int c_first = split ? wv : 0, c_step = split ? VIRT_BWD_WAVES : 1;
@@ -323,8 +332,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {
           const Vec t = vsilu_keep_d(d_pre);      // d_pre <- silu'(pre)
           WG_STORE(if (valid) vstore_u(b_t, oc, t);)
-          if constexpr (X3H) gemm64_x3(img3 + S_V2 * IMG3, t, vp);
-          else gemm64(img + S_V2 * IMG, t, vp);
+          gemm_op<SM>(simg, S_V2, sop(t), vp);
         }
         const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
         float att = 1.f;
@@ -334,20 +342,18 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           v = vscale(v0, att);
         }
         WG_STORE(if (valid) vstore_u(b_v, oc, v);)
-        Split vs;
-        if constexpr (X3H) vs = vsplit(v);   // feeds both coordinate heads
+        const SOp vs = sop(v);   // feeds both coordinate heads
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
         Vec g_v = rf ? vzero() : vmask(gpv_c, valid);
         if constexpr (!rf) {
           if (split) gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);   // the stage serves one channel at a time
-          else gemm64(w3ct_l, g_np_m, g_v);
+          else gemm64(w3ct_l, g_np_m, g_v);                                          // (g_np_m is rounded already in bf16 mode)
         }
         float g_vd[3];
         float sx, sX;
         {  // coord_mlp_r_virtual head: forward, then its adjoint
           Vec uxp = vload_vec(vec + VV_BXV0 * H, q);
-          if constexpr (X3H) gemm64_x3(img3 + 1 * IMG3, vs, uxp);
-          else gemm64(img + 1 * IMG, v, uxp);
+          gemm_op<SM>(simg, 1, vs, uxp);
           const Vec ux = vsilu_keep_d(uxp);       // uxp <- silu'(uxp)
           const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
           sx = tanh_on ? tanh_f(sr) : sr;
@@ -358,12 +364,11 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           vaxpy(acc_wxv2, g_sr, ux);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
           WG_STORE(if (valid) vstore_u(b_gux, oc, g_up);)
-          gemm64(img + S_WXV0T * IMG, g_up, g_v);
+          gemm64_m<FM>(img + S_WXV0T * IMG, g_up, g_v);
         }
         {  // coord_mlp_v_virtual head
           Vec uXp = vload_vec(vec + VV_BXX0 * H, q);
-          if constexpr (X3H) gemm64_x3(img3 + 2 * IMG3, vs, uXp);
-          else gemm64(img + 2 * IMG, v, uXp);
+          gemm_op<SM>(simg, 2, vs, uXp);
           const Vec uX = vsilu_keep_d(uXp);
           const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
           sX = tanh_on ? tanh_f(sr) : sr;
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           vaxpy(acc_wxx2, g_sr, uX);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
           WG_STORE(if (valid) vstore_u(b_guX, oc, g_up);)
-          gemm64(img + S_WXX0T * IMG, g_up, g_v);
+          gemm64_m<FM>(img + S_WXX0T * IMG, g_up, g_v);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) g_vd[k] = -sx * invC * gxn[k] + sX * gpX[k];
@@ -391,8 +396,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {
           const Vec g_vp = vmul(g_v0, vp);
           WG_STORE(if (valid) vstore_u(b_gvp, oc, g_vp);)
-          if constexpr (X3H) gemm64_x3(img3 + S_V2T * IMG3, g_vp, g_t);
-          else gemm64(img + S_V2T * IMG, g_vp, g_t);
+          gemm_op<SM>(simg, S_V2T, sop(g_vp), g_t);
         }
         const Vec g_pre = vmul(g_t, d_pre);
         vadd(g_A, g_pre);
@@ -530,21 +534,23 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   int grid = ntg < 256 ? ntg : 256;   // one workgroup per CU, each with an equal share of the tiles
   {
     ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st);
-    const bool x3h = BWD_X3 && C <= 32;
+    const bool x3h = C <= 32, bf = has(L, FASTEGNN_F_BF16);
     const size_t lds = virt_lds_bytes(C, 0, 0) + (virt_bwd_img_floats(x3h) + IMG + 4) * sizeof(float);
     const dim3 g3(grid), b3(64 * VIRT_BWD_WAVES);
+#define FE_VB(RF_, X3H_, BF_) hipLaunchKernelGGL((virt_bwd_kernel<RF_, X3H_, BF_>), g3, b3, lds, st, A)
     if (has(L, FASTEGNN_F_RF)) {
-      if (x3h) hipLaunchKernelGGL((virt_bwd_kernel<true, true>), g3, b3, lds, st, A);
-      else hipLaunchKernelGGL((virt_bwd_kernel<true, false>), g3, b3, lds, st, A);
+      if (x3h) { if (bf) FE_VB(true, true, true); else FE_VB(true, true, false); }
+      else { if (bf) FE_VB(true, false, true); else FE_VB(true, false, false); }
     } else {
-      if (x3h) hipLaunchKernelGGL((virt_bwd_kernel<false, true>), g3, b3, lds, st, A);
-      else hipLaunchKernelGGL((virt_bwd_kernel<false, false>), g3, b3, lds, st, A);
+      if (x3h) { if (bf) FE_VB(false, true, true); else FE_VB(false, true, false); }
+      else { if (bf) FE_VB(false, false, true); else FE_VB(false, false, false); }
     }
+#undef FE_VB
   }
   int rc = check_launch("virt_bwd_kernel");
   if (rc) return rc;
   const int ld_n0 = 2 * H + H * C + L->na;
-  WgradBatch wb(L->wg_slab, st);
+  WgradBatch wb(L->wg_slab, st, has(L, FASTEGNN_F_BF16));
   // node_mlp.2
   if ((rc = wb.add(L->g_h_out, H, A.wg_t3, H, N, g[FASTEGNN_P_NODE2_W], H, 0, 1, g[FASTEGNN_P_NODE2_B]))) return rc;
   // node_mlp.0: [h | agg | flat(v) | node_attr]
@@ -568,7 +574,7 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
 struct GraphPreBwdArgs {
   const float *xsum, *Z, *g_Bc, *g_Zp, *V0W;
   float *g_Z, *g_HvT, *g_xbar, *wg_mxt;
-  int B, C;
+  int B, C, bf16;
 };
 __global__ __launch_bounds__(256) void graph_pre_bwd_kernel(GraphPreBwdArgs a) {
   extern __shared__ float sm[];
@@ -591,7 +597,8 @@ __global__ __launch_bounds__(256) void graph_pre_bwd_kernel(GraphPreBwdArgs a) {
     int c = i >> 6, k = i & 63;
     const float *gb = a.g_Bc + ((size_t)b * C + c) * H;
     float acc = 0.f;
-    for (int o = 0; o < H; ++o) acc += gb[o] * a.V0W[(size_t)o * ld + H + k];
+    if (a.bf16) { for (int o = 0; o < H; ++o) acc += round_bf(gb[o]) * round_bf(a.V0W[(size_t)o * ld + H + k]); }   // V1b^T g_Bc: bf16 operands
+    else { for (int o = 0; o < H; ++o) acc += gb[o] * a.V0W[(size_t)o * ld + H + k]; }
     a.g_HvT[((size_t)b * C + c) * H + k] += acc;
   }
   // g_mX[c'][c] = sum_o g_Bc[b,c,o] V1d[o,c']
@@ -623,7 +630,7 @@ int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   const long M = (long)L->B * L->C;
   float *wg_mxt = L->wg_node;
   GraphPreBwdArgs a{L->xsum, L->Z, L->g_Bc, L->g_Zp, L->params[FASTEGNN_P_VIRT0_W], L->g_Z, L->g_HvT, L->g_xbar, wg_mxt,
-                    L->B, L->C};
+                    L->B, L->C, has(L, FASTEGNN_F_BF16) ? 1 : 0};
   const size_t lds = (size_t)(6 * L->C + L->C * L->C) * sizeof(float);
   { ProfScope _ps_graph_pre_bwd_kernel(K_GRAPH_PRE_BWD, st); hipLaunchKernelGGL(graph_pre_bwd_kernel, dim3(L->B), dim3(256), lds, st, a); }
   int rc = check_launch("graph_pre_bwd_kernel");
@@ -631,8 +638,9 @@ int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   float *const *g = L->grads;
   const int ld = 2 * H + 1 + L->C;
   // edge_mlp_virtual.0: columns [H,2H) <- Hv, columns [2H+1, 2H+1+C) <- mX[:,c], bias
-  WgradBatch wb(L->wg_slab, st);
+  WgradBatch wb(L->wg_slab, st, has(L, FASTEGNN_F_BF16));
   if ((rc = wb.add(L->g_Bc, H, L->HvT, H, M, g[FASTEGNN_P_VIRT0_W], ld, H, 1, g[FASTEGNN_P_VIRT0_B]))) return rc;
+  wb.round = false;   // the Gram columns of edge_mlp_virtual.0 are an fp32 product in every mode
   if ((rc = wb.add(L->g_Bc, H, wg_mxt, H, M, g[FASTEGNN_P_VIRT0_W], ld, 2 * H + 1, 1, nullptr, 1, 0, 0, 0, L->C))) return rc;
   return wb.finish();
 }
@@ -674,7 +682,7 @@ constexpr int PC_PROD = PC_WAVES - 1;       // producer waves
 constexpr int PC_RING = FE_PC_RING;                  // slots per ring; one ring per weight (kind 0: edge_mlp.2, kind 1: coord_mlp_r.0)
 constexpr int PC_RS = 68;                   // row stride of a slot tile
 constexpr int PC_SLOT = 2 * 16 * PC_RS;     // floats per slot: G tile | T tile
-constexpr int PC_IMG_FLOATS = BWD_X3 ? 4 * IMG3 : 4 * IMG;
+constexpr int PC_IMG_FLOATS = 4 * IMG3;
 enum { PC_HEAD = 0, PC_TOTAL = 2, PC_FILLED = 4, PC_DRAINED = 4 + 2 * PC_RING, PC_CTRL = 4 + 4 * PC_RING };
 struct Split8 {
   u32x4 h, m, l;
@@ -696,12 +704,20 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
   }
   return S;
 }
+// eight fp32 values -> one k-block of bf16 values, round to nearest even (bf16 operand mode)
+__device__ __forceinline__ u32x4 round8(const float (&x)[8]) {
+  u32x4 r;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) r[w] = pack_rne(x[2 * w], x[2 * w + 1]);
+  return r;
+}
 __device__ __forceinline__ int lds_ld(const int *p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void lds_st(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void pc_tile_store(float *tile, int j, int q, const Vec &v) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(tile + j * PC_RS + 16 * t + 4 * q) = v.t[t];
 }
+template <int MODE>
 __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const EdgeArgs &a = A.f;
@@ -710,8 +726,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   float *tiles = vec + EV_COUNT * H;   // per producer [16][TS]; the 4 pad columns of a row hold its g_d scalars
   float *ring = tiles + PC_PROD * 16 * TS;
   int *ctrl = reinterpret_cast<int *>(ring + 2 * PC_RING * PC_SLOT);
-  if constexpr (BWD_X3) load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, A.C, I_W2), 4);
-  else load_images(img, a.wpack + (size_t)I_W2 * IMG, 4);
+  load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, A.C, I_W2), 4);
   edge_load_vecs(vec, a);
   if (threadIdx.x < PC_CTRL) ctrl[threadIdx.x] = 0;
   __syncthreads();
@@ -775,7 +790,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       if (two)
         while (lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s1]) != r1w + 1) __builtin_amdgcn_s_sleep(2);
       const float *g0 = ring + (kind * PC_RING + s0) * PC_SLOT, *g1 = ring + (kind * PC_RING + s1) * PC_SLOT;
-      Split8 B[4];
+      Split8 B[4];   // bf16 mode: only .h is used (RNE-rounded operand, one product)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float x[8];
@@ -784,7 +799,8 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
           x[e] = g0[16 * PC_RS + (4 * q + e) * PC_RS + 16 * t + j];
           x[4 + e] = two ? g1[16 * PC_RS + (4 * q + e) * PC_RS + 16 * t + j] : 0.f;
         }
-        B[t] = split8(x);
+        if constexpr (MODE == GM_BF16) B[t].h = round8(x);
+        else B[t] = split8(x);
       }
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
@@ -796,6 +812,13 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs[ti] += x[e];
+        if constexpr (MODE == GM_BF16) {
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, round8(x));
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[ti][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, B[t].h), acc[ti][t], 0, 0, 0);
+          continue;
+        }
         const Split8 Aop = split8(x);
         const bf16x8 ah = __builtin_bit_cast(bf16x8, Aop.h), am = __builtin_bit_cast(bf16x8, Aop.m),
                      al = __builtin_bit_cast(bf16x8, Aop.l);
@@ -877,7 +900,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       edge_load_idx(a, e, cur_i);
       EdgeFwdState S;
       Vec pre;
-      edge_tile_forward<true, BWD_X3>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
+      edge_tile_forward<true, MODE>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
       const int dg = a.rowptr[S.row + 1] - a.rowptr[S.row];
       const float inv = valid ? rcp_f((float)(dg > 1 ? dg : 1)) : 0.f;
       const float invx = valid ? (mean ? inv : 1.f) : 0.f;
@@ -896,7 +919,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       const Vec g_up = vmul(vscale(vload_vec(vec + EV_WX2 * H, q), g_sr), S.up);
       publish(1, g_up, S.m);
       Vec g_m = vscale(vload_row(A.g_aggm + (size_t)S.row * H, q), inv);
-      gemm_i<BWD_X3>(img, 3, g_up, g_m);
+      gemm_i<MODE>(img, 3, g_up, g_m);
       Vec g_m0 = g_m;
       if (att_on) {
         const float g_a = vdot(g_m, S.m0);
@@ -914,7 +937,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         publish(0, g_mp, tpark);
       }
       Vec g_t = vzero();
-      gemm_i<BWD_X3>(img, 2, g_mp, g_t);
+      gemm_i<MODE>(img, 2, g_mp, g_t);
       const Vec g_pre = vmul(g_t, pre);
       const float g_r = vdot(g_pre, vload_vec(vec + EV_WR * H, q));
       float g_d[3];
@@ -1025,7 +1048,11 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
     A.slab = wb.tab.slab;
     A.slab_b = wb.tab.slab_b;
     const size_t lds = (PC_IMG_FLOATS + EV_COUNT * H + PC_PROD * 16 * TS + 2 * PC_RING * PC_SLOT + PC_CTRL) * sizeof(float);
-    { ProfScope _ps_edge_bwd_kernel(K_EDGE_BWD, st); hipLaunchKernelGGL(edge_bwd_pc_kernel, dim3(grid), dim3(64 * PC_WAVES), lds, st, A); }
+    {
+      ProfScope _ps_edge_bwd_kernel(K_EDGE_BWD, st);
+      if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL(edge_bwd_pc_kernel<GM_BF16>, dim3(grid), dim3(64 * PC_WAVES), lds, st, A);
+      else hipLaunchKernelGGL(edge_bwd_pc_kernel<GM_X3>, dim3(grid), dim3(64 * PC_WAVES), lds, st, A);
+    }
     if ((rc = check_launch("edge_bwd_pc_kernel"))) return rc;
     return wb.finish();
   }
@@ -1114,6 +1141,7 @@ struct NodePreBwdArgs {
   int N, gravity, has_vel;
   const float *vel, *wv0;   // FastRF velocity head: coord_mlp_vel(||vel||), wv0 = coord_mlp_vel.0.weight [H,1]
   float *d_wv0, *d_bv0;
+  int bf16;
 };
 __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodePreBwdArgs a) {
   // images WVEL0 WG0 | W1AT W1BT V1AT WVEL0T WG0T (consecutive ids) resident in LDS
@@ -1123,9 +1151,10 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodeP
   auto im = [&](int id) { return limg + (id - I_WVEL0) * IMG; };
   // one GEMM's operand reads at a time: without the fences the scheduler hoists the LDS reads of all seven
   // GEMMs of a tile (448 registers) and spills
+  const bool bf = a.bf16;   // bf16 operand mode: the B operand of every product is rounded
   auto gemm_f = [&](const float *img, const Vec &in, Vec &acc) {
     __builtin_amdgcn_sched_barrier(0);
-    gemm64(img, in, acc);
+    gemm64(img, bf ? vround(in) : in, acc);
     __builtin_amdgcn_sched_barrier(0);
   };
   const int l = lane_id(), j = l & 15, q = l >> 4;
@@ -1237,7 +1266,7 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
                    L->batch, L->g_h, L->g_x, L->g_vel, wg_gzv, wg_gzg,
                    g[FASTEGNN_P_VEL2_W], g[FASTEGNN_P_VEL2_B], g[FASTEGNN_P_GRAV2_W], g[FASTEGNN_P_GRAV2_B], N, grav ? 1 : 0,
                    (p[FASTEGNN_P_VEL0_W] && !rf) ? 1 : 0, L->vel, rf ? p[FASTEGNN_P_VEL0_W] : nullptr,
-                   g[FASTEGNN_P_VEL0_W], g[FASTEGNN_P_VEL0_B]};
+                   g[FASTEGNN_P_VEL0_W], g[FASTEGNN_P_VEL0_B], has(L, FASTEGNN_F_BF16) ? 1 : 0};
   FE_REQUIRE(!rf || (L->vel && p[FASTEGNN_P_VEL0_W] && g[FASTEGNN_P_VEL0_W] && g[FASTEGNN_P_VEL0_B] && g[FASTEGNN_P_VEL2_W] &&
                      g[FASTEGNN_P_VEL2_B]),
              "node_pre_backward: FastRF needs vel and the coord_mlp_vel parameters / gradients");
@@ -1248,7 +1277,7 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   if (rc) return rc;
   const int ld_e0 = 2 * H + 1 + L->ea, ld_v0 = 2 * H + 1 + L->C;
   // edge_mlp.0 columns [0,H) <- h[row] (P), [H,2H) <- h[col] (Q), bias through P
-  WgradBatch wb(L->wg_slab, st);
+  WgradBatch wb(L->wg_slab, st, has(L, FASTEGNN_F_BF16));
   const int c0 = has(L, FASTEGNN_F_EGNN) ? 1 : 0;   // EGNN baseline: [radial | h_row | h_col | edge_attr]
   if ((rc = wb.add(L->g_P, H, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, c0, 1, g[FASTEGNN_P_EDGE0_B]))) return rc;
   if ((rc = wb.add(L->g_QX, QXLD, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, c0 + H, 1, nullptr))) return rc;

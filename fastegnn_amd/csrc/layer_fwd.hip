@@ -14,6 +14,7 @@ struct NodePreArgs {
   float *P, *QX, *A, *svel, *sgrav;
   int N, gravity, has_vel;
   const float *vel, *wv0;   // FastRF: velocity scale from ||vel|| through coord_mlp_vel.0.weight [H,1]
+  int bf16;                 // bf16 operand mode: h is rounded (the images hold rounded weights)
 };
 
 __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodePreArgs a) {
@@ -38,7 +39,8 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodeP
     const int n = tile * 16 + j;
     const bool valid = n < a.N;
     const int nc = valid ? n : a.N - 1;
-    const Vec hv = vload_row(a.h + (size_t)nc * H, q);
+    Vec hv = vload_row(a.h + (size_t)nc * H, q);
+    if (a.bf16) hv = vround(hv);
     Vec acc = vload_vec(vec, q);
     gemm64_f(img + 0 * IMG, hv, acc);
     if (valid) vstore_row(a.P + (size_t)n * H, q, acc);
@@ -85,7 +87,7 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
                 p[FASTEGNN_P_VEL2_B], p[FASTEGNN_P_GRAV0_B], p[FASTEGNN_P_GRAV2_W], p[FASTEGNN_P_GRAV2_B],
                 L->P, L->QX, L->A, L->svel, L->sgrav, L->N, grav ? 1 : 0,
                 (p[FASTEGNN_P_VEL0_W] && !has(L, FASTEGNN_F_RF)) ? 1 : 0,
-                L->vel, has(L, FASTEGNN_F_RF) ? p[FASTEGNN_P_VEL0_W] : nullptr};
+                L->vel, has(L, FASTEGNN_F_RF) ? p[FASTEGNN_P_VEL0_W] : nullptr, has(L, FASTEGNN_F_BF16) ? 1 : 0};
   FE_REQUIRE(!has(L, FASTEGNN_F_RF) || (L->vel && p[FASTEGNN_P_VEL0_W] && p[FASTEGNN_P_VEL0_B] && p[FASTEGNN_P_VEL2_W] &&
                                          p[FASTEGNN_P_VEL2_B]),
              "node_pre_forward: FastRF needs vel and the coord_mlp_vel parameters");
@@ -165,7 +167,7 @@ int graph_xsum(const fastegnn_layer_t *L, hipStream_t st) {
 struct GraphPreArgs {
   const float *xsum, *Z, *HvT, *V0W, *V0B;
   float *Bc;
-  int B, C;
+  int B, C, bf16;
 };
 __global__ __launch_bounds__(256) void graph_pre_fwd_kernel(GraphPreArgs a) {
   extern __shared__ float sm[];
@@ -188,14 +190,16 @@ __global__ __launch_bounds__(256) void graph_pre_fwd_kernel(GraphPreArgs a) {
     const float *w = a.V0W + (size_t)o * ld;
     const float *hv = a.HvT + ((size_t)b * C + c) * H;
     float acc = a.V0B[o];
-    for (int k = 0; k < H; ++k) acc += w[H + k] * hv[k];
-    for (int d = 0; d < C; ++d) acc += w[2 * H + 1 + d] * mX[d * C + c];
+    if (a.bf16) { for (int k = 0; k < H; ++k) acc += round_bf(w[H + k]) * round_bf(hv[k]); }   // V1b Hv: bf16 operands
+    else { for (int k = 0; k < H; ++k) acc += w[H + k] * hv[k]; }
+    for (int d = 0; d < C; ++d) acc += w[2 * H + 1 + d] * mX[d * C + c];   // Gram columns: always fp32
     a.Bc[((size_t)b * C + c) * H + o] = acc;
   }
 }
 int graph_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(L->xsum && L->Z && L->HvT && L->Bc, "graph_pre_forward: null buffer");
-  GraphPreArgs a{L->xsum, L->Z, L->HvT, L->params[FASTEGNN_P_VIRT0_W], L->params[FASTEGNN_P_VIRT0_B], L->Bc, L->B, L->C};
+  GraphPreArgs a{L->xsum, L->Z, L->HvT, L->params[FASTEGNN_P_VIRT0_W], L->params[FASTEGNN_P_VIRT0_B], L->Bc, L->B, L->C,
+                 has(L, FASTEGNN_F_BF16) ? 1 : 0};
   const size_t lds = (size_t)(3 * L->C + L->C * L->C) * sizeof(float);
   { ProfScope _ps_graph_pre_fwd_kernel(K_GRAPH_PRE_FWD, st); hipLaunchKernelGGL(graph_pre_fwd_kernel, dim3(L->B), dim3(256), lds, st, a); }
   return check_launch("graph_pre_fwd_kernel");
@@ -207,14 +211,14 @@ int graph_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // One wave walks an edge-balanced chunk of CSR rows in 16-edge tiles; sums stay in registers
 // until the row changes, so every row is written exactly once (no atomics, deterministic).
 // =====================================================================================
-constexpr int EDGE_FWD_IMG_FLOATS = FWD_X3 ? 2 * IMG3 : 2 * IMG;
+constexpr int EDGE_FWD_IMG_FLOATS = 2 * IMG3;
+template <int MODE>
 __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs a, int C) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *img = lds;                              // W2, WX1 (fp32 or split images)
   float *vec = lds + EDGE_FWD_IMG_FLOATS;        // EV_COUNT vectors
   float *tiles = vec + EV_COUNT * H;             // per wave: [16][TS] + [16][4]
-  if constexpr (FWD_X3) load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, C, I_W2), 2);
-  else load_images(img, a.wpack + (size_t)I_W2 * IMG, 2);
+  load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, C, I_W2), 2);
   edge_load_vecs(vec, a);
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
@@ -223,16 +227,11 @@ __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs 
   const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);
   FE_T0()
-#if FE_EDGE_RANGE
   // this wave's share: a contiguous run of whole rows holding ~E/nwaves edges (chunk_row marks the row
   // boundary nearest to every CHUNK_EDGES-th edge)
   const int c0 = (int)((long)wave * a.n_chunks / nwaves), c1 = (int)((long)(wave + 1) * a.n_chunks / nwaves);
   {
     const int r0 = a.chunk_row[c0], r1 = a.chunk_row[c1];
-#else
-  for (int ch = wave; ch < a.n_chunks; ch += nwaves) {
-    const int r0 = a.chunk_row[ch], r1 = a.chunk_row[ch + 1];
-#endif
     if (r0 < r1) {
       const int e0 = a.rowptr[r0], e1 = a.rowptr[r1];
       int cur = -1;
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs 
         if (base + 16 < e1) edge_load_idx(a, min(base + 16 + j, e1 - 1), nxt_i);   // next tile's indices in flight
         EdgeFwdState S;
         Vec pre;
-        edge_tile_forward<false, FWD_X3>(a, img, vec, cur_i, q, S, pre FE_TA);
+        edge_tile_forward<false, MODE>(a, img, vec, cur_i, q, S, pre FE_TA);
         cur_i = nxt_i;
         tile_store(mt, j, q, S.m);
         if (q == 0) {
@@ -310,10 +309,13 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE((size_t)L->N * QXLD < (1u << 30) && (size_t)g.n_src * QXLD < (1u << 30) && (size_t)g.n_edges * 8 < (1u << 30),
              "edge_forward: tables exceed the 32-bit offset range of the gather path");
   int grid = cdiv(cdiv(g.n_edges, 256), EDGE_FWD_WAVES);   // at least sixteen tiles per wave
-  const int max_grid = FWD_X3 ? 256 : 512;
-  if (grid > max_grid) grid = max_grid;
+  if (grid > 256) grid = 256;
   const size_t lds = (EDGE_FWD_IMG_FLOATS + EV_COUNT * H + EDGE_FWD_WAVES * (16 * TS + 64)) * sizeof(float);
-  { ProfScope _ps_edge_fwd_kernel(K_EDGE_FWD, st); hipLaunchKernelGGL(edge_fwd_kernel, dim3(grid), dim3(64 * EDGE_FWD_WAVES), lds, st, a, L->C); }
+  {
+    ProfScope _ps_edge_fwd_kernel(K_EDGE_FWD, st);
+    if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL(edge_fwd_kernel<GM_BF16>, dim3(grid), dim3(64 * EDGE_FWD_WAVES), lds, st, a, L->C);
+    else hipLaunchKernelGGL(edge_fwd_kernel<GM_X3>, dim3(grid), dim3(64 * EDGE_FWD_WAVES), lds, st, a, L->C);
+  }
   return check_launch("edge_fwd_kernel");
 }
 
@@ -325,7 +327,8 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // =====================================================================================
 
 // LDS: images V2, WXV0, WXX0 | W3c[c] stage (split mode) | vectors | per-wave transpose tiles | pools
-constexpr int VIRT_FWD_IMG_FLOATS = FWD_X3 ? 4 * IMG3 : 3 * IMG;
+constexpr int VIRT_FWD_IMG_FLOATS = 4 * IMG3;
+template <int MODE>
 __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C;
@@ -335,8 +338,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   float *tiles = vec + VV_COUNT * H;             // per wave [16][TS]
   float *poolV_l = tiles + VIRT_WAVES * 16 * TS; // [C][64]
   float *poolX_l = poolV_l + C * H;              // [3][C]
-  if constexpr (FWD_X3) load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, C, I_V2), 3);
-  else load_images(img, a.wpack + (size_t)I_V2 * IMG, 3);
+  load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, C, I_V2), 3);
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) poolV_l[i] = 0.f;
   __syncthreads();
@@ -365,8 +367,8 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   // workgroup refills once per channel (all waves walk the channels in step); the next channel's
   // image is fetched into registers while the current one is being used.
   constexpr int STG = IMG3 / 4 / (64 * VIRT_WAVES);   // 16-byte pieces per thread
-  static_assert(!FWD_X3 || STG * 4 * 64 * VIRT_WAVES == IMG3, "stage copy must tile the image");
-  u32x4 pre_w[FWD_X3 ? STG : 1];
+  static_assert(STG * 4 * 64 * VIRT_WAVES == IMG3, "stage copy must tile the image");
+  u32x4 pre_w[STG];
   auto fetch_w3c = [&](int c) {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_x3(a.wpack, C, img_w3c(c)));
 #pragma unroll
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   for (int tb = t_lo; tb < t_hi; tb += VIRT_WAVES) {
     // a single left-over tile is dealt to the waves by channel (wave w takes c = w, w + VIRT_WAVES, ...); the
     // channel sums of the node-MLP accumulator and of the coordinate update are combined through LDS
-    const bool split = FWD_X3 && t_hi - tb == 1 && C >= VIRT_WAVES;
+    const bool split = t_hi - tb == 1 && C >= VIRT_WAVES;
     const bool own = !split || wv == 0;
     const int n0 = tb * 16, nend = min(a.N, min(t_hi, tb + VIRT_WAVES) * 16);
     const int bfirst = a.batch[n0], blast = a.batch[nend - 1];
@@ -406,20 +408,18 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     }
     float transv[3] = {0.f, 0.f, 0.f};
     Vec nodeacc = own ? vload_vec(vec + VV_B3 * H, q) : vzero();
-    if constexpr (FWD_X3) { if (C > 0 && !rf && !split) fetch_w3c(0); }
+    if (C > 0 && !rf && !split) fetch_w3c(0);
     const int c_step = split ? VIRT_WAVES : 1;
     for (int c = split ? wv : 0; c < C; c += c_step) {
-      if constexpr (FWD_X3) {
-        if (!rf && !split) {
-          __syncthreads();          // every wave is done with the previous channel's stage
-          commit_w3c();
-          __syncthreads();
-          if (c + 1 < C) fetch_w3c(c + 1);
-        }
+      if (!rf && !split) {
+        __syncthreads();          // every wave is done with the previous channel's stage
+        commit_w3c();
+        __syncthreads();
+        if (c + 1 < C) fetch_w3c(c + 1);
       }
       if (active) {
-        VirtFwdState S;
-        virt_tile_forward<FWD_X3>(a, img, vec, Ai, xi, b, c, q, S);
+        VirtFwdState<MODE> S;
+        virt_tile_forward<MODE>(a, img, vec, Ai, xi, b, c, q, S);
         transv[0] -= S.vd[0] * S.sx;
         transv[1] -= S.vd[1] * S.sx;
         transv[2] -= S.vd[2] * S.sx;
@@ -458,12 +458,8 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
           }
         }
         if (!rf) {
-          if constexpr (FWD_X3) {
-            if (split) gemm64_x3(wpack_x3(a.wpack, C, img_w3c(c)), S.vs, nodeacc);   // the stage serves one channel at a time
-            else gemm64_x3(stage, S.vs, nodeacc);
-          } else {
-            gemm64(a.wpack + (size_t)img_w3c(c) * IMG, S.v, nodeacc);
-          }
+          if (split) gemm_op<MODE>(wpack_x3(a.wpack, C, img_w3c(c)), 0, S.vs, nodeacc);   // the stage serves one channel at a time
+          else gemm_op<MODE>(stage, 0, S.vs, nodeacc);
         }
       }
     }
@@ -495,8 +491,8 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     if (active && !rf && own) {
       // node_model: node_mlp.0 on [h | agg | flat(v) | node_attr]  (:153-166)
       const Vec hv = vload_row(a.h + (size_t)nc * H, q);
-      gemm64(a.wpack + (size_t)I_W3A * IMG, hv, nodeacc);
-      gemm64(a.wpack + (size_t)I_W3B * IMG, vload_row(a.aggm + (size_t)nc * H, q), nodeacc);
+      gemm64_m<MODE>(a.wpack + (size_t)I_W3A * IMG, hv, nodeacc);
+      gemm64_m<MODE>(a.wpack + (size_t)I_W3B * IMG, vload_row(a.aggm + (size_t)nc * H, q), nodeacc);
       if (a.na > 0) {
         const int ld = 2 * H + H * C + a.na;
         for (int k = 0; k < a.na; ++k) {
@@ -510,7 +506,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       }
       if (valid) vstore_row(a.npre + (size_t)n * H, q, nodeacc);
       Vec out = vload_vec(vec + VV_B4 * H, q);
-      gemm64(a.wpack + (size_t)I_W4 * IMG, vsilu(nodeacc), out);
+      gemm64_m<MODE>(a.wpack + (size_t)I_W4 * IMG, vsilu(nodeacc), out);
       if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
       if (valid) vstore_row(a.h_out + (size_t)n * H, q, out);
     }
@@ -549,7 +545,12 @@ int virt_forward(const fastegnn_layer_t *L, hipStream_t st) {
   VirtArgs a = make_virt_args(L);
   const int ntg = cdiv(L->N, 16 * VIRT_WAVES);
   int grid = ntg < 256 ? ntg : 256;   // one workgroup per CU (LDS), each with an equal share of the tiles
-  { ProfScope _ps_virt_fwd_kernel(K_VIRT_FWD, st); hipLaunchKernelGGL(virt_fwd_kernel, dim3(grid), dim3(64 * VIRT_WAVES), virt_lds_bytes(L->C, 3) + (VIRT_FWD_IMG_FLOATS - 3 * IMG) * sizeof(float), st, a); }
+  {
+    ProfScope _ps_virt_fwd_kernel(K_VIRT_FWD, st);
+    const size_t lds = virt_lds_bytes(L->C, 3) + (VIRT_FWD_IMG_FLOATS - 3 * IMG) * sizeof(float);
+    if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL(virt_fwd_kernel<GM_BF16>, dim3(grid), dim3(64 * VIRT_WAVES), lds, st, a);
+    else hipLaunchKernelGGL(virt_fwd_kernel<GM_X3>, dim3(grid), dim3(64 * VIRT_WAVES), lds, st, a);
+  }
   return check_launch("virt_fwd_kernel");
 }
 
@@ -563,6 +564,7 @@ struct GraphPostArgs {
   int B, C, flags;
 };
 __global__ __launch_bounds__(256) void graph_post_fwd_kernel(GraphPostArgs a) {
+  const bool bf = a.flags & FASTEGNN_F_BF16;   // bf16 operand mode: activations rounded, images hold rounded weights
   const int l = lane_id(), j = l & 15, q = l >> 4;
   const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int M = a.B * a.C, ntiles = (M + 15) >> 4;
@@ -583,10 +585,11 @@ __global__ __launch_bounds__(256) void graph_post_fwd_kernel(GraphPostArgs a) {
     const Vec hv = vload_row(a.HvT + (size_t)mc * H, q);
     const Vec pm = vscale(vload_row(a.poolV + (size_t)mc * H, q), inv);
     Vec z5 = vload_vec(a.b5, q);
-    gemm64(a.wpack + (size_t)I_W5A * IMG, hv, z5);
-    gemm64(a.wpack + (size_t)I_W5B * IMG, pm, z5);
+    gemm64(a.wpack + (size_t)I_W5A * IMG, bf ? vround(hv) : hv, z5);
+    gemm64(a.wpack + (size_t)I_W5B * IMG, bf ? vround(pm) : pm, z5);
     Vec out = vload_vec(a.b6, q);
-    gemm64(a.wpack + (size_t)I_W6 * IMG, vsilu(z5), out);
+    const Vec u5 = vsilu(z5);
+    gemm64(a.wpack + (size_t)I_W6 * IMG, bf ? vround(u5) : u5, out);
     if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
     if (valid) vstore_row(a.HvT_out + (size_t)m * H, q, out);
   }

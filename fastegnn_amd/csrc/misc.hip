@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
     ot[s] = ((unsigned)(4 * s + q) * (unsigned)a.ldt + 4u * i) * 4u;
   }
   const bool want_bias = a.db != nullptr;
+  const bool rnd = a.round != 0;
   auto issue = [&](long m) {
     const char *gb = reinterpret_cast<const char *>(G + (size_t)m * a.ldg);
     const char *tb = reinterpret_cast<const char *>(T + (size_t)m * a.ldt);
@@ -153,9 +154,17 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
         av[t] = gt[(4 * s + q) * WTS + 16 * t + i];
         bv[t] = tt[(4 * s + q) * WTS + 16 * t + i];
       }
+      if (rnd) {   // bf16 operand mode (wave-uniform): products of bf16 values are exact in fp32-input MFMA
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (want_bias) bsum[t] += av[t];   // the bias gradient sums the unrounded rows
+          av[t] = round_bf(av[t]);
+          bv[t] = round_bf(bv[t]);
+        }
+      }
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        if (want_bias) bsum[ti] += av[ti];
+        if (want_bias && !rnd) bsum[ti] += av[ti];
 #pragma unroll
         for (int tk = 0; tk < 4; ++tk)
           acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti], bv[tk], acc[ti][tk], 0, 0, 0);
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
   }
 }
 
-WgradBatch::WgradBatch(float *slab, hipStream_t st_) : st(st_) {
+WgradBatch::WgradBatch(float *slab, hipStream_t st_, bool round_bf16) : st(st_), round(round_bf16) {
   tab.n_jobs = 0;
   tab.slab = slab;
   tab.slab_b = slab ? slab + (size_t)WG_SLABS * IMG : nullptr;
@@ -252,6 +261,7 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   j.ldg = ldg; j.ldt = ldt; j.lddw = lddw; j.c0 = c0; j.ks = ks; j.kmax = kmax;
   j.rows_per_wg = (int)rows; j.nsplit = (int)nsplit; j.nb = nb;
   j.wg_begin = n_wg; j.slab_begin = n_slab;
+  j.round = round ? 1 : 0;
   n_wg += (int)(nsplit * nb);
   n_slab += (int)(nsplit * nb);
   if (nb > max_nb) max_nb = nb;
@@ -267,6 +277,7 @@ int WgradBatch::add_slabs(float *dW, int lddw, int c0, int ks, float *db, int ns
   j.G = nullptr; j.T = nullptr; j.dW = dW; j.db = db; j.M = 0; j.sG = j.sT = j.sW = 0;
   j.ldg = j.ldt = H; j.lddw = lddw; j.c0 = c0; j.ks = ks; j.kmax = 64;
   j.rows_per_wg = 0; j.nsplit = nsplit; j.nb = 1;
+  j.round = 0;
   j.wg_begin = n_wg; j.slab_begin = n_slab;   // contributes no workgroups to wgrad_tn_kernel
   *slab_begin = n_slab;
   n_slab += nsplit;

@@ -12,7 +12,7 @@ struct PackDesc {
 struct PackArgs {
   const float *p[FASTEGNN_P_COUNT];
   float *wpack;
-  int C, ea, na, egnn, rf;
+  int C, ea, na, egnn, rf, bf16;
 };
 
 __device__ __forceinline__ PackDesc pack_desc(const PackArgs &a, int id) {
@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
   unsigned *d3 = const_cast<unsigned *>(wpack_x3(a.wpack, a.C, id));
   auto at = [&](int o, int k) -> float {
     if (!d.src) return 0.f;
-    return d.transposed ? d.src[(size_t)k * d.ld + d.c0 + o * d.ks] : d.src[(size_t)o * d.ld + d.c0 + k * d.ks];
+    const float w = d.transposed ? d.src[(size_t)k * d.ld + d.c0 + o * d.ks] : d.src[(size_t)o * d.ld + d.c0 + k * d.ks];
+    return a.bf16 ? round_bf(w) : w;   // bf16 operand mode: every image holds the bf16-rounded weights
   };
   for (int idx = threadIdx.x; idx < IMG; idx += 256) {
     int o = idx >> 6, k = idx & 63;
@@ -104,6 +105,7 @@ int pack_weights(const fastegnn_layer_t *L, hipStream_t st) {
   a.na = L->na;
   a.egnn = has(L, FASTEGNN_F_EGNN) ? 1 : 0;
   a.rf = has(L, FASTEGNN_F_RF) ? 1 : 0;
+  a.bf16 = has(L, FASTEGNN_F_BF16) ? 1 : 0;
   { ProfScope _ps_pack_kernel(K_PACK, st); hipLaunchKernelGGL(pack_kernel, dim3(I_FIXED + 2 * L->C), dim3(256), 0, st, a); }
   return check_launch("pack_kernel");
 }

@@ -5,21 +5,10 @@
 
 namespace fe {
 
-// FE_FWD_X3: the 64x64 layers of the forward edge / virtual kernels run as bf16x3 products on the
-// matrix pipe (common.h, gemm64_x3) instead of fp32-input MFMA on the vector ALUs.
-#ifndef FE_FWD_X3
-#define FE_FWD_X3 1
-#endif
-constexpr bool FWD_X3 = FE_FWD_X3;
-#ifndef FE_BWD_X3
-#define FE_BWD_X3 1   // same for the backward edge kernel (recompute + the two transposed layers)
-#endif
-constexpr bool BWD_X3 = FE_BWD_X3;
-#ifndef FE_EDGE_RANGE
-#define FE_EDGE_RANGE 1   // waves own contiguous row ranges (else: round-robin over the row chunks)
-#endif
+// The 64x64 layers of the edge / virtual kernels read split (bf16) weight images and run on the matrix pipe: as
+// bf16x3 products (fp32-grade, GM_X3) or, in the bf16 operand mode, as one bf16 product (GM_BF16); common.h.
 #ifndef FE_EDGE_FWD_WAVES
-#define FE_EDGE_FWD_WAVES (FE_FWD_X3 ? 16 : 8)
+#define FE_EDGE_FWD_WAVES 16
 #endif
 constexpr int EDGE_FWD_WAVES = FE_EDGE_FWD_WAVES;   // 48 KB of split images are shared by more waves
 #ifndef FE_NODE_PRE_WAVES
@@ -105,12 +94,13 @@ __device__ __forceinline__ void edge_gather(const EdgeArgs &a, const EdgeIdx &I,
 // forward math of one 16-edge tile (shared with the backward kernel for recomputation).
 // KEEP_D: pre, S.mp and S.up return silu'(.) of the pre-activations instead of the pre-activations
 // (the adjoint needs only the derivatives; one sigmoid serves both).
-// X3: img holds split (bf16x3) images and the two 64x64 layers run on the bf16 matrix pipe (gemm64_x3).
-template <bool X3>
+// MODE (GemmMode): GM_F32 = fp32 images / fp32-input MFMA; GM_X3 = split images, bf16x3 products on the matrix pipe;
+// GM_BF16 = split images of bf16-rounded weights, one bf16 product of the RNE-rounded activation (FASTEGNN_F_BF16).
+template <int MODE>
 __device__ __forceinline__ void gemm_i(const void *img, int i, const Vec &in, Vec &acc) {
-  if constexpr (X3) gemm64_x3(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
-  else gemm64(reinterpret_cast<const float *>(img) + i * IMG, in, acc);
+  gemm_op<MODE>(img, i, make_operand<MODE>(in), acc);
 }
+
 // part 1: consumes the gathered operands (geometry + first-layer pre-activation)
 __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *vec, const EdgeIdx &I, const EdgeRows &G,
                                               int q, EdgeFwdState &S, Vec &pre FE_TP) {
@@ -139,13 +129,13 @@ __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *ve
   FE_T(1)   // gathered rows arrived, pre-activation formed
 }
 // part 2: the two 64x64 layers and the coordinate head
-template <bool KEEP_D, bool X3 = false>
+template <bool KEEP_D, int MODE = GM_F32>
 __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img, const float *vec, int q, EdgeFwdState &S,
                                               Vec &pre FE_TP) {
   S.t = KEEP_D ? vsilu_keep_d(pre) : vsilu(pre);
   FE_T(2)   // silu 1
   S.mp = vload_vec(vec + EV_B2 * H, q);
-  gemm_i<X3>(img, 0, S.t, S.mp);
+  gemm_i<MODE>(img, 0, S.t, S.mp);
   FE_T(3)   // gemm 1
   S.m0 = KEEP_D ? vsilu_keep_d(S.mp) : vsilu(S.mp);
   if (a.flags & FASTEGNN_F_ATTENTION) {
@@ -157,20 +147,20 @@ __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img
   }
   FE_T(2)
   S.up = vload_vec(vec + EV_BX1 * H, q);
-  gemm_i<X3>(img, 1, S.m, S.up);
+  gemm_i<MODE>(img, 1, S.m, S.up);
   FE_T(3)
   S.u = KEEP_D ? vsilu_keep_d(S.up) : vsilu(S.up);
   const float sraw = vdot(S.u, vload_vec(vec + EV_WX2 * H, q)) + (a.bx2 ? a.bx2[0] : 0.f);
   S.s = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sraw) : sraw;
   FE_T(4)   // silu 3 + head dot
 }
-template <bool KEEP_D, bool X3 = false>
+template <bool KEEP_D, int MODE = GM_F32>
 __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const void *img, const float *vec,
                                                   const EdgeIdx &I, int q, EdgeFwdState &S, Vec &pre FE_TP) {
   EdgeRows G;
   edge_gather(a, I, q, G);
   edge_tile_pre(a, vec, I, G, q, S, pre FE_TA);
-  edge_tile_mlp<KEEP_D, X3>(a, img, vec, q, S, pre FE_TA);
+  edge_tile_mlp<KEEP_D, MODE>(a, img, vec, q, S, pre FE_TA);
 }
 
 inline EdgeArgs make_edge_args(const fastegnn_layer_t *L) {
@@ -194,9 +184,10 @@ struct VirtArgs {
 constexpr int VV_WVR = 0, VV_C2 = 1, VV_BXV0 = 2, VV_WXV2 = 3, VV_BXX0 = 4, VV_WXX2 = 5, VV_ATT = 6, VV_B3 = 7,
               VV_B4 = 8, VV_COUNT = 9;
 
+template <int MODE>
 struct VirtFwdState {
   Vec pre, t, vp, v0, v, uxp, uXp;
-  Split vs;
+  typename OperandOf<MODE>::type vs;   // v as the B operand of the two coordinate heads and of the node-MLP block
   float vd[3], vr, att, sx, sX;
 };
 
@@ -217,9 +208,9 @@ __device__ __forceinline__ void virt_load_vecs(float *vec, const VirtArgs &a) {
 }
 
 // forward math of one (16-node tile, channel c); img = resident V2, WXV0, WXX0
-template <bool X3 = false>
+template <int MODE = GM_F32>
 __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void *img, const float *vec, const Vec &Ai,
-                                                  const float xi[3], int b, int c, int q, VirtFwdState &S) {
+                                                  const float xi[3], int b, int c, int q, VirtFwdState<MODE> &S) {
   const int C = a.C;
   const float *Zb = a.Z + (size_t)b * 3 * C;
   S.vd[0] = Zb[c] - xi[0];
@@ -231,7 +222,7 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void 
   vaxpy(S.pre, S.vr, vload_vec(vec + VV_WVR * H, q));
   S.t = vsilu(S.pre);
   S.vp = vload_vec(vec + VV_C2 * H, q);
-  gemm_i<X3>(img, 0, S.t, S.vp);
+  gemm_i<MODE>(img, 0, S.t, S.vp);
   S.v0 = vsilu(S.vp);
   if (a.flags & FASTEGNN_F_ATTENTION) {
     S.att = sigmoid_f(vdot(S.v0, vload_vec(vec + VV_ATT * H, q)) + a.attb[0]);
@@ -241,17 +232,12 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void 
     S.v = S.v0;
   }
   S.uxp = vload_vec(vec + VV_BXV0 * H, q);
-  if constexpr (X3) {
-    S.vs = vsplit(S.v);   // one split feeds both coordinate heads and the node MLP
-    gemm64_x3(reinterpret_cast<const unsigned *>(img) + 1 * IMG3, S.vs, S.uxp);
-  } else {
-    gemm64(reinterpret_cast<const float *>(img) + 1 * IMG, S.v, S.uxp);
-  }
+  S.vs = make_operand<MODE>(S.v);   // one split / rounding feeds both coordinate heads and the node MLP
+  gemm_op<MODE>(img, 1, S.vs, S.uxp);
   float sr = vdot(vsilu(S.uxp), vload_vec(vec + VV_WXV2 * H, q));
   S.sx = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;
   S.uXp = vload_vec(vec + VV_BXX0 * H, q);
-  if constexpr (X3) gemm64_x3(reinterpret_cast<const unsigned *>(img) + 2 * IMG3, S.vs, S.uXp);
-  else gemm64(reinterpret_cast<const float *>(img) + 2 * IMG, S.v, S.uXp);
+  gemm_op<MODE>(img, 2, S.vs, S.uXp);
   sr = vdot(vsilu(S.uXp), vload_vec(vec + VV_WXX2 * H, q));
   S.sX = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;
 }

@@ -191,6 +191,7 @@ class _Spec:
         flags |= K.F_TANH if model.tanh else 0
         flags |= K.F_RESIDUAL if model.residual else 0
         flags |= K.F_GRAVITY if model.gravity is not None else 0
+        flags |= K.F_BF16 if getattr(model, "mlp_dtype", torch.float32) == torch.bfloat16 else 0
         self.flags = flags | model._extra_flags
         self.gravity = [float(v) for v in model.gravity] if model.gravity is not None else [0.0, 0.0, 0.0]
         # parameter order handed to the autograd function
@@ -340,8 +341,15 @@ class FastEGNN(nn.Module):
 
     def __init__(self, node_feat_nf, node_attr_nf, edge_attr_nf, hidden_nf, virtual_channels, device='cpu',
                  act_fn=nn.SiLU(), n_layers=4, residual=True, attention=False, normalize=False, tanh=False,
-                 gravity=None):
+                 gravity=None, *, mlp_dtype=torch.float32):
+        """Reference signature (models/FastEGNN.py:227-228) plus one keyword-only extension: ``mlp_dtype`` --
+        ``torch.float32`` (default: fp32-grade products) or ``torch.bfloat16`` (BASELINE configs[2]: the operands of
+        every 64-wide contraction are rounded to bf16, fp32 accumulate; parameters, coordinates and all reductions
+        stay fp32 -- FASTEGNN_F_BF16 in include/fastegnn_hip.h)."""
         super().__init__()
+        if mlp_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("fastegnn_amd: mlp_dtype must be torch.float32 or torch.bfloat16")
+        self.mlp_dtype = mlp_dtype
         assert virtual_channels > 0, f'Channels of virtual node must greater than 0 (got {virtual_channels})'
         if hidden_nf != H:
             raise NotImplementedError(f"fastegnn_amd: hidden_nf must be {H} in this build (got {hidden_nf})")

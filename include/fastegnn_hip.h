@@ -58,7 +58,14 @@ enum {
   /* FastRF reduced layer (models/FastRF.py:155-186) on the same kernels: node_mlp / node_mlp_virtual are
    * absent (h and the virtual features pass through unchanged, their parameter slots are null) and the
    * velocity scale is coord_mlp_vel(||vel||) with coord_mlp_vel.0.weight of shape [H,1] (:76-80,:139) */
-  FASTEGNN_F_RF = 128
+  FASTEGNN_F_RF = 128,
+  /* bf16 operand mode (BASELINE configs[2]; the reference has no reduced-precision mode): BOTH operands of every
+   * 64-wide contraction -- the [64,64] weights and the 64-column blocks of edge_mlp.0 / edge_mlp_virtual.0 / node_mlp.0 /
+   * node_mlp_virtual.0, in the forward, the input-gradient and the weight-gradient products -- are rounded to bf16
+   * (round to nearest even) and multiplied on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Coordinates, radial /
+   * vr / Gram terms and their weight columns, edge_attr / node_attr columns, the [1,64] heads, attention gates, biases,
+   * activations, segment sums and pools stay fp32.  Mirror: oracle/factored.py with Config.bf16. */
+  FASTEGNN_F_BF16 = 256
 };
 
 /* Per-layer parameter slots: the reference state_dict tensors of gcl_<i>, untouched

@@ -25,6 +25,33 @@ from .fastegnn_ref import Config, Params
 
 H = 64
 
+# bf16 operand mode (Config.bf16; the product's FASTEGNN_F_BF16): BOTH operands of every 64-wide contraction that the
+# kernels run on the matrix cores -- the [64,64] weights and the 64-column blocks of edge_mlp.0 / edge_mlp_virtual.0 /
+# node_mlp.0 / node_mlp_virtual.0, in the forward products, the transposed (input-gradient) products and the weight-
+# gradient products -- are rounded to bf16 (round to nearest even) and multiplied exactly with fp32 (here: the working
+# dtype's) accumulation.  Everything else stays in the working precision: coordinates, radial / vr / Gram terms and
+# their weight columns, edge_attr / node_attr columns, the [1,64] heads, attention gates, biases, activations,
+# segment sums and pools (hard part 7).
+_BF16 = False
+
+
+def R(t):
+    """operand rounding of the bf16 mode (identity otherwise)."""
+    return t.to(torch.bfloat16).to(t.dtype) if _BF16 else t
+
+
+class _mode:
+    def __init__(self, cfg):
+        self.on = bool(getattr(cfg, "bf16", False))
+
+    def __enter__(self):
+        global _BF16
+        self.prev, _BF16 = _BF16, self.on
+
+    def __exit__(self, *a):
+        global _BF16
+        _BF16 = self.prev
+
 
 def silu(z):
     return z * torch.sigmoid(z)
@@ -119,34 +146,36 @@ def _zeros_like_params(p: Params, L: str):
 # S1 node_pre
 # --------------------------------------------------------------------------
 def node_pre_fwd(w: LayerW, cfg: Config, h):
-    P = h @ w.W1a.T + w.b1
-    Q = h @ w.W1b.T
-    A = h @ w.V1a.T
-    svel = silu(h @ w.Wv0.T + w.bv0) @ w.wv2 + w.bv2
+    hr = R(h)
+    P = hr @ R(w.W1a).T + w.b1
+    Q = hr @ R(w.W1b).T
+    A = hr @ R(w.V1a).T
+    svel = silu(hr @ R(w.Wv0).T + w.bv0) @ w.wv2 + w.bv2
     sgrav = None
     if cfg.gravity is not None:
-        sgrav = silu(h @ w.Wg0.T + w.bg0) @ w.wg2 + w.bg2
+        sgrav = silu(hr @ R(w.Wg0).T + w.bg0) @ w.wg2 + w.bg2
     return P, Q, A, svel, sgrav
 
 
 def node_pre_bwd(w: LayerW, cfg: Config, G: Dict[str, torch.Tensor], L: str, h, g_P, g_Q, g_A, g_svel, g_sgrav):
     """returns d/dh contribution; accumulates weight grads into G."""
-    g_h = g_P @ w.W1a + g_Q @ w.W1b + g_A @ w.V1a
+    hr = R(h)
+    g_h = R(g_P) @ R(w.W1a) + R(g_Q) @ R(w.W1b) + R(g_A) @ R(w.V1a)
     dW1 = G[f"{L}.edge_mlp.0.weight"]
-    dW1[:, :H] += g_P.T @ h
-    dW1[:, H:2 * H] += g_Q.T @ h
+    dW1[:, :H] += R(g_P).T @ hr
+    dW1[:, H:2 * H] += R(g_Q).T @ hr
     G[f"{L}.edge_mlp.0.bias"] += g_P.sum(0)
-    G[f"{L}.edge_mlp_virtual.0.weight"][:, :H] += g_A.T @ h
+    G[f"{L}.edge_mlp_virtual.0.weight"][:, :H] += R(g_A).T @ hr
 
     def head(W0, b0, w2, g_s, name):
-        z = h @ W0.T + b0
+        z = hr @ R(W0).T + b0
         u = silu(z)
         G[f"{L}.{name}.2.weight"][0] += g_s @ u
         G[f"{L}.{name}.2.bias"][0] += g_s.sum()
         g_z = (g_s.unsqueeze(1) * w2) * dsilu(z)
-        G[f"{L}.{name}.0.weight"] += g_z.T @ h
+        G[f"{L}.{name}.0.weight"] += R(g_z).T @ hr
         G[f"{L}.{name}.0.bias"] += g_z.sum(0)
-        return g_z @ W0
+        return R(g_z) @ R(W0)
 
     g_h = g_h + head(w.Wv0, w.bv0, w.wv2, g_svel, "coord_mlp_vel")
     if cfg.gravity is not None:
@@ -168,7 +197,7 @@ def graph_pre_fwd(w: LayerW, cfg: Config, x, gptr, Z, HvT):
     mz = Z - xbar.unsqueeze(-1)                         # [B,3,C]
     mX = torch.einsum("bkc,bkd->bcd", mz, mz)           # [B,C,C]
     # feature vector of channel c is column c of mX: mX[b][:, c]
-    Bc = HvT @ w.V1b.T + mX.transpose(1, 2) @ w.V1d.T + w.c1       # [B,C,H]
+    Bc = R(HvT) @ R(w.V1b).T + mX.transpose(1, 2) @ w.V1d.T + w.c1       # [B,C,H]
     return xbar, mX, Bc
 
 
@@ -180,10 +209,10 @@ def graph_pre_bwd(w: LayerW, cfg: Config, G, L: str, x, gptr, Z, HvT, g_Bc):
     C = Z.size(2)
     g2 = g_Bc.reshape(-1, H)
     dV1 = G[f"{L}.edge_mlp_virtual.0.weight"]
-    dV1[:, H:2 * H] += g2.T @ HvT.reshape(-1, H)
+    dV1[:, H:2 * H] += R(g2).T @ R(HvT).reshape(-1, H)
     dV1[:, 2 * H + 1:] += g2.T @ mX.transpose(1, 2).reshape(-1, C)
     G[f"{L}.edge_mlp_virtual.0.bias"] += g2.sum(0)
-    g_HvT = g_Bc @ w.V1b
+    g_HvT = R(g_Bc) @ R(w.V1b)
     g_mXT = g_Bc @ w.V1d                                  # [B,C(c),C(c')] = d/d mX[b][c',c]
     g_mX = g_mXT.transpose(1, 2)
     g_mz = torch.einsum("bkd,bcd->bkc", mz, g_mX + g_mX.transpose(1, 2))
@@ -204,14 +233,14 @@ def _edge_recompute(w: LayerW, cfg: Config, csr: Csr, P, Q, x, ea, x_src=None):
     dn = d / (nrm + cfg.epsilon).unsqueeze(1) if cfg.normalize else d
     pre = P[csr.row] + Q[csr.col] + r.unsqueeze(1) * w.w_r + ea @ w.We.T
     t = silu(pre)
-    mp = t @ w.W2.T + w.b2
+    mp = R(t) @ R(w.W2).T + w.b2
     m0 = silu(mp)
     if cfg.attention:
         a = torch.sigmoid(m0 @ w.att_w + w.att_b)
         m = m0 * a.unsqueeze(1)
     else:
         a, m = None, m0
-    up = m @ w.Wx1.T + w.bx1
+    up = R(m) @ R(w.Wx1).T + w.bx1
     u = silu(up)
     sraw = u @ w.wx2
     s = torch.tanh(sraw) if cfg.tanh else sraw
@@ -243,8 +272,8 @@ def edge_bwd(w: LayerW, cfg: Config, G, L: str, csr: Csr, P, Q, x, ea, g_aggm, g
     G[f"{L}.coord_mlp_r.2.weight"][0] += g_sraw @ k["u"]
     g_up = (g_sraw.unsqueeze(1) * w.wx2) * dsilu(k["up"])
     G[f"{L}.coord_mlp_r.0.bias"] += g_up.sum(0)
-    G[f"{L}.coord_mlp_r.0.weight"] += g_up.T @ k["m"]
-    g_m = g_m + g_up @ w.Wx1
+    G[f"{L}.coord_mlp_r.0.weight"] += R(g_up).T @ R(k["m"])
+    g_m = g_m + R(g_up) @ R(w.Wx1)
     if cfg.attention:
         a = k["a"]
         g_a = (g_m * k["m0"]).sum(1)
@@ -256,8 +285,8 @@ def edge_bwd(w: LayerW, cfg: Config, G, L: str, csr: Csr, P, Q, x, ea, g_aggm, g
         g_m0 = g_m
     g_mp = g_m0 * dsilu(k["mp"])
     G[f"{L}.edge_mlp.2.bias"] += g_mp.sum(0)
-    G[f"{L}.edge_mlp.2.weight"] += g_mp.T @ k["t"]
-    g_pre = (g_mp @ w.W2) * dsilu(k["pre"])
+    G[f"{L}.edge_mlp.2.weight"] += R(g_mp).T @ R(k["t"])
+    g_pre = (R(g_mp) @ R(w.W2)) * dsilu(k["pre"])
     dW1 = G[f"{L}.edge_mlp.0.weight"]
     dW1[:, 2 * H] += g_pre.T @ k["r"]
     dW1[:, 2 * H + 1:] += g_pre.T @ ea
@@ -283,18 +312,18 @@ def _virt_recompute(w: LayerW, cfg: Config, A, Bc, x, Z, batch):
     vr = (vd * vd).sum(1).sqrt()                          # [N,C]
     pre = A.unsqueeze(1) + Bc[batch] + vr.unsqueeze(-1) * w.w_vr      # [N,C,H]
     t = silu(pre)
-    vp = t @ w.V2.T + w.c2
+    vp = R(t) @ R(w.V2).T + w.c2
     v0 = silu(vp)
     if cfg.attention:
         a = torch.sigmoid(v0 @ w.attv_w + w.attv_b)      # [N,C]
         v = v0 * a.unsqueeze(-1)
     else:
         a, v = None, v0
-    uxp = v @ w.Wxv0.T + w.bxv0
+    uxp = R(v) @ R(w.Wxv0).T + w.bxv0
     ux = silu(uxp)
     sxr = ux @ w.wxv2
     sx = torch.tanh(sxr) if cfg.tanh else sxr
-    uXp = v @ w.WX0.T + w.bX0
+    uXp = R(v) @ R(w.WX0).T + w.bX0
     uX = silu(uXp)
     sXr = uX @ w.wX2
     sX = torch.tanh(sXr) if cfg.tanh else sXr
@@ -308,10 +337,10 @@ def virt_fwd(w: LayerW, cfg: Config, h, A, Bc, x, vel, Z, batch, aggm, aggx, sve
     transv = (-k["vd"] * k["sx"].unsqueeze(1)).mean(-1)                     # [N,3]
     poolX = torch.zeros(B, 3, C, dtype=x.dtype).index_add_(0, batch, k["vd"] * k["sX"].unsqueeze(1))
     poolV = torch.zeros(B, C, H, dtype=x.dtype).index_add_(0, batch, k["v"])
-    nodepre = torch.einsum("ohc,nch->no", w.W3v, k["v"]) + h @ w.W3a.T + aggm @ w.W3b.T + w.b3
+    nodepre = torch.einsum("ohc,nch->no", R(w.W3v), R(k["v"])) + R(h) @ R(w.W3a).T + R(aggm) @ R(w.W3b).T + w.b3
     if node_attr is not None:
         nodepre = nodepre + node_attr @ w.W3d.T
-    out = silu(nodepre) @ w.W4.T + w.b4
+    out = R(silu(nodepre)) @ R(w.W4).T + w.b4
     h_new = h + out if cfg.residual else out
     x_new = x + aggx + transv + svel.unsqueeze(1) * vel
     if gravity is not None:
@@ -326,7 +355,7 @@ def virt_bwd(w: LayerW, cfg: Config, G, L: str, h, A, Bc, x, vel, Z, batch, aggm
     N = h.size(0)
     k = _virt_recompute(w, cfg, A, Bc, x, Z, batch)
     v = k["v"]
-    nodepre = torch.einsum("ohc,nch->no", w.W3v, v) + h @ w.W3a.T + aggm @ w.W3b.T + w.b3
+    nodepre = torch.einsum("ohc,nch->no", R(w.W3v), R(v)) + R(h) @ R(w.W3a).T + R(aggm) @ R(w.W3b).T + w.b3
     if node_attr is not None:
         nodepre = nodepre + node_attr @ w.W3d.T
     t3 = silu(nodepre)
@@ -334,18 +363,18 @@ def virt_bwd(w: LayerW, cfg: Config, G, L: str, h, A, Bc, x, vel, Z, batch, aggm
     g_out = g_hn
     g_h = g_hn.clone() if cfg.residual else torch.zeros_like(g_hn)
     G[f"{L}.node_mlp.2.bias"] += g_out.sum(0)
-    G[f"{L}.node_mlp.2.weight"] += g_out.T @ t3
-    g_np = (g_out @ w.W4) * dsilu(nodepre)
+    G[f"{L}.node_mlp.2.weight"] += R(g_out).T @ R(t3)
+    g_np = (R(g_out) @ R(w.W4)) * dsilu(nodepre)
     dW3 = G[f"{L}.node_mlp.0.weight"]
     G[f"{L}.node_mlp.0.bias"] += g_np.sum(0)
-    dW3[:, :H] += g_np.T @ h
-    dW3[:, H:2 * H] += g_np.T @ aggm
-    dW3[:, 2 * H:2 * H + H * C] += torch.einsum("no,nch->ohc", g_np, v).reshape(H, H * C)
+    dW3[:, :H] += R(g_np).T @ R(h)
+    dW3[:, H:2 * H] += R(g_np).T @ R(aggm)
+    dW3[:, 2 * H:2 * H + H * C] += torch.einsum("no,nch->ohc", R(g_np), R(v)).reshape(H, H * C)
     if node_attr is not None:
         dW3[:, 2 * H + H * C:] += g_np.T @ node_attr
-    g_h = g_h + g_np @ w.W3a
-    g_aggm = g_np @ w.W3b
-    g_v = torch.einsum("no,ohc->nch", g_np, w.W3v) + g_poolV[batch]
+    g_h = g_h + R(g_np) @ R(w.W3a)
+    g_aggm = R(g_np) @ R(w.W3b)
+    g_v = torch.einsum("no,ohc->nch", R(g_np), R(w.W3v)) + g_poolV[batch]
     # coordinate update
     g_x = g_xn.clone()
     g_aggx = g_xn
@@ -363,8 +392,8 @@ def virt_bwd(w: LayerW, cfg: Config, G, L: str, h, A, Bc, x, vel, Z, batch, aggm
         G[f"{L}.{name}.2.weight"][0] += torch.einsum("nc,nch->h", g_sr, u)
         g_up = (g_sr.unsqueeze(-1) * w2) * dsilu(up)
         G[f"{L}.{name}.0.bias"] += g_up.sum((0, 1))
-        G[f"{L}.{name}.0.weight"] += torch.einsum("nco,nch->oh", g_up, v)
-        return g_up @ W0
+        G[f"{L}.{name}.0.weight"] += torch.einsum("nco,nch->oh", R(g_up), R(v))
+        return R(g_up) @ R(W0)
 
     g_v = g_v + head(g_sx, k["sx"], k["ux"], k["uxp"], w.Wxv0, w.wxv2, "coord_mlp_r_virtual")
     g_v = g_v + head(g_sX, k["sX"], k["uX"], k["uXp"], w.WX0, w.wX2, "coord_mlp_v_virtual")
@@ -379,8 +408,8 @@ def virt_bwd(w: LayerW, cfg: Config, G, L: str, h, A, Bc, x, vel, Z, batch, aggm
         g_v0 = g_v
     g_vp = g_v0 * dsilu(k["vp"])
     G[f"{L}.edge_mlp_virtual.2.bias"] += g_vp.sum((0, 1))
-    G[f"{L}.edge_mlp_virtual.2.weight"] += torch.einsum("nco,nch->oh", g_vp, k["t"])
-    g_pre = (g_vp @ w.V2) * dsilu(k["pre"])                                 # [N,C,H]
+    G[f"{L}.edge_mlp_virtual.2.weight"] += torch.einsum("nco,nch->oh", R(g_vp), R(k["t"]))
+    g_pre = (R(g_vp) @ R(w.V2)) * dsilu(k["pre"])                                 # [N,C,H]
     g_A = g_pre.sum(1)
     g_Bc = torch.zeros(B, C, H, dtype=x.dtype).index_add_(0, batch, g_pre)
     G[f"{L}.edge_mlp_virtual.0.weight"][:, 2 * H] += torch.einsum("nch,nc->h", g_pre, k["vr"])
@@ -401,8 +430,8 @@ def graph_post_fwd(w: LayerW, cfg: Config, gptr, Z, HvT, poolV, poolX):
     n_b = (gptr[1:] - gptr[:-1]).clamp(min=1).to(Z.dtype)
     Z_new = Z + poolX / n_b.view(-1, 1, 1)
     pm = poolV / n_b.view(-1, 1, 1)
-    z5 = HvT @ w.W5a.T + pm @ w.W5b.T + w.b5
-    out = silu(z5) @ w.W6.T + w.b6
+    z5 = R(HvT) @ R(w.W5a).T + R(pm) @ R(w.W5b).T + w.b5
+    out = R(silu(z5)) @ R(w.W6).T + w.b6
     HvT_new = HvT + out if cfg.residual else out
     return Z_new, HvT_new
 
@@ -411,19 +440,19 @@ def graph_post_bwd(w: LayerW, cfg: Config, G, L: str, gptr, HvT, poolV, g_Zn, g_
     """returns g_Z, g_HvT, g_poolV, g_poolX."""
     n_b = (gptr[1:] - gptr[:-1]).clamp(min=1).to(HvT.dtype)
     pm = poolV / n_b.view(-1, 1, 1)
-    z5 = HvT @ w.W5a.T + pm @ w.W5b.T + w.b5
+    z5 = R(HvT) @ R(w.W5a).T + R(pm) @ R(w.W5b).T + w.b5
     u = silu(z5)
     g_out = g_HvTn
     g_HvT = g_HvTn.clone() if cfg.residual else torch.zeros_like(g_HvTn)
     G[f"{L}.node_mlp_virtual.2.bias"] += g_out.sum((0, 1))
-    G[f"{L}.node_mlp_virtual.2.weight"] += torch.einsum("bco,bch->oh", g_out, u)
-    g_z5 = (g_out @ w.W6) * dsilu(z5)
+    G[f"{L}.node_mlp_virtual.2.weight"] += torch.einsum("bco,bch->oh", R(g_out), R(u))
+    g_z5 = (R(g_out) @ R(w.W6)) * dsilu(z5)
     dW5 = G[f"{L}.node_mlp_virtual.0.weight"]
     G[f"{L}.node_mlp_virtual.0.bias"] += g_z5.sum((0, 1))
-    dW5[:, :H] += torch.einsum("bco,bch->oh", g_z5, HvT)
-    dW5[:, H:] += torch.einsum("bco,bch->oh", g_z5, pm)
-    g_HvT = g_HvT + g_z5 @ w.W5a
-    g_poolV = (g_z5 @ w.W5b) / n_b.view(-1, 1, 1)
+    dW5[:, :H] += torch.einsum("bco,bch->oh", R(g_z5), R(HvT))
+    dW5[:, H:] += torch.einsum("bco,bch->oh", R(g_z5), R(pm))
+    g_HvT = g_HvT + R(g_z5) @ R(w.W5a)
+    g_poolV = (R(g_z5) @ R(w.W5b)) / n_b.view(-1, 1, 1)
     g_poolX = g_Zn / n_b.view(-1, 1, 1)
     return g_Zn.clone(), g_HvT, g_poolV, g_poolX
 
@@ -463,6 +492,11 @@ def layer_backward(p, L, cfg, G, csr, gptr, batch, ea, vel, gravity, saved, g_hn
 
 def model_forward(p: Params, cfg: Config, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean,
                   edge_attr, node_attr=None):
+    with _mode(cfg):
+        return _model_forward(p, cfg, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr, node_attr)
+
+
+def _model_forward(p, cfg, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr, node_attr=None):
     N = node_loc.size(0)
     B = loc_mean.size(0)
     dt = node_loc.dtype
@@ -485,6 +519,11 @@ def model_forward(p: Params, cfg: Config, node_feat, node_loc, node_vel, edge_in
 
 def model_backward(p: Params, cfg: Config, ctx, g_loc, g_vloc):
     """returns (param grads dict, input grads dict)."""
+    with _mode(cfg):
+        return _model_backward(p, cfg, ctx, g_loc, g_vloc)
+
+
+def _model_backward(p, cfg, ctx, g_loc, g_vloc):
     G = {k: torch.zeros_like(v) for k, v in p.items()}
     N = g_loc.size(0)
     dt = g_loc.dtype

@@ -41,6 +41,8 @@ class Config:
     tanh: bool = False
     gravity: Optional[Sequence[float]] = None
     coords_agg: str = "mean"          # E_GCL_vel default, FastEGNN.py:12
+    bf16: bool = False                # bf16 operand mode of the product (BASELINE configs[2]); honoured by
+                                      # oracle/factored.py only -- the reference itself has no reduced-precision mode
     epsilon: float = 1e-8             # FastEGNN.py:21
 
 
