@@ -269,13 +269,14 @@ def cpu_baseline(cfg, args, seed, mode):
         loss_fn(loc, vloc, target).backward()
         return time.perf_counter() - t0
 
-    # thread count: --cpu-threads, else the fastest of {8,16,32,64,all} on a 4000-node frame (this op mix -- gathers,
+    # thread count: --cpu-threads, else the fastest of {8,16,32,64} on a 4000-node frame (this op mix -- gathers,
     # scatter_add_, small GEMMs -- does not scale with threads: measured 3.2 s at 8 vs 20 s at 256 threads on a 10 k frame)
     cal = None
     if args.cpu_threads:
         threads = max(1, min(args.cpu_threads, logical))
     else:
-        cand = sorted({t for t in (8, 16, 32, 64, logical) if t <= logical})
+        # (more than 64 threads is never faster here and costs minutes: 96 s per pass at 256 threads on the 4000-node frame)
+        cand = sorted({t for t in (8, 16, 32, 64) if t <= logical} or {logical})
         fr = make_frame(4000, C, seed, "cpu")
         cal = {}
         for t in cand:
@@ -340,6 +341,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (default: all visible CPUs)")
     ap.add_argument("--cache-graph", action="store_true", help="reuse the sorted graph across steps")
+    ap.add_argument("--hipgraph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the whole step (CSR build + forward + loss + backward) as ONE captured HIP graph: removes the "
+                         "~100 launch latencies per step that bound the small configurations; auto = on for cfg1/cfg2/cfg3 at 1 GPU")
     ap.add_argument("--train-step", action="store_true",
                     help="time a full training iteration instead (edge_attr augmentation, MSE+MMD loss, Adam: "
                          "fastegnn_amd.train.train_step); the default step is fwd+loss+bwd, the BASELINE metric")
@@ -405,6 +409,8 @@ def main():
         if world > 1:
             del frame
             torch.cuda.empty_cache()
+            # second leg of the N > 1 line: graphs as independent units (one frame per rank + gradient all-reduce)
+            dp_frame, dp_target = make_workload(cfg, 143 + rank, dev, args.nodes, args.channels)
 
     def step():
         if args.train_step:   # utils/train.py:30-170 on device (single-GPU only)
@@ -433,6 +439,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    use_graph = args.hipgraph == "on" or (args.hipgraph == "auto" and world == 1 and not sharded and not args.train_step
+                                          and cfg["kind"] != "water")
     # the per-kernel HIP-event profiler is on during warm-up too, so that its event pool exists
     # before the timed region (hipEventCreate is slow on a cold driver)
     K.lib().fastegnn_profile_enable(1)
@@ -442,23 +450,79 @@ def main():
         step()
     sync()
     K.profile_collect()
-    if sharded:
-        stats = CommStats()
-        smodel.stats = stats
-    t0 = time.perf_counter()
-    done = []   # bound the CPU run-ahead to two steps (deep HIP queues stall sporadically on this stack)
-    for _ in range(args.steps):
-        if len(done) >= 2:
-            done.pop(0).synchronize()
-        loss = step()
-        ev = torch.cuda.Event()
-        ev.record()
-        done.append(ev)
-    sync()
-    dt = time.perf_counter() - t0
-    K.lib().fastegnn_profile_enable(0)
-    prof = K.profile_collect()
+    prof_steps = args.steps
+    if use_graph:
+        # per-kernel durations from an eager pass (events cannot be timed inside a captured graph), then the step is
+        # captured once and the timed region replays it
+        prof_steps = min(args.steps, 20)
+        for _ in range(prof_steps):
+            step()
+        sync()
+        K.lib().fastegnn_profile_enable(0)
+        prof = K.profile_collect()
+        gstream = torch.cuda.Stream(dev)
+        gstream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(gstream):
+            step()                                   # allocator warm-up on the capture stream
+        torch.cuda.current_stream(dev).wait_stream(gstream)
+        hgraph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hgraph, stream=gstream):
+            loss = step()
+        for _ in range(max(args.warmup, 1)):
+            hgraph.replay()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hgraph.replay()
+        sync()
+        dt = time.perf_counter() - t0
+    else:
+        if sharded:
+            stats = CommStats()
+            smodel.stats = stats
+        t0 = time.perf_counter()
+        done = []   # bound the CPU run-ahead to two steps (deep HIP queues stall sporadically on this stack)
+        for _ in range(args.steps):
+            if len(done) >= 2:
+                done.pop(0).synchronize()
+            loss = step()
+            ev = torch.cuda.Event()
+            ev.record()
+            done.append(ev)
+        sync()
+        dt = time.perf_counter() - t0
+        K.lib().fastegnn_profile_enable(0)
+        prof = K.profile_collect()
     dt = max_over_ranks(dt, dev)
+
+    dp_leg = None
+    if sharded and world > 1:
+        # the same job as data-parallel replicas (weak scaling): every rank its own frame, no data-path collective,
+        # one flat gradient all-reduce -- reported beside the partitioned number, same steps / warm-up / barriers
+        def dp_step():
+            for p in params:
+                p.grad = None
+            loc, vloc = model(**dp_frame)
+            l = loss_fn(loc, vloc, dp_target)
+            l.backward()
+            allreduce_gradients(params)
+            return l
+        for _ in range(max(args.warmup, 1)):
+            dp_step()
+        sync()
+        t0 = time.perf_counter()
+        done = []
+        for _ in range(args.steps):
+            if len(done) >= 2:
+                done.pop(0).synchronize()
+            dp_step()
+            ev = torch.cuda.Event()
+            ev.record()
+            done.append(ev)
+        sync()
+        dt_dp = max_over_ranks(time.perf_counter() - t0, dev)
+        dp_leg = {"value": round(world * B * args.steps / dt_dp, 4), "unit": "graphs/s", "ms_per_step": round(dt_dp / args.steps * 1e3, 3),
+                  "scaling": "weak", "parallelism": f"dp{world}: one frame per GPU, RCCL gradient all-reduce (2.2 MB)"}
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -469,8 +533,8 @@ def main():
         km = kernel_model(kN, kE, B, C, L, gravity=cfg["gravity"] is not None)
         kernels = {}
         for name, (ms, cnt) in prof.items():
-            per_step = ms / args.steps
-            ent = {"ms_per_step": round(per_step, 4), "launches_per_step": cnt / args.steps,
+            per_step = ms / prof_steps
+            ent = {"ms_per_step": round(per_step, 4), "launches_per_step": cnt / prof_steps,
                    "avg_launch_ms": round(ms / cnt, 5)}
             if name in km:
                 fl, by = km[name]
@@ -514,7 +578,9 @@ def main():
             "config": {"workload": f"{cfg['text']}; {L}-layer FastEGNN H=64, {what}, CSR build "
                                    + ("cached" if args.cache_graph else "inside the step"),
                        "name": args.config, "nodes": N, "edges": E, "graphs_per_batch": B, "virtual_channels": C, "layers": L,
-                       "graphs_per_step": units_per_step, "parallelism": par, "loss": float(loss.detach())},
+                       "graphs_per_step": units_per_step, "parallelism": par, "loss": float(loss.detach()),
+                       "launch": ("whole step replayed as one captured HIP graph; per-kernel durations from an eager pass of "
+                                  f"{prof_steps} steps before the capture") if use_graph else "eager launches"},
             "value_per_gpu": round(value / world, 4),
             "roofline": roof,
             "edge_scatter": edge_scatter,
@@ -522,6 +588,8 @@ def main():
         }
         if stats is not None:
             out["collectives"] = stats.summary(args.steps)
+        if dp_leg is not None:
+            out["data_parallel_leg"] = dp_leg
         cb = "none" if args.no_cpu_baseline else args.cpu_baseline
         if cb == "auto":
             cb = "none" if world > 1 else ("scaled" if args.config == "cfg5" else "full")

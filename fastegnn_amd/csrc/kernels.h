@@ -52,17 +52,20 @@ struct WgTable {
   WgJob job[WG_MAX_JOBS];
   float *slab, *slab_b;
   int n_jobs;
+  int n_bundle;   // jobs [0, n_bundle) form the wave-parallel bundle (wgrad_bundle_kernel), the rest run in wgrad_tn_kernel
 };
 struct WgradBatch {
   WgTable tab;
   hipStream_t st;
-  int n_wg, n_slab, max_nb;
+  int n_wg, n_slab, max_nb, n_bundle_wg;
   bool round;   // applied to the jobs added from now on
+  int min_rows; // smallest row range given to one workgroup (short operands are split that far to fill the chip)
   WgradBatch(float *slab, hipStream_t st, bool round_bf16 = false);
   int add(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks, float *db,
           int nb = 1, long sG = 0, long sT = 0, long sW = 0, int kmax = 64);
   // a job whose partial slabs (nsplit of them, [64][64] + [64] bias each) are written by the caller's own kernel:
   // only the fixed-order reduction into dW / db runs here.  *slab_begin receives the first slab index.
+  int close_bundle();
   int add_slabs(float *dW, int lddw, int c0, int ks, float *db, int nsplit, int *slab_begin);
   int finish();
 };

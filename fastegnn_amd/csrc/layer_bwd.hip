@@ -194,7 +194,6 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       cur = bfirst;
     }
     const int nb = split ? n0 : n0 + wv * 16;
-    const int nvalid = max(0, min(16, nend - nb));
     {   // a wave without valid nodes runs the body on masked lanes (every contribution is zero): the
         // workgroup walks the channels in step for the W3cT stage below
       const int n = nb + j;
@@ -551,17 +550,25 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   if (rc) return rc;
   const int ld_n0 = 2 * H + H * C + L->na;
   WgradBatch wb(L->wg_slab, st, has(L, FASTEGNN_F_BF16));
+  if (C > 0) {
+    wb.min_rows = 128;   // a bundle's wave walks ALL rows of its workgroup: shorter row ranges than the 4-waves-per-range jobs
+    // the four contractions over the (node, channel) rows as ONE wave-parallel bundle, all in the batched geometry
+    // "N rows x C channel slices" so that the waves of a workgroup walk the same rows: the node_mlp.0 block of channel c
+    // (g_np, v[:,c]), the two coordinate heads (g_ux, v), (g_uX, v) and edge_mlp_virtual.2 (g_vp, t); `v` is read by
+    // three of them and reaches HBM once
+    const long cs = (long)C * H;
+    if ((rc = wb.add(A.wg_gnp, H, A.wg_v, (int)cs, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
+    if ((rc = wb.add(A.wg_gux, (int)cs, A.wg_v, (int)cs, N, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], C, H, H, 0))) return rc;
+    if ((rc = wb.add(A.wg_guX, (int)cs, A.wg_v, (int)cs, N, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], C, H, H, 0))) return rc;
+    if ((rc = wb.add(A.wg_gvp, (int)cs, A.wg_t, (int)cs, N, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], C, H, H, 0))) return rc;
+    if ((rc = wb.close_bundle())) return rc;
+    wb.min_rows = 256;
+  }
   // node_mlp.2
   if ((rc = wb.add(L->g_h_out, H, A.wg_t3, H, N, g[FASTEGNN_P_NODE2_W], H, 0, 1, g[FASTEGNN_P_NODE2_B]))) return rc;
   // node_mlp.0: [h | agg | flat(v) | node_attr]
   if ((rc = wb.add(A.wg_gnp, H, L->h, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 0, 1, g[FASTEGNN_P_NODE0_B]))) return rc;
   if ((rc = wb.add(A.wg_gnp, H, L->aggm, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, H, 1, nullptr))) return rc;
-  if (C > 0)
-    if ((rc = wb.add(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
-  // coordinate heads and edge_mlp_virtual.2 over the N*C (node, channel) rows (none when C = 0)
-  if ((rc = wb.add(A.wg_gux, H, A.wg_v, H, NC, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B]))) return rc;
-  if ((rc = wb.add(A.wg_guX, H, A.wg_v, H, NC, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B]))) return rc;
-  if ((rc = wb.add(A.wg_gvp, H, A.wg_t, H, NC, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B]))) return rc;
   if ((rc = wb.finish())) return rc;
   if (L->na > 0)
     if ((rc = launch_wgrad_small(A.wg_gnp, H, L->node_attr, L->na, L->na, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H + H * C, st))) return rc;
@@ -1039,7 +1046,7 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE((size_t)L->N * QXLD < (1u << 30) && (size_t)gr.n_src * QXLD < (1u << 30) && (size_t)gr.n_edges * 8 < (1u << 30),
              "edge_backward: tables exceed the 32-bit offset range of the gather path");
   {
-    int grid = cdiv(cdiv(gr.n_edges, 256), PC_PROD);
+    int grid = cdiv(gr.n_chunks, PC_PROD);   // small graphs: one 32-edge row chunk per producer wave (see edge_forward)
     if (grid > 256) grid = 256;
     WgradBatch wb(L->wg_slab, st);
     int rc;

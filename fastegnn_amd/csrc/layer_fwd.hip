@@ -102,61 +102,56 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // =====================================================================================
 // S2a graph_xsum: per-graph sum of coordinates and node count (global_mean_pool(coord), :212)
 // =====================================================================================
+// A wave owns 1024 consecutive nodes and walks them 64 at a time (lane = node).  data_batch is ascending, so a
+// 64-node group normally lies inside one graph: the lanes keep partial sums and the wave leaves ONE atomic set per
+// (wave, graph) run; groups that straddle graphs (mini-batches of tiny graphs) add per node.
 __global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const int32_t *batch, int N, float *xsum) {
-  constexpr int PER = 4096;
-  __shared__ float red[4][4];
-  const int n0 = blockIdx.x * PER;
-  const int n1 = min(N, n0 + PER);
+  constexpr int PER_WAVE = 1024;
+  const int l = lane_id();
+  const int n0 = global_wave_id() * PER_WAVE, n1 = min(N, n0 + PER_WAVE);
   if (n0 >= n1) return;
-  const int bf = batch[n0], bl = batch[n1 - 1];
-  const int l = lane_id(), w = wave_id();
-  if (bf == bl) {  // whole block inside one graph: tree-reduce, one atomic set per block
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int n = n0 + threadIdx.x; n < n1; n += 256) {
-      s[0] += x[(size_t)n * 3];
-      s[1] += x[(size_t)n * 3 + 1];
-      s[2] += x[(size_t)n * 3 + 2];
-      s[3] += 1.f;
-    }
+  int cur = -1;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  auto flush = [&]() {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float v = s[k];
       for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (l == 0) red[w][k] = v;
+      if (l == 0) atomicAdd(&xsum[cur * 4 + k], v);
+      s[k] = 0.f;
     }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-      float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-      atomicAdd(&xsum[bf * 4 + threadIdx.x], v);
-    }
-  } else {  // ragged block: per-thread runs
-    int cur = -1;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    // contiguous slice per thread keeps runs long
-    const int per = (n1 - n0 + 255) / 256;
-    const int a0 = n0 + threadIdx.x * per, a1 = min(n1, a0 + per);
-    for (int n = a0; n < a1; ++n) {
-      int b = batch[n];
-      if (b != cur) {
-        if (cur >= 0)
-          for (int k = 0; k < 4; ++k) atomicAdd(&xsum[cur * 4 + k], s[k]);
-        cur = b;
-        s[0] = s[1] = s[2] = s[3] = 0.f;
+  };
+  for (int base = n0; base < n1; base += 64) {
+    const int n = base + l;
+    const bool ok = n < n1;
+    const int b = batch[ok ? n : n1 - 1];
+    const int bf = __builtin_amdgcn_readfirstlane(b), bl = batch[min(base + 63, n1 - 1)];
+    float xv[3] = {0.f, 0.f, 0.f};
+    if (ok) { xv[0] = x[(size_t)n * 3]; xv[1] = x[(size_t)n * 3 + 1]; xv[2] = x[(size_t)n * 3 + 2]; }
+    if (bf == bl) {   // (wave-uniform) the whole group lies in graph bf
+      if (bf != cur) {
+        if (cur >= 0) flush();
+        cur = bf;
       }
-      s[0] += x[(size_t)n * 3];
-      s[1] += x[(size_t)n * 3 + 1];
-      s[2] += x[(size_t)n * 3 + 2];
-      s[3] += 1.f;
+      s[0] += xv[0]; s[1] += xv[1]; s[2] += xv[2]; s[3] += ok ? 1.f : 0.f;
+    } else {
+      if (cur >= 0) flush();
+      cur = -1;
+      if (ok) {
+        atomicAdd(&xsum[b * 4 + 0], xv[0]);
+        atomicAdd(&xsum[b * 4 + 1], xv[1]);
+        atomicAdd(&xsum[b * 4 + 2], xv[2]);
+        atomicAdd(&xsum[b * 4 + 3], 1.f);
+      }
     }
-    if (cur >= 0)
-      for (int k = 0; k < 4; ++k) atomicAdd(&xsum[cur * 4 + k], s[k]);
   }
+  if (cur >= 0) flush();
 }
 
 int graph_xsum(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(L->xsum && L->batch && L->x, "graph_xsum: null buffer");
   (void)hipMemsetAsync(L->xsum, 0, (size_t)L->B * 4 * sizeof(float), st);
-  if (L->N > 0) { ProfScope _ps_graph_xsum_kernel(K_XSUM, st); hipLaunchKernelGGL(graph_xsum_kernel, dim3(cdiv(L->N, 4096)), dim3(256), 0, st, L->x, L->batch, L->N, L->xsum); }
+  if (L->N > 0) { ProfScope _ps_graph_xsum_kernel(K_XSUM, st); hipLaunchKernelGGL(graph_xsum_kernel, dim3(cdiv(L->N, 4096)), dim3(256), 0, st, L->x, L->batch, L->N, L->xsum); }   // 4 waves x 1024 nodes
   return check_launch("graph_xsum_kernel");
 }
 
@@ -308,7 +303,9 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
   EdgeArgs a = make_edge_args(L);
   FE_REQUIRE((size_t)L->N * QXLD < (1u << 30) && (size_t)g.n_src * QXLD < (1u << 30) && (size_t)g.n_edges * 8 < (1u << 30),
              "edge_forward: tables exceed the 32-bit offset range of the gather path");
-  int grid = cdiv(cdiv(g.n_edges, 256), EDGE_FWD_WAVES);   // at least sixteen tiles per wave
+  // one workgroup per CU once there are >= 256 x 16 row chunks; small graphs spread their chunks (32 edges) over as
+  // many waves as there are chunks instead of serialising them in a few workgroups (the N-body mini-batches)
+  int grid = cdiv(g.n_chunks, EDGE_FWD_WAVES);
   if (grid > 256) grid = 256;
   const size_t lds = (EDGE_FWD_IMG_FLOATS + EV_COUNT * H + EDGE_FWD_WAVES * (16 * TS + 64)) * sizeof(float);
   {

@@ -70,47 +70,24 @@ __global__ void build_batch_kernel(const int64_t *b64, int N, int B, int32_t *ba
 // MFMA issue cycles) measured the same 6.0 ms per step -- the fp32-input MFMA form is kept.
 constexpr int WTS = 80;  // LDS row stride of the staged operand tiles (conflict-free b32 column reads)
 
-__global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
-  // 40 KB of staging tiles; the 64x64 reduction buffer aliases them after the main loop
-  __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 16 * WTS];
-  __shared__ float redb[H];
-  float *red = smem;
-  // locate the job of this workgroup
-  int jb = 0;
-#pragma unroll 1
-  while (jb + 1 < tab.n_jobs && (int)blockIdx.x >= tab.job[jb + 1].wg_begin) ++jb;
-  const WgJob &a = tab.job[jb];
-  const int local = blockIdx.x - a.wg_begin;
-  // batch index varies fastest: co-resident workgroups read the same row range of every batch slice
-  const int bidx = local % a.nb, split = local / a.nb;
-  const int l = lane_id(), i = l & 15, q = l >> 4, w = wave_id();
-  const float *G = a.G + (size_t)bidx * a.sG;
-  const float *T = a.T + (size_t)bidx * a.sT;
-  const long m0 = (long)split * a.rows_per_wg;
-  long m1 = m0 + a.rows_per_wg;
-  if (m1 > a.M) m1 = a.M;
-  if (threadIdx.x < H) redb[threadIdx.x] = 0.f;
-  float *gt = smem + (w * 2 + 0) * 16 * WTS, *tt = smem + (w * 2 + 1) * 16 * WTS;
-  f32x4 acc[4][4];
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-    for (int tk = 0; tk < 4; ++tk) acc[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // lane l loads 16 bytes of row (4s + q), columns 4i..4i+3: full 256-byte lines per row.  Addresses
-  // are a wave-uniform base (row m) plus loop-invariant 32-bit lane offsets: no per-load VALU math.
+// rows [m_first, m1) of one (G, T) pair in steps of `step` rows, 16 rows at a time, into the wave's 64x64 accumulator
+// (acc[ti][tk][r] = dW[16ti + 4q + r][16tk + i]); gt / tt: this wave's two 16 x WTS staging tiles.
+// lane l loads 16 bytes of row (4s + q), columns 4i..4i+3: full 256-byte lines per row.  Addresses are a
+// wave-uniform base (row m) plus loop-invariant 32-bit lane offsets: no per-load VALU math.
+__device__ __forceinline__ void wg_accumulate(const float *G, const float *T, int ldg, int ldt, long m_first, long m1,
+                                              int step, bool want_bias, bool rnd, float *gt, float *tt,
+                                              f32x4 (&acc)[4][4], float (&bsum)[4]) {
+  const int l = lane_id(), i = l & 15, q = l >> 4;
   f32x4 gv[4], tv[4];
   unsigned og[4], ot[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    og[s] = ((unsigned)(4 * s + q) * (unsigned)a.ldg + 4u * i) * 4u;
-    ot[s] = ((unsigned)(4 * s + q) * (unsigned)a.ldt + 4u * i) * 4u;
+    og[s] = ((unsigned)(4 * s + q) * (unsigned)ldg + 4u * i) * 4u;
+    ot[s] = ((unsigned)(4 * s + q) * (unsigned)ldt + 4u * i) * 4u;
   }
-  const bool want_bias = a.db != nullptr;
-  const bool rnd = a.round != 0;
   auto issue = [&](long m) {
-    const char *gb = reinterpret_cast<const char *>(G + (size_t)m * a.ldg);
-    const char *tb = reinterpret_cast<const char *>(T + (size_t)m * a.ldt);
+    const char *gb = reinterpret_cast<const char *>(G + (size_t)m * ldg);
+    const char *tb = reinterpret_cast<const char *>(T + (size_t)m * ldt);
     if (m + 16 <= m1) {   // full tile (wave-uniform): unmasked loads
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -126,9 +103,9 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
       }
     }
   };
-  long m = m0 + 16 * w;
+  long m = m_first;
   if (m < m1) issue(m);
-  for (; m < m1; m += 64) {
+  for (; m < m1; m += step) {
     __builtin_amdgcn_wave_barrier();
     if (m + 16 <= m1) {
 #pragma unroll
@@ -145,7 +122,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (m + 64 < m1) issue(m + 64);
+    if (m + step < m1) issue(m + step);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       float av[4], bv[4];
@@ -171,6 +148,37 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
+  // 40 KB of staging tiles; the 64x64 reduction buffer aliases them after the main loop
+  __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 16 * WTS];
+  __shared__ float redb[H];
+  float *red = smem;
+  // locate the job of this workgroup (the wave-parallel bundle, if any, is served by wgrad_bundle_kernel)
+  int jb = tab.n_bundle;
+#pragma unroll 1
+  while (jb + 1 < tab.n_jobs && (int)blockIdx.x >= tab.job[jb + 1].wg_begin) ++jb;
+  const WgJob &a = tab.job[jb];
+  const int local = blockIdx.x - a.wg_begin;
+  // batch index varies fastest: co-resident workgroups read the same row range of every batch slice
+  const int bidx = local % a.nb, split = local / a.nb;
+  const int l = lane_id(), i = l & 15, q = l >> 4, w = wave_id();
+  const float *G = a.G + (size_t)bidx * a.sG;
+  const float *T = a.T + (size_t)bidx * a.sT;
+  const long m0 = (long)split * a.rows_per_wg;
+  long m1 = m0 + a.rows_per_wg;
+  if (m1 > a.M) m1 = a.M;
+  if (threadIdx.x < H) redb[threadIdx.x] = 0.f;
+  float *gt = smem + (w * 2 + 0) * 16 * WTS, *tt = smem + (w * 2 + 1) * 16 * WTS;
+  f32x4 acc[4][4];
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tk = 0; tk < 4; ++tk) acc[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = a.db != nullptr;
+  wg_accumulate(G, T, a.ldg, a.ldt, m0 + 16 * w, m1, 64, want_bias, a.round != 0, gt, tt, acc, bsum);
   __syncthreads();   // all waves are done with their staging tiles
   for (int k = threadIdx.x; k < IMG; k += 256) red[k] = 0.f;
   __syncthreads();
@@ -194,6 +202,47 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
   if (threadIdx.x < H) tab.slab_b[sidx * H + threadIdx.x] = redb[threadIdx.x];
 }
 
+// Wave-parallel bundle: up to four jobs of the SAME geometry (M, nb, strides, row split) that share operand rows --
+// the virtual stage's (g_np, v), (g_ux, v), (g_uX, v), (g_vp, t) -- are contracted by the four waves of one workgroup
+// over the same row range: wave w runs job w over every 16-row tile of the range, so the shared `v` rows are fetched
+// from HBM once and hit in L1/L2 for the other two waves (5 operand streams instead of 8).  Each wave keeps its own
+// 64x64 accumulator and writes its own partial slab; nothing is reduced across waves.
+__global__ __launch_bounds__(256) void wgrad_bundle_kernel(WgTable tab) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 16 * WTS];
+  const int w = wave_id();
+  if (w >= tab.n_bundle) return;
+  const WgJob &a = tab.job[w];
+  const int bidx = blockIdx.x % a.nb, split = blockIdx.x / a.nb;
+  const int l = lane_id(), i = l & 15, q = l >> 4;
+  const float *G = a.G + (size_t)bidx * a.sG;
+  const float *T = a.T + (size_t)bidx * a.sT;
+  const long m0 = (long)split * a.rows_per_wg;
+  long m1 = m0 + a.rows_per_wg;
+  if (m1 > a.M) m1 = a.M;
+  float *gt = smem + (w * 2 + 0) * 16 * WTS, *tt = smem + (w * 2 + 1) * 16 * WTS;
+  f32x4 acc[4][4];
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tk = 0; tk < 4; ++tk) acc[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = a.db != nullptr;
+  wg_accumulate(G, T, a.ldg, a.ldt, m0, m1, 16, want_bias, a.round != 0, gt, tt, acc, bsum);
+  const size_t sidx = (size_t)a.slab_begin + (size_t)bidx * a.nsplit + split;
+  float *dst = tab.slab + sidx * IMG;
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(16 * ti + 4 * q + r) * H + 16 * tk + i] = acc[ti][tk][r];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    const float sb = qsum(bsum[ti]);
+    if (q == 0) tab.slab_b[sidx * H + 16 * ti + i] = sb;
+  }
+}
+
 
 // Sum the partial slabs of every (job, batch) and accumulate into the gradients.  A workgroup owns
 // 64 consecutive elements of one 64x64 tile; its 8 waves sum interleaved subsets of the splits
@@ -202,7 +251,10 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
   __shared__ float part[8][H];
   const WgJob &a = tab.job[blockIdx.x];
   const int bidx = blockIdx.y;
-  if (bidx >= a.nb) return;
+  // batches that all add into the same dW (sW == 0): their slabs are contiguous and reduced together
+  const bool merged = a.nb > 1 && a.sW == 0;
+  if (bidx >= (merged ? 1 : a.nb)) return;
+  const int n_part = merged ? a.nsplit * a.nb : a.nsplit;
   const size_t s0 = (size_t)a.slab_begin + (size_t)bidx * a.nsplit;
   float *dW = a.dW + (size_t)bidx * a.sW;
   const int e = threadIdx.x & 63, pl = threadIdx.x >> 6;
@@ -212,11 +264,11 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
   if (bias_block && !a.db) return;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int p = pl;
-  for (; p + 56 < a.nsplit; p += 64) {
+  for (; p + 56 < n_part; p += 64) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) s[u] += base[(size_t)(p + 8 * u) * stride];
   }
-  for (; p < a.nsplit; p += 8) s[0] += base[(size_t)p * stride];
+  for (; p < n_part; p += 8) s[0] += base[(size_t)p * stride];
   part[pl][e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
   if (pl == 0) {
@@ -234,6 +286,9 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
 
 WgradBatch::WgradBatch(float *slab, hipStream_t st_, bool round_bf16) : st(st_), round(round_bf16) {
   tab.n_jobs = 0;
+  tab.n_bundle = 0;
+  n_bundle_wg = 0;
+  min_rows = 256;
   tab.slab = slab;
   tab.slab_b = slab ? slab + (size_t)WG_SLABS * IMG : nullptr;
   n_wg = 0;
@@ -248,7 +303,9 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   FE_REQUIRE(tab.slab, "wgrad: wg_slab workspace is null");
   FE_REQUIRE(tab.n_jobs < WG_MAX_JOBS, "wgrad: too many jobs in one batch");
   FE_REQUIRE((ldg % 4) == 0 && (ldt % 4) == 0, "wgrad: operand rows must be 16-byte aligned");
-  long nsplit = (M + 1023) / 1024;            // >= 1024 rows per workgroup
+  long nsplit = (M + 1023) / 1024;            // 1024 rows per workgroup while that fills the chip ...
+  if (nsplit < 256) nsplit = (M + min_rows - 1) / min_rows;   // ... short operands: down to min_rows per workgroup
+  if (nsplit > 256 && M < 256 * 1024) nsplit = 256;
   long cap = 768 / nb;
   if (cap < 4) cap = 4;
   if (nsplit > cap) nsplit = cap;
@@ -265,6 +322,22 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   n_wg += (int)(nsplit * nb);
   n_slab += (int)(nsplit * nb);
   if (nb > max_nb) max_nb = nb;
+  return FASTEGNN_OK;
+}
+
+// The FIRST jobs added to a batch may form the wave-parallel bundle (wgrad_bundle_kernel): <= 4 jobs with identical
+// M / nb / row split whose operands overlap.  Call after adding them, before any other add().
+int WgradBatch::close_bundle() {
+  FE_REQUIRE(tab.n_bundle == 0 && tab.n_jobs <= 4, "wgrad: a bundle is the first <= 4 jobs of a batch");
+  if (tab.n_jobs == 0) return FASTEGNN_OK;
+  for (int k = 1; k < tab.n_jobs; ++k)
+    FE_REQUIRE(tab.job[k].M == tab.job[0].M && tab.job[k].nb == tab.job[0].nb && tab.job[k].rows_per_wg == tab.job[0].rows_per_wg &&
+                   tab.job[k].nsplit == tab.job[0].nsplit,
+               "wgrad: bundle jobs must share their geometry");
+  tab.n_bundle = tab.n_jobs;
+  n_bundle_wg = tab.job[0].nsplit * tab.job[0].nb;
+  n_wg = 0;                                   // the bundle's workgroups are not part of wgrad_tn_kernel's grid
+  for (int k = 0; k < tab.n_jobs; ++k) tab.job[k].wg_begin = -1;
   return FASTEGNN_OK;
 }
 
@@ -287,6 +360,11 @@ int WgradBatch::add_slabs(float *dW, int lddw, int c0, int ks, float *db, int ns
 int WgradBatch::finish() {
   if (tab.n_jobs == 0) return FASTEGNN_OK;
   int rc = FASTEGNN_OK;
+  if (tab.n_bundle > 0) {
+    { ProfScope _ps(K_WGRAD_TN, st); hipLaunchKernelGGL(wgrad_bundle_kernel, dim3((unsigned)n_bundle_wg), dim3(256), 0, st, tab); }
+    rc = check_launch("wgrad_bundle_kernel");
+    if (rc) return rc;
+  }
   if (n_wg > 0) {
     { ProfScope _ps(K_WGRAD_TN, st); hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, tab); }
     rc = check_launch("wgrad_tn_kernel");
@@ -294,6 +372,8 @@ int WgradBatch::finish() {
   }
   { ProfScope _ps(K_WGRAD_REDUCE, st); hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tab.n_jobs, (unsigned)max_nb, IMG / H + 1), dim3(512), 0, st, tab); }
   tab.n_jobs = 0;   // the batch may be refilled: slabs and workgroup ranges start over
+  tab.n_bundle = 0;
+  n_bundle_wg = 0;
   n_wg = 0;
   n_slab = 0;
   max_nb = 1;

@@ -1,0 +1,154 @@
+"""-m gpu: the bf16 operand mode (BASELINE configs[2]: FASTEGNN_F_BF16 / FastEGNN(mlp_dtype=torch.bfloat16)).
+
+The reference has no reduced-precision mode, so the oracle of this mode is its definition -- oracle/factored.py with
+Config.bf16: the stage math of the kernels with both operands of every 64-wide contraction rounded to bf16 (RNE),
+exact products, accumulation in the working precision; everything geometric stays unrounded.  Three comparisons:
+
+  1. against the mirror in fp32 and fp64.  Two correct evaluations differ where an operand lands within rounding
+     noise of a bf16 tie (a flip changes that operand by 2^-8 relative), so the measure is the same calibrated rule as
+     for fp32 -- the build's distance to the fp64 mirror against the fp32 mirror's own -- with the mode's floor;
+  2. against the fp32 reference goldens, with the stated tolerance of the mode: outputs 5e-3, gradients 1e-1 of
+     max|g| (8 significant bits per operand, 4 layers);
+  3. the reference's acceptance property (equivariant_test.py:62) on the cfg3 shape -- coordinates never pass
+     through bf16, so translation by +50 A and a rotation commute with the model to fp32 level.
+"""
+import dataclasses
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import fastegnn_amd
+from oracle import factored as F
+from oracle import fastegnn_ref as R
+from tests.helpers import Golden, golden_loss, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["c16_two_graphs", "ragged3_gravity", "nbody5_cfg1_trained", "ragged3_allflags", "equiv10", "ragged3_nodeattr"]
+# tolerances of the mode (measured with tools/gpu_bf16err.py, see DESIGN.md 'bf16 operand mode')
+# measured (gpurun_out/a2/bf16err.txt, round 2): loc vs the fp32 mirror 1e-9..6.1e-5, displacement vs the fp64 mirror
+# 2e-6..1.2e-4 (the fp32 mirror's own: 2e-6..6e-5); gradients vs the fp64 mirror: median 1e-6..4e-4, worst 1.4e-2 where
+# the fp32 mirror is at 1.4e-2 too, and 2.6e-3 on a tensor where the fp32 mirror happens to sit at 4e-6 (a flipped bf16
+# operand upstream); against the fp32 reference: loc <= 1.3e-3, displacement <= 7.1e-3, gradients median 3e-3..7e-3, max 5e-2
+OUT_VS_MIRROR = 2e-4          # loc / vloc against the fp32 mirror
+GRAD_FACTOR, GRAD_FLOOR = 3.0, 5e-3   # distance to the fp64 mirror: <= 3 x the fp32 mirror's own + 5e-3 of max|g|
+OUT_VS_FP32_REF, DISP_VS_FP32_REF, GRAD_VS_FP32_REF = 5e-3, 5e-2, 1.5e-1
+
+
+def _mirror(g, dt):
+    cfg = dataclasses.replace(g.cfg, bf16=True)
+    p = g.tensors(g.params, dtype=dt)
+    kw, target, wv = g.model_kwargs(dtype=dt)
+    loc, vloc, ctx = F.model_forward(p, cfg, **kw)
+    l2 = loc.clone().requires_grad_(True)
+    v2 = vloc.clone().requires_grad_(True)
+    golden_loss(l2, v2, target, wv).backward()
+    G, gin = F.model_backward(p, cfg, ctx, l2.grad, v2.grad)
+    return loc, vloc, G, gin
+
+
+def _hip(g):
+    c = g.cfg
+    m = fastegnn_amd.FastEGNN(c.node_feat_nf, c.node_attr_nf, c.edge_attr_nf, c.hidden_nf, c.virtual_channels, device="cuda",
+                              n_layers=c.n_layers, residual=c.residual, attention=c.attention, normalize=c.normalize,
+                              tanh=c.tanh, gravity=c.gravity, mlp_dtype=torch.bfloat16)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g.params.items()}, strict=True)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bf16_mode_matches_its_mirror_and_stays_near_the_fp32_reference(name):
+    g = Golden(name)
+    m = _hip(g)
+    kw, target, wv = g.model_kwargs(device="cuda")
+    leaf = {k: kw[k].clone().requires_grad_(True) for k in ("node_feat", "node_loc", "node_vel", "loc_mean")}
+    kw.update(leaf)
+    loc, vloc = m(**kw)
+    golden_loss(loc, vloc, target, wv).backward()
+    G = {k: (p.grad.cpu() if p.grad is not None else torch.zeros_like(p).cpu()) for k, p in m.named_parameters()}
+    gin = {k: v.grad.cpu() for k, v in leaf.items()}
+    l32, v32, G32, gin32 = _mirror(g, torch.float32)
+    l64, v64, G64, gin64 = _mirror(g, torch.float64)
+    bad = []
+    # 1. the mirror
+    if rel_err(loc, l32) > OUT_VS_MIRROR: bad.append(("loc vs mirror", rel_err(loc, l32)))
+    if rel_err(vloc, v32) > OUT_VS_MIRROR: bad.append(("vloc vs mirror", rel_err(vloc, v32)))
+    x0 = torch.from_numpy(g.inp["node_loc"]).double()
+    pairs = [("displacement", loc.detach().cpu().double() - x0, l32.double() - x0, l64 - x0)]
+    pairs += [(k, G[k], G32[k], G64[k]) for k in G64]
+    pairs += [("gin/" + k, gin[k], gin32[k], gin64[k]) for k in gin64]
+    for k, got, m32, m64 in pairs:
+        e_got, e_ref = rel_err(got, m64), rel_err(m32, m64)
+        if e_got > GRAD_FACTOR * e_ref + GRAD_FLOOR:
+            bad.append((k, f"{e_got:.2e}", f"mirror32 {e_ref:.2e}"))
+    # 2. the fp32 reference
+    if rel_err(loc, g.out["loc"]) > OUT_VS_FP32_REF: bad.append(("loc vs fp32 ref", rel_err(loc, g.out["loc"])))
+    if rel_err(vloc, g.out["vloc"]) > OUT_VS_FP32_REF: bad.append(("vloc vs fp32 ref", rel_err(vloc, g.out["vloc"])))
+    d_ref = torch.from_numpy(g.out["loc"]).double() - x0
+    if rel_err(loc.detach().cpu().double() - x0, d_ref) > DISP_VS_FP32_REF:
+        bad.append(("displacement vs fp32 ref", rel_err(loc.detach().cpu().double() - x0, d_ref)))
+    for k in g.gp:
+        if float(np.abs(g.gp[k]).max()) > 0 and rel_err(G[k], g.gp[k]) > GRAD_VS_FP32_REF:
+            bad.append((k + " vs fp32 ref", rel_err(G[k], g.gp[k])))
+    assert not bad, bad
+
+
+def _rot(seed):
+    g = np.random.RandomState(seed)
+    a, b, c = g.uniform(0, 2 * math.pi, 3)
+    rx = np.array([[1, 0, 0], [0, math.cos(a), -math.sin(a)], [0, math.sin(a), math.cos(a)]])
+    ry = np.array([[math.cos(b), 0, math.sin(b)], [0, 1, 0], [-math.sin(b), 0, math.cos(b)]])
+    rz = np.array([[math.cos(c), -math.sin(c), 0], [math.sin(c), math.cos(c), 0], [0, 0, 1]])
+    return torch.from_numpy(rx @ ry @ rz).float()
+
+
+def test_bf16_cfg3_shape_equivariance_and_mirror():
+    """BASELINE configs[2] shape: protein-like contact graphs (3 341 points in a 36 A cube, +50 A offset, 10 A contacts
+    minus the longest 50 %), C=8, bf16 operands.  Rotation + translation equivariance (equivariant_test.py:62, atol
+    scaled to the 50-100 A coordinates), and outputs against the mirror on the same inputs."""
+    from bench import make_protein_batch
+    batch, target = make_protein_batch(2, 3341, 8, 0.5, 43, "cuda")
+    torch.manual_seed(3)
+    m = fastegnn_amd.FastEGNN(2, 0, 2, 64, 8, device="cuda", n_layers=4, mlp_dtype=torch.bfloat16)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith(("coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
+                p.mul_(50.0)          # trained-like coordinate heads (default init leaves the displacement at 1e-5 A)
+        loc0, vl0 = m(**batch)
+        Rm, t = _rot(5).cuda(), torch.tensor([7.0, -11.0, 4.0]).cuda()
+        b2 = dict(batch, node_loc=batch["node_loc"] @ Rm + t, node_vel=batch["node_vel"] @ Rm,
+                  loc_mean=(batch["loc_mean"].permute(0, 2, 1) @ Rm + t).permute(0, 2, 1).contiguous())
+        loc1, vl1 = m(**b2)
+    disp = (loc0 - batch["node_loc"]).abs().max().item()
+    assert disp > 1e-3                                     # the coordinate path is exercised
+    # fp32 rotation of 50-100 A coordinates alone is ~1e-5 A; a flipped bf16 operand moves a node by << its displacement
+    assert (loc0 @ Rm + t - loc1).abs().max().item() < 2e-3 * max(disp, 1.0) + 1e-4
+    assert ((vl0.permute(0, 2, 1) @ Rm + t).permute(0, 2, 1) - vl1).abs().max().item() < 2e-3 * max(disp, 1.0) + 1e-4
+    # mirror on the same inputs (CPU, fp32)
+    cfg = R.Config(2, 0, 2, 64, 8, n_layers=4, bf16=True)
+    p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    lm, vm, _ = F.model_forward(p, cfg, **{k: v.cpu() for k, v in batch.items()})
+    x0 = batch["node_loc"].cpu()
+    assert rel_err(loc0, lm) < OUT_VS_MIRROR and rel_err(vl0, vm) < OUT_VS_MIRROR
+    assert rel_err(loc0.cpu() - x0, lm - x0) < 2e-2
+
+
+def test_bf16_flag_changes_the_arithmetic_and_fp32_default_does_not():
+    """Guards against a silently ignored flag: on the same weights the bf16 mode differs from the fp32 mode by the
+    expected 1e-4..1e-2 of the displacement, not by 0 and not by more."""
+    g = Golden("nbody5_cfg1_trained")
+    kw, _, _ = g.model_kwargs(device="cuda")
+    with torch.no_grad():
+        a = _hip(g)(**kw)[0]
+        c = g.cfg
+        m32 = fastegnn_amd.FastEGNN(c.node_feat_nf, c.node_attr_nf, c.edge_attr_nf, c.hidden_nf, c.virtual_channels, device="cuda",
+                                    n_layers=c.n_layers, gravity=c.gravity)
+        m32.load_state_dict({k: torch.from_numpy(v) for k, v in g.params.items()}, strict=True)
+        b = m32.cuda()(**kw)[0]
+    x0 = kw["node_loc"]
+    e = rel_err(a - x0, b - x0)
+    assert 1e-5 < e < 5e-2, e
+    with pytest.raises(ValueError):
+        fastegnn_amd.FastEGNN(2, 0, 2, 64, 3, mlp_dtype=torch.float16)
