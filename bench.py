@@ -361,13 +361,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # FASTEGNN_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (the ranks share the
+    # visible devices and the collectives are staged through host memory; RCCL refuses two ranks on one device)
+    backend = os.environ.get("FASTEGNN_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     import fastegnn_amd
     from fastegnn_amd import _lib as K
     from fastegnn_amd.dist import allreduce_gradients, init_from_env, max_over_ranks
-    init_from_env("nccl")
+    init_from_env(backend)
 
     cfg = CONFIGS[args.config]
     C, L = args.channels or cfg["C"], args.layers

@@ -12,6 +12,19 @@
 
 namespace fe {
 
+// in-kernel phase stamps of virt_bwd (diagnostic builds only: -DFE_STAMP; tools/gpu_stamp_vb.py)
+#ifdef FE_STAMP
+__device__ unsigned long long g_vb_stamps[16];
+#define VB_T0() unsigned _vb_prev = (unsigned)__builtin_amdgcn_s_memtime(); unsigned _vb_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define VB_T(i) { __builtin_amdgcn_sched_barrier(0); const unsigned _t = (unsigned)__builtin_amdgcn_s_memtime(); \
+                  _vb_acc[i] += _t - _vb_prev; _vb_prev = _t; __builtin_amdgcn_sched_barrier(0); }
+#define VB_TEND() if (lane_id() == 0) { for (int _k = 0; _k < 9; ++_k) atomicAdd(&g_vb_stamps[_k], (unsigned long long)_vb_acc[_k]); }
+#else
+#define VB_T0()
+#define VB_T(i)
+#define VB_TEND()
+#endif
+
 __device__ __forceinline__ Vec vdsilu_mul(const Vec &g, const Vec &z) {
   return vmap2(g, z, [](float a, float b) { return a * dsilu_f(b); });
 }
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   Vec acc_wxv2 = vzero(), acc_wxx2 = vzero(), acc_wvr = vzero(), acc_att = vzero();
   float acc_attb = 0.f;
   int cur = -1;
+  VB_T0()
   auto flush_pools = [&]() {
     for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
       atomicAdd(&A.g_Bc[(size_t)cur * C * H + i], gBc_l[i]);
@@ -210,6 +224,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       float *b_gA = A.g_A + g0 * H;
       float *b_v = A.wg_v + g0 * C * H, *b_t = A.wg_t + g0 * C * H, *b_gux = A.wg_gux + g0 * C * H;
       float *b_guX = A.wg_guX + g0 * C * H, *b_gvp = A.wg_gvp + g0 * C * H;
+      VB_T(7)   // tile bookkeeping (previous tile's tail, pool flush, batch lookups)
       // ---- node MLP adjoint (node_model, :153-166); FastRF: h passes through, no segment-mean message
       const Vec g_out = vmask(vload_u(b_gho, offN), valid);
       Vec g_np = vzero();
@@ -219,22 +234,40 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           vstore_u(b_gam, offN, vzero());
         }
       } else {
+        // The three node-level images (W4T, W3AT, W3BT) pass through the W3cT stage, one after the other: read straight
+        // from global memory by a single wave per SIMD they cost 49 k cycles per tile (phase stamps), 11 % of the kernel.
+        // The workgroup's waves reach this point together (the channel loop below runs in lock step).
+        constexpr int NSTG = IMG / 4 / (64 * VIRT_BWD_WAVES);
+        auto stage_image = [&](int id) {
+          const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (size_t)id * IMG);
+          f32x4 tmp[NSTG];
+#pragma unroll
+          for (int i = 0; i < NSTG; ++i) tmp[i] = src[threadIdx.x + i * 64 * VIRT_BWD_WAVES];
+          __syncthreads();          // every wave is done with the previous content of the stage
+          f32x4 *dst = reinterpret_cast<f32x4 *>(w3ct_l);
+#pragma unroll
+          for (int i = 0; i < NSTG; ++i) dst[threadIdx.x + i * 64 * VIRT_BWD_WAVES] = tmp[i];
+          __syncthreads();
+        };
         {
           const Vec npre = vload_u(b_npre, offN);
           Vec g_t3 = vzero();
-          gemm64_m<FM>(a.wpack + (size_t)I_W4T * IMG, g_out, g_t3);
+          stage_image(I_W4T);
+          gemm64_m<FM>(w3ct_l, g_out, g_t3);
           g_np = vdsilu_mul(g_t3, npre);
           if (valid && own) vstore_u(b_t3, offN, vsilu(npre));
         }
         if (valid && own) vstore_u(b_gnp, offN, g_np);
         {
           Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
-          gemm64_m<FM>(a.wpack + (size_t)I_W3AT * IMG, g_np, g_h);
+          stage_image(I_W3AT);
+          gemm64_m<FM>(w3ct_l, g_np, g_h);
           if (valid && own) vstore_u(b_gh, offN, g_h);
         }
         {
           Vec g_am = vzero();
-          gemm64_m<FM>(a.wpack + (size_t)I_W3BT * IMG, g_np, g_am);
+          stage_image(I_W3BT);
+          gemm64_m<FM>(w3ct_l, g_np, g_am);
           if (valid && own) vstore_u(b_gam, offN, g_am);
         }
       }
@@ -258,6 +291,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         A.g_svel[n] = sv;
         if (a.flags & FASTEGNN_F_GRAVITY) A.g_sgrav[n] = sg;
       }
+      VB_T(0)   // node-MLP adjoint of the tile
       Vec g_A = vzero();
       const float *Zb = a.Z + (size_t)b * 3 * C;
       // Channel-invariant rows stay in registers, and the per-channel rows of channel c+1 are requested
@@ -288,6 +322,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       };
       if constexpr (!rf) { if (C > 0 && !split) fetch_w3ct(0); }
       for (int c = c_first; c < C; c += c_step) {
+        VB_T(7)
         // Recompute the forward of (tile, c) interleaved with its adjoint so that each activation is
         // dead as soon as its gradient is formed.
         asm volatile("" ::: "memory");
@@ -319,6 +354,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+        VB_T(1)   // channel top: workgroup sync, W3cT stage, next-channel rows requested
         const float vr = sqrt_f(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
         auto make_pre = [&]() {
           Vec p = Arow;
@@ -343,6 +379,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         WG_STORE(if (valid) vstore_u(b_v, oc, v);)
         const SOp vs = sop(v);   // feeds both coordinate heads
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
+        VB_T(2)   // pre, silu, V2 product, silu, operand of the heads
         Vec g_v = rf ? vzero() : vmask(gpv_c, valid);
         if constexpr (!rf) {
           if (split) gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);   // the stage serves one channel at a time
@@ -350,6 +387,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         }
         float g_vd[3];
         float sx, sX;
+        VB_T(3)   // W3cT product
         {  // coord_mlp_r_virtual head: forward, then its adjoint
           Vec uxp = vload_vec(vec + VV_BXV0 * H, q);
           gemm_op<SM>(simg, 1, vs, uxp);
@@ -365,6 +403,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           WG_STORE(if (valid) vstore_u(b_gux, oc, g_up);)
           gemm64_m<FM>(img + S_WXV0T * IMG, g_up, g_v);
         }
+        VB_T(4)   // head x: forward product, silu, dot, transposed product
         {  // coord_mlp_v_virtual head
           Vec uXp = vload_vec(vec + VV_BXX0 * H, q);
           gemm_op<SM>(simg, 2, vs, uXp);
@@ -380,6 +419,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           WG_STORE(if (valid) vstore_u(b_guX, oc, g_up);)
           gemm64_m<FM>(img + S_WXX0T * IMG, g_up, g_v);
         }
+        VB_T(5)   // head X
 #pragma unroll
         for (int k = 0; k < 3; ++k) g_vd[k] = -sx * invC * gxn[k] + sX * gpX[k];
         Vec g_v0 = g_v;
@@ -397,6 +437,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           WG_STORE(if (valid) vstore_u(b_gvp, oc, g_vp);)
           gemm_op<SM>(simg, S_V2T, sop(g_vp), g_t);
         }
+        VB_T(6)   // attention adjoint, g_vp, V2T product
         const Vec g_pre = vmul(g_t, d_pre);
         vadd(g_A, g_pre);
         vaxpy(acc_wvr, vr, g_pre);
@@ -437,6 +478,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
                 atomicAdd(&A.g_Bc[((size_t)b * C + c) * H + 16 * t + 4 * q + r], g_pre.t[t][r]);
           }
         }
+        VB_T(8)   // g_pre consumers: g_A, w_vr, vr adjoint, pools
       }
       if (split) {   // sum the four waves' channel shares of g_A and g_x ([16][68] floats in the idle W3cT stage)
         float *comb = w3ct_l;
@@ -471,6 +513,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   }
   __syncthreads();
   if (cur >= 0) flush_pools();
+  VB_TEND()
   // rank-1 weight gradients held per lane -> LDS (reuse the vector area) -> one atomic set per workgroup
   float *red = vec;   // [5][64]; the weight vectors are dead now
   __syncthreads();
@@ -1298,3 +1341,14 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
 }
 
 }  // namespace fe
+
+#ifdef FE_STAMP
+extern "C" int fastegnn_debug_read_vb_stamps(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::g_vb_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(fe::g_vb_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif

@@ -104,7 +104,8 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // =====================================================================================
 // A wave owns 1024 consecutive nodes and walks them 64 at a time (lane = node).  data_batch is ascending, so a
 // 64-node group normally lies inside one graph: the lanes keep partial sums and the wave leaves ONE atomic set per
-// (wave, graph) run; groups that straddle graphs (mini-batches of tiny graphs) add per node.
+// (wave, graph) run; groups that straddle graphs (mini-batches of small graphs) are reduced by a segmented scan over the
+// lanes (data_batch is sorted, so a graph is a run of lanes) and add once per (group, graph).
 __global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const int32_t *batch, int N, float *xsum) {
   constexpr int PER_WAVE = 1024;
   const int l = lane_id();
@@ -137,11 +138,24 @@ __global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const i
     } else {
       if (cur >= 0) flush();
       cur = -1;
-      if (ok) {
-        atomicAdd(&xsum[b * 4 + 0], xv[0]);
-        atomicAdd(&xsum[b * 4 + 1], xv[1]);
-        atomicAdd(&xsum[b * 4 + 2], xv[2]);
-        atomicAdd(&xsum[b * 4 + 3], 1.f);
+      // segmented inclusive scan: after it the LAST lane of every run of equal graph ids holds the run's sums
+      const int bb = ok ? b : -1;
+      float v[4] = {xv[0], xv[1], xv[2], ok ? 1.f : 0.f};
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int bu = __shfl_up(bb, off);
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = __shfl_up(v[k], off);
+        if (l >= off && bu == bb) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] += u[k];
+        }
+      }
+      const int bn = __shfl_down(bb, 1);
+      if (ok && (l == 63 || bn != bb)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&xsum[b * 4 + k], v[k]);
       }
     }
   }
@@ -485,27 +499,55 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     if (active && rf && own) {   // the node features pass through unchanged (FastRF.py:186)
       if (valid) vstore_row(a.h_out + (size_t)n * H, q, vload_row(a.h + (size_t)nc * H, q));
     }
-    if (active && !rf && own) {
-      // node_model: node_mlp.0 on [h | agg | flat(v) | node_attr]  (:153-166)
-      const Vec hv = vload_row(a.h + (size_t)nc * H, q);
-      gemm64_m<MODE>(a.wpack + (size_t)I_W3A * IMG, hv, nodeacc);
-      gemm64_m<MODE>(a.wpack + (size_t)I_W3B * IMG, vload_row(a.aggm + (size_t)nc * H, q), nodeacc);
-      if (a.na > 0) {
-        const int ld = 2 * H + H * C + a.na;
-        for (int k = 0; k < a.na; ++k) {
-          const float av = a.node_attr[(size_t)nc * a.na + k];
+    if (!rf) {
+      // node_model: node_mlp.0 on [h | agg | flat(v) | node_attr]  (:153-166).  The three node-level images (W3A, W3B,
+      // W4) pass through the idle W3c stage, one after the other -- every wave of the workgroup takes part in the copy,
+      // the waves that own a tile run the products (read straight from global memory these three products cost more
+      // than the whole channel loop of a tile, cf. the phase stamps of virt_bwd).
+      const bool mine = active && own;
+      float *fstage = reinterpret_cast<float *>(stage);
+      constexpr int NSTG = IMG / 4 / (64 * VIRT_WAVES);
+      static_assert(NSTG * 4 * 64 * VIRT_WAVES == IMG, "stage copy must tile the fp32 image");
+      auto stage_image = [&](int id) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (size_t)id * IMG);
+        f32x4 tmp[NSTG];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < NSTG; ++i) tmp[i] = src[threadIdx.x + i * 64 * VIRT_WAVES];
+        __syncthreads();          // every wave is done with the previous content of the stage
+        f32x4 *dst = reinterpret_cast<f32x4 *>(fstage);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              nodeacc.t[t][r] += av * a.N0W[(size_t)(16 * t + 4 * q + r) * ld + 2 * H + H * C + k];
-        }
+        for (int i = 0; i < NSTG; ++i) dst[threadIdx.x + i * 64 * VIRT_WAVES] = tmp[i];
+        __syncthreads();
+      };
+      Vec hv = vzero();
+      stage_image(I_W3A);
+      if (mine) {
+        hv = vload_row(a.h + (size_t)nc * H, q);
+        gemm64_m<MODE>(fstage, hv, nodeacc);
       }
-      if (valid) vstore_row(a.npre + (size_t)n * H, q, nodeacc);
-      Vec out = vload_vec(vec + VV_B4 * H, q);
-      gemm64_m<MODE>(a.wpack + (size_t)I_W4 * IMG, vsilu(nodeacc), out);
-      if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
-      if (valid) vstore_row(a.h_out + (size_t)n * H, q, out);
+      stage_image(I_W3B);
+      if (mine) {
+        gemm64_m<MODE>(fstage, vload_row(a.aggm + (size_t)nc * H, q), nodeacc);
+        if (a.na > 0) {
+          const int ld = 2 * H + H * C + a.na;
+          for (int k = 0; k < a.na; ++k) {
+            const float av = a.node_attr[(size_t)nc * a.na + k];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                nodeacc.t[t][r] += av * a.N0W[(size_t)(16 * t + 4 * q + r) * ld + 2 * H + H * C + k];
+          }
+        }
+        if (valid) vstore_row(a.npre + (size_t)n * H, q, nodeacc);
+      }
+      stage_image(I_W4);
+      if (mine) {
+        Vec out = vload_vec(vec + VV_B4 * H, q);
+        gemm64_m<MODE>(fstage, vsilu(nodeacc), out);
+        if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
+        if (valid) vstore_row(a.h_out + (size_t)n * H, q, out);
+      }
     }
     if (active && own) {
       if (valid) {

@@ -106,8 +106,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   if (t >= a.count) return;
   float *p = a.p[t], *m = a.m[t], *v = a.v[t];
   const float *g = a.g[t];
+  if (!g) return;   // torch.optim.Adam skips parameters whose .grad is None: no decay, no moment update
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n[t]; i += (long)gridDim.x * 256) {
-    const float gi = (g ? g[i] : 0.f) + a.wd * p[i];
+    const float gi = g[i] + a.wd * p[i];
     const float mi = a.b1 * m[i] + (1.f - a.b1) * gi;
     const float vi = a.b2 * v[i] + (1.f - a.b2) * gi * gi;
     m[i] = mi;

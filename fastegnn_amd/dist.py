@@ -93,6 +93,8 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, averag
 
 
 def max_over_ranks(value: float, device) -> float:
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([value], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

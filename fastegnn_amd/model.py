@@ -327,6 +327,12 @@ class _FastEGNNFunction(torch.autograd.Function):
         K.check(lib.fastegnn_embed_backward(K.ptr(node_feat), K.ptr(g_h), N, spec.nf, K.ptr(params[1]),
                                             K.ptr(grads[1]), K.ptr(grads[2]), K.ptr(g_nf), st),
                 "fastegnn_embed_backward")
+        # The last layer's node_mlp / node_mlp_virtual only feed h and Hv, which nothing reads after the last layer: the
+        # reference's autograd leaves their .grad None (and torch.optim.Adam then skips them); the kernels wrote zeros.
+        last = spec.n_layers - 1
+        for s_, suffix in zip(spec.layer_slots[last], K.PARAM_SLOTS):
+            if s_ is not None and suffix.startswith(("node_mlp.", "node_mlp_virtual.")) and not (spec.flags & K.F_RF):
+                grads[s_] = None
         return (None, None, None, None, None, None, g_nf, g_x, g_vel, g_Z, *grads)
 
 

@@ -68,7 +68,6 @@ class FusedAdam:
         self.step_count = 0
         n = len(self.params)
         self._numel = (C.c_int64 * n)(*[p.numel() for p in self.params])
-        self._p = (C.c_void_p * n)(*[p.data_ptr() for p in self.params])
         self._m = (C.c_void_p * n)(*[t.data_ptr() for t in self.exp_avg])
         self._v = (C.c_void_p * n)(*[t.data_ptr() for t in self.exp_avg_sq])
 
@@ -87,7 +86,14 @@ class FusedAdam:
             grads.append(g)
         gp = (C.c_void_p * n)(*[(g.data_ptr() if g is not None else None) for g in grads])
         dev = self.params[0].device
-        K.check(K.lib().fastegnn_adam_step(self._p, gp, self._m, self._v, self._numel, n, self.step_count,
+        # parameter pointers are read at every step: a model moved with .to() / .cuda() after the optimizer was built
+        # has new storages (the moments follow the device of the parameters)
+        pp = (C.c_void_p * n)(*[p.data_ptr() for p in self.params])
+        for i, p in enumerate(self.params):
+            if self.exp_avg[i].device != p.device:
+                self.exp_avg[i], self.exp_avg_sq[i] = self.exp_avg[i].to(p.device), self.exp_avg_sq[i].to(p.device)
+                self._m[i], self._v[i] = self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
+        K.check(K.lib().fastegnn_adam_step(pp, gp, self._m, self._v, self._numel, n, self.step_count,
                                            float(self.lr), float(self.betas[0]), float(self.betas[1]),
                                            float(self.eps), float(self.weight_decay), _stream(dev)),
                 "fastegnn_adam_step")

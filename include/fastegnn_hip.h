@@ -278,7 +278,8 @@ int fastegnn_loss_mse_mmd(const float *loc_pred, const float *loc_t, const float
                           int32_t N, int32_t B, int32_t C, int32_t S, float sigma, float weight, float *loss2,
                           float *g_loc, float *g_vloc, void *stream);
 /* torch.optim.Adam step (no amsgrad, L2 weight decay; main_nbody.py:137) over n_tensors tensors given as HOST arrays
- * of device pointers; grads[i] may be null (treated as zero); step counts from 1. */
+ * of device pointers; a tensor whose grads[i] is null is skipped entirely, as torch.optim.Adam skips parameters whose
+ * .grad is None (no weight decay, no moment update); step counts from 1. */
 int fastegnn_adam_step(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                        const int64_t *numel, int32_t n_tensors, int32_t step, float lr, float beta1, float beta2,
                        float eps, float weight_decay, void *stream);

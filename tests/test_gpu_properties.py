@@ -77,7 +77,7 @@ def _check_vs_oracle(cfg, inp, seed, case=None, extra_flags=0):
     kw = {k: v.cuda() for k, v in inp.items()}
     loc, vloc = m(**kw)
     _loss(loc, vloc, tgt.cuda()).backward()
-    got = {k: v.grad.cpu() for k, v in m.named_parameters()}
+    got = {k: (v.grad.cpu() if v.grad is not None else torch.zeros_like(v).cpu()) for k, v in m.named_parameters()}
     # oracle fp32 and fp64
     res = {}
     for dt in (torch.float32, torch.float64):
@@ -237,7 +237,7 @@ def test_cfg5_full_size_properties():
         loc, vloc = m(**f)
         torch.nn.functional.mse_loss(loc, target + shift).backward()
         assert torch.isfinite(loc).all() and torch.isfinite(vloc).all()
-        g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        g = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
         assert torch.isfinite(g).all()
         outs.append((loc.detach(), vloc.detach(), g))
         del loc, vloc
@@ -277,6 +277,25 @@ def test_many_tiles_per_workgroup_vs_oracle():
     _check_vs_oracle(cfg, _batch([20000, 12000, 4900], 2, 8, seed=13), seed=13)
 
 
+def test_unused_last_layer_heads_have_no_gradient():
+    """The reference's autograd leaves .grad None for the last layer's node_mlp / node_mlp_virtual (their outputs feed
+    nothing); torch.optim.Adam skips such parameters.  Same here, and FusedAdam skips them too."""
+    from fastegnn_amd.train import FusedAdam
+    cfg = R.Config(2, 0, 2, 64, 4, n_layers=2)
+    _, m = _models(cfg, 3)
+    inp = {k: v.cuda() for k, v in _batch([40, 23], 3, 4, seed=8).items()}
+    loc, vloc = m(**inp)
+    _loss(loc, vloc, inp["node_loc"] + 0.5).backward()
+    none = sorted(k for k, p in m.named_parameters() if p.grad is None)
+    assert none == sorted(f"gcl_1.{n}.{i}.{w}" for n in ("node_mlp", "node_mlp_virtual") for i in (0, 2) for w in ("weight", "bias"))
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    opt = FusedAdam(m.parameters(), lr=1e-2, weight_decay=0.1)
+    opt.step()
+    for k, p in m.named_parameters():
+        changed = not torch.equal(p.detach(), before[k])
+        assert changed == (k not in none), k
+
+
 def test_no_edges_and_isolated_nodes():
     cfg = R.Config(2, 0, 2, 64, 4, n_layers=2)
     inp = _batch([40, 23], 3, 4, seed=8)
@@ -301,7 +320,7 @@ def test_cfg4_full_size_properties():
         loc, vloc = m(**f)
         torch.nn.functional.mse_loss(loc, target + shift).backward()
         assert torch.isfinite(loc).all() and torch.isfinite(vloc).all()
-        g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        g = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
         assert torch.isfinite(g).all()
         outs.append((loc.detach(), vloc.detach(), g))
     # translation equivariance of the outputs, translation invariance of the gradients
