@@ -345,6 +345,68 @@ __device__ __forceinline__ void gemm64_b1(const unsigned *img3, const BfOp &in, 
   }
 }
 
+// ---- row-major split images: ONE LDS copy of a weight serves the product AND its transpose ------------------------
+// Part p (h | m | l) of W [64 out x 64 in] as plain rows of bf16: element (p, o, k) at byte p*RM_PART + o*RM_RS + 2k.
+// The product y = W x reads a lane's A fragment -- 8 bf16 of row o = 16t + i, k = 32s + 4q + {0..3} and + 16 -- with two
+// ds_read_b64; the transposed product y = W^T g reads it with two ds_read_b64_tr_b16 (gfx950: a 16-lane group fetches a
+// block of 4 rows x 16 columns and every lane receives one COLUMN of it): rows o = 32s + 4q + {0..3} (and + 16) at column
+// k = 16t + i.  Both orders equal bf3_k, the k order of the chained D layout, so either product takes the usual operand.
+// The 144-byte row stride keeps the row reads conflict-free (bank = 36 o + 2 q mod 64 over a 32-lane half) and leaves the
+// transposed reads 2-way on 4 of 64 banks.
+constexpr int RM_RS = 144;
+constexpr int RM_PART = 64 * RM_RS;       // 9 216 bytes
+constexpr int RM_BYTES = 3 * RM_PART;     // 27 648 bytes = 27 wave-instructions of an LDS-DMA copy
+constexpr int RM_WORDS = RM_BYTES / 4;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 lds_tr_read(const char *p) {   // EXEC must be all ones (the gather crosses lanes)
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                       (__attribute__((address_space(3))) s16x4 *)(p)));
+}
+// A fragment of part `part`, tile t, k-step s of W (TR = false) or W^T (TR = true)
+template <bool TR>
+__device__ __forceinline__ bf16x8 rm_frag(const char *img, int part, int t, int s) {
+  const int l = lane_id(), i = l & 15, q = l >> 4;
+  u32x2 lo, hi;
+  if constexpr (TR) {
+    const char *p = img + part * RM_PART + (32 * s + 4 * q + (i >> 2)) * RM_RS + (16 * t + 4 * (i & 3)) * 2;
+    lo = lds_tr_read(p);
+    hi = lds_tr_read(p + 16 * RM_RS);
+  } else {
+    const char *p = img + part * RM_PART + (16 * t + i) * RM_RS + (32 * s + 4 * q) * 2;
+    lo = *reinterpret_cast<const u32x2 *>(p);
+    hi = *reinterpret_cast<const u32x2 *>(p + 32);
+  }
+  return __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+}
+template <bool TR>
+__device__ __forceinline__ void gemm64_x3_rm(const char *img, const Split &in, Vec &acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16x8 ah = rm_frag<TR>(img, 0, t, s), am = rm_frag<TR>(img, 1, t, s), al = rm_frag<TR>(img, 2, t, s);
+      const bf16x8 xh = __builtin_bit_cast(bf16x8, in.p[0][s]);
+      const bf16x8 xm = __builtin_bit_cast(bf16x8, in.p[1][s]);
+      const bf16x8 xl = __builtin_bit_cast(bf16x8, in.p[2][s]);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xm, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xh, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xm, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc.t[t], 0, 0, 0);
+    }
+}
+template <bool TR>
+__device__ __forceinline__ void gemm64_b1_rm(const char *img, const BfOp &in, Vec &acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const bf16x8 x = __builtin_bit_cast(bf16x8, in.p[s]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rm_frag<TR>(img, 0, t, s), x, acc.t[t], 0, 0, 0);
+  }
+}
+
 // Arithmetic form of the 64x64 layers of a kernel (template parameter of the stage kernels)
 enum GemmMode { GM_F32 = 0, GM_X3 = 1, GM_BF16 = 2 };
 // the B operand of one or several products in the chosen form: made once, used by every layer that reads it
@@ -366,6 +428,13 @@ __device__ __forceinline__ void gemm_op(const void *img, int i, const typename O
 }
 // a product on an fp32 image (fp32-input MFMA) inside a kernel of form MODE: in bf16 mode the activation is rounded
 // (the image already holds bf16-representable weights), so the product has the bf16-mode semantics exactly
+// product (TR = false) or transposed product (TR = true) on a row-major split image, forms GM_X3 / GM_BF16
+template <int MODE, bool TR>
+__device__ __forceinline__ void gemm_rm(const char *img, const typename OperandOf<MODE>::type &in, Vec &acc) {
+  static_assert(MODE == GM_X3 || MODE == GM_BF16, "row-major images hold bf16 parts");
+  if constexpr (MODE == GM_X3) gemm64_x3_rm<TR>(img, in, acc);
+  else gemm64_b1_rm<TR>(img, in, acc);
+}
 template <int MODE>
 __device__ __forceinline__ void gemm64_m(const float *img, const Vec &in, Vec &acc) {
   if constexpr (MODE == GM_BF16) gemm64(img, vround(in), acc);
@@ -406,9 +475,17 @@ enum ImgId {
 };
 __host__ __device__ inline int img_w3c(int c) { return I_FIXED + c; }
 __host__ __device__ inline int img_w3ct(int C, int c) { return I_FIXED + C + c; }
-// wpack = [fp32 images n x 4096 floats][split images n x IMG3 words (h | m | l)]
+// wpack = [fp32 images n x 4096 floats][split images n x IMG3 words (h | m | l)][row-major split images (3 + C) x RM_WORDS]
+// row-major images (virt_bwd): slot 0 V2, 1 WXV0, 2 WXX0, 3 + c: W3c[c]
 __host__ __device__ inline size_t wpack_images(int C) { return (size_t)(I_FIXED + 2 * C); }
-__host__ __device__ inline size_t wpack_floats(int C) { return wpack_images(C) * (IMG + IMG3); }
+__host__ __device__ inline size_t wpack_rm_images(int C) { return (size_t)(3 + (C > 0 ? C : 0)); }
+__host__ __device__ inline size_t wpack_floats(int C) { return wpack_images(C) * (IMG + IMG3) + wpack_rm_images(C) * RM_WORDS; }
+__host__ __device__ inline int rm_slot(int id) {   // -1: the image has no row-major copy
+  return id == I_V2 ? 0 : id == I_WXV0 ? 1 : id == I_WXX0 ? 2 : -1;
+}
+__host__ __device__ inline const char *wpack_rm(const float *wpack, int C, int slot) {
+  return reinterpret_cast<const char *>(wpack + wpack_images(C) * (IMG + IMG3)) + (size_t)slot * RM_BYTES;
+}
 __host__ __device__ inline const unsigned *wpack_x3(const float *wpack, int C, int id) {
   return reinterpret_cast<const unsigned *>(wpack + wpack_images(C) * IMG) + (size_t)id * IMG3;
 }

@@ -137,7 +137,7 @@ struct VirtBwdArgs {
   int ld_v0;
 };
 
-constexpr int virt_bwd_img_floats(bool x3h) { return x3h ? 2 * IMG + 4 * IMG3 : 6 * IMG; }
+constexpr int virt_bwd_img_floats(bool x3h) { return x3h ? 5 * RM_WORDS : 6 * IMG; }   // X3H: 3 images + 2 stage buffers
 // RF (FastRF reduced layer) is a compile-time switch: as a run-time flag it cost the FastEGNN path 10 %
 // (register allocation of the channel loop)
 // BF: bf16 operand mode (FASTEGNN_F_BF16): split-image sites run one bf16 product of the rounded activation, fp32-image
@@ -148,25 +148,48 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   constexpr int FM = BF ? GM_BF16 : GM_F32;                    // fp32-image sites: gemm64_m<FM> rounds in bf16 mode
   typedef typename OperandOf<SM>::type SOp;
   auto sop = [](const Vec &v) -> SOp { return make_operand<SM>((BF && !X3H) ? vround(v) : v); };
+  (void)FM;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VirtArgs &a = A.f;
   const int C = a.C;
-  // fp32 images V2 WXV0 WXX0 V2T WXV0T WXX0T; X3H (LDS permitting: C <= 32): V2, WXV0, WXX0 and V2T as split
-  // images for the bf16 matrix pipe, only the two transposed head layers stay fp32: WXV0T WXX0T | V2 WXV0 WXX0 V2T
+  // X3H (C <= 32): three ROW-MAJOR split images V2, WXV0, WXX0 (common.h) serve the three recomputed products by row
+  // reads and their three transposes by ds_read_b64_tr_b16 -- no V2T / WXV0T / WXX0T copies, every product on the matrix
+  // pipe -- followed by two stage buffers for the row-major image of W3c[c] (read transposed), filled by LDS-DMA one
+  // channel ahead.  Otherwise (C > 32): six fp32 images V2 WXV0 WXX0 V2T WXV0T WXX0T and an fp32 W3cT stage behind the pools.
   float *img = lds;
-  const unsigned *img3 = reinterpret_cast<const unsigned *>(lds + 2 * IMG);   // split images (X3H)
-  constexpr int S_V2 = 0, S_V2T = 3, S_WXV0T = X3H ? 0 : 4, S_WXX0T = X3H ? 1 : 5;
-  const void *simg = X3H ? static_cast<const void *>(img3) : static_cast<const void *>(img);   // images of the split-image sites
+  char *rmimg = reinterpret_cast<char *>(lds);
+  char *stage0 = rmimg + 3 * RM_BYTES, *stage1 = stage0 + RM_BYTES;
+  constexpr int S_V2T = 3;
+  const void *simg = static_cast<const void *>(img);   // (C > 32) images of the recomputed products
   float *vec = lds + virt_bwd_img_floats(X3H);
   float *gBc_l = vec + 16 * H;                   // [C][64]
   float *gZ_l = gBc_l + C * H;                   // [3][C]
-  float *w3ct_l = gZ_l + ((3 * C + 3) & ~3);     // W3cT[c] of the channel in flight (fp32 image)
+  // fp32 stage: W3cT[c] of the channel in flight (C > 32), the node-level images of a tile's prologue, the combine tile
+  float *w3ct_l = X3H ? reinterpret_cast<float *>(stage1) : gZ_l + ((3 * C + 3) & ~3);
   if constexpr (X3H) {
-    load_images(img, a.wpack + (size_t)I_WXV0T * IMG, 2);
-    load_images_x3(reinterpret_cast<unsigned *>(lds + 2 * IMG), wpack_x3(a.wpack, C, I_V2), 4);   // ids V2..V2T are consecutive
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, C, 0));   // slots 0..2 are consecutive
+    u32x4 *dst = reinterpret_cast<u32x4 *>(rmimg);
+    for (int i = threadIdx.x; i < 3 * RM_BYTES / 16; i += blockDim.x) dst[i] = src[i];
   } else {
     load_images(img, a.wpack + (size_t)I_V2 * IMG, 6);
   }
+  // the product with resident weight `which` (0 V2, 1 WXV0, 2 WXX0) and with its transpose
+  auto mm = [&](int which, const SOp &op, Vec &acc) {
+    if constexpr (X3H) gemm_rm<SM, false>(rmimg + which * RM_BYTES, op, acc);
+    else gemm_op<SM>(simg, which, op, acc);
+  };
+  auto mmT = [&](int which, const Vec &g, Vec &acc) {
+    if constexpr (X3H) gemm_rm<SM, true>(rmimg + which * RM_BYTES, make_operand<SM>(g), acc);
+    else gemm64_m<FM>(img + (S_V2T + which) * IMG, g, acc);
+  };
+  // LDS-DMA of the row-major image of W3c[c] (27 wave-instructions of 1 KiB, dealt to the four waves)
+  auto dma_w3c = [&](int c, char *dst) {
+    const char *src = wpack_rm(a.wpack, C, 3 + c);
+    const int ln = lane_id();
+    for (int ch = wave_id(); ch < RM_BYTES / 1024; ch += VIRT_BWD_WAVES)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ch * 1024 + ln * 16),
+                                       (__attribute__((address_space(3))) void *)(dst + ch * 1024), 16, 0, 0);
+  };
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) gBc_l[i] = 0.f;
   __syncthreads();
@@ -244,6 +267,9 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
 #pragma unroll
           for (int i = 0; i < NSTG; ++i) tmp[i] = src[threadIdx.x + i * 64 * VIRT_BWD_WAVES];
           __syncthreads();          // every wave is done with the previous content of the stage
+          if constexpr (X3H) {      // both stage buffers are free now: channel 0's image lands under the prologue
+            if (id == I_W4T && C > 0 && !split) dma_w3c(0, stage0);
+          }
           f32x4 *dst = reinterpret_cast<f32x4 *>(w3ct_l);
 #pragma unroll
           for (int i = 0; i < NSTG; ++i) dst[threadIdx.x + i * 64 * VIRT_BWD_WAVES] = tmp[i];
@@ -311,28 +337,38 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C + c_first];
         }
       }
-      // W3cT[c] goes through an LDS stage refilled once per workgroup and channel; the image of channel
-      // c+1 is fetched into registers at the top of channel c (ahead of that channel's stores)
+      // W3cT[c] goes through an LDS stage refilled once per workgroup and channel.  C > 32: the fp32 image of channel
+      // c+1 is fetched into registers at the top of channel c (ahead of that channel's stores) and committed at the top
+      // of c+1 between two barriers.  X3H: the row-major image of W3c[c+1] is sent to the other stage buffer by LDS-DMA
+      // right after the single barrier of channel c (that barrier's vmcnt(0) retires the copy of channel c).
       constexpr int STG = IMG / 4 / (64 * VIRT_BWD_WAVES);
-      f32x4 pre_w[STG];
+      f32x4 pre_w[X3H ? 1 : STG];
       auto fetch_w3ct = [&](int c) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (size_t)img_w3ct(C, c) * IMG);
+        if constexpr (!X3H) {
+          const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (size_t)img_w3ct(C, c) * IMG);
 #pragma unroll
-        for (int i = 0; i < STG; ++i) pre_w[i] = src[threadIdx.x + i * 64 * VIRT_BWD_WAVES];
+          for (int i = 0; i < STG; ++i) pre_w[i] = src[threadIdx.x + i * 64 * VIRT_BWD_WAVES];
+        }
       };
-      if constexpr (!rf) { if (C > 0 && !split) fetch_w3ct(0); }
+      if constexpr (!rf && !X3H) { if (C > 0 && !split) fetch_w3ct(0); }
       for (int c = c_first; c < C; c += c_step) {
         VB_T(7)
         // Recompute the forward of (tile, c) interleaved with its adjoint so that each activation is
         // dead as soon as its gradient is formed.
         asm volatile("" ::: "memory");
         if constexpr (!rf) if (!split) {
-          __syncthreads();          // every wave is done with the previous channel's stage
-          f32x4 *dst = reinterpret_cast<f32x4 *>(w3ct_l);
+          if constexpr (X3H) {
+            __syncthreads();          // channel c's image has landed (every wave waited for its share of the copy) and
+                                      // every wave is done with channel c-1, whose buffer the next copy overwrites
+            if (c + 1 < C) dma_w3c(c + 1, ((c + 1) & 1) ? stage1 : stage0);
+          } else {
+            __syncthreads();          // every wave is done with the previous channel's stage
+            f32x4 *dst = reinterpret_cast<f32x4 *>(w3ct_l);
 #pragma unroll
-          for (int i = 0; i < STG; ++i) dst[threadIdx.x + i * 64 * VIRT_BWD_WAVES] = pre_w[i];
-          __syncthreads();
-          fetch_w3ct(c + 1 < C ? c + 1 : c);
+            for (int i = 0; i < STG; ++i) dst[threadIdx.x + i * 64 * VIRT_BWD_WAVES] = pre_w[i];
+            __syncthreads();
+            fetch_w3ct(c + 1 < C ? c + 1 : c);
+          }
         }
         const unsigned oc = offNC + (unsigned)c * H;
         const Vec Bc_c = nBc, gpv_c = nGpv;
@@ -367,7 +403,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {
           const Vec t = vsilu_keep_d(d_pre);      // d_pre <- silu'(pre)
           WG_STORE(if (valid) vstore_u(b_t, oc, t);)
-          gemm_op<SM>(simg, S_V2, sop(t), vp);
+          mm(0, sop(t), vp);
         }
         const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
         float att = 1.f;
@@ -383,6 +419,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         Vec g_v = rf ? vzero() : vmask(gpv_c, valid);
         if constexpr (!rf) {
           if (split) gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);   // the stage serves one channel at a time
+          else if constexpr (X3H) gemm_rm<SM, true>((c & 1) ? stage1 : stage0, make_operand<SM>(g_np_m), g_v);
           else gemm64(w3ct_l, g_np_m, g_v);                                          // (g_np_m is rounded already in bf16 mode)
         }
         float g_vd[3];
@@ -390,7 +427,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         VB_T(3)   // W3cT product
         {  // coord_mlp_r_virtual head: forward, then its adjoint
           Vec uxp = vload_vec(vec + VV_BXV0 * H, q);
-          gemm_op<SM>(simg, 1, vs, uxp);
+          mm(1, vs, uxp);
           const Vec ux = vsilu_keep_d(uxp);       // uxp <- silu'(uxp)
           const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
           sx = tanh_on ? tanh_f(sr) : sr;
@@ -401,12 +438,12 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           vaxpy(acc_wxv2, g_sr, ux);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
           WG_STORE(if (valid) vstore_u(b_gux, oc, g_up);)
-          gemm64_m<FM>(img + S_WXV0T * IMG, g_up, g_v);
+          mmT(1, g_up, g_v);
         }
         VB_T(4)   // head x: forward product, silu, dot, transposed product
         {  // coord_mlp_v_virtual head
           Vec uXp = vload_vec(vec + VV_BXX0 * H, q);
-          gemm_op<SM>(simg, 2, vs, uXp);
+          mm(2, vs, uXp);
           const Vec uX = vsilu_keep_d(uXp);
           const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
           sX = tanh_on ? tanh_f(sr) : sr;
@@ -417,7 +454,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           vaxpy(acc_wxx2, g_sr, uX);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
           WG_STORE(if (valid) vstore_u(b_guX, oc, g_up);)
-          gemm64_m<FM>(img + S_WXX0T * IMG, g_up, g_v);
+          mmT(2, g_up, g_v);
         }
         VB_T(5)   // head X
 #pragma unroll
@@ -435,7 +472,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {
           const Vec g_vp = vmul(g_v0, vp);
           WG_STORE(if (valid) vstore_u(b_gvp, oc, g_vp);)
-          gemm_op<SM>(simg, S_V2T, sop(g_vp), g_t);
+          mmT(0, g_vp, g_t);
         }
         VB_T(6)   // attention adjoint, g_vp, V2T product
         const Vec g_pre = vmul(g_t, d_pre);
@@ -577,7 +614,7 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   {
     ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st);
     const bool x3h = C <= 32, bf = has(L, FASTEGNN_F_BF16);
-    const size_t lds = virt_lds_bytes(C, 0, 0) + (virt_bwd_img_floats(x3h) + IMG + 4) * sizeof(float);
+    const size_t lds = virt_lds_bytes(C, 0, 0) + (virt_bwd_img_floats(x3h) + (x3h ? 0 : IMG) + 4) * sizeof(float);
     const dim3 g3(grid), b3(64 * VIRT_BWD_WAVES);
 #define FE_VB(RF_, X3H_, BF_) hipLaunchKernelGGL((virt_bwd_kernel<RF_, X3H_, BF_>), g3, b3, lds, st, A)
     if (has(L, FASTEGNN_F_RF)) {

@@ -468,6 +468,32 @@ __global__ __launch_bounds__(64) void selftest_gemm_kernel(const float *W, const
   vstore_row(Y + j * H, q, acc);
 }
 
+// Row-major split image (common.h): Y[j][.] = W X[j] (transposed = 0) or W^T X[j] (1) for one 16-item tile, in the
+// bf16x3 form (mode 0) or the single-product bf16 form on rounded operands (mode 1); the image is built in LDS
+// exactly as pack_kernel writes it.
+__global__ __launch_bounds__(64) void selftest_rm_kernel(const float *W, const float *X, float *Y, int transposed, int mode) {
+  __shared__ __attribute__((aligned(16))) unsigned rm[RM_WORDS];
+  for (int idx = threadIdx.x; idx < 64 * (RM_RS / 4); idx += 64) {
+    const int o = idx / (RM_RS / 4), w = idx % (RM_RS / 4);
+    float w0 = w < 32 ? W[o * H + 2 * w] : 0.f, w1 = w < 32 ? W[o * H + 2 * w + 1] : 0.f;
+    if (mode == 1) { w0 = round_bf(w0); w1 = round_bf(w1); }
+    for (int p = 0; p < 3; ++p) rm[p * (RM_PART / 4) + idx] = split_word(w0, w1, p);
+  }
+  __syncthreads();
+  const int l = lane_id(), j = l & 15, q = l >> 4;
+  const Vec in = vload_row(X + j * H, q);
+  Vec acc = vzero();
+  const char *img = reinterpret_cast<const char *>(rm);
+  if (mode == 0) {
+    if (transposed) gemm_rm<GM_X3, true>(img, vsplit(in), acc);
+    else gemm_rm<GM_X3, false>(img, vsplit(in), acc);
+  } else {
+    if (transposed) gemm_rm<GM_BF16, true>(img, vpack_bf(in), acc);
+    else gemm_rm<GM_BF16, false>(img, vpack_bf(in), acc);
+  }
+  vstore_row(Y + j * H, q, acc);
+}
+
 // bf16x3 counterpart of chain_kernel (mode bit0: SiLU, bit2: single layer written to out for checks)
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void chain_bf3_kernel(const float *W, const float *X, float *out, int iters,
@@ -584,6 +610,12 @@ int fastegnn_selftest_gemm(const float *W, const float *X, float *Y, int32_t tra
   FE_REQUIRE(W && X && Y, "selftest_gemm: null pointer");
   hipLaunchKernelGGL(selftest_gemm_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, W, X, Y, transposed);
   return check_launch("selftest_gemm_kernel");
+}
+
+int fastegnn_selftest_rm(const float *W, const float *X, float *Y, int32_t transposed, int32_t mode, void *stream) {
+  FE_REQUIRE(W && X && Y, "selftest_rm: null pointer");
+  hipLaunchKernelGGL(selftest_rm_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, W, X, Y, transposed, mode);
+  return check_launch("selftest_rm_kernel");
 }
 
 int fastegnn_selftest_chain(const float *wimg, float *out, int32_t iters, int32_t mode, int32_t waves, int32_t grid,

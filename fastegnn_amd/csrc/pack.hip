@@ -93,6 +93,18 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     d3[img3_index(1, o, k)] = split_word(w0, w1, 1);
     d3[img3_index(2, o, k)] = split_word(w0, w1, 2);
   }
+  // row-major split image (common.h: one LDS copy for W and W^T in virt_bwd) of V2, WXV0, WXX0 and W3c[c]
+  int slot = rm_slot(id);
+  if (id >= I_FIXED && id < I_FIXED + a.C) slot = 3 + (id - I_FIXED);
+  if (slot >= 0) {
+    unsigned *rm = reinterpret_cast<unsigned *>(const_cast<char *>(wpack_rm(a.wpack, a.C, slot)));
+    for (int idx = threadIdx.x; idx < 64 * (RM_RS / 4); idx += 256) {
+      const int o = idx / (RM_RS / 4), w = idx % (RM_RS / 4);   // word w of row o: k = 2w, 2w+1 (w >= 32: row padding)
+      const float w0 = w < 32 ? at(o, 2 * w) : 0.f, w1 = w < 32 ? at(o, 2 * w + 1) : 0.f;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) rm[p * (RM_PART / 4) + idx] = split_word(w0, w1, p);
+    }
+  }
 }
 
 int pack_weights(const fastegnn_layer_t *L, hipStream_t st) {

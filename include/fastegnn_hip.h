@@ -313,6 +313,9 @@ int fastegnn_profile_collect(double *total_ms, int64_t *launches);
  * Y[j][o] = sum_k A[o][k] X[j][k] for one 16-row tile through the MFMA image path (A = W or W^T,
  * W 64x64 row-major);  dW += G^T T, db += colsum(G) over M rows of 64. */
 int fastegnn_selftest_gemm(const float *W, const float *X, float *Y, int32_t transposed, void *stream);
+/* same through a row-major split image in LDS (one copy serves W and W^T: ds_read_b64 / ds_read_b64_tr_b16);
+ * mode 0: bf16x3 products, 1: one bf16 product of the rounded operands */
+int fastegnn_selftest_rm(const float *W, const float *X, float *Y, int32_t transposed, int32_t mode, void *stream);
 /* `iters` dependent 64x64 MFMA layers per wave (mode bit0: SiLU between layers, bit1: image from
  * global memory instead of LDS); out receives one 16x64 tile.  Calibrates the MFMA building block. */
 int fastegnn_selftest_chain(const float *wimg, float *out, int32_t iters, int32_t mode, int32_t waves, int32_t grid,

@@ -28,6 +28,28 @@ def test_mfma_image_gemm(transposed):
     assert torch.equal(Y.cpu(), (X.cpu() @ A.cpu().T))
 
 
+@pytest.mark.parametrize("transposed", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_row_major_image_serves_product_and_transpose(transposed, mode):
+    """One row-major bf16 image in LDS, read by rows (ds_read_b64) for W x and by columns (ds_read_b64_tr_b16) for W^T x.
+    Integer data (exact in bf16 and in fp32): any row/column or k-order slip of the transposed read shows as a wrong
+    integer; mode 0 additionally checks the three-part split on fp32 data against fp64."""
+    g = torch.Generator().manual_seed(7 + transposed)
+    W = torch.randint(-8, 9, (64, 64), generator=g).float().cuda()
+    X = torch.randint(-8, 9, (16, 64), generator=g).float().cuda()
+    Y = torch.zeros(16, 64, device="cuda")
+    K.check(K.lib().fastegnn_selftest_rm(K.ptr(W), K.ptr(X), K.ptr(Y), transposed, mode, _st()), "selftest_rm")
+    A = W.T if transposed else W
+    assert torch.equal(Y.cpu(), (X.cpu() @ A.cpu().T))
+    if mode == 0:
+        Wf = torch.randn(64, 64, generator=g).cuda()
+        Xf = torch.randn(16, 64, generator=g).cuda()
+        K.check(K.lib().fastegnn_selftest_rm(K.ptr(Wf), K.ptr(Xf), K.ptr(Y), transposed, 0, _st()), "selftest_rm")
+        Af = (Wf.T if transposed else Wf).double().cpu()
+        ref = Xf.double().cpu() @ Af.T
+        assert (Y.cpu().double() - ref).abs().max().item() < 4e-7 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M", [1, 15, 16, 257, 5000])
 def test_wgrad_tn(M):
     g = torch.Generator().manual_seed(M)
