@@ -877,6 +877,14 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       if (two)
         while (lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s1]) != r1w + 1) __builtin_amdgcn_s_sleep(2);
       const float *g0 = ring + (kind * PC_RING + s0) * PC_SLOT, *g1 = ring + (kind * PC_RING + s1) * PC_SLOT;
+#ifdef FE_DIAG_NOCONS   // diagnostic: the consumer only drains its slots (is the kernel consumer-bound?)
+      if (l == 0) {
+        lds_st(&ctrl[PC_DRAINED + kind * PC_RING + s0], r0w + 1);
+        if (two) lds_st(&ctrl[PC_DRAINED + kind * PC_RING + s1], r1w + 1);
+      }
+      (void)g0; (void)g1; (void)acc; (void)bs;
+      return;
+#endif
       Split8 B[4];   // bf16 mode: only .h is used (RNE-rounded operand, one product)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {

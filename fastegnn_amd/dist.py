@@ -63,10 +63,12 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, averag
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     # Fast path: the backward of fastegnn_amd.FastEGNN hands autograd slices of ONE flat buffer, and autograd
     # keeps them as the .grad tensors -- reduce that buffer in place (no gather / scatter copies, one collective).
-    if all(p.grad is not None and p.grad.dtype == dt and p.grad.is_contiguous() for p in params):
-        stor = params[0].grad.untyped_storage()
-        if all(p.grad.untyped_storage().data_ptr() == stor.data_ptr() for p in params):
-            flat = torch.empty(0, device=dev, dtype=dt).set_(stor, 0, (stor.nbytes() // params[0].grad.element_size(),))
+    # (parameters without a gradient -- the last layer's unused heads -- are the same on every rank and stay None)
+    with_grad = [p for p in params if p.grad is not None]
+    if with_grad and all(p.grad.dtype == dt and p.grad.is_contiguous() for p in with_grad):
+        stor = with_grad[0].grad.untyped_storage()
+        if all(p.grad.untyped_storage().data_ptr() == stor.data_ptr() for p in with_grad):
+            flat = torch.empty(0, device=dev, dtype=dt).set_(stor, 0, (stor.nbytes() // with_grad[0].grad.element_size(),))
             _all_reduce(flat)
             if average:
                 flat.div_(world)
