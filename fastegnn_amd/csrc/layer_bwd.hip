@@ -750,19 +750,20 @@ struct EdgeBwdArgs {
 #endif
 
 // ---- producer/consumer variant: the two 64x64 weight gradients of the edge stage are contracted inside the
-// workgroup.  Waves 0..6 run the tile adjoint (producers) and hand each operand pair (g_mp,t) / (g_up,m) as two
-// 16x64 tiles to wave 7 (consumer) through a ring of LDS slots; the consumer owns the two 64x64 accumulators and
+// workgroup.  Six waves run the tile adjoint (producers) and hand each operand pair (g_mp,t) / (g_up,m) as two
+// 16x64 tiles to the consumer wave of that weight through a ring of LDS slots; a consumer owns one 64x64 accumulator and
 // writes one partial slab per workgroup and weight (summed by wgrad_reduce_kernel in a fixed order).  The
 // operands never reach HBM.  The consumer contracts two slots of a ring at a time (K = 32 edges) as bf16x3
 // products on the matrix pipe.  Slot protocol (tickets taken from an LDS counter per ring, consumed in order):
 // producer waits drained[s] == round, writes, sets filled[s] = round + 1; consumer waits filled[s] == round + 1,
 // contracts, sets drained[s] = round + 1.
-#ifndef FE_PC_WAVES
-#define FE_PC_WAVES 7
-#endif
-constexpr int PC_WAVES = FE_PC_WAVES;       // 8: consumer shares its SIMD with a producer; 7: wave 3 (consumer) has SIMD 3 alone
-constexpr int PC_CONS = PC_WAVES == 7 ? 3 : PC_WAVES - 1;
-constexpr int PC_PROD = PC_WAVES - 1;       // producer waves
+// Eight waves: waves are dealt round-robin to the four SIMDs, so waves 3 and 7 share SIMD 3 and have it to themselves --
+// they are the two CONSUMERS, one per ring (wave 3: edge_mlp.2, wave 7: coord_mlp_r.0); the six producers sit two per SIMD
+// on SIMDs 0..2.  A single consumer serving both rings was latency-exposed (dependent LDS reads -> split -> MFMA chain at
+// one wave on its SIMD): with the contractions skipped the kernel ran 18 % faster (-DFE_DIAG_NOCONS).
+constexpr int PC_WAVES = 8;
+constexpr int PC_CONS = 3, PC_CONS2 = 7;
+constexpr int PC_PROD = 6;                  // producer waves
 #ifndef FE_PC_RING
 #define FE_PC_RING 2
 #endif
@@ -818,8 +819,9 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   if (threadIdx.x < PC_CTRL) ctrl[threadIdx.x] = 0;
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
-  const bool consumer = wv == PC_CONS;
-  const int pw = wv > PC_CONS ? wv - 1 : wv;   // producer index
+  const bool consumer = wv == PC_CONS || wv == PC_CONS2;
+  const int ckind = wv == PC_CONS ? 0 : 1;     // the ring a consumer wave serves
+  const int pw = wv > PC_CONS ? wv - 1 : wv;   // producer index (waves 0,1,2,4,5,6 -> 0..5)
   float *pt = tiles + (consumer ? 0 : pw) * 16 * TS;
   const int wave = (int)blockIdx.x * PC_PROD + pw, nwaves = (int)gridDim.x * PC_PROD;
   const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);
@@ -860,12 +862,12 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
     __builtin_amdgcn_s_setprio(FE_PC_PRIO);   // the consumer must never be the slower side: it wins issue arbitration on its SIMD
 #endif
     const int total = lds_ld(&ctrl[PC_TOTAL]);   // tiles of this workgroup = tickets per ring
-    f32x4 accA[4][4], accB[4][4];
-    float bsA[4] = {0.f, 0.f, 0.f, 0.f}, bsB[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 accA[4][4];
+    float bsA[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-      for (int tk = 0; tk < 4; ++tk) accA[ti][tk] = accB[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int tk = 0; tk < 4; ++tk) accA[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
     // K = 32 edges per step: tickets tk, tk+1 of one ring; lane (q,i) takes feature i of the rows 4q+e of the first
     // (e < 4) and of the second slot (e >= 4), the same map for both operands.  With the 68-float row stride the
     // rows of the two quarter-waves read together sit 16 banks apart: conflict-free b32 reads
@@ -937,46 +939,34 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         if (two) lds_st(&ctrl[PC_DRAINED + kind * PC_RING + s1], r1w + 1);
       }
     };
-    // work-conserving service: whichever ring has its next K-step complete (two filled slots, or the last
-    // single one) is contracted; a full ring always has a complete step, so no producer waits on an idle consumer
+    // this wave's ring: its next K-step is complete with two filled slots, or with the last single one
     auto ready = [&](int kind, int done) {
       const int s0 = done % PC_RING, s1 = (done + 1) % PC_RING;
       if (lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s0]) != done / PC_RING + 1) return false;
       return done + 1 >= total || lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s1]) == (done + 1) / PC_RING + 1;
     };
-    int done0 = 0, done1 = 0;
-    while (done0 < total || done1 < total) {
-      bool progress = false;
-      if (done1 < total && ready(1, done1)) {
-        contract(1, done1, accB, bsB);
-        done1 += 2;
-        progress = true;
+    int done = 0;
+    while (done < total) {
+      if (ready(ckind, done)) {
+        contract(ckind, done, accA, bsA);
+        done += 2;
+      } else {
+        __builtin_amdgcn_s_sleep(1);
       }
-      if (done0 < total && ready(0, done0)) {
-        contract(0, done0, accA, bsA);
-        done0 += 2;
-        progress = true;
-      }
-      if (!progress) __builtin_amdgcn_s_sleep(1);
     }
     // one partial slab per workgroup and weight: [o][k] row-major, o = G feature, k = T feature
-    float *sa = A.slab + ((size_t)A.slab_w2 + blockIdx.x) * IMG, *sb = A.slab + ((size_t)A.slab_wx1 + blockIdx.x) * IMG;
+    const size_t sl = (size_t)(ckind == 0 ? A.slab_w2 : A.slab_wx1) + blockIdx.x;
+    float *sa = A.slab + sl * IMG;
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
       for (int tk2 = 0; tk2 < 4; ++tk2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sa[(16 * ti + 4 * q + r) * H + 16 * tk2 + j] = accA[ti][tk2][r];
-          sb[(16 * ti + 4 * q + r) * H + 16 * tk2 + j] = accB[ti][tk2][r];
-        }
+        for (int r = 0; r < 4; ++r) sa[(16 * ti + 4 * q + r) * H + 16 * tk2 + j] = accA[ti][tk2][r];
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
-      const float s0 = qsum(bsA[ti]), s1 = qsum(bsB[ti]);
-      if (q == 0) {
-        A.slab_b[((size_t)A.slab_w2 + blockIdx.x) * H + 16 * ti + j] = s0;
-        A.slab_b[((size_t)A.slab_wx1 + blockIdx.x) * H + 16 * ti + j] = s1;
-      }
+      const float s0 = qsum(bsA[ti]);
+      if (q == 0) A.slab_b[sl * H + 16 * ti + j] = s0;
     }
   }
   if (!consumer && r0 < r1) {
