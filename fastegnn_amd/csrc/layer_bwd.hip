@@ -630,12 +630,14 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   if (rc) return rc;
   const int ld_n0 = 2 * H + H * C + L->na;
   WgradBatch wb(L->wg_slab, st, has(L, FASTEGNN_F_BF16));
-  if (C > 0) {
+  if (C > 0 && C <= 16) {
     wb.min_rows = 128;   // a bundle's wave walks ALL rows of its workgroup: shorter row ranges than the 4-waves-per-range jobs
     // the four contractions over the (node, channel) rows as ONE wave-parallel bundle, all in the batched geometry
     // "N rows x C channel slices" so that the waves of a workgroup walk the same rows: the node_mlp.0 block of channel c
     // (g_np, v[:,c]), the two coordinate heads (g_ux, v), (g_uX, v) and edge_mlp_virtual.2 (g_vp, t); `v` is read by
-    // three of them and reaches HBM once
+    // three of them and reaches HBM once.  Measured (ms per step, weight-gradient kernels): cfg4 (C = 16) plain jobs 3.85,
+    // this bundle 3.52-3.64, a three-job bundle over the contiguous N*C rows 4.31; cfg5 (C = 32, consecutive rows of a
+    // channel 8 KB apart) plain 47.7, this bundle 52.9, three-job bundle 57.1 -- hence the switch on C.
     const long cs = (long)C * H;
     if ((rc = wb.add(A.wg_gnp, H, A.wg_v, (int)cs, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
     if ((rc = wb.add(A.wg_gux, (int)cs, A.wg_v, (int)cs, N, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], C, H, H, 0))) return rc;
@@ -643,6 +645,12 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
     if ((rc = wb.add(A.wg_gvp, (int)cs, A.wg_t, (int)cs, N, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], C, H, H, 0))) return rc;
     if ((rc = wb.close_bundle())) return rc;
     wb.min_rows = 256;
+  } else if (C > 0) {
+    if ((rc = wb.add(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
+    // coordinate heads and edge_mlp_virtual.2 over the N*C (node, channel) rows
+    if ((rc = wb.add(A.wg_gux, H, A.wg_v, H, NC, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B]))) return rc;
+    if ((rc = wb.add(A.wg_guX, H, A.wg_v, H, NC, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B]))) return rc;
+    if ((rc = wb.add(A.wg_gvp, H, A.wg_t, H, NC, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B]))) return rc;
   }
   // node_mlp.2
   if ((rc = wb.add(L->g_h_out, H, A.wg_t3, H, N, g[FASTEGNN_P_NODE2_W], H, 0, 1, g[FASTEGNN_P_NODE2_B]))) return rc;
