@@ -984,6 +984,13 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       A.g_P[(size_t)cur * H + l] = acc;
       if (l < 3) A.g_xrow[(size_t)cur * 3 + l] = accx;   // lanes 0..2 hold x,y,z (lane 3: pad)
     };
+    // rows without edges inside this wave's range [r0, r1) are zeroed here (no memset ahead of the kernel)
+    auto zero_rows = [&](int ra, int rb) {
+      for (int r = ra; r < rb; ++r) {
+        A.g_P[(size_t)r * H + l] = 0.f;
+        if (l < 3) A.g_xrow[(size_t)r * 3 + l] = 0.f;
+      }
+    };
     for (int base = e0; base < e1; base += 16) {
       asm volatile("" ::: "memory");
       const int nvalid = min(16, e1 - base);
@@ -1059,6 +1066,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
           const int rw = __builtin_amdgcn_readlane(rowv, ee);
           if (rw != cur) {
             if (cur >= 0) flush();
+            zero_rows(cur >= 0 ? cur + 1 : r0, rw);
             cur = rw;
             acc = 0.f;
             accx = 0.f;
@@ -1078,6 +1086,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       __builtin_amdgcn_wave_barrier();
     }
     if (cur >= 0) flush();
+    zero_rows(cur >= 0 ? cur + 1 : r0, r1);
   }
   float *red = vec;   // [3 + 8][64]; the weight vectors are dead now
   __syncthreads();
@@ -1115,9 +1124,11 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
                  L->wpack,
              "edge_backward: null buffer");
   const fastegnn_graph_t &gr = L->graph;
-  (void)hipMemsetAsync(L->g_P, 0, (size_t)L->N * H * sizeof(float), st);
-  (void)hipMemsetAsync(L->g_xrow, 0, (size_t)L->N * 3 * sizeof(float), st);
-  if (gr.n_edges == 0 || L->N == 0) return check_launch("edge_backward(memset)");
+  if (gr.n_edges == 0 || L->N == 0) {   // nothing to walk (with edges the kernel writes every row of g_P / g_xrow)
+    (void)hipMemsetAsync(L->g_P, 0, (size_t)L->N * H * sizeof(float), st);
+    (void)hipMemsetAsync(L->g_xrow, 0, (size_t)L->N * 3 * sizeof(float), st);
+    return check_launch("edge_backward(memset)");
+  }
   float *const *g = L->grads;
   EdgeBwdArgs A;
   A.f = make_edge_args(L);

@@ -252,6 +252,14 @@ __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs 
         a.aggm[(size_t)cur * H + l] = acc * inv;
         if (l < 3) a.aggx[(size_t)cur * 3 + l] = mean ? accx * inv : accx;
       };
+      // rows without edges inside this wave's range get their zeros here (no memset of aggm / aggx ahead of the kernel):
+      // the wave owns the rows [r0, r1) and writes each of them exactly once
+      auto zero_rows = [&](int ra, int rb) {
+        for (int r = ra; r < rb; ++r) {
+          a.aggm[(size_t)r * H + l] = 0.f;
+          if (l < 3) a.aggx[(size_t)r * 3 + l] = 0.f;
+        }
+      };
       EdgeIdx cur_i, nxt_i;
       if (e0 < e1) edge_load_idx(a, min(e0 + j, e1 - 1), cur_i);
       for (int base = e0; base < e1; base += 16) {
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs 
             const int rw = __builtin_amdgcn_readlane(rowv, ee);
             if (rw != cur) {
               if (cur >= 0) flush();
+              zero_rows(cur >= 0 ? cur + 1 : r0, rw);
               cur = rw;
               acc = 0.f;
               accx = 0.f;
@@ -299,6 +308,7 @@ __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs 
         FE_T(6)   // row-segmented reduction
       }
       if (cur >= 0) flush();
+      zero_rows(cur >= 0 ? cur + 1 : r0, r1);
     }
   }
   FE_TEND()
@@ -310,9 +320,11 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (L->params[FASTEGNN_P_ATT_W] && L->params[FASTEGNN_P_ATT_B]),
              "edge_forward: attention params null");
   const fastegnn_graph_t &g = L->graph;
-  (void)hipMemsetAsync(L->aggm, 0, (size_t)L->N * H * sizeof(float), st);
-  (void)hipMemsetAsync(L->aggx, 0, (size_t)L->N * 3 * sizeof(float), st);
-  if (g.n_edges == 0 || L->N == 0) return check_launch("edge_forward(memset)");
+  if (g.n_edges == 0 || L->N == 0) {   // nothing to walk: the aggregates are zero (with edges the kernel writes every row)
+    (void)hipMemsetAsync(L->aggm, 0, (size_t)L->N * H * sizeof(float), st);
+    (void)hipMemsetAsync(L->aggx, 0, (size_t)L->N * 3 * sizeof(float), st);
+    return check_launch("edge_forward(memset)");
+  }
   FE_REQUIRE(g.rowptr && g.erow && g.col && g.chunk_row && (L->ea == 0 || L->ea_sorted), "edge_forward: null graph");
   EdgeArgs a = make_edge_args(L);
   FE_REQUIRE((size_t)L->N * QXLD < (1u << 30) && (size_t)g.n_src * QXLD < (1u << 30) && (size_t)g.n_edges * 8 < (1u << 30),
