@@ -72,6 +72,14 @@ using namespace fe;
     return fn(L, (hipStream_t)stream);                                \
   }
 
+// backward stages with weight gradients: the staged entry point contracts and reduces its own jobs
+#define STAGE_B(name, fn)                                             \
+  int name(const fastegnn_layer_t *L, void *stream) {                 \
+    int rc = check_layer(L, #name);                                   \
+    if (rc) return rc;                                                \
+    return fn(L, (hipStream_t)stream, nullptr);                       \
+  }
+
 extern "C" {
 
 const char *fastegnn_last_error(void) { return g_last_error.c_str(); }
@@ -88,12 +96,12 @@ STAGE(fastegnn_graph_pre_forward, graph_pre_forward)
 STAGE(fastegnn_edge_forward, edge_forward)
 STAGE(fastegnn_virt_forward, virt_forward)
 STAGE(fastegnn_graph_post_forward, graph_post_forward)
-STAGE(fastegnn_graph_post_backward, graph_post_backward)
-STAGE(fastegnn_virt_backward, virt_backward)
-STAGE(fastegnn_graph_pre_backward, graph_pre_backward)
-STAGE(fastegnn_edge_backward, edge_backward)
+STAGE_B(fastegnn_graph_post_backward, graph_post_backward)
+STAGE_B(fastegnn_virt_backward, virt_backward)
+STAGE_B(fastegnn_graph_pre_backward, graph_pre_backward)
+STAGE_B(fastegnn_edge_backward, edge_backward)
 STAGE(fastegnn_edge_col_reduce, edge_col_reduce)
-STAGE(fastegnn_node_pre_backward, node_pre_backward)
+STAGE_B(fastegnn_node_pre_backward, node_pre_backward)
 
 int fastegnn_profile_enable(int32_t on) {
   g_prof_on = on != 0;
@@ -140,18 +148,24 @@ int fastegnn_layer_backward(const fastegnn_layer_t *L, void *stream) {
   int rc = check_layer(L, "fastegnn_layer_backward");
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  // the node-level / graph-level weight-gradient jobs of all stages and the edge stage's slabs are contracted and reduced
+  // together at the end of the layer: one wgrad_tn launch and one wgrad_reduce launch instead of a pair per stage
+  FE_REQUIRE(L->wg_slab, "fastegnn_layer_backward: wg_slab null");
+  WgradBatch wb(L->wg_slab, st);
   if (has(L, FASTEGNN_F_EGNN)) {
-    if ((rc = virt_backward(L, st))) return rc;
-    if ((rc = edge_backward(L, st))) return rc;
+    if ((rc = virt_backward(L, st, &wb))) return rc;
+    if ((rc = edge_backward(L, st, &wb))) return rc;
     if ((rc = edge_col_reduce(L, st))) return rc;
-    return node_pre_backward(L, st);
+    if ((rc = node_pre_backward(L, st, &wb))) return rc;
+    return wb.finish();
   }
-  if ((rc = graph_post_backward(L, st))) return rc;
-  if ((rc = virt_backward(L, st))) return rc;
-  if ((rc = graph_pre_backward(L, st))) return rc;
-  if ((rc = edge_backward(L, st))) return rc;
+  if ((rc = graph_post_backward(L, st, &wb))) return rc;
+  if ((rc = virt_backward(L, st, &wb))) return rc;
+  if ((rc = graph_pre_backward(L, st, &wb))) return rc;
+  if ((rc = edge_backward(L, st, &wb))) return rc;
   if ((rc = edge_col_reduce(L, st))) return rc;
-  return node_pre_backward(L, st);
+  if ((rc = node_pre_backward(L, st, &wb))) return rc;
+  return wb.finish();
 }
 
 }  // extern "C"

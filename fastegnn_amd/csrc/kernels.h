@@ -39,8 +39,8 @@ struct ProfScope {
 // generic weight-gradient contraction (misc.hip):
 //   dW[o*lddw + c0 + k*ks] += sum_m G[m*ldg + o] * T[m*ldt + k]   (o < 64, k < kmax),  db[o] += sum_m G[m*ldg+o]
 //   batched over `nb` with strides (sG, sT, sW) in floats.  Jobs are queued and run by finish().
-constexpr int WG_MAX_JOBS = 12;
-constexpr int WG_SLABS = 6400;   // 64x64 partial slabs in the wg_slab workspace (+ 64-float bias slabs)
+constexpr int WG_MAX_JOBS = 24;
+constexpr int WG_SLABS = 8192;   // the upper half is the virtual-stage bundle's (WgradBatch slab_base)   // 64x64 partial slabs in the wg_slab workspace (+ 64-float bias slabs)
 struct WgJob {
   const float *G, *T;
   float *dW, *db;
@@ -60,7 +60,8 @@ struct WgradBatch {
   int n_wg, n_slab, max_nb, n_bundle_wg;
   bool round;   // applied to the jobs added from now on
   int min_rows; // smallest row range given to one workgroup (short operands are split that far to fill the chip)
-  WgradBatch(float *slab, hipStream_t st, bool round_bf16 = false);
+  int slab_base, slab_cap;   // this batch's share of the slab workspace: [slab_base, slab_base + slab_cap)
+  WgradBatch(float *slab, hipStream_t st, bool round_bf16 = false, int slab_base = 0, int slab_cap = WG_SLABS / 2);
   int add(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks, float *db,
           int nb = 1, long sG = 0, long sT = 0, long sW = 0, int kmax = 64);
   // a job whose partial slabs (nsplit of them, [64][64] + [64] bias each) are written by the caller's own kernel:
@@ -82,11 +83,17 @@ int graph_pre_forward(const fastegnn_layer_t *L, hipStream_t st);
 int edge_forward(const fastegnn_layer_t *L, hipStream_t st);
 int virt_forward(const fastegnn_layer_t *L, hipStream_t st);
 int graph_post_forward(const fastegnn_layer_t *L, hipStream_t st);
-int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st);
-int virt_backward(const fastegnn_layer_t *L, hipStream_t st);
-int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st);
-int edge_backward(const fastegnn_layer_t *L, hipStream_t st);
+// `shared`: a weight-gradient batch that outlives the stage (fastegnn_layer_backward: ONE contraction launch and ONE
+// reduction launch per layer instead of one pair per stage); null: the stage contracts and reduces its own jobs.
+int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
+int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
+int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
+int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
 int edge_col_reduce(const fastegnn_layer_t *L, hipStream_t st);
-int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st);
+int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
+// operand regions of the node-level / graph-level weight gradients inside wg_node (disjoint, so that the jobs of a whole
+// layer can be contracted together): [0,2M) virt, [2M,4M) node_pre, [4M,7M) graph_post, [7M,8M) graph_pre rows of 64 floats,
+// M = max(N, B*C)
+inline size_t wg_node_rows(const fastegnn_layer_t *L) { const size_t bc = (size_t)L->B * L->C; return (size_t)L->N > bc ? (size_t)L->N : bc; }
 
 }  // namespace fe

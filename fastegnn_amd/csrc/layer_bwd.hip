@@ -99,12 +99,13 @@ __global__ __launch_bounds__(256) void graph_post_bwd_kernel(GraphPostBwdArgs a)
   }
 }
 
-int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st) {
+int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
   FE_REQUIRE(L->xsum && L->HvT && L->poolV && L->g_Z_out && L->g_HvT_out && L->g_Z && L->g_HvT && L->g_poolV &&
                  L->g_poolX && L->wg_node && L->grads && L->wpack,
              "graph_post_backward: null buffer");
   const long M = (long)L->B * L->C;
-  float *wg_u = L->wg_node, *wg_gz5 = L->wg_node + M * H, *wg_pm = L->wg_node + 2 * M * H;
+  float *wg_gp = L->wg_node + 4 * wg_node_rows(L) * H;   // this stage's operand region of wg_node (kernels.h)
+  float *wg_u = wg_gp, *wg_gz5 = wg_gp + M * H, *wg_pm = wg_gp + 2 * M * H;
   GraphPostBwdArgs a{L->xsum, L->HvT, L->poolV, L->g_Z_out, L->g_HvT_out, L->wpack, L->params[FASTEGNN_P_NODEV0_B],
                      L->g_Z, L->g_HvT, L->g_poolV, L->g_poolX, wg_u, wg_gz5, wg_pm, L->B, L->C, L->flags};
   int grid = cdiv(cdiv(M, 16), 4);
@@ -115,13 +116,15 @@ int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st) {
   if (rc) return rc;
   if (has(L, FASTEGNN_F_RF)) return FASTEGNN_OK;   // no node_mlp_virtual
   float *const *g = L->grads;
-  WgradBatch wb(L->wg_slab, st, has(L, FASTEGNN_F_BF16));
+  WgradBatch local(L->wg_slab, st);
+  WgradBatch &wb = shared ? *shared : local;
+  wb.round = has(L, FASTEGNN_F_BF16);
   // node_mlp_virtual.2: dW6 += g_out^T u, db6 += colsum g_out
   if ((rc = wb.add(L->g_HvT_out, H, wg_u, H, M, g[FASTEGNN_P_NODEV2_W], H, 0, 1, g[FASTEGNN_P_NODEV2_B]))) return rc;
   // node_mlp_virtual.0: [Hv | pooled v]
   if ((rc = wb.add(wg_gz5, H, L->HvT, H, M, g[FASTEGNN_P_NODEV0_W], 2 * H, 0, 1, g[FASTEGNN_P_NODEV0_B]))) return rc;
   if ((rc = wb.add(wg_gz5, H, wg_pm, H, M, g[FASTEGNN_P_NODEV0_W], 2 * H, H, 1, nullptr))) return rc;
-  return wb.finish();
+  return shared ? FASTEGNN_OK : wb.finish();
 }
 
 // =====================================================================================
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   }
 }
 
-int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
+int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
   const bool egnn = has(L, FASTEGNN_F_EGNN);
   FE_REQUIRE(L->h && L->A && L->x && L->vel && L->aggm && L->npre && L->batch && L->wpack && (!egnn || L->aggx),
              "virt_backward: null saved buffer");
@@ -629,9 +632,13 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   int rc = check_launch("virt_bwd_kernel");
   if (rc) return rc;
   const int ld_n0 = 2 * H + H * C + L->na;
-  WgradBatch wb(L->wg_slab, st, has(L, FASTEGNN_F_BF16));
+  WgradBatch local(L->wg_slab, st);
+  WgradBatch &wb = shared ? *shared : local;
+  wb.round = has(L, FASTEGNN_F_BF16);
   if (C > 0 && C <= 16) {
-    wb.min_rows = 128;   // a bundle's wave walks ALL rows of its workgroup: shorter row ranges than the 4-waves-per-range jobs
+    // (a batch of its own, in the upper half of the slab workspace: a bundle is the first jobs of a batch)
+    WgradBatch bb(L->wg_slab, st, has(L, FASTEGNN_F_BF16), WG_SLABS / 2, WG_SLABS / 2);
+    bb.min_rows = 128;
     // the four contractions over the (node, channel) rows as ONE wave-parallel bundle, all in the batched geometry
     // "N rows x C channel slices" so that the waves of a workgroup walk the same rows: the node_mlp.0 block of channel c
     // (g_np, v[:,c]), the two coordinate heads (g_ux, v), (g_uX, v) and edge_mlp_virtual.2 (g_vp, t); `v` is read by
@@ -639,12 +646,12 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
     // this bundle 3.52-3.64, a three-job bundle over the contiguous N*C rows 4.31; cfg5 (C = 32, consecutive rows of a
     // channel 8 KB apart) plain 47.7, this bundle 52.9, three-job bundle 57.1 -- hence the switch on C.
     const long cs = (long)C * H;
-    if ((rc = wb.add(A.wg_gnp, H, A.wg_v, (int)cs, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
-    if ((rc = wb.add(A.wg_gux, (int)cs, A.wg_v, (int)cs, N, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], C, H, H, 0))) return rc;
-    if ((rc = wb.add(A.wg_guX, (int)cs, A.wg_v, (int)cs, N, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], C, H, H, 0))) return rc;
-    if ((rc = wb.add(A.wg_gvp, (int)cs, A.wg_t, (int)cs, N, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], C, H, H, 0))) return rc;
-    if ((rc = wb.close_bundle())) return rc;
-    wb.min_rows = 256;
+    if ((rc = bb.add(A.wg_gnp, H, A.wg_v, (int)cs, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
+    if ((rc = bb.add(A.wg_gux, (int)cs, A.wg_v, (int)cs, N, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], C, H, H, 0))) return rc;
+    if ((rc = bb.add(A.wg_guX, (int)cs, A.wg_v, (int)cs, N, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], C, H, H, 0))) return rc;
+    if ((rc = bb.add(A.wg_gvp, (int)cs, A.wg_t, (int)cs, N, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], C, H, H, 0))) return rc;
+    if ((rc = bb.close_bundle())) return rc;
+    if ((rc = bb.finish())) return rc;
   } else if (C > 0) {
     if ((rc = wb.add(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
     // coordinate heads and edge_mlp_virtual.2 over the N*C (node, channel) rows
@@ -657,7 +664,7 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st) {
   // node_mlp.0: [h | agg | flat(v) | node_attr]
   if ((rc = wb.add(A.wg_gnp, H, L->h, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 0, 1, g[FASTEGNN_P_NODE0_B]))) return rc;
   if ((rc = wb.add(A.wg_gnp, H, L->aggm, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, H, 1, nullptr))) return rc;
-  if ((rc = wb.finish())) return rc;
+  if (!shared && (rc = wb.finish())) return rc;
   if (L->na > 0)
     if ((rc = launch_wgrad_small(A.wg_gnp, H, L->node_attr, L->na, L->na, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H + H * C, st))) return rc;
   return FASTEGNN_OK;
@@ -719,11 +726,11 @@ __global__ __launch_bounds__(256) void graph_pre_bwd_kernel(GraphPreBwdArgs a) {
     a.g_xbar[b * 3 + threadIdx.x] = -acc / cnt;
   }
 }
-int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
+int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
   FE_REQUIRE(L->xsum && L->Z && L->HvT && L->g_Bc && L->g_Zp && L->g_Z && L->g_HvT && L->g_xbar && L->wg_node && L->grads,
              "graph_pre_backward: null buffer");
   const long M = (long)L->B * L->C;
-  float *wg_mxt = L->wg_node;
+  float *wg_mxt = L->wg_node + 7 * wg_node_rows(L) * H;   // this stage's operand region of wg_node (kernels.h)
   GraphPreBwdArgs a{L->xsum, L->Z, L->g_Bc, L->g_Zp, L->params[FASTEGNN_P_VIRT0_W], L->g_Z, L->g_HvT, L->g_xbar, wg_mxt,
                     L->B, L->C, has(L, FASTEGNN_F_BF16) ? 1 : 0};
   const size_t lds = (size_t)(6 * L->C + L->C * L->C) * sizeof(float);
@@ -733,11 +740,13 @@ int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   float *const *g = L->grads;
   const int ld = 2 * H + 1 + L->C;
   // edge_mlp_virtual.0: columns [H,2H) <- Hv, columns [2H+1, 2H+1+C) <- mX[:,c], bias
-  WgradBatch wb(L->wg_slab, st, has(L, FASTEGNN_F_BF16));
+  WgradBatch local(L->wg_slab, st);
+  WgradBatch &wb = shared ? *shared : local;
+  wb.round = has(L, FASTEGNN_F_BF16);
   if ((rc = wb.add(L->g_Bc, H, L->HvT, H, M, g[FASTEGNN_P_VIRT0_W], ld, H, 1, g[FASTEGNN_P_VIRT0_B]))) return rc;
   wb.round = false;   // the Gram columns of edge_mlp_virtual.0 are an fp32 product in every mode
   if ((rc = wb.add(L->g_Bc, H, wg_mxt, H, M, g[FASTEGNN_P_VIRT0_W], ld, 2 * H + 1, 1, nullptr, 1, 0, 0, 0, L->C))) return rc;
-  return wb.finish();
+  return shared ? FASTEGNN_OK : wb.finish();
 }
 
 // =====================================================================================
@@ -1119,7 +1128,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   }
 }
 
-int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
+int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
   FE_REQUIRE(L->P && L->QX && L->g_aggm && L->g_aggx && L->g_P && L->g_xrow && L->g_QXe && L->grads &&
                  L->wpack,
              "edge_backward: null buffer");
@@ -1145,7 +1154,8 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
   {
     int grid = cdiv(gr.n_chunks, PC_PROD);   // small graphs: one 32-edge row chunk per producer wave (see edge_forward)
     if (grid > 256) grid = 256;
-    WgradBatch wb(L->wg_slab, st);
+    WgradBatch local(L->wg_slab, st);
+    WgradBatch &wb = shared ? *shared : local;
     int rc;
     if ((rc = wb.add_slabs(g[FASTEGNN_P_EDGE2_W], H, 0, 1, g[FASTEGNN_P_EDGE2_B], grid, &A.slab_w2))) return rc;
     if ((rc = wb.add_slabs(g[FASTEGNN_P_CR0_W], H, 0, 1, g[FASTEGNN_P_CR0_B], grid, &A.slab_wx1))) return rc;
@@ -1158,7 +1168,7 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st) {
       else hipLaunchKernelGGL(edge_bwd_pc_kernel<GM_X3>, dim3(grid), dim3(64 * PC_WAVES), lds, st, A);
     }
     if ((rc = check_launch("edge_bwd_pc_kernel"))) return rc;
-    return wb.finish();
+    return shared ? FASTEGNN_OK : wb.finish();
   }
 }
 
@@ -1355,7 +1365,7 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodeP
   }
 }
 
-int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
+int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
   FE_REQUIRE(L->h && L->wpack && L->g_P && L->g_QX && L->g_A && L->g_svel && L->g_xrow && L->g_xbar && L->g_x_out &&
                  L->svel && L->g_h && L->g_x && L->wg_node && L->grads && L->batch,
              "node_pre_backward: null buffer");
@@ -1364,7 +1374,8 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   const float *const *p = L->params;
   float *const *g = L->grads;
   const int N = L->N;
-  float *wg_gzv = L->wg_node, *wg_gzg = L->wg_node + (size_t)N * H;
+  float *wg_np = L->wg_node + 2 * wg_node_rows(L) * H;   // this stage's operand region of wg_node (kernels.h)
+  float *wg_gzv = wg_np, *wg_gzg = wg_np + (size_t)N * H;
   NodePreBwdArgs a{L->h, L->wpack, L->g_P, L->g_QX, L->g_A, L->g_svel, L->g_sgrav, L->g_xrow, L->g_xbar, L->g_x_out,
                    L->svel, p[FASTEGNN_P_VEL0_B], p[FASTEGNN_P_VEL2_W], p[FASTEGNN_P_GRAV0_B], p[FASTEGNN_P_GRAV2_W],
                    L->batch, L->g_h, L->g_x, L->g_vel, wg_gzv, wg_gzg,
@@ -1381,7 +1392,9 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
   if (rc) return rc;
   const int ld_e0 = 2 * H + 1 + L->ea, ld_v0 = 2 * H + 1 + L->C;
   // edge_mlp.0 columns [0,H) <- h[row] (P), [H,2H) <- h[col] (Q), bias through P
-  WgradBatch wb(L->wg_slab, st, has(L, FASTEGNN_F_BF16));
+  WgradBatch local(L->wg_slab, st);
+  WgradBatch &wb = shared ? *shared : local;
+  wb.round = has(L, FASTEGNN_F_BF16);
   const int c0 = has(L, FASTEGNN_F_EGNN) ? 1 : 0;   // EGNN baseline: [radial | h_row | h_col | edge_attr]
   if ((rc = wb.add(L->g_P, H, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, c0, 1, g[FASTEGNN_P_EDGE0_B]))) return rc;
   if ((rc = wb.add(L->g_QX, QXLD, L->h, H, N, g[FASTEGNN_P_EDGE0_W], ld_e0, c0 + H, 1, nullptr))) return rc;
@@ -1391,7 +1404,7 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st) {
     if ((rc = wb.add(wg_gzv, H, L->h, H, N, g[FASTEGNN_P_VEL0_W], H, 0, 1, g[FASTEGNN_P_VEL0_B]))) return rc;
   if (grav)
     if ((rc = wb.add(wg_gzg, H, L->h, H, N, g[FASTEGNN_P_GRAV0_W], H, 0, 1, g[FASTEGNN_P_GRAV0_B]))) return rc;
-  return wb.finish();
+  return shared ? FASTEGNN_OK : wb.finish();
 }
 
 }  // namespace fe

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
   }
 }
 
-WgradBatch::WgradBatch(float *slab, hipStream_t st_, bool round_bf16) : st(st_), round(round_bf16) {
+WgradBatch::WgradBatch(float *slab, hipStream_t st_, bool round_bf16, int slab_base_, int slab_cap_)
+    : st(st_), round(round_bf16), slab_base(slab_base_), slab_cap(slab_cap_) {
   tab.n_jobs = 0;
   tab.n_bundle = 0;
   n_bundle_wg = 0;
@@ -292,7 +293,7 @@ WgradBatch::WgradBatch(float *slab, hipStream_t st_, bool round_bf16) : st(st_),
   tab.slab = slab;
   tab.slab_b = slab ? slab + (size_t)WG_SLABS * IMG : nullptr;
   n_wg = 0;
-  n_slab = 0;
+  n_slab = slab_base;
   max_nb = 1;
 }
 
@@ -312,7 +313,7 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   long rows = (M + nsplit - 1) / nsplit;
   rows = (rows + 63) / 64 * 64;
   nsplit = (M + rows - 1) / rows;
-  FE_REQUIRE(n_slab + nsplit * nb <= WG_SLABS, "wgrad: slab workspace exhausted");
+  FE_REQUIRE(n_slab + nsplit * nb <= slab_base + slab_cap, "wgrad: slab workspace exhausted");
   WgJob &j = tab.job[tab.n_jobs++];
   j.G = G; j.T = T; j.dW = dW; j.db = db; j.M = M; j.sG = sG; j.sT = sT; j.sW = sW;
   j.ldg = ldg; j.ldt = ldt; j.lddw = lddw; j.c0 = c0; j.ks = ks; j.kmax = kmax;
@@ -345,7 +346,7 @@ int WgradBatch::add_slabs(float *dW, int lddw, int c0, int ks, float *db, int ns
   FE_REQUIRE(dW && slab_begin && nsplit > 0, "wgrad: add_slabs arguments");
   FE_REQUIRE(tab.slab, "wgrad: wg_slab workspace is null");
   FE_REQUIRE(tab.n_jobs < WG_MAX_JOBS, "wgrad: too many jobs in one batch");
-  FE_REQUIRE(n_slab + nsplit <= WG_SLABS, "wgrad: slab workspace exhausted");
+  FE_REQUIRE(n_slab + nsplit <= slab_base + slab_cap, "wgrad: slab workspace exhausted");
   WgJob &j = tab.job[tab.n_jobs++];
   j.G = nullptr; j.T = nullptr; j.dW = dW; j.db = db; j.M = 0; j.sG = j.sT = j.sW = 0;
   j.ldg = j.ldt = H; j.lddw = lddw; j.c0 = c0; j.ks = ks; j.kmax = 64;
@@ -375,7 +376,7 @@ int WgradBatch::finish() {
   tab.n_bundle = 0;
   n_bundle_wg = 0;
   n_wg = 0;
-  n_slab = 0;
+  n_slab = slab_base;
   max_nb = 1;
   return check_launch("wgrad_reduce_kernel");
 }
