@@ -152,6 +152,9 @@ int fastegnn_layer_backward(const fastegnn_layer_t *L, void *stream) {
   // together at the end of the layer: one wgrad_tn launch and one wgrad_reduce launch instead of a pair per stage
   FE_REQUIRE(L->wg_slab, "fastegnn_layer_backward: wg_slab null");
   WgradBatch wb(L->wg_slab, st);
+  // up to eight node-level jobs of N rows + the edge stage's 2 x 256 slabs share the lower half of the slab workspace
+  // (4096 slabs): 384 partial slabs per job at most (at cfg4 sizes a job takes 256 anyway)
+  wb.max_split = 384;
   if (has(L, FASTEGNN_F_EGNN)) {
     if ((rc = virt_backward(L, st, &wb))) return rc;
     if ((rc = edge_backward(L, st, &wb))) return rc;

@@ -60,6 +60,7 @@ struct WgradBatch {
   int n_wg, n_slab, max_nb, n_bundle_wg;
   bool round;   // applied to the jobs added from now on
   int min_rows; // smallest row range given to one workgroup (short operands are split that far to fill the chip)
+  int max_split; // most workgroups (= partial slabs) one job may take, times its batch count
   int slab_base, slab_cap;   // this batch's share of the slab workspace: [slab_base, slab_base + slab_cap)
   WgradBatch(float *slab, hipStream_t st, bool round_bf16 = false, int slab_base = 0, int slab_cap = WG_SLABS / 2);
   int add(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks, float *db,

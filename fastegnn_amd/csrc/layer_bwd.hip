@@ -653,11 +653,14 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
     if ((rc = bb.close_bundle())) return rc;
     if ((rc = bb.finish())) return rc;
   } else if (C > 0) {
-    if ((rc = wb.add(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
+    // plain jobs over the N*C rows, in a batch of their own (upper half of the slab workspace, 768 workgroups per job)
+    WgradBatch bb(L->wg_slab, st, has(L, FASTEGNN_F_BF16), WG_SLABS / 2, WG_SLABS / 2);
+    if ((rc = bb.add(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
     // coordinate heads and edge_mlp_virtual.2 over the N*C (node, channel) rows
-    if ((rc = wb.add(A.wg_gux, H, A.wg_v, H, NC, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B]))) return rc;
-    if ((rc = wb.add(A.wg_guX, H, A.wg_v, H, NC, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B]))) return rc;
-    if ((rc = wb.add(A.wg_gvp, H, A.wg_t, H, NC, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B]))) return rc;
+    if ((rc = bb.add(A.wg_gux, H, A.wg_v, H, NC, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B]))) return rc;
+    if ((rc = bb.add(A.wg_guX, H, A.wg_v, H, NC, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B]))) return rc;
+    if ((rc = bb.add(A.wg_gvp, H, A.wg_t, H, NC, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B]))) return rc;
+    if ((rc = bb.finish())) return rc;
   }
   // node_mlp.2
   if ((rc = wb.add(L->g_h_out, H, A.wg_t3, H, N, g[FASTEGNN_P_NODE2_W], H, 0, 1, g[FASTEGNN_P_NODE2_B]))) return rc;

@@ -290,6 +290,7 @@ WgradBatch::WgradBatch(float *slab, hipStream_t st_, bool round_bf16, int slab_b
   tab.n_bundle = 0;
   n_bundle_wg = 0;
   min_rows = 256;
+  max_split = 768;
   tab.slab = slab;
   tab.slab_b = slab ? slab + (size_t)WG_SLABS * IMG : nullptr;
   n_wg = 0;
@@ -307,7 +308,7 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   long nsplit = (M + 1023) / 1024;            // 1024 rows per workgroup while that fills the chip ...
   if (nsplit < 256) nsplit = (M + min_rows - 1) / min_rows;   // ... short operands: down to min_rows per workgroup
   if (nsplit > 256 && M < 256 * 1024) nsplit = 256;
-  long cap = 768 / nb;
+  long cap = max_split / nb;
   if (cap < 4) cap = 4;
   if (nsplit > cap) nsplit = cap;
   long rows = (M + nsplit - 1) / nsplit;
