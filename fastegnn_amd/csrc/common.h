@@ -175,14 +175,14 @@ __device__ __forceinline__ float vdot(const Vec &v, const Vec &w) {
 #ifdef FE_STAMP
 __device__ unsigned long long g_stamps[16];
 struct Stamp {
-  unsigned long long prev, acc[8];
+  unsigned long long prev, acc[12];
 };
 #define FE_TP , Stamp &_st
 #define FE_TA , _st
-#define FE_T0() Stamp _st; for (int _k = 0; _k < 8; ++_k) _st.acc[_k] = 0; _st.prev = __builtin_amdgcn_s_memtime();
+#define FE_T0() Stamp _st; for (int _k = 0; _k < 12; ++_k) _st.acc[_k] = 0; _st.prev = __builtin_amdgcn_s_memtime();
 #define FE_T(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long _t = __builtin_amdgcn_s_memtime(); \
                   _st.acc[i] += _t - _st.prev; _st.prev = _t; __builtin_amdgcn_sched_barrier(0); }
-#define FE_TEND() if (lane_id() == 0) { for (int _k = 0; _k < 8; ++_k) atomicAdd(&g_stamps[_k], _st.acc[_k]); }
+#define FE_TEND() if (lane_id() == 0) { for (int _k = 0; _k < 12; ++_k) atomicAdd(&g_stamps[_k], _st.acc[_k]); }
 #else
 #define FE_TP
 #define FE_TA

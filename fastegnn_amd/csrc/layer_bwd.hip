@@ -825,7 +825,10 @@ __device__ __forceinline__ void pc_tile_store(float *tile, int j, int q, const V
 #pragma unroll
   for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(tile + j * PC_RS + 16 * t + 4 * q) = v.t[t];
 }
-template <int MODE>
+// EA: edge_attr slots whose weight-column sums are accumulated in the row walk, without guards (2 covers edge_attr_nf <= 2 --
+// every BASELINE configuration --, 7 the rest): a per-slot `k < ea_dim` test inside the 16-edge walk compiled into ~130
+// scalar branches per tile and made the walk 23 % of the producers' time (phase stamps).
+template <int MODE, int EA>
 __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const EdgeArgs &a = A.f;
@@ -1029,7 +1032,9 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       vaxpy(acc_wx2, g_sr, S.u);
       if (q == 0) acc_bx2 += g_sr;
       const Vec g_up = vmul(vscale(vload_vec(vec + EV_WX2 * H, q), g_sr), S.up);
+      FE_T(5)   // degree / g_aggx rows, head adjoint, g_up
       publish(1, g_up, S.m);
+      FE_T(6)   // publish (g_up, m)
       Vec g_m = vscale(vload_row(A.g_aggm + (size_t)S.row * H, q), inv);
       gemm_i<MODE>(img, 3, g_up, g_m);
       Vec g_m0 = g_m;
@@ -1046,7 +1051,9 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         Vec tpark;
 #pragma unroll
         for (int t = 0; t < 4; ++t) tpark.t[t] = *reinterpret_cast<const f32x4 *>(pt + j * TS + 16 * t + 4 * q);
+        FE_T(7)   // g_aggm row, WX1^T product, attention adjoint, g_mp
         publish(0, g_mp, tpark);
+        FE_T(8)   // publish (g_mp, t)
       }
       Vec g_t = vzero();
       gemm_i<MODE>(img, 2, g_mp, g_t);
@@ -1061,6 +1068,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         vstore_row(qe, q, g_pre);
         if (q == 0) *reinterpret_cast<f32x4 *>(qe + H) = f32x4{-g_d[0], -g_d[1], -g_d[2], 0.f};
       }
+      FE_T(9)   // W2^T product, g_pre, g_d, per-edge stores
       // row-side segment sums: g_P[row] = sum g_pre, g_xrow[row] = sum g_d
       tile_store(pt, j, q, g_pre);
       if (q == 0) *reinterpret_cast<f32x4 *>(pt + j * TS + H) = f32x4{g_d[0], g_d[1], g_d[2], 0.f};
@@ -1090,15 +1098,16 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
           // the per-edge scalars come from the owning lane's registers (v_readlane), not from LDS
           accW[0] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.r), ee));
 #pragma unroll
-          for (int k = 0; k < 7; ++k)
-            if (k < a.ea_dim)
-              accW[1 + k] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.eav[k]), ee));
+          for (int k = 0; k < EA; ++k)   // slots beyond ea_dim hold zeros
+            accW[1 + k] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.eav[k]), ee));
         }
       }
       __builtin_amdgcn_wave_barrier();
+      FE_T(10)   // transpose tile + row-segmented sums
     }
     if (cur >= 0) flush();
     zero_rows(cur >= 0 ? cur + 1 : r0, r1);
+    FE_TEND()
   }
   float *red = vec;   // [3 + 8][64]; the weight vectors are dead now
   __syncthreads();
@@ -1167,8 +1176,14 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
     const size_t lds = (PC_IMG_FLOATS + EV_COUNT * H + PC_PROD * 16 * TS + 2 * PC_RING * PC_SLOT + PC_CTRL) * sizeof(float);
     {
       ProfScope _ps_edge_bwd_kernel(K_EDGE_BWD, st);
-      if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL(edge_bwd_pc_kernel<GM_BF16>, dim3(grid), dim3(64 * PC_WAVES), lds, st, A);
-      else hipLaunchKernelGGL(edge_bwd_pc_kernel<GM_X3>, dim3(grid), dim3(64 * PC_WAVES), lds, st, A);
+      const dim3 g3(grid), b3(64 * PC_WAVES);
+      if (L->ea <= 2) {
+        if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_BF16, 2>), g3, b3, lds, st, A);
+        else hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_X3, 2>), g3, b3, lds, st, A);
+      } else {
+        if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_BF16, 7>), g3, b3, lds, st, A);
+        else hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_X3, 7>), g3, b3, lds, st, A);
+      }
     }
     if ((rc = check_launch("edge_bwd_pc_kernel"))) return rc;
     return shared ? FASTEGNN_OK : wb.finish();
@@ -1418,6 +1433,17 @@ extern "C" int fastegnn_debug_read_vb_stamps(unsigned long long *out, int reset)
   if (reset) {
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(fe::g_vb_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
+
+#ifdef FE_STAMP
+extern "C" int fastegnn_debug_read_eb_stamps(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(fe::g_stamps), z, sizeof(z));
   }
   return 0;
 }

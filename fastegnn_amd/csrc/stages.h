@@ -64,7 +64,9 @@ __device__ __forceinline__ void edge_load_idx(const EdgeArgs &a, int e, EdgeIdx 
   I.row = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(a.erow) + eo);
   I.col = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(a.col) + eo);
   // ea_dim is wave-uniform: scalar branches, and no select on a loaded value (a select would make the
-  // load wait at issue).  Slots k >= ea_dim stay unset; every use is guarded by k < ea_dim.
+  // load wait at issue).  Slots k >= ea_dim are zero (the backward's weight-column sums run unguarded over them).
+#pragma unroll
+  for (int k = 0; k < 8; ++k) I.eav[k] = 0.f;
   if (a.ea_dim == 2) {
     const float2 v = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(a.ea) + 2u * eo);
     I.eav[0] = v.x;

@@ -191,6 +191,15 @@ def test_c32_vs_oracle():
     _check_vs_oracle(cfg, _batch([257], 15, 32, seed=6), seed=6)
 
 
+def test_wide_edge_attr_and_node_feat_vs_oracle():
+    """edge_attr_nf = 5 (the generic edge-attribute path of the edge kernels: every BASELINE configuration has 2), node_feat_nf = 4,
+    one attribute-less variant (edge_attr_nf = 0 is what EGNN-style callers without edge features pass)."""
+    for ea in (5, 0):
+        cfg = R.Config(4, 0, ea, 64, 4, n_layers=2, gravity=[0, -1, 0])
+        inp = _batch([260, 190], 7, 4, seed=17 + ea, nf=4, ea=ea)
+        _check_vs_oracle(cfg, inp, seed=17 + ea, case="test_wide_edge_attr_vs_oracle")
+
+
 def test_coords_agg_sum_vs_oracle():
     """E_GCL_vel(coords_agg='sum') (models/FastEGNN.py:126-127): FASTEGNN_F_COORDS_SUM in both edge kernels.  The
     reference FastEGNN constructor never passes it (always 'mean'), so the module takes it as an extra flag."""
