@@ -77,7 +77,12 @@ def spawn_ranks(n: int) -> int:
     rc = procs[0].returncode
     for p in procs[1:]:
         rc = max(rc, abs(p.wait()))
-    sys.stdout.write(out.decode())
+    # stdout carries the ONE JSON line; anything else rank 0 printed there (communicator banners) goes to stderr
+    for line in out.decode().splitlines():
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line + "\n")
+        elif line.strip():
+            sys.stderr.write(line + "\n")
     sys.stdout.flush()
     return rc
 
