@@ -1,5 +1,6 @@
 // Small kernels: model prologue/epilogue, row permutation, generic weight-gradient GEMMs,
 // and the toolkit self-test.
+#include <cstdlib>
 #include "kernels.h"
 
 namespace fe {
@@ -306,8 +307,12 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   FE_REQUIRE(tab.n_jobs < WG_MAX_JOBS, "wgrad: too many jobs in one batch");
   FE_REQUIRE((ldg % 4) == 0 && (ldt % 4) == 0, "wgrad: operand rows must be 16-byte aligned");
   long nsplit = (M + 1023) / 1024;            // 1024 rows per workgroup while that fills the chip ...
-  if (nsplit < 256) nsplit = (M + min_rows - 1) / min_rows;   // ... short operands: down to min_rows per workgroup
-  if (nsplit > 256 && M < 256 * 1024) nsplit = 256;
+  // ... short operands: down to min_rows per workgroup, up to `fill` workgroups per job.  A layer's batch holds ~8 jobs of
+  // N rows, so 128 per job already put 4 workgroups on every CU: measured at cfg4 (weight-gradient kernels per step)
+  // fill 64: 2.96 ms, 128: 2.91 ms, 256: 3.25 ms, 512: 3.57 ms (FE_WG_FILL overrides it for such sweeps)
+  static const long fill = getenv("FE_WG_FILL") ? atol(getenv("FE_WG_FILL")) : 128;
+  if (nsplit < fill) nsplit = (M + min_rows - 1) / min_rows;
+  if (nsplit > fill && M < fill * 1024) nsplit = fill;
   long cap = max_split / nb;
   if (cap < 4) cap = 4;
   if (nsplit > cap) nsplit = cap;
