@@ -291,7 +291,10 @@ WgradBatch::WgradBatch(float *slab, hipStream_t st_, bool round_bf16, int slab_b
   tab.n_bundle = 0;
   n_bundle_wg = 0;
   min_rows = 256;
-  max_split = 768;
+  // most workgroups (= partial slabs) per job: sweep at cfg4 (contraction + reduction, ms per step) 256: 3.22, 512: 3.17,
+  // 768: 3.23, 1024: 3.28 (FE_WG_CAP overrides it for such sweeps)
+  static const int cap_default = getenv("FE_WG_CAP") ? atoi(getenv("FE_WG_CAP")) : 512;
+  max_split = cap_default;
   tab.slab = slab;
   tab.slab_b = slab ? slab + (size_t)WG_SLABS * IMG : nullptr;
   n_wg = 0;
