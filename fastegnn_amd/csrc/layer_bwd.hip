@@ -681,9 +681,13 @@ struct GraphPreBwdArgs {
   float *g_Z, *g_HvT, *g_xbar, *wg_mxt;
   int B, C, bf16;
 };
+// grid (B, GPB_SPLIT): the per-(channel, feature) outputs of a graph are dealt to GPB_SPLIT workgroups; each of them
+// recomputes the graph's small matrices (mz, g_mX, g_mz), workgroup 0 writes the centroid gradient
+constexpr int GPB_SPLIT = 4;
 __global__ __launch_bounds__(256) void graph_pre_bwd_kernel(GraphPreBwdArgs a) {
   extern __shared__ float sm[];
   const int C = a.C, b = blockIdx.x, ld = 2 * H + 1 + C;
+  const int i0 = blockIdx.y * 256 + threadIdx.x, istep = 256 * gridDim.y;
   float *mz = sm;               // [3][C]
   float *gmX = sm + 3 * C;      // [C][C]  d/d mX[c'][c] stored at [c'*C + c]
   float *gmz = gmX + C * C;     // [3][C]
@@ -691,14 +695,14 @@ __global__ __launch_bounds__(256) void graph_pre_bwd_kernel(GraphPreBwdArgs a) {
   for (int i = threadIdx.x; i < 3 * C; i += 256) mz[i] = a.Z[(size_t)b * 3 * C + i] - a.xsum[b * 4 + i / C] / cnt;
   __syncthreads();
   // mX^T rows (feature vector of channel c = column c of mX), zero padded to 64, for dV1d
-  for (int i = threadIdx.x; i < C * H; i += 256) {
+  for (int i = i0; i < C * H; i += istep) {
     int c = i >> 6, d = i & 63;
     float v = 0.f;
     if (d < C) v = mz[c] * mz[d] + mz[C + c] * mz[C + d] + mz[2 * C + c] * mz[2 * C + d];
     a.wg_mxt[((size_t)b * C + c) * H + d] = v;
   }
   // g_HvT[b,c,k] += sum_o g_Bc[b,c,o] V1b[o,k]
-  for (int i = threadIdx.x; i < C * H; i += 256) {
+  for (int i = i0; i < C * H; i += istep) {
     int c = i >> 6, k = i & 63;
     const float *gb = a.g_Bc + ((size_t)b * C + c) * H;
     float acc = 0.f;
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(256) void graph_pre_bwd_kernel(GraphPreBwdArgs a) {
     else { for (int o = 0; o < H; ++o) acc += gb[o] * a.V0W[(size_t)o * ld + H + k]; }
     a.g_HvT[((size_t)b * C + c) * H + k] += acc;
   }
-  // g_mX[c'][c] = sum_o g_Bc[b,c,o] V1d[o,c']
+  // g_mX[c'][c] = sum_o g_Bc[b,c,o] V1d[o,c']   (every workgroup: all of it)
   for (int i = threadIdx.x; i < C * C; i += 256) {
     int cp = i / C, c = i % C;
     const float *gb = a.g_Bc + ((size_t)b * C + c) * H;
@@ -720,10 +724,10 @@ __global__ __launch_bounds__(256) void graph_pre_bwd_kernel(GraphPreBwdArgs a) {
     float acc = 0.f;
     for (int d = 0; d < C; ++d) acc += (gmX[c * C + d] + gmX[d * C + c]) * mz[k * C + d];
     gmz[i] = acc;
-    a.g_Z[(size_t)b * 3 * C + i] += acc + a.g_Zp[(size_t)b * 3 * C + i];
+    if (i % gridDim.y == blockIdx.y) a.g_Z[(size_t)b * 3 * C + i] += acc + a.g_Zp[(size_t)b * 3 * C + i];
   }
   __syncthreads();
-  if (threadIdx.x < 3) {
+  if (threadIdx.x < 3 && blockIdx.y == 0) {
     float acc = 0.f;
     for (int c = 0; c < C; ++c) acc += gmz[threadIdx.x * C + c];
     a.g_xbar[b * 3 + threadIdx.x] = -acc / cnt;
@@ -737,7 +741,7 @@ int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *sh
   GraphPreBwdArgs a{L->xsum, L->Z, L->g_Bc, L->g_Zp, L->params[FASTEGNN_P_VIRT0_W], L->g_Z, L->g_HvT, L->g_xbar, wg_mxt,
                     L->B, L->C, has(L, FASTEGNN_F_BF16) ? 1 : 0};
   const size_t lds = (size_t)(6 * L->C + L->C * L->C) * sizeof(float);
-  { ProfScope _ps_graph_pre_bwd_kernel(K_GRAPH_PRE_BWD, st); hipLaunchKernelGGL(graph_pre_bwd_kernel, dim3(L->B), dim3(256), lds, st, a); }
+  { ProfScope _ps_graph_pre_bwd_kernel(K_GRAPH_PRE_BWD, st); hipLaunchKernelGGL(graph_pre_bwd_kernel, dim3(L->B, GPB_SPLIT), dim3(256), lds, st, a); }
   int rc = check_launch("graph_pre_bwd_kernel");
   if (rc) return rc;
   float *const *g = L->grads;
