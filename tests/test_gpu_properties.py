@@ -305,6 +305,15 @@ def test_unused_last_layer_heads_have_no_gradient():
         assert changed == (k not in none), k
 
 
+@pytest.mark.parametrize("C", [1, 3, 5])
+def test_many_tiles_odd_channel_counts_vs_oracle(C):
+    """Workgroups that walk several tile rounds with an ODD number of channels (and C = 1): the W3c stage of virt_bwd
+    alternates between two LDS buffers by channel parity, so the last channel of a tile and the first of the next use
+    the same buffer when C is odd; C < 4 also keeps the channel-split path of the last tile off."""
+    cfg = R.Config(2, 0, 2, 64, C, n_layers=2, gravity=[0, -1, 0])
+    _check_vs_oracle(cfg, _batch([21000, 11900], 2, C, seed=30 + C), seed=30 + C, case=f"test_many_tiles_odd_C{C}")
+
+
 def test_no_edges_and_isolated_nodes():
     cfg = R.Config(2, 0, 2, 64, 4, n_layers=2)
     inp = _batch([40, 23], 3, 4, seed=8)
