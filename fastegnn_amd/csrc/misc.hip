@@ -70,6 +70,9 @@ __global__ void build_batch_kernel(const int64_t *b64, int N, int B, int32_t *ba
 // (fastegnn_selftest_stream): it is HBM-bound, and a bf16x3 version of the inner product (6x fewer
 // MFMA issue cycles) measured the same 6.0 ms per step -- the fp32-input MFMA form is kept.
 constexpr int WTS = 80;  // LDS row stride of the staged operand tiles (conflict-free b32 column reads)
+#ifndef FE_WG_OCC
+#define FE_WG_OCC 2   // waves per SIMD the contraction kernels are compiled for (measured per step: 2 -> 2.84 ms, 3 -> 2.94 ms with 44-52 B of scratch, 4 -> 5.8 ms)
+#endif
 
 // rows [m_first, m1) of one (G, T) pair in steps of `step` rows, 16 rows at a time, into the wave's 64x64 accumulator
 // (acc[ti][tk][r] = dW[16ti + 4q + r][16tk + i]); gt / tt: this wave's two 16 x WTS staging tiles.
@@ -151,7 +154,7 @@ __device__ __forceinline__ void wg_accumulate(const float *G, const float *T, in
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
+__global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_tn_kernel(WgTable tab) {
   // 40 KB of staging tiles; the 64x64 reduction buffer aliases them after the main loop
   __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 16 * WTS];
   __shared__ float redb[H];
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgTable tab) {
 // over the same row range: wave w runs job w over every 16-row tile of the range, so the shared `v` rows are fetched
 // from HBM once and hit in L1/L2 for the other two waves (5 operand streams instead of 8).  Each wave keeps its own
 // 64x64 accumulator and writes its own partial slab; nothing is reduced across waves.
-__global__ __launch_bounds__(256) void wgrad_bundle_kernel(WgTable tab) {
+__global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_bundle_kernel(WgTable tab) {
   __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 16 * WTS];
   const int w = wave_id();
   if (w >= tab.n_bundle) return;
