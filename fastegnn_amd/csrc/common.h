@@ -407,6 +407,35 @@ __device__ __forceinline__ void gemm64_b1_rm(const char *img, const BfOp &in, Ve
   }
 }
 
+// ---- one k-block (8 values per lane) of a weight-gradient contraction, as bf16 parts ----
+struct Split8 {
+  u32x4 h, m, l;
+};
+// eight fp32 values -> their three bf16 parts, packed as one k-block of v_mfma_f32_16x16x32_bf16
+__device__ __forceinline__ Split8 split8(const float (&x)[8]) {
+  float r1[8], r2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    r1[e] = x[e] - trunc_bf(x[e]);
+    r2[e] = r1[e] - trunc_bf(r1[e]);
+  }
+  Split8 S;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    S.h[w] = pack_hi(x[2 * w], x[2 * w + 1]);
+    S.m[w] = pack_hi(r1[2 * w], r1[2 * w + 1]);
+    S.l[w] = pack_hi(r2[2 * w], r2[2 * w + 1]);
+  }
+  return S;
+}
+// eight fp32 values -> one k-block of bf16 values, round to nearest even (bf16 operand mode)
+__device__ __forceinline__ u32x4 round8(const float (&x)[8]) {
+  u32x4 r;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) r[w] = pack_rne(x[2 * w], x[2 * w + 1]);
+  return r;
+}
+
 // Arithmetic form of the 64x64 layers of a kernel (template parameter of the stage kernels)
 enum GemmMode { GM_F32 = 0, GM_X3 = 1, GM_BF16 = 2 };
 // the B operand of one or several products in the chosen form: made once, used by every layer that reads it

@@ -796,33 +796,6 @@ constexpr int PC_RS = 68;                   // row stride of a slot tile
 constexpr int PC_SLOT = 2 * 16 * PC_RS;     // floats per slot: G tile | T tile
 constexpr int PC_IMG_FLOATS = 4 * IMG3;
 enum { PC_HEAD = 0, PC_TOTAL = 2, PC_FILLED = 4, PC_DRAINED = 4 + 2 * PC_RING, PC_CTRL = 4 + 4 * PC_RING };
-struct Split8 {
-  u32x4 h, m, l;
-};
-// eight fp32 values -> their three bf16 parts, packed as one k-block of v_mfma_f32_16x16x32_bf16
-__device__ __forceinline__ Split8 split8(const float (&x)[8]) {
-  float r1[8], r2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    r1[e] = x[e] - trunc_bf(x[e]);
-    r2[e] = r1[e] - trunc_bf(r1[e]);
-  }
-  Split8 S;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    S.h[w] = pack_hi(x[2 * w], x[2 * w + 1]);
-    S.m[w] = pack_hi(r1[2 * w], r1[2 * w + 1]);
-    S.l[w] = pack_hi(r2[2 * w], r2[2 * w + 1]);
-  }
-  return S;
-}
-// eight fp32 values -> one k-block of bf16 values, round to nearest even (bf16 operand mode)
-__device__ __forceinline__ u32x4 round8(const float (&x)[8]) {
-  u32x4 r;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) r[w] = pack_rne(x[2 * w], x[2 * w + 1]);
-  return r;
-}
 __device__ __forceinline__ int lds_ld(const int *p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void lds_st(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void pc_tile_store(float *tile, int j, int q, const Vec &v) {

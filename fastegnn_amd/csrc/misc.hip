@@ -68,7 +68,8 @@ __global__ void build_batch_kernel(const int64_t *b64, int N, int B, int32_t *ba
 // contention (4096 atomics x hundreds of workgroups onto one 16 KB tile cost ~50 us per launch).
 // The kernel streams its operands at ~4.0 TB/s against 5.3 TB/s for a bare read loop on this part
 // (fastegnn_selftest_stream): it is HBM-bound, and a bf16x3 version of the inner product (6x fewer
-// MFMA issue cycles) measured the same 6.0 ms per step -- the fp32-input MFMA form is kept.
+// MFMA issue cycles) measured the same in round 1 (6.0 ms per step) and again in round 2 on the bundle geometry
+// (2.93 vs 2.91 ms per step) -- the fp32-input MFMA form is kept.
 constexpr int WTS = 80;  // LDS row stride of the staged operand tiles (conflict-free b32 column reads)
 #ifndef FE_WG_OCC
 #define FE_WG_OCC 2   // waves per SIMD the contraction kernels are compiled for (measured per step: 2 -> 2.84 ms, 3 -> 2.94 ms with 44-52 B of scratch, 4 -> 5.8 ms)
