@@ -73,6 +73,8 @@ struct WgradBatch {
 };
 inline size_t wg_slab_floats() { return (size_t)WG_SLABS * (IMG + H); }
 //   dW[o*lddw + c0 + a] += sum_m G[m*ldg + o] * F[m*ldf + a],  a < kf <= 8
+int launch_dgrad_small(const float *G, long N, int kf, const float *W, int ldw, int c0, float *g_in, int accumulate,
+                       hipStream_t st);
 int launch_wgrad_small(const float *G, int ldg, const float *F, int ldf, int kf, long M, float *dW, int lddw, int c0,
                        hipStream_t st);
 

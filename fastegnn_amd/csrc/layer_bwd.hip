@@ -668,8 +668,12 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
   if ((rc = wb.add(A.wg_gnp, H, L->h, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 0, 1, g[FASTEGNN_P_NODE0_B]))) return rc;
   if ((rc = wb.add(A.wg_gnp, H, L->aggm, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, H, 1, nullptr))) return rc;
   if (!shared && (rc = wb.finish())) return rc;
-  if (L->na > 0)
+  if (L->na > 0) {
     if ((rc = launch_wgrad_small(A.wg_gnp, H, L->node_attr, L->na, L->na, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H + H * C, st))) return rc;
+    // d loss / d node_attr (+=, only when the caller asks): g_np x the node_attr columns of node_mlp.0.weight
+    if (L->g_node_attr && !has(L, FASTEGNN_F_RF))
+      if ((rc = launch_dgrad_small(A.wg_gnp, N, L->na, L->params[FASTEGNN_P_NODE0_W], ld_n0, 2 * H + H * C, L->g_node_attr, 1, st))) return rc;
+  }
   return FASTEGNN_OK;
 }
 
@@ -763,6 +767,7 @@ struct EdgeBwdArgs {
   EdgeArgs f;
   const float *g_aggm, *g_aggx;
   float *g_P, *g_xrow, *g_QXe;
+  float *g_ea;   // [E,ea] d loss / d edge_attr (sorted-edge order, +=) or null
   float *d_wx2, *d_attw, *d_attb, *d_bx2;
   float *d_wr, *d_we;   // edge_mlp.0.weight grad: radial column and first edge_attr column (row stride ld_e0)
   int ld_e0, C;
@@ -1045,6 +1050,12 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         vstore_row(qe, q, g_pre);
         if (q == 0) *reinterpret_cast<f32x4 *>(qe + H) = f32x4{-g_d[0], -g_d[1], -g_d[2], 0.f};
       }
+      if (A.g_ea) {   // d/d edge_attr[e,k] = <g_pre[e], edge_mlp.0.weight[:, 2H+1+k]>  (wave-uniform: only when asked for)
+        for (int k = 0; k < a.ea_dim; ++k) {
+          const float ge = vdot(g_pre, vload_vec(vec + (EV_WE + k) * H, q));
+          if (valid && q == 0) A.g_ea[(size_t)e * a.ea_dim + k] += ge;
+        }
+      }
       FE_T(9)   // W2^T product, g_pre, g_d, per-edge stores
       // row-side segment sums: g_P[row] = sum g_pre, g_xrow[row] = sum g_d
       tile_store(pt, j, q, g_pre);
@@ -1131,6 +1142,7 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
   EdgeBwdArgs A;
   A.f = make_edge_args(L);
   A.g_aggm = L->g_aggm; A.g_aggx = L->g_aggx; A.g_P = L->g_P; A.g_xrow = L->g_xrow; A.g_QXe = L->g_QXe;
+  A.g_ea = L->ea > 0 ? L->g_ea_sorted : nullptr;
   A.ld_e0 = 2 * H + 1 + L->ea;
   A.d_wr = g[FASTEGNN_P_EDGE0_W] + (has(L, FASTEGNN_F_EGNN) ? 0 : 2 * H);   // basic.py:313: radial is column 0
   A.d_we = g[FASTEGNN_P_EDGE0_W] + 2 * H + 1;

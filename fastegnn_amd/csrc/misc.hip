@@ -14,13 +14,16 @@ __global__ void embed_fwd_kernel(const float *nf, int N, int nfd, const float *W
   for (int a = 0; a < nfd; ++a) acc += nf[(size_t)n * nfd + a] * W[o * nfd + a];
   h[idx] = acc;
 }
-__global__ void embed_bwd_input_kernel(const float *g_h, int N, int nfd, const float *W, float *g_nf) {
+// g_in[n, a] (+)= sum_o G[n, o] * W[o * ldw + c0 + a]: the input gradient of a narrow column block of a 64-row Linear
+// (embedding_in: all nf columns; node_mlp.0: the node_attr columns).  N * kf threads, a few MB of traffic.
+__global__ void dgrad_small_kernel(const float *G, long N, int kf, const float *W, int ldw, int c0, float *g_in, int accumulate) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)N * nfd) return;
-  int n = (int)(idx / nfd), a = (int)(idx % nfd);
+  if (idx >= N * kf) return;
+  long n = idx / kf;
+  int a = (int)(idx % kf);
   float acc = 0.f;
-  for (int o = 0; o < H; ++o) acc += g_h[(size_t)n * H + o] * W[o * nfd + a];
-  g_nf[idx] = acc;
+  for (int o = 0; o < H; ++o) acc += G[(size_t)n * H + o] * W[(size_t)o * ldw + c0 + a];
+  g_in[idx] = accumulate ? g_in[idx] + acc : acc;
 }
 
 // ---------------------------------------------------------------- virtual_node_feat.repeat (:268)
@@ -441,6 +444,13 @@ static int launch_wgrad_small_b(const float *G, int ldg, const float *F, int ldf
   { ProfScope _ps_wgrad_small_kernel(K_WGRAD_SMALL, st); hipLaunchKernelGGL(wgrad_small_kernel, dim3((unsigned)nsplit), dim3(256), 0, st, a); }
   return check_launch("wgrad_small_kernel");
 }
+int launch_dgrad_small(const float *G, long N, int kf, const float *W, int ldw, int c0, float *g_in, int accumulate,
+                       hipStream_t st) {
+  if (N == 0 || kf == 0) return FASTEGNN_OK;
+  hipLaunchKernelGGL(dgrad_small_kernel, dim3(cdiv(N * kf, 256)), dim3(256), 0, st, G, N, kf, W, ldw, c0, g_in, accumulate);
+  return check_launch("dgrad_small_kernel");
+}
+
 int launch_wgrad_small(const float *G, int ldg, const float *F, int ldf, int kf, long M, float *dW, int lddw, int c0,
                        hipStream_t st) {
   return launch_wgrad_small_b(G, ldg, F, ldf, kf, M, dW, lddw, c0, nullptr, st);
@@ -584,9 +594,7 @@ int fastegnn_embed_backward(const float *node_feat, const float *g_h, int32_t N,
   int rc = launch_wgrad_small_b(g_h, H, node_feat, nf, nf, N, gW, nf, 0, gb, st);
   if (rc) return rc;
   if (g_node_feat) {
-    hipLaunchKernelGGL(embed_bwd_input_kernel, dim3(cdiv((long)N * nf, 256)), dim3(256), 0, st, g_h, N, nf, W,
-                       g_node_feat);
-    return check_launch("embed_bwd_input_kernel");
+    return launch_dgrad_small(g_h, N, nf, W, nf, 0, g_node_feat, 0, st);
   }
   return FASTEGNN_OK;
 }

@@ -223,9 +223,14 @@ class _FastEGNNFunction(torch.autograd.Function):
     """Whole-model forward/backward on the HIP library (one C-ABI call per layer and direction)."""
 
     @staticmethod
-    def forward(ctx, spec: _Spec, graph: SortedGraph, batch32, gptr, ea_sorted, node_attr,
+    def forward(ctx, spec: _Spec, graph: SortedGraph, batch32, gptr, edge_attr, node_attr,
                 node_feat, node_loc, node_vel, loc_mean, *params):
         lib = K.lib()
+        # edge_attr / node_attr are differentiable inputs (the reference harness detaches them, utils/train.py:33,46-47,
+        # but the module itself is differentiable in them): their gradients are accumulated by the edge / virtual backward
+        # kernels when asked for
+        ea_sorted = graph.permute(edge_attr.detach() if edge_attr is not None else None)
+        node_attr = node_attr.detach().contiguous().float() if node_attr is not None else None
         dev = node_loc.device
         st = _stream(dev)
         N, B, Cn = node_loc.size(0), loc_mean.size(0), spec.C
@@ -296,6 +301,10 @@ class _FastEGNNFunction(torch.autograd.Function):
         g_Z = (g_vloc if g_vloc is not None else torch.zeros(B, 3, Cn, **f32)).contiguous().float()
         g_HvT = torch.zeros(B, Cn, H, **f32)
         g_vel = torch.zeros(N, 3, **f32)
+        want_ea = ctx.needs_input_grad[4] and ea_sorted is not None and E > 0
+        want_na = ctx.needs_input_grad[5] and node_attr is not None
+        g_ea_sorted = torch.zeros(E, spec.ea, **f32) if want_ea else None
+        g_na = torch.zeros(N, spec.na, **f32) if want_na else None
         scratch = _carve(dev, dict(
             g_poolV=(B, Cn, H), g_poolX=(B, 3, Cn), g_Bc=(B, Cn, H), g_Zp=(B, 3, Cn), g_xbar=(B, 4),
             g_A=(N, H), g_P=(N, H), g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,),
@@ -318,12 +327,20 @@ class _FastEGNNFunction(torch.autograd.Function):
                 L.ea_sorted = ea_sorted.data_ptr()
             if node_attr is not None:
                 L.node_attr = node_attr.data_ptr()
+            if g_ea_sorted is not None:
+                L.g_ea_sorted = g_ea_sorted.data_ptr()
+            if g_na is not None:
+                L.g_node_attr = g_na.data_ptr()
             K.check(lib.fastegnn_layer_backward(C.byref(L), st), f"fastegnn_layer_backward[{i}]")
             g_h, g_x, g_Z, g_HvT = out["g_h"], out["g_x"], out["g_Z"], out["g_HvT"]
             saved[i] = None
         K.check(lib.fastegnn_virtual_init_backward(K.ptr(g_HvT), B, Cn, K.ptr(grads[0]), st),
                 "fastegnn_virtual_init_backward")
         g_nf = torch.empty_like(node_feat) if ctx.needs_input_grad[6] else None
+        g_ea = None
+        if g_ea_sorted is not None:   # back to the caller's edge order: sorted edge k is input edge perm[k]
+            g_ea = torch.empty_like(g_ea_sorted)
+            g_ea.index_copy_(0, graph.perm[:E].long(), g_ea_sorted)
         K.check(lib.fastegnn_embed_backward(K.ptr(node_feat), K.ptr(g_h), N, spec.nf, K.ptr(params[1]),
                                             K.ptr(grads[1]), K.ptr(grads[2]), K.ptr(g_nf), st),
                 "fastegnn_embed_backward")
@@ -333,7 +350,7 @@ class _FastEGNNFunction(torch.autograd.Function):
         for s_, suffix in zip(spec.layer_slots[last], K.PARAM_SLOTS):
             if s_ is not None and suffix.startswith(("node_mlp.", "node_mlp_virtual.")) and not (spec.flags & K.F_RF):
                 grads[s_] = None
-        return (None, None, None, None, None, None, g_nf, g_x, g_vel, g_Z, *grads)
+        return (None, None, None, None, g_ea, g_na, g_nf, g_x, g_vel, g_Z, *grads)
 
 
 # ------------------------------------------------------------------------------------------
@@ -403,9 +420,6 @@ class FastEGNN(nn.Module):
         if not node_loc.is_cuda:
             raise RuntimeError("fastegnn_amd.FastEGNN runs on a gfx950 GPU only (no CPU fallback): move the model "
                                "and its inputs to 'cuda'")
-        for name, t in (("edge_attr", edge_attr), ("node_attr", node_attr)):
-            if t is not None and t.requires_grad:
-                raise NotImplementedError(f"fastegnn_amd: gradient w.r.t. {name} is not implemented")
         if (edge_attr.size(1) if edge_attr is not None else 0) != self.edge_attr_nf:
             raise ValueError("edge_attr width does not match edge_attr_nf")
         if (node_attr.size(1) if node_attr is not None else 0) != self.node_attr_nf:
@@ -427,7 +441,7 @@ class FastEGNN(nn.Module):
         gptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
         K.check(lib.fastegnn_build_batch(K.ptr(data_batch.contiguous()), N, B, K.ptr(batch32), K.ptr(gptr), _stream(dev)),
                 "fastegnn_build_batch")
-        ea_sorted = graph.permute(edge_attr.detach() if edge_attr is not None else None)
-        na = node_attr.detach().contiguous().float() if node_attr is not None else None
-        return _FastEGNNFunction.apply(spec, graph, batch32, gptr, ea_sorted, na, node_feat, node_loc, node_vel,
+        if edge_attr is not None and edge_attr.size(1) == 0:
+            edge_attr = None
+        return _FastEGNNFunction.apply(spec, graph, batch32, gptr, edge_attr, node_attr, node_feat, node_loc, node_vel,
                                        loc_mean, *self._plist)

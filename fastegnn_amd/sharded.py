@@ -387,6 +387,9 @@ class ShardedFastEGNN(torch.nn.Module):
                      node_attr=None) -> Dict[str, torch.Tensor]:
         """This rank's share of a batch: its node rows, the edges aggregating into them (global column ids),
         the replicated per-graph tensors."""
+        for name, t in (("edge_attr", edge_attr), ("node_attr", node_attr)):
+            if t is not None and t.requires_grad:   # the single-GPU module returns these; the sharded caller does not (yet)
+                raise NotImplementedError(f"fastegnn_amd.ShardedFastEGNN: gradient w.r.t. {name} is not implemented")
         world, rank = self._world_rank()
         plan = ShardPlan(node_loc.size(0), world, rank)
         ei, ea = plan.edges(edge_index, edge_attr.detach() if edge_attr is not None else None)

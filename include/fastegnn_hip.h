@@ -173,6 +173,8 @@ typedef struct {
   /* backward outputs: d loss / d layer inputs */
   float *g_h, *g_x, *g_Z, *g_HvT;
   float *g_vel;            /* [N,3] accumulated (+=), may be null */
+  float *g_ea_sorted;      /* [E,ea] d loss / d edge_attr in sorted-edge order, accumulated (+=) over the layers; null: not wanted */
+  float *g_node_attr;      /* [N,na] d loss / d node_attr, accumulated (+=) over the layers; null: not wanted */
 
   /* backward scratch (caller allocates; the shapes below, the wg_* sizes from fastegnn_wg_*_floats, the total from
    * fastegnn_backward_scratch_floats) */

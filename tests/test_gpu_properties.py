@@ -200,6 +200,40 @@ def test_wide_edge_attr_and_node_feat_vs_oracle():
         _check_vs_oracle(cfg, inp, seed=17 + ea, case="test_wide_edge_attr_vs_oracle")
 
 
+@pytest.mark.parametrize("ea,na,C", [(2, 3, 4), (5, 2, 16), (1, 0, 3)])
+def test_input_gradients_vs_oracle(ea, na, C):
+    """Gradients w.r.t. every floating-point INPUT of `forward` -- edge_attr and node_attr included (the reference
+    module is differentiable in them through edge_mlp.0 / node_mlp.0, models/FastEGNN.py:89,132; its harness happens to
+    detach them) -- against the oracle's autograd, same calibrated rule as the parameter gradients."""
+    cfg = R.Config(3, na, ea, 64, C, n_layers=3, gravity=[0, -1, 0], attention=True)
+    inp = _batch([150, 77, 201], 6, C, seed=40 + ea, nf=3, ea=ea)
+    g = torch.Generator().manual_seed(77)
+    if na:
+        inp["node_attr"] = torch.rand(inp["node_loc"].size(0), na, generator=g)
+    p, m = _models(cfg, seed=41)
+    tgt = inp["node_loc"] + 0.5
+    names = [k for k, v in inp.items() if v.is_floating_point()]
+    kw = {k: (v.cuda().requires_grad_(True) if k in names else v.cuda()) for k, v in inp.items()}
+    loc, vloc = m(**kw)
+    _loss(loc, vloc, tgt.cuda()).backward()
+    got = {k: kw[k].grad.cpu() for k in names}
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        pp = {k: v.detach().to(dt) for k, v in p.items()}
+        ii = {k: (v.to(dt).detach().clone().requires_grad_(True) if k in names else v) for k, v in inp.items()}
+        l, v = R.forward(pp, cfg, **ii)
+        _loss(l, v, tgt.to(dt)).backward()
+        res[dt] = {k: ii[k].grad for k in names}
+    bad = []
+    for k in names:
+        assert got[k].shape == res[torch.float64][k].shape
+        grad_check("test_input_gradients_vs_oracle", "input." + k, got[k], res[torch.float32][k], res[torch.float64][k], bad)
+    assert not bad, bad
+    # a second forward that asks for no input gradient allocates none and still works
+    loc2, _ = m(**{k: v.detach() for k, v in kw.items()})
+    assert rel_err(loc2.cpu(), loc.detach().cpu()) < 1e-6   # (float atomics in the pools: not bit-reproducible)
+
+
 def test_coords_agg_sum_vs_oracle():
     """E_GCL_vel(coords_agg='sum') (models/FastEGNN.py:126-127): FASTEGNN_F_COORDS_SUM in both edge kernels.  The
     reference FastEGNN constructor never passes it (always 'mean'), so the module takes it as an extra flag."""
