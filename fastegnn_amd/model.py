@@ -219,6 +219,44 @@ def _new_layer(spec: _Spec, N: int, B: int, graph: SortedGraph) -> K.LayerT:
     return L
 
 
+# ------------------------------------------------------------------------------------------
+# hidden_nf < 64: zero padding to the kernels' 64-wide tiles
+# ------------------------------------------------------------------------------------------
+_HIDDEN_OUT = ("edge_mlp.0", "edge_mlp.2", "edge_mlp_virtual.0", "edge_mlp_virtual.2", "coord_mlp_r.0",
+               "coord_mlp_r_virtual.0", "coord_mlp_v_virtual.0", "coord_mlp_vel.0", "gravity_mlp.0", "node_mlp.0",
+               "node_mlp.2", "node_mlp_virtual.0", "node_mlp_virtual.2", "embedding_in")
+
+
+def _pad_param(name: str, p: torch.Tensor, h: int, C_: int, rf: bool) -> torch.Tensor:
+    """The 64-wide image of a parameter of a ``hidden_nf = h < 64`` model: every hidden-sized row / column block is
+    zero-extended to 64.  A zero row of a Linear gives a zero pre-activation, SiLU(0) = 0, and a zero column ignores
+    its input, so the padded model computes exactly the reference's function (models/FastEGNN.py:28-99 with
+    hidden_nf = h); built from differentiable torch ops, so autograd slices the gradients back."""
+    pad = torch.nn.functional.pad
+    if name == "virtual_node_feat":                       # [1, h, C]
+        return pad(p, (0, 0, 0, H - h))
+    mod, kind = name.rsplit(".", 1)
+    mod = mod.split(".", 1)[1] if mod.startswith("gcl_") else mod
+    if kind == "bias":
+        return pad(p, (0, H - h)) if mod in _HIDDEN_OUT else p
+    # input columns: the blocks of the reference's torch.cat, hidden-sized ones first (FastEGNN.py:104,114,157,171)
+    if mod in ("edge_mlp.0", "edge_mlp_virtual.0", "node_mlp_virtual.0"):
+        sizes = [h, h]
+    elif mod == "node_mlp.0":
+        sizes = [h, h, h * C_]                            # flat(v) is feature-major: column 2h + i*C + c
+    elif mod == "embedding_in" or (rf and mod == "coord_mlp_vel.0"):
+        sizes = []                                        # inputs that are not hidden features
+    else:
+        sizes = [h]
+    blocks, at = [], 0
+    for sz in sizes:
+        blocks.append(pad(p[:, at:at + sz], (0, sz // h * (H - h))))
+        at += sz
+    blocks.append(p[:, at:])
+    w = torch.cat(blocks, dim=1) if len(blocks) > 1 else blocks[0]
+    return pad(w, (0, 0, 0, H - h)) if mod in _HIDDEN_OUT else w
+
+
 class _FastEGNNFunction(torch.autograd.Function):
     """Whole-model forward/backward on the HIP library (one C-ABI call per layer and direction)."""
 
@@ -374,8 +412,8 @@ class FastEGNN(nn.Module):
             raise ValueError("fastegnn_amd: mlp_dtype must be torch.float32 or torch.bfloat16")
         self.mlp_dtype = mlp_dtype
         assert virtual_channels > 0, f'Channels of virtual node must greater than 0 (got {virtual_channels})'
-        if hidden_nf != H:
-            raise NotImplementedError(f"fastegnn_amd: hidden_nf must be {H} in this build (got {hidden_nf})")
+        if not 1 <= hidden_nf <= H:   # (< 64 runs zero-padded on the 64-wide tiles, see _pad_param)
+            raise NotImplementedError(f"fastegnn_amd: hidden_nf must be at most {H} in this build (got {hidden_nf})")
         if not isinstance(act_fn, nn.SiLU):
             raise NotImplementedError("fastegnn_amd: the HIP kernels implement SiLU (the reference default) only")
         if virtual_channels > 64 or edge_attr_nf > 7 or node_feat_nf > 8:
@@ -443,5 +481,9 @@ class FastEGNN(nn.Module):
                 "fastegnn_build_batch")
         if edge_attr is not None and edge_attr.size(1) == 0:
             edge_attr = None
+        plist = self._plist
+        if self.hidden_nf < H:
+            rf = bool(spec.flags & K.F_RF)
+            plist = [_pad_param(n, p, self.hidden_nf, spec.C, rf) for n, p in zip(spec.names, plist)]
         return _FastEGNNFunction.apply(spec, graph, batch32, gptr, edge_attr, node_attr, node_feat, node_loc, node_vel,
-                                       loc_mean, *self._plist)
+                                       loc_mean, *plist)

@@ -372,6 +372,8 @@ class ShardedFastEGNN(torch.nn.Module):
 
     def __init__(self, model: FastEGNN, group=None, backend=None, stats: Optional[CommStats] = None):
         super().__init__()
+        if model.hidden_nf != K.H:   # the zero-padded path of model.py (_pad_param) is single-GPU only
+            raise NotImplementedError(f"fastegnn_amd.ShardedFastEGNN: hidden_nf must be {K.H}")
         self.model = model
         self.group = group
         self.backend = backend

@@ -234,6 +234,21 @@ def test_input_gradients_vs_oracle(ea, na, C):
     assert rel_err(loc2.cpu(), loc.detach().cpu()) < 1e-6   # (float atomics in the pools: not bit-reproducible)
 
 
+@pytest.mark.parametrize("hidden,C", [(32, 4), (20, 3)])
+def test_narrow_hidden_nf_vs_oracle(hidden, C):
+    """hidden_nf < 64 (`--dim_hidden`, main_nbody.py:27): the module zero-pads every hidden-sized block of the parameters
+    to the kernels' 64-wide tiles, which computes the same function; outputs and the gradients of the h-sized
+    parameters against the oracle built with the true hidden_nf.  state_dict keeps the reference's shapes."""
+    cfg = R.Config(2, 2, 2, hidden, C, n_layers=3, gravity=[0, -1, 0], attention=True)
+    inp = _batch([130, 61], 6, C, seed=50 + hidden)
+    inp["node_attr"] = torch.rand(inp["node_loc"].size(0), 2, generator=torch.Generator().manual_seed(5))
+    _check_vs_oracle(cfg, inp, seed=50 + hidden, case="test_narrow_hidden_nf_vs_oracle")
+    _, m = _models(cfg, seed=1)
+    assert m.gcl_0.node_mlp[0].weight.shape == (hidden, 2 * hidden + hidden * C + 2)
+    with pytest.raises(NotImplementedError):
+        fastegnn_amd.FastEGNN(2, 0, 2, 128, 4, device="cuda")
+
+
 def test_coords_agg_sum_vs_oracle():
     """E_GCL_vel(coords_agg='sum') (models/FastEGNN.py:126-127): FASTEGNN_F_COORDS_SUM in both edge kernels.  The
     reference FastEGNN constructor never passes it (always 'mean'), so the module takes it as an extra flag."""
