@@ -109,6 +109,7 @@ def lib():
     L.fastegnn_cutoff_tmp_bytes.restype = C.c_size_t
     L.fastegnn_cutoff_tmp_bytes.argtypes = [C.c_int64]
     L.fastegnn_cutoff_edges.argtypes = [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]
+    L.fastegnn_nbody_cutoff_edges.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp, _vp]
     L.fastegnn_selftest_gemm.argtypes = [_vp, _vp, _vp, _i32, _vp]
     L.fastegnn_selftest_rm.argtypes = [_vp, _vp, _vp, _i32, _i32, _vp]
     L.fastegnn_selftest_chain.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _vp]
@@ -148,7 +149,7 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_rm", "fastegnn_selftest_wgrad", "fastegnn_selftest_stream", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
     "fastegnn_augment_edge_attr", "fastegnn_loss_mse_mmd", "fastegnn_adam_step",
     "fastegnn_radius_graph_ws_bytes", "fastegnn_radius_graph_count", "fastegnn_radius_graph_fill",
-    "fastegnn_cutoff_tmp_bytes", "fastegnn_cutoff_edges",
+    "fastegnn_cutoff_tmp_bytes", "fastegnn_cutoff_edges", "fastegnn_nbody_cutoff_edges",
     "fastegnn_profile_enable", "fastegnn_profile_kernels", "fastegnn_profile_name", "fastegnn_profile_collect",
 ]
 

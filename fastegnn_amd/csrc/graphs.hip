@@ -191,6 +191,54 @@ static RgWs carve_ws(void *ws, size_t bytes, int N) {
   return w;
 }
 
+// ---------------------------------------------------------------- N-body: shortest ordered pairs of the complete graph
+// One workgroup per system: the n(n-1) ordered pairs get the key (distance bits << 32 | pair index) -- distances are
+// non-negative, so their bit patterns order like the values; the pair index makes the order total and deterministic --
+// and are sorted by a bitonic network in LDS (n <= 128: 16 384 keys, 128 KB).  The first k keys are the edge list in
+// ascending length (datasets/nbody/dataset.py:102-113 does this with cdist + topk on the host).
+constexpr int NB_MAX_N = 128;
+constexpr int NB_THREADS = 1024;
+__global__ __launch_bounds__(NB_THREADS) void nbody_cutoff_kernel(const float *loc, int n, int k, int npad, int64_t *ei,
+                                                                   float *ea) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long nb_keys[];
+  __shared__ float xs[NB_MAX_N * 3];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const float *x = loc + (size_t)s * n * 3;
+  for (int i = tid; i < n * 3; i += NB_THREADS) xs[i] = x[i];
+  __syncthreads();
+  for (int e = tid; e < npad; e += NB_THREADS) {
+    unsigned long long key = ~0ull;
+    if (e < n * n) {
+      const int i = e / n, j = e - i * n;
+      if (i != j) {
+        const float dx = xs[3 * i] - xs[3 * j], dy = xs[3 * i + 1] - xs[3 * j + 1], dz = xs[3 * i + 2] - xs[3 * j + 2];
+        const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)e;
+      }
+    }
+    nb_keys[e] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npad; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < npad / 2; t += NB_THREADS) {
+        const int lo = 2 * t - (t & (stride - 1));   // index with bit `stride` cleared
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = nb_keys[lo], b = nb_keys[hi];
+        if ((a > b) == up) { nb_keys[lo] = b; nb_keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int r = tid; r < k; r += NB_THREADS) {
+    const unsigned long long key = nb_keys[r];
+    const int e = (int)(unsigned)key, i = e / n, j = e - i * n;
+    ei[((size_t)s * 2 + 0) * k + r] = i;
+    ei[((size_t)s * 2 + 1) * k + r] = j;
+    ea[(size_t)s * k + r] = __uint_as_float((unsigned)(key >> 32));
+  }
+}
+
 }  // namespace fe
 
 using namespace fe;
@@ -273,6 +321,20 @@ int fastegnn_cutoff_edges(const int64_t *edge_index, const float *dist, int64_t 
   hipLaunchKernelGGL(take_edges_kernel, dim3(cdiv(keep, 256)), dim3(256), 0, st, edge_index, dist, vals_s, E, keep,
                      edge_index_out, dist_out);
   return check_launch("cutoff_edges");
+}
+
+int fastegnn_nbody_cutoff_edges(const float *loc, int32_t S, int32_t n, int32_t k, int64_t *edge_index, float *dist,
+                                void *stream) {
+  FE_REQUIRE(S >= 0 && n >= 1 && k >= 0 && (int64_t)k <= (int64_t)n * (n - 1), "nbody_cutoff_edges: bad sizes");
+  FE_REQUIRE(n <= NB_MAX_N, "nbody_cutoff_edges: more than 128 particles per system");
+  if (S == 0 || k == 0) return FASTEGNN_OK;
+  FE_REQUIRE(loc && edge_index && dist, "nbody_cutoff_edges: null pointer");
+  int npad = 2;
+  while (npad < n * n) npad <<= 1;
+  const size_t lds = (size_t)npad * sizeof(unsigned long long);
+  hipLaunchKernelGGL(nbody_cutoff_kernel, dim3(S), dim3(NB_THREADS), lds, (hipStream_t)stream, loc, n, k, npad, edge_index,
+                     dist);
+  return check_launch("nbody_cutoff_kernel");
 }
 
 }  // extern "C"

@@ -150,11 +150,17 @@ class NBodySystemDataset:
             R = R.to(loc_0.device, torch.float32)
             loc_0, loc_t, vel_0 = loc_0 @ R, loc_t @ R, vel_0 @ R
         k = int(n * (n - 1) * (1 - self.cutoff_rate))
-        dist = torch.cdist(loc_0, loc_0, p=2) + torch.eye(n, device=loc_0.device) * 1e18
-        idc = torch.topk(dist.reshape(S, n * n), k, dim=1, largest=False).indices
-        ei = torch.stack([idc.div(n, rounding_mode="trunc"), idc.remainder(n)], 1).long()      # [S,2,k]
-        d = loc_0.gather(1, ei[:, 0, :, None].expand(-1, -1, 3)) - loc_0.gather(1, ei[:, 1, :, None].expand(-1, -1, 3))
-        ea = d.pow(2).sum(-1).sqrt().unsqueeze(-1)                                            # [S,k,1]
+        if loc_0.is_cuda and n <= 128:
+            from .graphs import nbody_cutoff_edges
+            # device tensors: one workgroup per system sorts its n(n-1) pairs in LDS (csrc/graphs.hip)
+            ei, ea = nbody_cutoff_edges(loc_0, k)
+            ea = ea.unsqueeze(-1)                                                              # [S,k,1]
+        else:   # host-side dataset build (what the reference does), or systems beyond the kernel's 128 particles
+            dist = torch.cdist(loc_0, loc_0, p=2) + torch.eye(n, device=loc_0.device) * 1e18
+            idc = torch.topk(dist.reshape(S, n * n), k, dim=1, largest=False).indices
+            ei = torch.stack([idc.div(n, rounding_mode="trunc"), idc.remainder(n)], 1).long()  # [S,2,k]
+            d = loc_0.gather(1, ei[:, 0, :, None].expand(-1, -1, 3)) - loc_0.gather(1, ei[:, 1, :, None].expand(-1, -1, 3))
+            ea = d.pow(2).sum(-1).sqrt().unsqueeze(-1)                                        # [S,k,1]
         return [Frame(ei[s], ea[s], loc_0[s], loc_t[s], vel_0[s], _node_feat(vel_0[s], charges[s]), charges[s],
                       _loc_mean(loc_0[s], self.virtual_channels)) for s in range(S)]
 

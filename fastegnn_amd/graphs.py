@@ -47,3 +47,20 @@ def cutoff_edges(edge_index: torch.Tensor, dist: torch.Tensor, cutoff_rate: floa
         K.check(L.fastegnn_cutoff_edges(K.ptr(edge_index.contiguous()), K.ptr(dist.contiguous()), E, keep, K.ptr(out),
                                         K.ptr(dout), K.ptr(tmp), nbytes, _stream(dev)), "fastegnn_cutoff_edges")
     return out, dout
+
+
+NBODY_MAX_PARTICLES = 128
+
+
+def nbody_cutoff_edges(loc: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """For each system of ``loc`` [S,n,3] (n <= 128) the ``k`` shortest ordered pairs of the complete graph without self
+    loops, in ascending length (``datasets/nbody/dataset.py:102-113``: cdist + cutoff_edge on the host).  Returns
+    (edge_index int64 [S,2,k] with ids local to the system, dist fp32 [S,k]); equal lengths come in ascending i*n+j."""
+    assert loc.is_cuda and loc.dim() == 3 and loc.size(2) == 3
+    loc = loc.contiguous().float()
+    S, n, dev = loc.size(0), loc.size(1), loc.device
+    ei = torch.empty(S, 2, k, dtype=torch.int64, device=dev)
+    dist = torch.empty(S, k, dtype=torch.float32, device=dev)
+    K.check(K.lib().fastegnn_nbody_cutoff_edges(K.ptr(loc), S, n, k, K.ptr(ei), K.ptr(dist), _stream(dev)),
+            "fastegnn_nbody_cutoff_edges")
+    return ei, dist

@@ -302,6 +302,12 @@ size_t fastegnn_cutoff_tmp_bytes(int64_t E);
 int fastegnn_cutoff_edges(const int64_t *edge_index, const float *dist, int64_t E, int64_t keep, int64_t *edge_index_out,
                           float *dist_out, void *tmp, size_t tmp_bytes, void *stream);
 
+/* N-body systems (datasets/nbody/dataset.py:102-113): for each of S systems of n <= 128 particles (loc [S,n,3]) the k
+ * shortest ordered pairs (i, j != i) of the complete graph in ascending length (fp32 distance, each operation rounded
+ * separately; equal lengths in ascending i*n+j): edge_index int64 [S,2,k] (particle ids within the system), dist [S,k]. */
+int fastegnn_nbody_cutoff_edges(const float *loc, int32_t S, int32_t n, int32_t k, int64_t *edge_index, float *dist,
+                                void *stream);
+
 /* ---- per-kernel timing with HIP events recorded on the launch stream (bench.py) ----
  * enable(1) brackets every kernel launch of this library with two events; collect() waits for
  * them and returns, per kernel id in [0, fastegnn_profile_kernels()), the summed duration in ms

@@ -78,7 +78,7 @@ def test_error_behaviour():
     with pytest.raises(AssertionError):
         fastegnn_amd.FastEGNN(2, 0, 2, 64, 0)                 # models/FastEGNN.py:255
     with pytest.raises(NotImplementedError):
-        fastegnn_amd.FastEGNN(2, 0, 2, 32, 3)
+        fastegnn_amd.FastEGNN(2, 0, 2, 128, 3)                # wider than the 64-wide tiles (narrower runs zero-padded)
     with pytest.raises(NotImplementedError):
         fastegnn_amd.FastEGNN(2, 0, 2, 64, 3, act_fn=torch.nn.ReLU())
     g = Golden("equiv10")

@@ -106,3 +106,53 @@ def test_water3d_frames_collate_and_train_on_device():
     l0, mse0 = train_step(m, opt, b, sample_nodes=sample, sigma=1.0, weight=0.01)
     l1, mse1 = train_step(m, opt, b, sample_nodes=sample, sigma=1.0, weight=0.01)
     assert np.isfinite(float(l0)) and np.isfinite(float(l1)) and float(mse1) != float(mse0)
+
+
+@pytest.mark.parametrize("n,rate", [(5, 0.0), (5, 0.5), (100, 0.0), (100, 0.3), (128, 0.9), (37, 0.123)])
+def test_nbody_cutoff_edges_vs_topk(n, rate):
+    """The k shortest ordered pairs per system (datasets/nbody/dataset.py:102-113) against torch.topk on the same
+    fp32 distances: ascending lengths, no self loops, the same edge set (both directions of a pair have the same
+    length, so the last edge of an odd k may be either direction -- compared as unordered pairs there)."""
+    from fastegnn_amd.graphs import nbody_cutoff_edges
+    g = torch.Generator().manual_seed(n)
+    S = 7
+    loc = torch.randn(S, n, 3, generator=g).cuda()
+    k = int(n * (n - 1) * (1 - rate))
+    ei, dist = nbody_cutoff_edges(loc, k)
+    assert ei.shape == (S, 2, k) and dist.shape == (S, k)
+    assert (ei[:, 0] != ei[:, 1]).all() and ei.min() >= 0 and ei.max() < n
+    assert (dist[:, 1:] >= dist[:, :-1]).all()
+    d = loc.gather(1, ei[:, 0, :, None].expand(-1, -1, 3)) - loc.gather(1, ei[:, 1, :, None].expand(-1, -1, 3))
+    assert torch.allclose(d.pow(2).sum(-1).sqrt(), dist, rtol=1e-6, atol=0)
+    full = (loc[:, :, None, :] - loc[:, None, :, :]).pow(2).sum(-1).sqrt() + torch.eye(n, device="cuda") * 1e18
+    ref = torch.topk(full.reshape(S, n * n), k, dim=1, largest=False)
+    assert torch.allclose(ref.values, dist, rtol=1e-6, atol=0)
+    for s in range(S):
+        got = set((ei[s, 0] * n + ei[s, 1]).tolist())
+        assert len(got) == k
+        want = set(ref.indices[s].tolist())
+        unordered = lambda q: {(min(e // n, e % n), max(e // n, e % n)) for e in q}   # noqa: E731
+        assert len(got ^ want) <= 2 and unordered(got) == unordered(want)
+
+
+def test_nbody_dataset_on_device_matches_host_build(tmp_path):
+    """NBodySystemDataset built from device tensors (kernel) and from host tensors (torch path) give the same frames."""
+    import numpy as np
+    from fastegnn_amd.data import NBodySystemDataset
+    g = np.random.RandomState(0)
+    S, T, n = 6, 3, 5
+    for part in ("train",):
+        np.save(tmp_path / f"loc_{part}_charged5.npy", g.randn(S, T, n, 3))
+        np.save(tmp_path / f"vel_{part}_charged5.npy", g.randn(S, T, n, 3))
+        np.save(tmp_path / f"charges_{part}_charged5.npy", g.choice([-1.0, 1.0], size=(S, n, 1)))
+    kw = dict(dataset_name="5", data_dir=str(tmp_path), virtual_channels=3, partition="train", frame_0=0, frame_T=2,
+              cutoff_rate=0.4)
+    a = NBodySystemDataset(device="cuda", **kw)
+    b = NBodySystemDataset(device="cpu", **kw)
+    assert len(a) == len(b) == S
+    for fa, fb in zip(a.data, b.data):
+        ea_, eb_ = fa.edge_index.cpu(), fb.edge_index
+        assert ea_.shape == eb_.shape
+        assert set(map(tuple, ea_.t().tolist())) == set(map(tuple, eb_.t().tolist()))   # k = 12: even, whole pairs
+        assert torch.allclose(fa.edge_attr.cpu(), fb.edge_attr, rtol=1e-6)
+        assert torch.equal(fa.loc_0.cpu(), fb.loc_0)
