@@ -215,6 +215,13 @@ __global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_tn_kernel(WgTable tab) {
 // over the same row range: wave w runs job w over every 16-row tile of the range, so the shared `v` rows are fetched
 // from HBM once and hit in L1/L2 for the other two waves (5 operand streams instead of 8).  Each wave keeps its own
 // 64x64 accumulator and writes its own partial slab; nothing is reduced across waves.
+// Round-2 counters say the sharing is only partial: FETCH_SIZE x 2 = 3.44 GB per cfg4 launch against 2.05 GB of distinct
+// operand bytes (the three readers of `v` drift apart), moved at ~6 TB/s, so the kernel sits on both its byte and its
+// fp32-MFMA budget (0.33 ms of matrix-pipe time in a 0.56 ms launch).  Variants measured against 2.93 ms per step for
+// all weight-gradient kernels, none kept: `v` staged once per workgroup behind one barrier per tile 4.05 (every step
+// waits for the slowest of four load streams); two tiles of prefetch per wave 3.07 (not latency-bound); a wave
+// contracting a pair of jobs that share `v` (two accumulators, 6 streams instead of 8) 3.70 (256 registers, serialised
+// LDS reads in front of 128 MFMAs per tile).
 __global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_bundle_kernel(WgTable tab) {
   __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 16 * WTS];
   const int w = wave_id();
