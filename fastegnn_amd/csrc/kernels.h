@@ -39,6 +39,7 @@ struct ProfScope {
 // generic weight-gradient contraction (misc.hip):
 //   dW[o*lddw + c0 + k*ks] += sum_m G[m*ldg + o] * T[m*ldt + k]   (o < 64, k < kmax),  db[o] += sum_m G[m*ldg+o]
 //   batched over `nb` with strides (sG, sT, sW) in floats.  Jobs are queued and run by finish().
+constexpr int WGV_PAD = 16;        // padding rows (x C) behind each [N*C,64] operand array of the virtual backward
 constexpr int WG_MAX_JOBS = 24;
 constexpr int WG_SLABS = 8192;   // the upper half is the virtual-stage bundle's (WgradBatch slab_base)   // 64x64 partial slabs in the wg_slab workspace (+ 64-float bias slabs)
 struct WgJob {

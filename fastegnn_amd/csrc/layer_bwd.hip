@@ -189,9 +189,23 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   auto dma_w3c = [&](int c, char *dst) {
     const char *src = wpack_rm(a.wpack, C, 3 + c);
     const int ln = lane_id();
-    for (int ch = wave_id(); ch < RM_BYTES / 1024; ch += VIRT_BWD_WAVES)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ch * 1024 + ln * 16),
-                                       (__attribute__((address_space(3))) void *)(dst + ch * 1024), 16, 0, 0);
+    // a FIXED number of copy instructions per wave (the odd last one repeats chunk 26): the compiler can then count the
+    // outstanding vector-memory operations across the channel loop instead of falling back to vmcnt(0) behind the copy
+    constexpr int NCH = RM_BYTES / 1024, PER = (NCH + VIRT_BWD_WAVES - 1) / VIRT_BWD_WAVES;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int ch = wave_id() + k * VIRT_BWD_WAVES;
+      ch = ch < NCH ? ch : NCH - 1;
+      // Issued as inline assembly on purpose: for the builtin the compiler tracks "LDS written by an outstanding vector
+      // memory operation" and, the carved LDS array being one object to its alias analysis, puts s_waitcnt vmcnt(0) in
+      // front of the next LDS read of ANY image -- i.e. it waited for the copy it had just issued (and for the operand
+      // stores in flight) at the first product of every channel.  The waits that order this copy are explicit: vmcnt
+      // before the workgroup barrier at the top of the channel that reads the image.  (Operations the compiler does
+      // not count only make its own vmcnt(N) waits stricter, never wrong: vmcnt retires in issue order.)
+      const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)(dst + ch * 1024);
+      const char *ga = src + ch * 1024 + ln * 16;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(ga) : "memory");
+    }
   };
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) gBc_l[i] = 0.f;
@@ -204,6 +218,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   const int t_lo = (int)((long)blockIdx.x * ntiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   const float invC = C > 0 ? 1.0f / (float)C : 0.f;
   const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION;
+  const float attb0 = att_on ? a.attb[0] : 0.f;   // (read once: a load in the channel body would wait behind that channel's stores)
   const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;
   constexpr bool rf = RF;
   const float *gpv_base = rf ? a.Bc : A.g_poolV;   // FastRF: no pooled-message gradient (the rows are ignored)
@@ -243,13 +258,18 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       // wave-uniform bases of this 128-node group + one 32-bit lane offset per array family
       const size_t g0 = (size_t)n0;
       const unsigned offN = (unsigned)(nc - n0) * H + 4u * q;            // [N,64] arrays
-      const unsigned offNC = (unsigned)(nc - n0) * C * H + 4u * q;       // [N*C,64] arrays (+ c*H)
       const unsigned offB = (unsigned)b * C * H + 4u * q;                // [B,C,64] arrays (+ c*H)
       const float *b_gho = A.g_h_out + g0 * H, *b_npre = A.npre_in + g0 * H, *b_A = a.A + g0 * H;
       float *b_t3 = A.wg_t3 + g0 * H, *b_gnp = A.wg_gnp + g0 * H, *b_gh = A.g_h + g0 * H, *b_gam = A.g_aggm + g0 * H;
       float *b_gA = A.g_A + g0 * H;
-      float *b_v = A.wg_v + g0 * C * H, *b_t = A.wg_t + g0 * C * H, *b_gux = A.wg_gux + g0 * C * H;
-      float *b_guX = A.wg_guX + g0 * C * H, *b_gvp = A.wg_gvp + g0 * C * H;
+      // operand stores are unconditional (no exec-mask branch in the channel body, a fixed number of stores per channel):
+      // lanes past the last node fall into the padding rows behind each array (row n >= N), a wave whose tile belongs to
+      // the next workgroup stores to those rows too
+      const bool live = split || tb + wv < t_hi;
+      const size_t gs = live ? g0 : (size_t)a.N;
+      const unsigned offST = (live ? (unsigned)(n - n0) : (unsigned)j) * C * H + 4u * q;
+      float *b_v = A.wg_v + gs * C * H, *b_t = A.wg_t + gs * C * H, *b_gux = A.wg_gux + gs * C * H;
+      float *b_guX = A.wg_guX + gs * C * H, *b_gvp = A.wg_gvp + gs * C * H;
       VB_T(7)   // tile bookkeeping (previous tile's tail, pool flush, batch lookups)
       // ---- node MLP adjoint (node_model, :153-166); FastRF: h passes through, no segment-mean message
       const Vec g_out = vmask(vload_u(b_gho, offN), valid);
@@ -340,6 +360,22 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C + c_first];
         }
       }
+      // The first channel's rows are waited for HERE, ahead of the loop: the loop body re-requests them one channel
+      // ahead and waits for them at its END with an exact count (vmcnt(20): the channel's 20 operand stores stay in
+      // flight).  Entering the loop with the requests still pending made the compiler merge "just issued" into the loop
+      // header's state, and the first use of a row at the top of EVERY channel -- behind the freshly issued LDS-DMA
+      // copy of the next image -- became s_waitcnt vmcnt(0): one copy round trip per channel, the "channel top" phase
+      // of the stamps (2.6-3.1 k of 25.6 k cycles).
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        asm volatile("" : "+v"(nBc.t[t]));
+        asm volatile("" : "+v"(nGpv.t[t]));
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        asm volatile("" : "+v"(nZ[k]));
+        asm volatile("" : "+v"(nGpx[k]));
+      }
       // W3cT[c] goes through an LDS stage refilled once per workgroup and channel.  C > 32: the fp32 image of channel
       // c+1 is fetched into registers at the top of channel c (ahead of that channel's stores) and committed at the top
       // of c+1 between two barriers.  X3H: the row-major image of W3c[c+1] is sent to the other stage buffer by LDS-DMA
@@ -361,8 +397,21 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         asm volatile("" ::: "memory");
         if constexpr (!rf) if (!split) {
           if constexpr (X3H) {
-            __syncthreads();          // channel c's image has landed (every wave waited for its share of the copy) and
-                                      // every wave is done with channel c-1, whose buffer the next copy overwrites
+            // channel c's image has landed (every wave waits for its share of the copy) and every wave is done with
+            // channel c-1, whose buffer the next copy overwrites.  Behind the first channel of a tile the wait is NOT
+            // vmcnt(0): the copy of channel c was issued at the top of channel c-1, ahead of that channel's row
+            // requests and of its 20 operand stores (unconditional, see offST) -- vmcnt counts in issue order, so
+            // "at most 16 outstanding" retires the copy and the rows without waiting for the stores to reach L2
+            // (with vmcnt(0) the channel top cost 2.6-3.1 k of the 25.6 k cycles of a (tile, channel), stamps).
+            if (c == c_first) {
+              __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): channel 0's copy was issued in the tile prologue
+              __syncthreads();
+            } else {
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+              __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16) expcnt(7) lgkmcnt(0)
+              __builtin_amdgcn_s_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            }
             if (c + 1 < C) dma_w3c(c + 1, ((c + 1) & 1) ? stage1 : stage0);
           } else {
             __syncthreads();          // every wave is done with the previous channel's stage
@@ -373,7 +422,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
             fetch_w3ct(c + 1 < C ? c + 1 : c);
           }
         }
-        const unsigned oc = offNC + (unsigned)c * H;
+        const unsigned oc = offST + (unsigned)c * H;
         const Vec Bc_c = nBc, gpv_c = nGpv;
         float vd[3], gpX[3];
 #pragma unroll
@@ -405,17 +454,17 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         Vec d_pre = make_pre();
         {
           const Vec t = vsilu_keep_d(d_pre);      // d_pre <- silu'(pre)
-          WG_STORE(if (valid) vstore_u(b_t, oc, t);)
+          WG_STORE(vstore_u(b_t, oc, t);)
           mm(0, sop(t), vp);
         }
         const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
         float att = 1.f;
         Vec v = v0;
         if (att_on) {
-          att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + a.attb[0]);
+          att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + attb0);
           v = vscale(v0, att);
         }
-        WG_STORE(if (valid) vstore_u(b_v, oc, v);)
+        WG_STORE(vstore_u(b_v, oc, v);)
         const SOp vs = sop(v);   // feeds both coordinate heads
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
         VB_T(2)   // pre, silu, V2 product, silu, operand of the heads
@@ -440,7 +489,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           const float g_sr = tanh_on ? g_sx * (1.f - sx * sx) : g_sx;
           vaxpy(acc_wxv2, g_sr, ux);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
-          WG_STORE(if (valid) vstore_u(b_gux, oc, g_up);)
+          WG_STORE(vstore_u(b_gux, oc, g_up);)
           mmT(1, g_up, g_v);
         }
         VB_T(4)   // head x: forward product, silu, dot, transposed product
@@ -456,7 +505,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           const float g_sr = tanh_on ? g_sX * (1.f - sX * sX) : g_sX;
           vaxpy(acc_wxx2, g_sr, uX);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
-          WG_STORE(if (valid) vstore_u(b_guX, oc, g_up);)
+          WG_STORE(vstore_u(b_guX, oc, g_up);)
           mmT(2, g_up, g_v);
         }
         VB_T(5)   // head X
@@ -474,7 +523,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         Vec g_t = vzero();
         {
           const Vec g_vp = vmul(g_v0, vp);
-          WG_STORE(if (valid) vstore_u(b_gvp, oc, g_vp);)
+          WG_STORE(vstore_u(b_gvp, oc, g_vp);)
           mmT(0, g_vp, g_t);
         }
         VB_T(6)   // attention adjoint, g_vp, V2T product
@@ -492,19 +541,25 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         // of the tile runs on DPP row rotations in the D layout (no transpose tile in LDS: that space holds
         // split images instead); g_pre of a masked lane is zero.
         if (fast) {
+          // (all sums first, then ONE masked block of LDS atomics: sixteen separate `if (j == 0)` blocks cut the
+          // channel body into as many scheduling regions)
+          float pz[3], sr[4][4];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            float pv = (valid && q == 0) ? g_vd[k] : 0.f;
-            pv = jsum(pv);
-            if (l == 0) atomicAdd(&gZ_l[k * C + c], pv);
-          }
+          for (int k = 0; k < 3; ++k) pz[k] = jsum((valid && q == 0) ? g_vd[k] : 0.f);
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float sr = jsum_dpp(g_pre.t[t][r]);
-              if (j == 0) atomicAdd(&gBc_l[c * H + 16 * t + 4 * q + r], sr);
+            for (int r = 0; r < 4; ++r) sr[t][r] = jsum_dpp(g_pre.t[t][r]);
+          if (j == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) atomicAdd(&gBc_l[c * H + 16 * t + 4 * q + r], sr[t][r]);
+            if (q == 0) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) atomicAdd(&gZ_l[k * C + c], pz[k]);
             }
+          }
         } else {
           if (valid && q == 0) {
 #pragma unroll
@@ -604,8 +659,10 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
   A.g_h = L->g_h; A.g_x = L->g_x; A.g_A = L->g_A; A.g_aggm = L->g_aggm; A.g_aggx = L->g_aggx;
   A.g_svel = L->g_svel; A.g_sgrav = L->g_sgrav; A.g_Bc = L->g_Bc; A.g_Zp = L->g_Zp;
   A.wg_t3 = L->wg_node; A.wg_gnp = L->wg_node + (size_t)N * H;
-  A.wg_v = L->wg_virt; A.wg_t = L->wg_virt + NC * H; A.wg_gux = L->wg_virt + 2 * NC * H;
-  A.wg_guX = L->wg_virt + 3 * NC * H; A.wg_gvp = L->wg_virt + 4 * NC * H;
+  // (each array is followed by WGV_PAD rows x C that masked lanes store to: the operand stores carry no exec mask)
+  const size_t vstride = (NC + (size_t)WGV_PAD * C) * H;
+  A.wg_v = L->wg_virt; A.wg_t = L->wg_virt + vstride; A.wg_gux = L->wg_virt + 2 * vstride;
+  A.wg_guX = L->wg_virt + 3 * vstride; A.wg_gvp = L->wg_virt + 4 * vstride;
   A.ld_v0 = 2 * H + 1 + C;
   A.d_wxv2 = g[FASTEGNN_P_CRV2_W]; A.d_wxx2 = g[FASTEGNN_P_CVV2_W];
   A.d_wvr = g[FASTEGNN_P_VIRT0_W] ? g[FASTEGNN_P_VIRT0_W] + 2 * H : nullptr;
@@ -1186,7 +1243,7 @@ extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { (void)E; return 4; }
 // weight-gradient operand workspaces of the virtual / node-level stages (layouts: virt_backward, graph_post_backward,
 // graph_pre_backward, node_pre_backward above)
 extern "C" size_t fastegnn_wg_virt_floats(int32_t N, int32_t C) {
-  const size_t n = (size_t)5 * (size_t)(N > 0 ? N : 0) * (size_t)(C > 0 ? C : 0) * fe::H;
+  const size_t n = (size_t)5 * ((size_t)(N > 0 ? N : 0) + fe::WGV_PAD) * (size_t)(C > 0 ? C : 0) * fe::H;
   return n > 4 ? n : 4;
 }
 extern "C" size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C) {
