@@ -1045,13 +1045,26 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         if (l < 3) A.g_xrow[(size_t)r * 3 + l] = 0.f;
       }
     };
+    // the indices of a tile are requested one tile ahead (4 registers at EA = 2): of the two dependent round trips at the
+    // head of a tile (index -> gathered rows / coordinates; 4.1 k + 1.8 k of 26 k cycles in the stamps) the first is gone
+    // (the generic edge_attr variant, EA = 7, would need 9 registers and spill: it keeps the load at the head of the tile)
+    constexpr bool PF_IDX = EA <= 2;
+    EdgeIdx nxt_i;
+    if (PF_IDX && e0 < e1) edge_load_idx(a, min(e0 + j, e1 - 1), nxt_i);
+    // (requesting the gathered rows ahead as well -- before the row walk that ends a tile -- costs 40 live registers
+    // there and spills 24-36 of them: not done)
     for (int base = e0; base < e1; base += 16) {
       asm volatile("" ::: "memory");
       const int nvalid = min(16, e1 - base);
       const bool valid = j < nvalid;
       const int e = min(base + j, e1 - 1);
       EdgeIdx cur_i;
-      edge_load_idx(a, e, cur_i);
+      if constexpr (PF_IDX) {
+        cur_i = nxt_i;
+        if (base + 16 < e1) edge_load_idx(a, min(base + 16 + j, e1 - 1), nxt_i);
+      } else {
+        edge_load_idx(a, e, cur_i);
+      }
       EdgeFwdState S;
       Vec pre;
       edge_tile_forward<true, MODE>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
