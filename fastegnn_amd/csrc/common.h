@@ -504,13 +504,14 @@ enum ImgId {
 };
 __host__ __device__ inline int img_w3c(int c) { return I_FIXED + c; }
 __host__ __device__ inline int img_w3ct(int C, int c) { return I_FIXED + C + c; }
-// wpack = [fp32 images n x 4096 floats][split images n x IMG3 words (h | m | l)][row-major split images (3 + C) x RM_WORDS]
-// row-major images (virt_bwd): slot 0 V2, 1 WXV0, 2 WXX0, 3 + c: W3c[c]
+// wpack = [fp32 images n x 4096 floats][split images n x IMG3 words (h | m | l)][row-major split images (5 + C) x RM_WORDS]
+// row-major images: slot 0 V2, 1 WXV0, 2 WXX0 (virt_bwd), 3 W2, 4 WX1 (edge_bwd), RM_FIXED + c: W3c[c] (virt_bwd)
+constexpr int RM_FIXED = 5;
 __host__ __device__ inline size_t wpack_images(int C) { return (size_t)(I_FIXED + 2 * C); }
-__host__ __device__ inline size_t wpack_rm_images(int C) { return (size_t)(3 + (C > 0 ? C : 0)); }
+__host__ __device__ inline size_t wpack_rm_images(int C) { return (size_t)(RM_FIXED + (C > 0 ? C : 0)); }
 __host__ __device__ inline size_t wpack_floats(int C) { return wpack_images(C) * (IMG + IMG3) + wpack_rm_images(C) * RM_WORDS; }
 __host__ __device__ inline int rm_slot(int id) {   // -1: the image has no row-major copy
-  return id == I_V2 ? 0 : id == I_WXV0 ? 1 : id == I_WXX0 ? 2 : -1;
+  return id == I_V2 ? 0 : id == I_WXV0 ? 1 : id == I_WXX0 ? 2 : id == I_W2 ? 3 : id == I_WX1 ? 4 : -1;
 }
 __host__ __device__ inline const char *wpack_rm(const float *wpack, int C, int slot) {
   return reinterpret_cast<const char *>(wpack + wpack_images(C) * (IMG + IMG3)) + (size_t)slot * RM_BYTES;

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
   };
   // LDS-DMA of the row-major image of W3c[c] (27 wave-instructions of 1 KiB, dealt to the four waves)
   auto dma_w3c = [&](int c, char *dst) {
-    const char *src = wpack_rm(a.wpack, C, 3 + c);
+    const char *src = wpack_rm(a.wpack, C, RM_FIXED + c);
     const int ln = lane_id();
     // a FIXED number of copy instructions per wave (the odd last one repeats chunk 26): the compiler can then count the
     // outstanding vector-memory operations across the channel loop instead of falling back to vmcnt(0) behind the copy
@@ -851,12 +851,12 @@ constexpr int PC_WAVES = 8;
 constexpr int PC_CONS = 3, PC_CONS2 = 7;
 constexpr int PC_PROD = 6;                  // producer waves
 #ifndef FE_PC_RING
-#define FE_PC_RING 2
+#define FE_PC_RING 4
 #endif
 constexpr int PC_RING = FE_PC_RING;                  // slots per ring; one ring per weight (kind 0: edge_mlp.2, kind 1: coord_mlp_r.0)
 constexpr int PC_RS = 68;                   // row stride of a slot tile
 constexpr int PC_SLOT = 2 * 16 * PC_RS;     // floats per slot: G tile | T tile
-constexpr int PC_IMG_FLOATS = 4 * IMG3;
+constexpr int PC_IMG_FLOATS = 2 * RM_WORDS;   // W2 | WX1 as row-major split images: each serves the product and its transpose
 enum { PC_HEAD = 0, PC_TOTAL = 2, PC_FILLED = 4, PC_DRAINED = 4 + 2 * PC_RING, PC_CTRL = 4 + 4 * PC_RING };
 __device__ __forceinline__ int lds_ld(const int *p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void lds_st(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
@@ -871,12 +871,16 @@ template <int MODE, int EA>
 __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const EdgeArgs &a = A.f;
-  float *img = lds;                    // W2, WX1, W2T, WX1T (split images)
+  float *img = lds;                    // W2, WX1 (row-major split images, common.h)
   float *vec = lds + PC_IMG_FLOATS;
   float *tiles = vec + EV_COUNT * H;   // per producer [16][TS]; the 4 pad columns of a row hold its g_d scalars
   float *ring = tiles + PC_PROD * 16 * TS;
   int *ctrl = reinterpret_cast<int *>(ring + 2 * PC_RING * PC_SLOT);
-  load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, A.C, I_W2), 4);
+  {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, A.C, 3));   // slots 3, 4 are consecutive
+    u32x4 *dst = reinterpret_cast<u32x4 *>(img);
+    for (int i = threadIdx.x; i < 2 * RM_BYTES / 16; i += blockDim.x) dst[i] = src[i];
+  }
   edge_load_vecs(vec, a);
   if (threadIdx.x < PC_CTRL) ctrl[threadIdx.x] = 0;
   __syncthreads();
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       }
       EdgeFwdState S;
       Vec pre;
-      edge_tile_forward<true, MODE>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
+      edge_tile_forward<true, MODE, true>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
       const int dg = a.rowptr[S.row + 1] - a.rowptr[S.row];
       const float inv = valid ? rcp_f((float)(dg > 1 ? dg : 1)) : 0.f;
       const float invx = valid ? (mean ? inv : 1.f) : 0.f;
@@ -1090,7 +1094,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       publish(1, g_up, S.m);
       FE_T(6)   // publish (g_up, m)
       Vec g_m = vscale(vload_row(A.g_aggm + (size_t)S.row * H, q), inv);
-      gemm_i<MODE>(img, 3, g_up, g_m);
+      gemm_e<MODE, 3, true>(img, g_up, g_m);
       Vec g_m0 = g_m;
       if (att_on) {
         const float g_a = vdot(g_m, S.m0);
@@ -1110,7 +1114,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         FE_T(8)   // publish (g_mp, t)
       }
       Vec g_t = vzero();
-      gemm_i<MODE>(img, 2, g_mp, g_t);
+      gemm_e<MODE, 2, true>(img, g_mp, g_t);
       const Vec g_pre = vmul(g_t, pre);
       const float g_r = vdot(g_pre, vload_vec(vec + EV_WR * H, q));
       float g_d[3];

@@ -93,9 +93,9 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     d3[img3_index(1, o, k)] = split_word(w0, w1, 1);
     d3[img3_index(2, o, k)] = split_word(w0, w1, 2);
   }
-  // row-major split image (common.h: one LDS copy for W and W^T in virt_bwd) of V2, WXV0, WXX0 and W3c[c]
+  // row-major split image (common.h: one LDS copy serves W and W^T in the backward kernels) of V2, WXV0, WXX0, W2, WX1, W3c[c]
   int slot = rm_slot(id);
-  if (id >= I_FIXED && id < I_FIXED + a.C) slot = 3 + (id - I_FIXED);
+  if (id >= I_FIXED && id < I_FIXED + a.C) slot = RM_FIXED + (id - I_FIXED);
   if (slot >= 0) {
     unsigned *rm = reinterpret_cast<unsigned *>(const_cast<char *>(wpack_rm(a.wpack, a.C, slot)));
     for (int idx = threadIdx.x; idx < 64 * (RM_RS / 4); idx += 256) {

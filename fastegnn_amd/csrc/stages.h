@@ -102,6 +102,13 @@ template <int MODE>
 __device__ __forceinline__ void gemm_i(const void *img, int i, const Vec &in, Vec &acc) {
   gemm_op<MODE>(img, i, make_operand<MODE>(in), acc);
 }
+// the edge stage's four products I = 0 W2, 1 WX1, 2 W2^T, 3 WX1^T: from four split images (RM = false: img + I) or from the
+// two row-major images W2 | WX1 read plain or transposed (RM = true, edge_bwd: half the LDS, which its rings take)
+template <int MODE, int I, bool RM>
+__device__ __forceinline__ void gemm_e(const void *img, const Vec &in, Vec &acc) {
+  if constexpr (RM) gemm_rm<MODE, (I >= 2)>(static_cast<const char *>(img) + (I & 1) * RM_BYTES, make_operand<MODE>(in), acc);
+  else gemm_i<MODE>(img, I, in, acc);
+}
 
 // part 1: consumes the gathered operands (geometry + first-layer pre-activation)
 __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *vec, const EdgeIdx &I, const EdgeRows &G,
@@ -131,13 +138,13 @@ __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *ve
   FE_T(1)   // gathered rows arrived, pre-activation formed
 }
 // part 2: the two 64x64 layers and the coordinate head
-template <bool KEEP_D, int MODE = GM_F32>
+template <bool KEEP_D, int MODE = GM_F32, bool RM = false>
 __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img, const float *vec, int q, EdgeFwdState &S,
                                               Vec &pre FE_TP) {
   S.t = KEEP_D ? vsilu_keep_d(pre) : vsilu(pre);
   FE_T(2)   // silu 1
   S.mp = vload_vec(vec + EV_B2 * H, q);
-  gemm_i<MODE>(img, 0, S.t, S.mp);
+  gemm_e<MODE, 0, RM>(img, S.t, S.mp);
   FE_T(3)   // gemm 1
   S.m0 = KEEP_D ? vsilu_keep_d(S.mp) : vsilu(S.mp);
   if (a.flags & FASTEGNN_F_ATTENTION) {
@@ -149,20 +156,20 @@ __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img
   }
   FE_T(2)
   S.up = vload_vec(vec + EV_BX1 * H, q);
-  gemm_i<MODE>(img, 1, S.m, S.up);
+  gemm_e<MODE, 1, RM>(img, S.m, S.up);
   FE_T(3)
   S.u = KEEP_D ? vsilu_keep_d(S.up) : vsilu(S.up);
   const float sraw = vdot(S.u, vload_vec(vec + EV_WX2 * H, q)) + (a.bx2 ? a.bx2[0] : 0.f);
   S.s = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sraw) : sraw;
   FE_T(4)   // silu 3 + head dot
 }
-template <bool KEEP_D, int MODE = GM_F32>
+template <bool KEEP_D, int MODE = GM_F32, bool RM = false>
 __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const void *img, const float *vec,
                                                   const EdgeIdx &I, int q, EdgeFwdState &S, Vec &pre FE_TP) {
   EdgeRows G;
   edge_gather(a, I, q, G);
   edge_tile_pre(a, vec, I, G, q, S, pre FE_TA);
-  edge_tile_mlp<KEEP_D, MODE>(a, img, vec, q, S, pre FE_TA);
+  edge_tile_mlp<KEEP_D, MODE, RM>(a, img, vec, q, S, pre FE_TA);
 }
 
 inline EdgeArgs make_edge_args(const fastegnn_layer_t *L) {
