@@ -135,7 +135,8 @@ struct VirtBwdArgs {
   const float *g_h_out, *g_x_out, *g_poolV, *g_poolX, *npre_in;
   float *g_h, *g_x, *g_A, *g_aggm, *g_aggx, *g_svel, *g_sgrav, *g_Bc, *g_Zp;
   float *wg_t3, *wg_gnp;                     // [N,64] node-level operands
-  float *wg_v, *wg_t, *wg_gux, *wg_guX, *wg_gvp;  // [N*C,64] (node,channel) operands
+  float *wg_v, *wg_t, *wg_gux, *wg_guX, *wg_gvp;  // [C][N + WGV_PAD][64] (channel, node) operands
+  size_t wg_cstride;                              // floats per channel block = (N + WGV_PAD) * 64
   float *d_wxv2, *d_wxx2, *d_wvr, *d_attw, *d_attb;  // rank-1 gradients (d_wvr strided by ld)
   int ld_v0;
 };
@@ -266,10 +267,12 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       // lanes past the last node fall into the padding rows behind each array (row n >= N), a wave whose tile belongs to
       // the next workgroup stores to those rows too
       const bool live = split || tb + wv < t_hi;
+      // (channel-major arrays: the 16 rows a wave stores for one channel are 4 KB of consecutive bytes, and the
+      // weight-gradient kernels stream a channel's rows instead of striding over them)
       const size_t gs = live ? g0 : (size_t)a.N;
-      const unsigned offST = (live ? (unsigned)(n - n0) : (unsigned)j) * C * H + 4u * q;
-      float *b_v = A.wg_v + gs * C * H, *b_t = A.wg_t + gs * C * H, *b_gux = A.wg_gux + gs * C * H;
-      float *b_guX = A.wg_guX + gs * C * H, *b_gvp = A.wg_gvp + gs * C * H;
+      const unsigned offST = (live ? (unsigned)(n - n0) : (unsigned)j) * H + 4u * q;
+      float *b_v = A.wg_v + gs * H, *b_t = A.wg_t + gs * H, *b_gux = A.wg_gux + gs * H;
+      float *b_guX = A.wg_guX + gs * H, *b_gvp = A.wg_gvp + gs * H;
       VB_T(7)   // tile bookkeeping (previous tile's tail, pool flush, batch lookups)
       // ---- node MLP adjoint (node_model, :153-166); FastRF: h passes through, no segment-mean message
       const Vec g_out = vmask(vload_u(b_gho, offN), valid);
@@ -422,7 +425,8 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
             fetch_w3ct(c + 1 < C ? c + 1 : c);
           }
         }
-        const unsigned oc = offST + (unsigned)c * H;
+        const unsigned oc = offST;
+        const size_t cb = (size_t)c * A.wg_cstride;   // this channel's block (wave-uniform)
         const Vec Bc_c = nBc, gpv_c = nGpv;
         float vd[3], gpX[3];
 #pragma unroll
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         Vec d_pre = make_pre();
         {
           const Vec t = vsilu_keep_d(d_pre);      // d_pre <- silu'(pre)
-          WG_STORE(vstore_u(b_t, oc, t);)
+          WG_STORE(vstore_u(b_t + cb, oc, t);)
           mm(0, sop(t), vp);
         }
         const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + attb0);
           v = vscale(v0, att);
         }
-        WG_STORE(vstore_u(b_v, oc, v);)
+        WG_STORE(vstore_u(b_v + cb, oc, v);)
         const SOp vs = sop(v);   // feeds both coordinate heads
         // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
         VB_T(2)   // pre, silu, V2 product, silu, operand of the heads
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           const float g_sr = tanh_on ? g_sx * (1.f - sx * sx) : g_sx;
           vaxpy(acc_wxv2, g_sr, ux);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
-          WG_STORE(vstore_u(b_gux, oc, g_up);)
+          WG_STORE(vstore_u(b_gux + cb, oc, g_up);)
           mmT(1, g_up, g_v);
         }
         VB_T(4)   // head x: forward product, silu, dot, transposed product
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           const float g_sr = tanh_on ? g_sX * (1.f - sX * sX) : g_sX;
           vaxpy(acc_wxx2, g_sr, uX);
           const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
-          WG_STORE(vstore_u(b_guX, oc, g_up);)
+          WG_STORE(vstore_u(b_guX + cb, oc, g_up);)
           mmT(2, g_up, g_v);
         }
         VB_T(5)   // head X
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         Vec g_t = vzero();
         {
           const Vec g_vp = vmul(g_v0, vp);
-          WG_STORE(vstore_u(b_gvp, oc, g_vp);)
+          WG_STORE(vstore_u(b_gvp + cb, oc, g_vp);)
           mmT(0, g_vp, g_t);
         }
         VB_T(6)   // attention adjoint, g_vp, V2T product
@@ -652,15 +656,17 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
   }
   if (N == 0) return check_launch("virt_backward(memset)");
   float *const *g = L->grads;
-  const long NC = (long)N * C;
   VirtBwdArgs A;
   A.f = make_virt_args(L);
   A.g_h_out = L->g_h_out; A.g_x_out = L->g_x_out; A.g_poolV = L->g_poolV; A.g_poolX = L->g_poolX; A.npre_in = L->npre;
   A.g_h = L->g_h; A.g_x = L->g_x; A.g_A = L->g_A; A.g_aggm = L->g_aggm; A.g_aggx = L->g_aggx;
   A.g_svel = L->g_svel; A.g_sgrav = L->g_sgrav; A.g_Bc = L->g_Bc; A.g_Zp = L->g_Zp;
   A.wg_t3 = L->wg_node; A.wg_gnp = L->wg_node + (size_t)N * H;
-  // (each array is followed by WGV_PAD rows x C that masked lanes store to: the operand stores carry no exec mask)
-  const size_t vstride = (NC + (size_t)WGV_PAD * C) * H;
+  // (arrays are [C][N + WGV_PAD][64]: every channel block ends in WGV_PAD rows that masked lanes store to -- the operand
+  // stores carry no exec mask)
+  const size_t np_rows = (size_t)N + WGV_PAD;           // rows per channel block
+  const size_t vstride = np_rows * (size_t)C * H;
+  A.wg_cstride = np_rows * H;
   A.wg_v = L->wg_virt; A.wg_t = L->wg_virt + vstride; A.wg_gux = L->wg_virt + 2 * vstride;
   A.wg_guX = L->wg_virt + 3 * vstride; A.wg_gvp = L->wg_virt + 4 * vstride;
   A.ld_v0 = 2 * H + 1 + C;
@@ -692,7 +698,10 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
   WgradBatch local(L->wg_slab, st);
   WgradBatch &wb = shared ? *shared : local;
   wb.round = has(L, FASTEGNN_F_BF16);
-  if (C > 0 && C <= 16) {
+#ifndef FE_BUNDLE_MAXC
+#define FE_BUNDLE_MAXC 16
+#endif
+  if (C > 0 && C <= FE_BUNDLE_MAXC) {
     // (a batch of its own, in the upper half of the slab workspace: a bundle is the first jobs of a batch)
     WgradBatch bb(L->wg_slab, st, has(L, FASTEGNN_F_BF16), WG_SLABS / 2, WG_SLABS / 2);
     bb.min_rows = 128;
@@ -702,21 +711,23 @@ int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
     // three of them and reaches HBM once.  Measured (ms per step, weight-gradient kernels): cfg4 (C = 16) plain jobs 3.85,
     // this bundle 3.52-3.64, a three-job bundle over the contiguous N*C rows 4.31; cfg5 (C = 32, consecutive rows of a
     // channel 8 KB apart) plain 47.7, this bundle 52.9, three-job bundle 57.1 -- hence the switch on C.
-    const long cs = (long)C * H;
-    if ((rc = bb.add(A.wg_gnp, H, A.wg_v, (int)cs, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
-    if ((rc = bb.add(A.wg_gux, (int)cs, A.wg_v, (int)cs, N, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], C, H, H, 0))) return rc;
-    if ((rc = bb.add(A.wg_guX, (int)cs, A.wg_v, (int)cs, N, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], C, H, H, 0))) return rc;
-    if ((rc = bb.add(A.wg_gvp, (int)cs, A.wg_t, (int)cs, N, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], C, H, H, 0))) return rc;
+    const long cb = (long)A.wg_cstride;   // channel block stride: batch slice c of a job = channel c
+    // (order: wave w of a bundle workgroup runs job w)
+    if ((rc = bb.add(A.wg_gnp, H, A.wg_v, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, cb, 1))) return rc;
+    if ((rc = bb.add(A.wg_gux, H, A.wg_v, H, N, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], C, cb, cb, 0))) return rc;
+    if ((rc = bb.add(A.wg_guX, H, A.wg_v, H, N, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], C, cb, cb, 0))) return rc;
+    if ((rc = bb.add(A.wg_gvp, H, A.wg_t, H, N, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], C, cb, cb, 0))) return rc;
     if ((rc = bb.close_bundle())) return rc;
     if ((rc = bb.finish())) return rc;
   } else if (C > 0) {
-    // plain jobs over the N*C rows, in a batch of their own (upper half of the slab workspace, 768 workgroups per job)
+    // plain jobs, one batch slice per channel, in a batch of their own (upper half of the slab workspace)
     WgradBatch bb(L->wg_slab, st, has(L, FASTEGNN_F_BF16), WG_SLABS / 2, WG_SLABS / 2);
-    if ((rc = bb.add(A.wg_gnp, H, A.wg_v, C * H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, H, 1))) return rc;
-    // coordinate heads and edge_mlp_virtual.2 over the N*C (node, channel) rows
-    if ((rc = bb.add(A.wg_gux, H, A.wg_v, H, NC, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B]))) return rc;
-    if ((rc = bb.add(A.wg_guX, H, A.wg_v, H, NC, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B]))) return rc;
-    if ((rc = bb.add(A.wg_gvp, H, A.wg_t, H, NC, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B]))) return rc;
+    const long cb = (long)A.wg_cstride;
+    if ((rc = bb.add(A.wg_gnp, H, A.wg_v, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, cb, 1))) return rc;
+    // coordinate heads and edge_mlp_virtual.2 over the (channel, node) rows
+    if ((rc = bb.add(A.wg_gux, H, A.wg_v, H, N, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], C, cb, cb, 0))) return rc;
+    if ((rc = bb.add(A.wg_guX, H, A.wg_v, H, N, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], C, cb, cb, 0))) return rc;
+    if ((rc = bb.add(A.wg_gvp, H, A.wg_t, H, N, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], C, cb, cb, 0))) return rc;
     if ((rc = bb.finish())) return rc;
   }
   // node_mlp.2

@@ -239,7 +239,7 @@ def test_narrow_hidden_nf_vs_oracle(hidden, C):
     """hidden_nf < 64 (`--dim_hidden`, main_nbody.py:27): the module zero-pads every hidden-sized block of the parameters
     to the kernels' 64-wide tiles, which computes the same function; outputs and the gradients of the h-sized
     parameters against the oracle built with the true hidden_nf.  state_dict keeps the reference's shapes."""
-    cfg = R.Config(2, 2, 2, hidden, C, n_layers=3, gravity=[0, -1, 0], attention=True)
+    cfg = R.Config(2, 2, 2, hidden, C, n_layers=3, gravity=[0, -1, 0])
     inp = _batch([130, 61], 6, C, seed=50 + hidden)
     inp["node_attr"] = torch.rand(inp["node_loc"].size(0), 2, generator=torch.Generator().manual_seed(5))
     _check_vs_oracle(cfg, inp, seed=50 + hidden, case="test_narrow_hidden_nf_vs_oracle")
