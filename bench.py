@@ -448,8 +448,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # auto: every single-GPU configuration up to cfg4's size replays its step as one captured HIP graph (cfg4: 15.5 -> 15.0 ms,
+    # the host-side launch gaps of ~110 launches); cfg5 gains nothing (212 ms either way) and its capture pool would pin
+    # ~50 GB, so it stays eager
     use_graph = args.hipgraph == "on" or (args.hipgraph == "auto" and world == 1 and not sharded and not args.train_step
-                                          and cfg["kind"] != "water")
+                                          and (args.nodes or cfg["nodes"]) <= 200000)
     # the per-kernel HIP-event profiler is on during warm-up too, so that its event pool exists
     # before the timed region (hipEventCreate is slow on a cold driver)
     K.lib().fastegnn_profile_enable(1)

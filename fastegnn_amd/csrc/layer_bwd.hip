@@ -1084,8 +1084,16 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       }
       EdgeFwdState S;
       Vec pre;
+      // the row-keyed operands of the adjoint (degree, g_aggx row, g_aggm row) depend on the row index only: requested here,
+      // they arrive under the forward recompute instead of being waited for one after the other in the middle of the tile
+      const int rp0 = a.rowptr[cur_i.row], rp1 = a.rowptr[cur_i.row + 1];
+      float gax[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gax[k] = A.g_aggx[(size_t)cur_i.row * 3 + k];
+      Vec gam;   // (EA = 7 variant: 16 more live registers would spill; it keeps this row's load at its use)
+      if constexpr (PF_IDX) gam = vload_row(A.g_aggm + (size_t)cur_i.row * H, q);
       edge_tile_forward<true, MODE, true>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
-      const int dg = a.rowptr[S.row + 1] - a.rowptr[S.row];
+      const int dg = rp1 - rp0;
       const float inv = valid ? rcp_f((float)(dg > 1 ? dg : 1)) : 0.f;
       const float invx = valid ? (mean ? inv : 1.f) : 0.f;
       tile_store(pt, j, q, S.t);   // parked until its partner g_mp exists (the tile is free until the row walk)
@@ -1093,7 +1101,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       float g_tr[3], g_dn[3], g_s = 0.f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        g_tr[k] = A.g_aggx[(size_t)S.row * 3 + k] * invx;
+        g_tr[k] = gax[k] * invx;
         g_s += S.dn[k] * g_tr[k];
         g_dn[k] = S.s * g_tr[k];
       }
@@ -1104,7 +1112,8 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       FE_T(5)   // degree / g_aggx rows, head adjoint, g_up
       publish(1, g_up, S.m);
       FE_T(6)   // publish (g_up, m)
-      Vec g_m = vscale(vload_row(A.g_aggm + (size_t)S.row * H, q), inv);
+      if constexpr (!PF_IDX) gam = vload_row(A.g_aggm + (size_t)S.row * H, q);
+      Vec g_m = vscale(gam, inv);
       gemm_e<MODE, 3, true>(img, g_up, g_m);
       Vec g_m0 = g_m;
       if (att_on) {
