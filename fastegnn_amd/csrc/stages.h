@@ -78,8 +78,9 @@ __device__ __forceinline__ void edge_load_idx(const EdgeArgs &a, int e, EdgeIdx 
   }
 }
 
-// gathered operands of one 16-edge tile: issued one tile ahead of their use by the forward kernel, so
-// the (index -> gathered row) latency is covered by the previous tile's arithmetic
+// gathered operands of one 16-edge tile (requested at the head of the tile from indices that were requested one tile
+// earlier: one of the two dependent round trips is exposed, the other waves of the SIMD cover it -- requesting the rows
+// a tile ahead as well costs 40 registers, i.e. a wave per SIMD, and measured slower in both edge kernels)
 struct EdgeRows {
   Vec p, qv;        // P[row], Q[col] in D layout
   f32x4 xr, xc;     // coordinates of the two end points
