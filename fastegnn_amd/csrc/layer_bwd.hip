@@ -928,10 +928,11 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
     tk = __builtin_amdgcn_readfirstlane(tk);
     const int sl = tk % PC_RING, round = tk / PC_RING;
     while (lds_ld(&ctrl[PC_DRAINED + kind * PC_RING + sl]) != round) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");   // (compiler order: the tile stores stay behind the flag read)
     float *slot = ring + (kind * PC_RING + sl) * PC_SLOT;
     pc_tile_store(slot, j, q, Gv);
     pc_tile_store(slot + 16 * PC_RS, j, q, Tv);
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is in LDS before the flag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // lgkmcnt(0): the tile is in LDS before the flag
     if (l == 0) lds_st(&ctrl[PC_FILLED + kind * PC_RING + sl], round + 1);
   };
   if (consumer) {
@@ -955,6 +956,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       while (lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s0]) != r0w + 1) __builtin_amdgcn_s_sleep(2);
       if (two)
         while (lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s1]) != r1w + 1) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");   // the slot reads stay behind the flag reads
       const float *g0 = ring + (kind * PC_RING + s0) * PC_SLOT, *g1 = ring + (kind * PC_RING + s1) * PC_SLOT;
 #ifdef FE_DIAG_NOCONS   // diagnostic: the consumer only drains its slots (is the kernel consumer-bound?)
       if (l == 0) {
@@ -977,7 +979,9 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
           xa[t][e] = g0[(4 * q + e) * PC_RS + 16 * t + j];
           xa[t][4 + e] = two ? g1[(4 * q + e) * PC_RS + 16 * t + j] : 0.f;
         }
-      __builtin_amdgcn_s_waitcnt(0xc07f);   // every read of the slots has returned
+      // every read of the slots has returned (lgkmcnt(0)) and, for the compiler, none of them may sink below the hand-back
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_s_waitcnt(0xc07f);
       if (l == 0) {
         lds_st(&ctrl[PC_DRAINED + kind * PC_RING + s0], r0w + 1);
         if (two) lds_st(&ctrl[PC_DRAINED + kind * PC_RING + s1], r1w + 1);
