@@ -442,6 +442,10 @@ class FastEGNN(nn.Module):
         return dict(self.named_parameters())
 
     def sorted_graph(self, edge_index: torch.Tensor, n_nodes: int) -> SortedGraph:
+        """CSR of `edge_index`, cached (``self.cache_graphs``, 8 entries) under (data_ptr, size, torch's version counter,
+        n_nodes).  Caveat: a writer that bypasses torch's version counter -- a raw-pointer kernel such as this library's
+        own ``fastegnn_radius_graph_fill`` refilling a reused buffer -- is not seen; pass a fresh tensor, or set
+        ``cache_graphs = False``, when edge lists are rewritten in place that way."""
         key = (edge_index.data_ptr(), edge_index.size(1), edge_index._version, n_nodes, n_nodes, 0)
         g = self._graph_cache.get(key) if self.cache_graphs else None
         if g is None:
