@@ -463,6 +463,7 @@ def main():
     sync()
     K.profile_collect()
     prof_steps = args.steps
+    prof_taken = False
     if use_graph:
         # per-kernel durations from an eager pass (events cannot be timed inside a captured graph), then the step is
         # captured once and the timed region replays it
@@ -472,14 +473,21 @@ def main():
         sync()
         K.lib().fastegnn_profile_enable(0)
         prof = K.profile_collect()
+        prof_taken = True
         gstream = torch.cuda.Stream(dev)
         gstream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(gstream):
             step()                                   # allocator warm-up on the capture stream
         torch.cuda.current_stream(dev).wait_stream(gstream)
         hgraph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(hgraph, stream=gstream):
-            loss = step()
+        try:
+            with torch.cuda.graph(hgraph, stream=gstream):
+                loss = step()
+        except Exception as exc:                      # a box whose runtime cannot capture the step: time eager launches
+            print(f"bench: HIP graph capture failed ({type(exc).__name__}: {exc}); timing eager launches", file=sys.stderr)
+            torch.cuda.synchronize(dev)
+            use_graph, hgraph = False, None
+    if use_graph:
         for _ in range(max(args.warmup, 1)):
             hgraph.replay()
         sync()
@@ -503,8 +511,9 @@ def main():
             done.append(ev)
         sync()
         dt = time.perf_counter() - t0
-        K.lib().fastegnn_profile_enable(0)
-        prof = K.profile_collect()
+        if not prof_taken:   # (after a failed graph capture the per-kernel table of the eager pre-pass is kept)
+            K.lib().fastegnn_profile_enable(0)
+            prof = K.profile_collect()
     dt = max_over_ranks(dt, dev)
 
     dp_leg = None
