@@ -35,3 +35,29 @@ def test_padded_parameters_compute_the_same_function(h, C, na):
             assert p[k].grad is None or p[k].grad.abs().max() == 0, k
         else:
             assert (p[k].grad - q[k].grad).abs().max() <= 1e-9 * (1 + q[k].grad.abs().max()), k
+
+
+def test_padded_fastrf_parameters_compute_the_same_function():
+    """Same algebra for the FastRF sibling (models/FastRF.py): its coord_mlp_vel.0 takes the 1-wide velocity norm, which
+    is not a hidden-sized block (rf=True in _pad_param)."""
+    import fastegnn_amd
+    from oracle import fastrf_ref as RF
+    h, C = 24, 2
+    torch.manual_seed(5)
+    m = fastegnn_amd.FastRF(2, 0, 2, h, C, n_layers=2, attention=True, gravity=[0, -1, 0])
+    p = {k: v.detach().double() for k, v in m.state_dict().items()}
+    pp = {k: _pad_param(k, v, h, C, True) for k, v in p.items()}
+    m64 = fastegnn_amd.FastRF(2, 0, 2, 64, C, n_layers=2, attention=True, gravity=[0, -1, 0])
+    for k, v in m64.state_dict().items():
+        assert pp[k].shape == v.shape, k
+    kw = dict(n_layers=2, gravity=[0, -1, 0], attention=True)
+    cfg, cfg64 = R.Config(2, 0, 2, h, C, **kw), R.Config(2, 0, 2, 64, C, **kw)
+    g = torch.Generator().manual_seed(1)
+    N, E = 30, 120
+    inp = dict(node_feat=torch.rand(N, 2, generator=g).double(), node_loc=torch.randn(N, 3, generator=g).double(),
+               node_vel=torch.randn(N, 3, generator=g).double(), edge_index=torch.randint(0, N, (2, E), generator=g),
+               data_batch=torch.cat([torch.zeros(18), torch.ones(12)]).long(),
+               loc_mean=torch.randn(2, 3, C, generator=g).double(), edge_attr=torch.rand(E, 2, generator=g).double())
+    a = RF.forward(p, cfg, **inp)
+    b = RF.forward(pp, cfg64, **inp)
+    assert (a[0] - b[0]).abs().max() < 1e-12 and (a[1] - b[1]).abs().max() < 1e-12
