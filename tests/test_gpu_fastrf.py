@@ -93,3 +93,34 @@ def test_fastrf_many_tiles_per_workgroup_vs_oracle():
         got = p.grad.cpu() if p.grad is not None else torch.zeros_like(p32[k])
         grad_check("fastrf_many_tiles", k, got, g32[k], g64[k], bad)
     assert not bad, bad
+
+
+def test_fastrf_narrow_hidden_nf_vs_oracle():
+    """hidden_nf = 24 on the FastRF sibling: zero-padded parameters on the 64-wide kernels (model.py:_pad_param, rf=True)
+    against the oracle evaluated with the true hidden_nf: outputs and parameter gradients."""
+    from oracle import fastegnn_ref as R
+    from tests.test_gpu_properties import _batch
+    h, C = 24, 3
+    cfg = R.Config(2, 0, 2, h, C, n_layers=2, gravity=[0, -1, 0])
+    inp = _batch([90, 41], 5, C, seed=31)
+    torch.manual_seed(9)
+    m = fastegnn_amd.FastRF(2, 0, 2, h, C, device="cuda", n_layers=2, gravity=[0, -1, 0])
+    tgt = inp["node_loc"] + 0.5
+    loc, vloc = m(**{k: v.cuda() for k, v in inp.items()})
+    (torch.nn.functional.mse_loss(loc, tgt.cuda()) + 0.05 * vloc.pow(2).mean()).backward()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        p = {k: v.detach().cpu().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+        ii = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in inp.items()}
+        l, v = RF.forward(p, cfg, **ii)
+        (torch.nn.functional.mse_loss(l, tgt.to(dt)) + 0.05 * v.pow(2).mean()).backward()
+        res[dt] = (l.detach(), v.detach(), {k: (t.grad if t.grad is not None else torch.zeros_like(t)) for k, t in p.items()})
+    l32, v32, g32 = res[torch.float32]
+    _, _, g64 = res[torch.float64]
+    assert rel_err(loc, l32) < OUT_TOL and rel_err(vloc, v32) < OUT_TOL
+    bad = []
+    for k, prm in m.named_parameters():
+        got = prm.grad.cpu() if prm.grad is not None else torch.zeros_like(prm).cpu()
+        assert got.shape == g64[k].shape
+        grad_check("test_fastrf_narrow_hidden_nf_vs_oracle", k, got, g32[k], g64[k], bad)
+    assert not bad, bad
