@@ -9,7 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfastegnn_hip.so")
+# FASTEGNN_SAFE_WAITS=1 loads the -DFE_SAFE_WAITS build of the same sources (csrc/Makefile): every hand-counted wait,
+# LDS-DMA copy and relaxed LDS flag in its conservative form.  Same ABI, same results; a diagnostic, not a fallback.
+SAFE_WAITS = os.environ.get("FASTEGNN_SAFE_WAITS", "0") not in ("", "0")
+LIB_PATH = os.path.join(_HERE, "libfastegnn_hip_safe.so" if SAFE_WAITS else "libfastegnn_hip.so")
 
 H = 64
 QX_LD = 68

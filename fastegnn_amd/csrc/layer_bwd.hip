@@ -205,9 +205,19 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
       // not count only make its own vmcnt(N) waits stricter, never wrong: vmcnt retires in issue order.)
       const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)(dst + ch * 1024);
       const char *ga = src + ch * 1024 + ln * 16;
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(ga) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(ga) : "memory");   // (m0 is a reserved register: the compiler keeps nothing in it across the statement)
     }
   };
+#ifdef FE_SAFE_WAITS
+  // -DFE_SAFE_WAITS (libfastegnn_hip_safe.so): no LDS-DMA and no counted waits -- the image of channel c is copied through
+  // registers by the whole workgroup between two full barriers at the top of channel c
+  auto copy_w3c_sync = [&](int c, char *dst) {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, C, RM_FIXED + c));
+    __syncthreads();
+    for (int i = threadIdx.x; i < RM_BYTES / 16; i += blockDim.x) reinterpret_cast<u32x4 *>(dst)[i] = src[i];
+    __syncthreads();
+  };
+#endif
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) gBc_l[i] = 0.f;
   __syncthreads();
@@ -293,9 +303,11 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
 #pragma unroll
           for (int i = 0; i < NSTG; ++i) tmp[i] = src[threadIdx.x + i * 64 * VIRT_BWD_WAVES];
           __syncthreads();          // every wave is done with the previous content of the stage
+#ifndef FE_SAFE_WAITS
           if constexpr (X3H) {      // both stage buffers are free now: channel 0's image lands under the prologue
             if (id == I_W4T && C > 0 && !split) dma_w3c(0, stage0);
           }
+#endif
           f32x4 *dst = reinterpret_cast<f32x4 *>(w3ct_l);
 #pragma unroll
           for (int i = 0; i < NSTG; ++i) dst[threadIdx.x + i * 64 * VIRT_BWD_WAVES] = tmp[i];
@@ -406,6 +418,10 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
             // requests and of its 20 operand stores (unconditional, see offST) -- vmcnt counts in issue order, so
             // "at most 16 outstanding" retires the copy and the rows without waiting for the stores to reach L2
             // (with vmcnt(0) the channel top cost 2.6-3.1 k of the 25.6 k cycles of a (tile, channel), stamps).
+#ifdef FE_SAFE_WAITS
+            copy_w3c_sync(c, (c & 1) ? stage1 : stage0);
+            (void)dma_w3c;
+#else
             if (c == c_first) {
               __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): channel 0's copy was issued in the tile prologue
               __syncthreads();
@@ -416,6 +432,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             }
             if (c + 1 < C) dma_w3c(c + 1, ((c + 1) & 1) ? stage1 : stage0);
+#endif
           } else {
             __syncthreads();          // every wave is done with the previous channel's stage
             f32x4 *dst = reinterpret_cast<f32x4 *>(w3ct_l);
@@ -869,8 +886,13 @@ constexpr int PC_RS = 68;                   // row stride of a slot tile
 constexpr int PC_SLOT = 2 * 16 * PC_RS;     // floats per slot: G tile | T tile
 constexpr int PC_IMG_FLOATS = 2 * RM_WORDS;   // W2 | WX1 as row-major split images: each serves the product and its transpose
 enum { PC_HEAD = 0, PC_TOTAL = 2, PC_FILLED = 4, PC_DRAINED = 4 + 2 * PC_RING, PC_CTRL = 4 + 4 * PC_RING };
+#ifdef FE_SAFE_WAITS   // ring flags as workgroup-scope acquire loads / release stores instead of relaxed accesses between fences
+__device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#else
 __device__ __forceinline__ int lds_ld(const int *p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void lds_st(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+#endif
 __device__ __forceinline__ void pc_tile_store(float *tile, int j, int q, const Vec &v) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(tile + j * PC_RS + 16 * t + 4 * q) = v.t[t];

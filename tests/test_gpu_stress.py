@@ -1,0 +1,58 @@
+"""-m gpu: repeat / stress tests of the synchronisation-heavy kernels.
+
+* >= 100 forward+backward passes on the headline shape (20 000 nodes, C=16, L=4), on the many-tiles shape and on a
+  mini-batch of tiny graphs; every output and gradient of every pass against pass 0 (tests/stress_runner.py);
+* the same under the -DFE_SAFE_WAITS build (libfastegnn_hip_safe.so: no counted s_waitcnt, no inline-assembly LDS-DMA,
+  acquire/release ring flags), in a fresh process, and the first passes of the two builds against each other.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ITERS = int(os.environ.get("FASTEGNN_STRESS_ITERS", "100"))
+
+
+def _run(tmp, safe):
+    env = dict(os.environ, FASTEGNN_SAFE_WAITS="1" if safe else "0")
+    out = subprocess.run([sys.executable, "-m", "tests.stress_runner", str(ITERS), str(tmp)], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=1500)
+    line = [l for l in out.stdout.splitlines() if l.startswith("STRESS ")]
+    assert line, f"stress runner produced no result (rc {out.returncode}):\n{out.stdout[-2000:]}\n{out.stderr[-2000:]}"
+    res = json.loads(line[-1][7:])
+    assert res["safe_waits"] == safe and res["lib"] == ("libfastegnn_hip_safe.so" if safe else "libfastegnn_hip.so")
+    return res, out.returncode
+
+
+@pytest.fixture(scope="module")
+def runs(tmp_path_factory):
+    d0, d1 = tmp_path_factory.mktemp("stress_default"), tmp_path_factory.mktemp("stress_safe")
+    return (_run(d0, False), d0), (_run(d1, True), d1)
+
+
+@pytest.mark.parametrize("which", [0, 1], ids=["default_build", "safe_waits_build"])
+def test_repeat_passes_match_first_pass(runs, which):
+    (res, rc), _ = runs[which]
+    for c in res["cases"]:
+        assert c["iters"] >= 100 or ITERS < 100
+        assert c["n_bad"] == 0, f"{c['case']}: {c['n_bad']} passes differ from pass 0: {c['bad']} (worst {c['worst']})"
+    assert rc == 0
+
+
+def test_default_and_safe_builds_agree(runs):
+    """First pass of the default build against the first pass of the conservative build: same inputs, same weights."""
+    from tests.stress_runner import _limit
+    (_, d0), (_, d1) = runs
+    for name in ("headline20k", "manytiles", "tiny100x5"):
+        a, b = np.load(os.path.join(d0, name + ".npz")), np.load(os.path.join(d1, name + ".npz"))
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            den = np.abs(b[k]).max()
+            e = np.abs(a[k] - b[k]).max() / (den if den > 0 else 1.0)
+            assert e <= _limit(k), f"{name}/{k}: default vs safe build differ by {e:.2e}"
