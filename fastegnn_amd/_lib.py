@@ -87,6 +87,10 @@ def lib():
     L.fastegnn_wg_edge_floats.argtypes = [_i32]
     L.fastegnn_wg_virt_floats.restype = C.c_size_t
     L.fastegnn_wg_virt_floats.argtypes = [_i32, _i32]
+    L.fastegnn_wg_virt_floats_for.restype = C.c_size_t
+    L.fastegnn_wg_virt_floats_for.argtypes = [_i32, _i32, _i32]
+    L.fastegnn_backward_scratch_floats_for.restype = C.c_size_t
+    L.fastegnn_backward_scratch_floats_for.argtypes = [_i32, _i32, _i32, _i32, _i32, _i32]
     L.fastegnn_wg_node_floats.restype = C.c_size_t
     L.fastegnn_wg_node_floats.argtypes = [_i32, _i32, _i32]
     L.fastegnn_backward_scratch_floats.restype = C.c_size_t
@@ -146,7 +150,7 @@ STAGE_FUNCS = [
 
 # every symbol include/fastegnn_hip.h declares (checked by tests/test_abi_cpu.py)
 EXPORTED = STAGE_FUNCS + [
-    "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_wg_edge_floats", "fastegnn_wg_virt_floats", "fastegnn_wg_node_floats", "fastegnn_backward_scratch_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes", "fastegnn_chunk_rows", "fastegnn_chunk_edges",
+    "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_wg_edge_floats", "fastegnn_wg_virt_floats", "fastegnn_wg_virt_floats_for", "fastegnn_backward_scratch_floats_for", "fastegnn_wg_node_floats", "fastegnn_backward_scratch_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes", "fastegnn_chunk_rows", "fastegnn_chunk_edges",
     "fastegnn_build_csr", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_rm", "fastegnn_selftest_wgrad", "fastegnn_selftest_stream", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",

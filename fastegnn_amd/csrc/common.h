@@ -50,8 +50,13 @@ __device__ __forceinline__ void silu_both(float z, float &y, float &d) {
 __device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sqrt_f(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float tanh_f(float z) {
-  // tanh(z) = 2*sigmoid(2z) - 1
-  return 2.0f * sigmoid_f(2.0f * z) - 1.0f;
+  // tanh(z) = 2*sigmoid(2z) - 1 cancels for small |z| (absolute error ~1e-7, i.e. 1e-4 relative at |z| = 1e-3 -- and the
+  // coordinate heads this is applied to are initialised with gain 1e-3): below 0.25 the odd Taylor polynomial to z^9
+  // (relative error < 3e-7) is used instead.  One value per item, so the cost does not matter.
+  const float z2 = z * z;
+  const float p = z * (1.0f + z2 * (-0.33333334f + z2 * (0.13333334f + z2 * (-0.053968254f + z2 * 0.021869488f))));
+  const float s = 2.0f * sigmoid_f(2.0f * z) - 1.0f;
+  return fabsf(z) < 0.25f ? p : s;
 }
 
 __device__ __forceinline__ Vec vzero() {
@@ -281,8 +286,10 @@ __device__ __forceinline__ Split vsplit(const Vec &v) {
   return S;
 }
 // img3: split image, IMG3 words = parts h | m | l (2048 words each), normally LDS resident.
+// (fragments of group g+1 requested ahead of the MFMAs of group g: see gemm64_x3_rm)
 __device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Split &in, Vec &acc) {
   const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + lane_id();
+#ifdef FE_NO_GEMM_PIPE
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -301,6 +308,37 @@ __device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Split &in,
       acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xm, acc.t[t], 0, 0, 0);
       acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc.t[t], 0, 0, 0);
     }
+#else
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4 fr[2][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) fr[0][p] = ip[p * 512];
+  __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 DS reads (one ds_read_b128 per fragment)
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int s = g >> 2, t = g & 3, cb = g & 1;
+    if (g + 1 < 8) {
+      const int sn = (g + 1) >> 2, tn = (g + 1) & 3;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fr[cb ^ 1][p] = ip[p * 512 + (tn * 2 + sn) * 64];
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    }
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, fr[cb][0]), am = __builtin_bit_cast(bf16x8, fr[cb][1]),
+                 al = __builtin_bit_cast(bf16x8, fr[cb][2]);
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, in.p[0][s]);
+    const bf16x8 xm = __builtin_bit_cast(bf16x8, in.p[1][s]);
+    const bf16x8 xl = __builtin_bit_cast(bf16x8, in.p[2][s]);
+    // smallest terms first: (weight part, activation part) = (l,h) (m,m) (h,l) | (m,h) (h,m) | (h,h)
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, acc.t[t], 0, 0, 0);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xm, acc.t[t], 0, 0, 0);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, acc.t[t], 0, 0, 0);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xh, acc.t[t], 0, 0, 0);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xm, acc.t[t], 0, 0, 0);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc.t[t], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // 6 MFMAs
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 __device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Vec &in, Vec &acc) { gemm64_x3(img3, vsplit(in), acc); }
 
@@ -379,8 +417,13 @@ __device__ __forceinline__ bf16x8 rm_frag(const char *img, int part, int t, int 
   }
   return __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
 }
+// The eight (k-step, out-tile) groups of a product are software-pipelined by hand: the three fragments of group g+1 are
+// requested BEFORE the six MFMAs of group g are issued (sched_group_barrier pins the order; the compiler's own schedule was
+// "6 MFMA, 6 reads, wait" -- every group then waited a full LDS round trip with an idle matrix pipe behind it).  Costs 12
+// more live registers; -DFE_NO_GEMM_PIPE restores the compiler's order.
 template <bool TR>
 __device__ __forceinline__ void gemm64_x3_rm(const char *img, const Split &in, Vec &acc) {
+#ifdef FE_NO_GEMM_PIPE
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -396,6 +439,34 @@ __device__ __forceinline__ void gemm64_x3_rm(const char *img, const Split &in, V
       acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xm, acc.t[t], 0, 0, 0);
       acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc.t[t], 0, 0, 0);
     }
+#else
+  __builtin_amdgcn_sched_barrier(0);
+  bf16x8 fr[2][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) fr[0][p] = rm_frag<TR>(img, p, 0, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // 6 DS reads (two ds_read_b64 per fragment)
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int s = g >> 2, t = g & 3, cb = g & 1;
+    if (g + 1 < 8) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fr[cb ^ 1][p] = rm_frag<TR>(img, p, (g + 1) & 3, (g + 1) >> 2);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    }
+    const bf16x8 ah = fr[cb][0], am = fr[cb][1], al = fr[cb][2];
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, in.p[0][s]);
+    const bf16x8 xm = __builtin_bit_cast(bf16x8, in.p[1][s]);
+    const bf16x8 xl = __builtin_bit_cast(bf16x8, in.p[2][s]);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, acc.t[t], 0, 0, 0);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xm, acc.t[t], 0, 0, 0);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, acc.t[t], 0, 0, 0);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xh, acc.t[t], 0, 0, 0);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xm, acc.t[t], 0, 0, 0);
+    acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc.t[t], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // 6 MFMAs
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 template <bool TR>
 __device__ __forceinline__ void gemm64_b1_rm(const char *img, const BfOp &in, Vec &acc) {

@@ -25,7 +25,7 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 enum KernelId {
   K_PACK = 0, K_NODE_PRE_FWD, K_XSUM, K_GRAPH_PRE_FWD, K_EDGE_FWD, K_VIRT_FWD, K_GRAPH_POST_FWD,
   K_GRAPH_POST_BWD, K_VIRT_BWD, K_GRAPH_PRE_BWD, K_EDGE_BWD, K_COL_REDUCE, K_NODE_PRE_BWD,
-  K_WGRAD_TN, K_WGRAD_SMALL, K_CSR, K_MISC, K_WGRAD_REDUCE, K_COUNT
+  K_WGRAD_TN, K_WGRAD_SMALL, K_CSR, K_MISC, K_WGRAD_REDUCE, K_VIRT_BWD_NODE, K_VIRT_BWD_GV, K_WGRAD_BUNDLE, K_COUNT
 };
 extern bool g_prof_on;
 void prof_begin(int id, hipStream_t st);
@@ -93,6 +93,10 @@ int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *s
 int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
 int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
 int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
+// virt_bwd.hip: the producer/consumer form of B4 (1 <= C <= 32, FastEGNN wiring); virt_backward dispatches to it
+bool virt_backward_uses_pc(const fastegnn_layer_t *L);
+int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared);
+size_t virt_pc_wg_floats(size_t N, size_t C);
 int edge_col_reduce(const fastegnn_layer_t *L, hipStream_t st);
 int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
 // operand regions of the node-level / graph-level weight gradients inside wg_node (disjoint, so that the jobs of a whole

@@ -658,6 +658,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
 }
 
 int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
+  if (virt_backward_uses_pc(L)) return virt_backward_pc(L, st, shared);   // virt_bwd.hip
   const bool egnn = has(L, FASTEGNN_F_EGNN);
   FE_REQUIRE(L->h && L->A && L->x && L->vel && L->aggm && L->npre && L->batch && L->wpack && (!egnn || L->aggx),
              "virt_backward: null saved buffer");
@@ -858,6 +859,7 @@ struct EdgeBwdArgs {
   int ld_e0, C;
   float *slab, *slab_b;   // producer/consumer variant: partial slabs of the two in-kernel weight gradients
   int slab_w2, slab_wx1;
+  float *cons_scratch;    // [grid][2][64*64] running sums of the two consumers, accumulator order (wg_edge)
 };
 #ifndef FE_PC_PRIO
 #define FE_PC_PRIO 3
@@ -882,6 +884,7 @@ constexpr int PC_PROD = 6;                  // producer waves
 #define FE_PC_RING 4
 #endif
 constexpr int PC_RING = FE_PC_RING;                  // slots per ring; one ring per weight (kind 0: edge_mlp.2, kind 1: coord_mlp_r.0)
+constexpr int PC_FLUSH = 48;                // tickets (16-edge operand sets) a consumer accumulates in registers between two scratch updates
 constexpr int PC_RS = 68;                   // row stride of a slot tile
 constexpr int PC_SLOT = 2 * 16 * PC_RS;     // floats per slot: G tile | T tile
 constexpr int PC_IMG_FLOATS = 2 * RM_WORDS;   // W2 | WX1 as row-major split images: each serves the product and its transpose
@@ -1050,11 +1053,35 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       if (lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s0]) != done / PC_RING + 1) return false;
       return done + 1 >= total || lds_ld(&ctrl[PC_FILLED + kind * PC_RING + s1]) == (done + 1) / PC_RING + 1;
     };
-    int done = 0;
+    // The accumulator leaves the registers every PC_FLUSH tickets (768 edges): ONE fp32 chain over all of a workgroup's edges
+    // (7 500 at cfg4) carries 2-4x the rounding noise of 780-row chains on cancelling sums (measured on the virtual stage,
+    // virt_bwd.hip).  The running sum lives in a scratch tile of this wave in accumulator order (sixteen 16-byte
+    // read-modify-writes per lane, L2 resident); the [o][k] slab is written once, at the end.
+    f32x4 *sc = reinterpret_cast<f32x4 *>(A.cons_scratch + ((size_t)blockIdx.x * 2 + ckind) * IMG) + l;
+    float bs_tot[4] = {0.f, 0.f, 0.f, 0.f};
+    bool flushed = false;
+    int done = 0, since = 0;
     while (done < total) {
       if (ready(ckind, done)) {
         contract(ckind, done, accA, bsA);
         done += 2;
+        since += 2;
+        if (since >= PC_FLUSH && done < total) {
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) {
+#pragma unroll
+            for (int tk2 = 0; tk2 < 4; ++tk2) {
+              f32x4 *d = sc + (ti * 4 + tk2) * 64;
+              if (flushed) accA[ti][tk2] += *d;
+              *d = accA[ti][tk2];
+              accA[ti][tk2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            bs_tot[ti] += bsA[ti];
+            bsA[ti] = 0.f;
+          }
+          flushed = true;
+          since = 0;
+        }
       } else {
         __builtin_amdgcn_s_sleep(1);
       }
@@ -1065,12 +1092,15 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-      for (int tk2 = 0; tk2 < 4; ++tk2)
+      for (int tk2 = 0; tk2 < 4; ++tk2) {
+        f32x4 v = accA[ti][tk2];
+        if (flushed) v += sc[(ti * 4 + tk2) * 64];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sa[(16 * ti + 4 * q + r) * H + 16 * tk2 + j] = accA[ti][tk2][r];
+        for (int r = 0; r < 4; ++r) sa[(16 * ti + 4 * q + r) * H + 16 * tk2 + j] = v[r];
+      }
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
-      const float s0 = qsum(bsA[ti]);
+      const float s0 = qsum(bs_tot[ti] + bsA[ti]);
       if (q == 0) A.slab_b[sl * H + 16 * ti + j] = s0;
     }
   }
@@ -1284,6 +1314,8 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
     if ((rc = wb.add_slabs(g[FASTEGNN_P_CR0_W], H, 0, 1, g[FASTEGNN_P_CR0_B], grid, &A.slab_wx1))) return rc;
     A.slab = wb.tab.slab;
     A.slab_b = wb.tab.slab_b;
+    FE_REQUIRE(L->wg_edge, "edge_backward: wg_edge null");
+    A.cons_scratch = L->wg_edge;
     const size_t lds = (PC_IMG_FLOATS + EV_COUNT * H + PC_PROD * 16 * TS + 2 * PC_RING * PC_SLOT + PC_CTRL) * sizeof(float);
     {
       ProfScope _ps_edge_bwd_kernel(K_EDGE_BWD, st);
@@ -1302,13 +1334,22 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
 }
 
 }  // namespace fe
-// the edge stage contracts its weight gradients inside the workgroup: no operand workspace (4 floats keep the
-// caller's carve non-empty)
-extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { (void)E; return 4; }
+// the edge stage contracts its weight gradients inside the workgroup: no operand workspace, only the running sums of its
+// two consumer waves per workgroup (256 x 2 tiles of 64x64)
+extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { (void)E; return (size_t)256 * 2 * fe::IMG; }
 // weight-gradient operand workspaces of the virtual / node-level stages (layouts: virt_backward, graph_post_backward,
-// graph_pre_backward, node_pre_backward above)
+// graph_pre_backward, node_pre_backward above; virt_backward_pc in virt_bwd.hip).  The flag-less queries return the
+// largest size any wiring needs (the FastRF / C > 32 form of B4 materialises five operand arrays); the _for variants
+// take the layer's flags: the FastEGNN wiring with C <= 32 keeps v and Gv only (+ the per-group parts of g_A / g_x).
 extern "C" size_t fastegnn_wg_virt_floats(int32_t N, int32_t C) {
   const size_t n = (size_t)5 * ((size_t)(N > 0 ? N : 0) + fe::WGV_PAD) * (size_t)(C > 0 ? C : 0) * fe::H;
+  return n > 4 ? n : 4;
+}
+extern "C" size_t fastegnn_wg_virt_floats_for(int32_t N, int32_t C, int32_t flags) {
+  fastegnn_layer_t L{};
+  L.N = N; L.C = C; L.flags = flags;
+  if (!fe::virt_backward_uses_pc(&L)) return fastegnn_wg_virt_floats(N, C);
+  const size_t n = fe::virt_pc_wg_floats((size_t)(N > 0 ? N : 0), (size_t)C);
   return n > 4 ? n : 4;
 }
 extern "C" size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C) {
@@ -1317,16 +1358,21 @@ extern "C" size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C) {
 }
 // floats of ALL backward scratch arrays of fastegnn_layer_t (g_poolV .. wg_slab), each rounded up to a multiple of 4
 // floats (16-byte aligned carving of one allocation)
-extern "C" size_t fastegnn_backward_scratch_floats(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C) {
+static size_t scratch_floats(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C, size_t wg_virt) {
   auto r4 = [](size_t n) { return (n + 3) / 4 * 4; };
   const size_t n = N > 0 ? N : 0, e = E > 0 ? E : 1, s = n_src > 0 ? n_src : 0, bc = (size_t)(B > 0 ? B : 0) * (size_t)(C > 0 ? C : 0);
   size_t t = 0;
   t += 2 * r4(bc * fe::H) + 2 * r4(bc * 3) + r4((size_t)B * 4);          // g_poolV g_Bc | g_poolX g_Zp | g_xbar
   t += 3 * r4(n * fe::H) + 2 * r4(n * 3) + 2 * r4(n);                    // g_A g_P g_aggm | g_aggx g_xrow | g_svel g_sgrav
   t += r4(e * fe::QXLD) + r4(s * fe::QXLD);                              // g_QXe | g_QX_src
-  t += r4(fastegnn_wg_edge_floats(E)) + r4(fastegnn_wg_virt_floats(N, C)) + r4(fastegnn_wg_node_floats(N, B, C)) +
-       r4(fastegnn_wg_slab_floats());
+  t += r4(fastegnn_wg_edge_floats(E)) + r4(wg_virt) + r4(fastegnn_wg_node_floats(N, B, C)) + r4(fastegnn_wg_slab_floats());
   return t;
+}
+extern "C" size_t fastegnn_backward_scratch_floats(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C) {
+  return scratch_floats(N, E, n_src, B, C, fastegnn_wg_virt_floats(N, C));
+}
+extern "C" size_t fastegnn_backward_scratch_floats_for(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C, int32_t flags) {
+  return scratch_floats(N, E, n_src, B, C, fastegnn_wg_virt_floats_for(N, C, flags));
 }
 namespace fe {
 

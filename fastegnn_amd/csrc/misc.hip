@@ -336,7 +336,16 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   long rows = (M + nsplit - 1) / nsplit;
   rows = (rows + 63) / 64 * 64;
   nsplit = (M + rows - 1) / rows;
-  FE_REQUIRE(n_slab + nsplit * nb <= slab_base + slab_cap, "wgrad: slab workspace exhausted");
+  // the batch's share of the slab workspace may be nearly used up (many long jobs in one layer-wide batch, large N with
+  // large B*C): the job then takes the slabs that are left -- fewer, longer row ranges -- instead of failing
+  const long left = ((long)slab_base + slab_cap - n_slab) / nb;
+  FE_REQUIRE(left >= 1, "wgrad: slab workspace exhausted");
+  if (nsplit > left) {
+    nsplit = left;
+    rows = (M + nsplit - 1) / nsplit;
+    rows = (rows + 63) / 64 * 64;
+    nsplit = (M + rows - 1) / rows;
+  }
   WgJob &j = tab.job[tab.n_jobs++];
   j.G = G; j.T = T; j.dW = dW; j.db = db; j.M = M; j.sG = sG; j.sT = sT; j.sW = sW;
   j.ldg = ldg; j.ldt = ldt; j.lddw = lddw; j.c0 = c0; j.ks = ks; j.kmax = kmax;
@@ -385,7 +394,7 @@ int WgradBatch::finish() {
   if (tab.n_jobs == 0) return FASTEGNN_OK;
   int rc = FASTEGNN_OK;
   if (tab.n_bundle > 0) {
-    { ProfScope _ps(K_WGRAD_TN, st); hipLaunchKernelGGL(wgrad_bundle_kernel, dim3((unsigned)n_bundle_wg), dim3(256), 0, st, tab); }
+    { ProfScope _ps(K_WGRAD_BUNDLE, st); hipLaunchKernelGGL(wgrad_bundle_kernel, dim3((unsigned)n_bundle_wg), dim3(256), 0, st, tab); }
     rc = check_launch("wgrad_bundle_kernel");
     if (rc) return rc;
   }

@@ -1,0 +1,795 @@
+// B4 (virtual stage backward) for 1 <= C <= 32 without the FastRF / EGNN wirings: the adjoint of
+// edge_mode_virtual / coord_model_vel (virtual part) / coord_model_virtual / node_model
+// (models/FastEGNN.py:111-119,136-166) as three kernels.  Math: oracle/factored.py (virt_bwd).
+//
+//   virt_bwd_node_kernel  node_mlp adjoint of every node: g_np, g_h (partial), g_aggm, the node-level weight-gradient
+//                         operands, the per-node scalars of the coordinate update.
+//   virt_bwd_gv_kernel    Gv[c][n] = g_poolV[b,c] + W3c[c]^T g_np[n]: the part of d/dv that does not depend on the
+//                         recomputed forward, as one dense product (a workgroup keeps four W3c images resident and
+//                         streams its share of the nodes).  Taking it out of the channel loop removes that loop's per-channel
+//                         W3c stage (55 KB of LDS, one workgroup barrier per channel, an LDS-DMA pipeline with counted
+//                         waits) -- the waves of the main kernel no longer walk the channels in lock step.
+//   virt_bwd_pc_kernel    per (16-node tile, channel): forward recompute interleaved with its adjoint, six producer
+//                         waves; the three 64x64 weight gradients over the (node, channel) rows -- coord_mlp_r_virtual.0,
+//                         coord_mlp_v_virtual.0, edge_mlp_virtual.2 -- are contracted INSIDE the workgroup by two consumer
+//                         waves fed through LDS rings (as in edge_bwd_pc_kernel); only `v` still goes to HBM, for the
+//                         per-channel node_mlp.0 blocks.  Round 2 stored five [C][N][64] operand arrays here (2.05 GB
+//                         per cfg4 launch) and read them back in wgrad_bundle_kernel.
+#include <cstdlib>
+#include "stages.h"
+
+namespace fe {
+
+#ifdef FE_SAFE_WAITS   // ring flags as workgroup-scope acquire loads / release stores instead of relaxed accesses between fences
+__device__ __forceinline__ int vb_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void vb_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#else
+__device__ __forceinline__ int vb_ld(const int *p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void vb_st(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+#endif
+
+// in-kernel phase stamps of virt_bwd_pc_kernel (diagnostic builds only: -DFE_STAMP; tools/gpu_stamp_vb2.py)
+#ifdef FE_STAMP
+__device__ unsigned long long g_vb2_stamps[32];
+#define VB2_T0() unsigned _vp = (unsigned)__builtin_amdgcn_s_memtime(); unsigned _va[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define VB2_T(i) { __builtin_amdgcn_sched_barrier(0); const unsigned _t = (unsigned)__builtin_amdgcn_s_memtime(); \
+                   _va[i] += _t - _vp; _vp = _t; __builtin_amdgcn_sched_barrier(0); }
+#define VB2_TEND(base) if (lane_id() == 0) { for (int _k = 0; _k < 12; ++_k) atomicAdd(&g_vb2_stamps[(base) + _k], (unsigned long long)_va[_k]); }
+#else
+#define VB2_T0()
+#define VB2_T(i)
+#define VB2_TEND(base)
+#endif
+
+__device__ __forceinline__ Vec vb_dsilu_mul(const Vec &g, const Vec &z) {
+  return vmap2(g, z, [](float a, float b) { return a * dsilu_f(b); });
+}
+__device__ __forceinline__ Vec vb_mask(const Vec &v, bool keep) { return keep ? v : vzero(); }
+
+// =====================================================================================
+// B4a node level: adjoint of node_mlp (node_model, :153-166) + per-node scalars of coord_model_vel (:136-142)
+// =====================================================================================
+struct VirtNodeArgs {
+  const float *g_h_out, *npre, *g_x_out, *vel, *aggx, *wpack;
+  float *wg_t3, *wg_gnp, *g_h, *g_aggm, *g_aggx, *g_svel, *g_sgrav;
+  int N, flags;
+  float g[3];
+};
+constexpr int VB_NODE_WAVES = 8;
+template <bool BF>
+__global__ __launch_bounds__(64 * VB_NODE_WAVES) void virt_bwd_node_kernel(VirtNodeArgs a) {
+  constexpr int FM = BF ? GM_BF16 : GM_F32;   // fp32 images; bf16 mode rounds the activation operand
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  load_images(lds, a.wpack + (size_t)I_W3AT * IMG, 3);   // W3AT, W3BT, W4T (consecutive ids)
+  __syncthreads();
+  const float *w3at = lds, *w3bt = lds + IMG, *w4t = lds + 2 * IMG;
+  const int l = lane_id(), j = l & 15, q = l >> 4;
+  const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int ntiles = (a.N + 15) >> 4;
+  const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int n = tile * 16 + j;
+    const bool valid = n < a.N;
+    const int nc = valid ? n : a.N - 1;
+    const Vec g_out = vb_mask(vload_row(a.g_h_out + (size_t)nc * H, q), valid);
+    const Vec npre = vload_row(a.npre + (size_t)nc * H, q);
+    Vec g_t3 = vzero();
+    __builtin_amdgcn_sched_barrier(0);
+    gemm64_m<FM>(w4t, g_out, g_t3);
+    __builtin_amdgcn_sched_barrier(0);
+    const Vec g_np = vb_dsilu_mul(g_t3, npre);
+    if (valid) {
+      vstore_row(a.wg_t3 + (size_t)n * H, q, vsilu(npre));
+      vstore_row(a.wg_gnp + (size_t)n * H, q, g_np);
+    }
+    Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
+    gemm64_m<FM>(w3at, g_np, g_h);
+    __builtin_amdgcn_sched_barrier(0);
+    if (valid) vstore_row(a.g_h + (size_t)n * H, q, g_h);
+    Vec g_am = vzero();
+    gemm64_m<FM>(w3bt, g_np, g_am);
+    __builtin_amdgcn_sched_barrier(0);
+    if (valid) vstore_row(a.g_aggm + (size_t)n * H, q, g_am);
+    if (valid && q == 0) {
+      float sv = 0.f, sg = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float gxn = a.g_x_out[(size_t)n * 3 + k];
+        // clamp(tot_f, -100, 100) of the EGNN baseline passes the gradient only inside the interval
+        const bool pass = !clamp_aggx || fabsf(a.aggx[(size_t)n * 3 + k]) <= 100.f;
+        a.g_aggx[(size_t)n * 3 + k] = pass ? gxn : 0.f;
+        sv += gxn * a.vel[(size_t)n * 3 + k];
+        sg += gxn * a.g[k];
+      }
+      a.g_svel[n] = sv;
+      if (a.flags & FASTEGNN_F_GRAVITY) a.g_sgrav[n] = sg;
+    }
+  }
+}
+
+// =====================================================================================
+// B4b  Gv[c][n][:] = g_poolV[batch[n], c][:] + W3c[c]^T g_np[n][:]
+// (d loss / d v[n,c,:] through node_mlp.0's flat(v) block (:157-158) and node_model_virtual's pool (:170))
+// =====================================================================================
+struct VirtGvArgs {
+  const float *g_np, *g_poolV, *wpack;
+  const int32_t *batch;
+  float *Gv;
+  size_t cstride;   // floats per channel block of Gv
+  int N, C, ngroups, nranges;
+};
+constexpr int VB_GV_CH = 4;      // W3c images resident per workgroup
+constexpr int VB_GV_WAVES = 8;
+template <bool BF>
+__global__ __launch_bounds__(64 * VB_GV_WAVES) void virt_bwd_gv_kernel(VirtGvArgs a) {
+  constexpr int SM = BF ? GM_BF16 : GM_X3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char *img = reinterpret_cast<char *>(lds);
+  const int grp = (int)blockIdx.x % a.ngroups, range = (int)blockIdx.x / a.ngroups;
+  const int c0 = grp * VB_GV_CH, ncv = min(VB_GV_CH, a.C - c0);
+  {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, a.C, RM_FIXED + c0));   // consecutive slots
+    u32x4 *dst = reinterpret_cast<u32x4 *>(img);
+    for (int i = threadIdx.x; i < ncv * (RM_BYTES / 16); i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
+  const int ntiles = (a.N + 15) >> 4;
+  const int t_lo = (int)((long)range * ntiles / a.nranges), t_hi = (int)((long)(range + 1) * ntiles / a.nranges);
+  for (int tile = t_lo + wv; tile < t_hi; tile += VB_GV_WAVES) {
+    const int n = tile * 16 + j;
+    const bool valid = n < a.N;
+    const int nc = valid ? n : a.N - 1;
+    const int b = a.batch[nc];
+    Vec g = vb_mask(vload_row(a.g_np + (size_t)nc * H, q), valid);
+    if constexpr (BF) g = vround(g);
+    const typename OperandOf<SM>::type op = make_operand<SM>(g);
+    const float *pv = a.g_poolV + ((size_t)b * a.C + c0) * H;
+#pragma unroll 1
+    for (int k = 0; k < ncv; ++k) {
+      Vec acc = vload_row(pv + (size_t)k * H, q);
+      gemm_rm<SM, true>(img + k * RM_BYTES, op, acc);
+      if (valid) vstore_row(a.Gv + (size_t)(c0 + k) * a.cstride + (size_t)n * H, q, acc);
+    }
+  }
+}
+
+// =====================================================================================
+// B4c main kernel
+// =====================================================================================
+// Work units of a workgroup (its producers take them from an LDS ticket counter): whole tiles first, then the last
+// VB_FINE_TILES tiles of the workgroup's run in units of VB_GF channels, so that the producers finish within a few channels
+// of each other (with whole tiles only, the last tile of the slowest producer was 10 % of the kernel: phase stamps).  The
+// channel groups 1.. of a fine tile write their share of g_A / g_x to a small `part` tile; virt_bwd_combine_kernel adds them.
+constexpr int VB_FLUSH = 48;      // tickets (16-row operand sets) a consumer accumulates in registers between two slab updates
+constexpr int VB_FINE_TILES = 3;
+constexpr int VB_GF = 2;
+constexpr int VB_WAVES = 8;
+// Waves w and w + 4 of a workgroup share a SIMD.  Consumers: waves 3 and 7 (a SIMD of their own) and wave 6 (beside
+// producer wave 2); producers: waves 0, 1, 2, 4, 5.
+constexpr int VB_CONS_X = 3, VB_CONS_XX = 7, VB_CONS_V2 = 6;
+constexpr int VB_RS = 68;                     // row stride of a ring tile
+constexpr int VB_TILE = 16 * VB_RS;           // floats per 16 x 64 tile
+constexpr int VB_SLOT_A = 3 * VB_TILE;        // g_ux | g_uX | v   (read by consumers X and XX)
+constexpr int VB_SLOT_B = 2 * VB_TILE;        // g_vp | t          (read by consumer V2)
+constexpr int VB_MAXRING = 4;
+// control words (LDS ints): unit ticket, ring heads A / B, per ring slot: filled, drained (ring A: one per consumer)
+enum { VBC_UNIT = 0, VBC_HEAD = 1, VBC_FILLED = 4, VBC_DRAINED = 4 + 2 * VB_MAXRING, VBC_CTRL = 4 + 5 * VB_MAXRING };
+// rank-1 gradient accumulators of the workgroup in LDS: [w_xv2 | w_xx2 | w_vr | att_w | att_b], in up to VB_MAXBANK banks
+// (producer p adds to bank p % nbank: shorter fp32 chains; as many banks as the LDS budget leaves)
+constexpr int VB_RACC = 5 * H;
+constexpr int VB_MAXBANK = 5;
+
+struct VirtBwd2Args {
+  VirtArgs f;
+  const float *g_x_out, *g_poolX, *Gv;
+  float *g_x, *g_A, *g_Bc, *g_Zp;
+  float *gA_part, *gx_part;   // channel groups 1.. of the fine tiles: [grid * VB_FINE_TILES][NGF-1][16][64] and ...[16][4]
+  float *wg_v;                // [C][N + pad][64]
+  float *cons_scratch;        // [grid][3][64*64] running sums of the three consumers (accumulator order)
+  size_t cstride;
+  float *d_wxv2, *d_wxx2, *d_wvr, *d_attw, *d_attb;   // rank-1 gradients (d_wvr strided by ld_v0)
+  int ld_v0;
+  float *slab, *slab_b;
+  int slab_x, slab_X, slab_v2;   // first partial slab of coord_mlp_r_virtual.0 / coord_mlp_v_virtual.0 / edge_mlp_virtual.2
+  int NGF, ringA, ringB, nbank;   // NGF: channel groups of a fine tile
+};
+
+inline size_t vb_lds_floats(int C, int ringA, int ringB, int nbank) {
+  return (size_t)3 * RM_WORDS + VV_COUNT * H + (size_t)nbank * VB_RACC + (size_t)C * H + ((3 * C + 3) & ~3) + (size_t)ringA * VB_SLOT_A +
+         (size_t)ringB * VB_SLOT_B + VBC_CTRL;
+}
+
+__device__ __forceinline__ void vb_tile_store(float *tile, int j, int q, const Vec &v) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(tile + j * VB_RS + 16 * t + 4 * q) = v.t[t];
+}
+// row[o] += sum over the 16 items of the tile of u[o][item]: DPP row rotations, then one LDS atomic per feature
+__device__ __forceinline__ void vb_accum_items(float *row, const Vec &u, int j, int q) {
+  float s[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[t][r] = jsum_dpp(u.t[t][r]);
+  if (j == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&row[16 * t + 4 * q + r], s[t][r]);
+  }
+}
+
+template <bool BF, bool ATT>
+__global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args A) {
+  constexpr int SM = BF ? GM_BF16 : GM_X3;
+  typedef typename OperandOf<SM>::type SOp;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const VirtArgs &a = A.f;
+  const int C = a.C;
+  char *rmimg = reinterpret_cast<char *>(lds);          // V2 | WXV0 | WXX0, row-major split images (product and transpose)
+  float *vec = lds + 3 * RM_WORDS;
+  float *racc0 = vec + VV_COUNT * H;                    // [nbank][5][64]
+  float *gBc_l = racc0 + A.nbank * VB_RACC;             // [C][64]
+  float *gZ_l = gBc_l + C * H;                          // [3][C]
+  float *ringA = gZ_l + ((3 * C + 3) & ~3);
+  float *ringB = ringA + A.ringA * VB_SLOT_A;
+  int *ctrl = reinterpret_cast<int *>(ringB + A.ringB * VB_SLOT_B);
+  {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, C, 0));   // slots 0..2 are consecutive
+    u32x4 *dst = reinterpret_cast<u32x4 *>(rmimg);
+    for (int i = threadIdx.x; i < 3 * RM_BYTES / 16; i += blockDim.x) dst[i] = src[i];
+  }
+  virt_load_vecs(vec, a);
+  for (int i = threadIdx.x; i < A.nbank * VB_RACC + C * H + 3 * C; i += blockDim.x) racc0[i] = 0.f;
+  if (threadIdx.x < VBC_CTRL) ctrl[threadIdx.x] = 0;
+  __syncthreads();
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
+  const bool consumer = wv == VB_CONS_X || wv == VB_CONS_XX || wv == VB_CONS_V2;
+  const int ntiles = (a.N + 15) >> 4;
+  const int t_lo = (int)((long)blockIdx.x * ntiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  const int n_fine = min(t_hi - t_lo, VB_FINE_TILES), n_coarse = t_hi - t_lo - n_fine;
+  const int n_units = n_coarse + n_fine * A.NGF;
+  const int total = (t_hi - t_lo) * C;            // (tile, channel) operand sets = tickets per ring
+  const int cur = a.batch[t_lo * 16];             // graph whose pools this workgroup accumulates in LDS
+  const bool tanh_on = a.flags & FASTEGNN_F_TANH;
+
+#ifdef VB_NO_CONS
+  if (false) {
+#else
+  if (consumer) {
+#endif
+    // ---------------------------------------------------------------------------------------------------------
+    // consumers (as in edge_bwd_pc_kernel): one 64x64 accumulator each, two tickets of the ring per step (K = 32 rows),
+    // operands split into bf16 parts here, six bf16x3 products per 16x16 tile (one in bf16 mode); the slots are handed
+    // back as soon as their values are in registers.  X: (g_ux, v), XX: (g_uX, v) -- both read ring A, each has its own
+    // drained flag per slot --, V2: (g_vp, t) from ring B.
+    // ---------------------------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);
+    const int role = wv == VB_CONS_X ? 0 : (wv == VB_CONS_XX ? 1 : 2);
+    const int RING = role < 2 ? A.ringA : A.ringB;
+    const int slot_f = role < 2 ? VB_SLOT_A : VB_SLOT_B;
+    const float *ring = role < 2 ? ringA : ringB;
+    const int g_off = role == 1 ? VB_TILE : 0, t_off = role < 2 ? 2 * VB_TILE : VB_TILE;
+    const int *filled = ctrl + VBC_FILLED + (role < 2 ? 0 : VB_MAXRING);
+    int *drained = ctrl + VBC_DRAINED + role * VB_MAXRING;
+    f32x4 acc[4][4];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, bs_tot[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of G (bias gradient), two levels
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk) acc[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The accumulator leaves the registers every VB_FLUSH tickets (768 rows): one fp32 chain over all of a workgroup's rows
+    // (6 144 at C = 16, 12 288 at C = 32) measured 2-4x the rounding noise of round 2's 780-row chains on the cancelling
+    // layer-0 sums (test_cfg5_shape_c32_vs_oracle).  The slab is this wave's own: plain read-modify-write, L2 resident.
+    // (The running sum lives in a scratch tile of this wave in ACCUMULATOR order -- sixteen 16-byte read-modify-writes per
+    // lane off one base address, L2 resident; the [o][k] slab is written once, at the end.)
+    f32x4 *sc = reinterpret_cast<f32x4 *>(A.cons_scratch + ((size_t)blockIdx.x * 3 + role) * IMG) + l;
+    bool flushed = false;
+    auto flush = [&]() {
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk) {
+          f32x4 *d = sc + (ti * 4 + tk) * 64;
+          if (flushed) acc[ti][tk] += *d;
+          *d = acc[ti][tk];
+          acc[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        bs_tot[ti] += bs[ti];
+        bs[ti] = 0.f;
+      }
+      flushed = true;
+    };
+    int done = 0, since = 0;
+    VB2_T0()
+    while (done < total) {
+      VB2_T(2)
+      const int s0 = done % RING, r0w = done / RING;
+      const bool two = done + 1 < total;
+      const int s1 = (done + 1) % RING, r1w = (done + 1) / RING;
+      while (vb_ld(&filled[s0]) != r0w + 1) __builtin_amdgcn_s_sleep(1);
+      if (two)
+        while (vb_ld(&filled[s1]) != r1w + 1) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");   // the slot reads stay behind the flag reads
+      VB2_T(0)   // consumer: waiting for filled slots
+      const float *g0 = ring + s0 * slot_f, *g1 = ring + s1 * slot_f;
+      // lane (q,i) takes feature 16t + i of the rows 4q + e of the first (e < 4) and of the second slot (e >= 4), the same
+      // map for both operands; with the 68-float row stride the reads are conflict-free
+      float xb[4][8], xa[4][8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xb[t][e] = g0[t_off + (4 * q + e) * VB_RS + 16 * t + j];
+          xb[t][4 + e] = two ? g1[t_off + (4 * q + e) * VB_RS + 16 * t + j] : 0.f;
+          xa[t][e] = g0[g_off + (4 * q + e) * VB_RS + 16 * t + j];
+          xa[t][4 + e] = two ? g1[g_off + (4 * q + e) * VB_RS + 16 * t + j] : 0.f;
+        }
+      // every read of the slots has returned (lgkmcnt(0)) and, for the compiler, none of them may sink below the hand-back
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (l == 0) {
+        vb_st(&drained[s0], r0w + 1);
+        if (two) vb_st(&drained[s1], r1w + 1);
+      }
+      Split8 Bop[4];   // bf16 mode: only .h is used (RNE-rounded operand, one product)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if constexpr (BF) Bop[t].h = round8(xb[t]);
+        else Bop[t] = split8(xb[t]);
+      }
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        const float (&x)[8] = xa[ti];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[ti] += x[e];
+        if constexpr (BF) {
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, round8(x));
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[ti][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, Bop[t].h), acc[ti][t], 0, 0, 0);
+        } else {
+          const Split8 Aop = split8(x);
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, Aop.h), am = __builtin_bit_cast(bf16x8, Aop.m),
+                       al = __builtin_bit_cast(bf16x8, Aop.l);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, Bop[t].h), bm = __builtin_bit_cast(bf16x8, Bop[t].m),
+                         bl = __builtin_bit_cast(bf16x8, Bop[t].l);
+            f32x4 c = acc[ti][t];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+            acc[ti][t] = c;
+          }
+        }
+      }
+      done += 2;
+      since += 2;
+      if (since >= VB_FLUSH && done < total) {
+        flush();
+        since = 0;
+      }
+      VB2_T(1)   // consumer: reads, splits, products
+    }
+    VB2_TEND(16 + 4 * role)
+    // one partial slab per workgroup and weight: [o][k] row-major, o = G feature, k = T feature
+    const size_t sl = (size_t)(role == 0 ? A.slab_x : (role == 1 ? A.slab_X : A.slab_v2)) + blockIdx.x;
+    float *sa = A.slab + sl * IMG;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk) {
+        f32x4 v = acc[ti][tk];
+        if (flushed) v += sc[(ti * 4 + tk) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sa[(16 * ti + 4 * q + r) * H + 16 * tk + j] = v[r];
+      }
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const float s0 = qsum(bs_tot[ti] + bs[ti]);
+      if (q == 0) A.slab_b[sl * H + 16 * ti + j] = s0;
+    }
+#ifdef VB_NO_PROD
+  } else if (false) {
+#else
+  } else {
+#endif
+    // ---------------------------------------------------------------------------------------------------------
+    // producers: forward recompute of (tile, channel) interleaved with its adjoint.  Register budget: 256 per wave
+    // (two waves per SIMD), so the channel-invariant rows are re-read per channel (L2), the tile's g_A accumulates
+    // through memory (the rows stay in L2 between the channels of a unit) and the rank-1 gradients leave the wave per
+    // channel (DPP sum over the tile, LDS atomics) instead of living in per-lane accumulators.
+    // ---------------------------------------------------------------------------------------------------------
+    const float invC = 1.0f / (float)C;
+    const float attb0 = ATT ? a.attb[0] : 0.f;
+    float *racc = racc0 + ((wv > 3 ? wv - 1 : wv) % A.nbank) * VB_RACC;   // this producer's bank (producers: waves 0,1,2,4,5)
+    auto mm = [&](int which, const SOp &op, Vec &acc) { gemm_rm<SM, false>(rmimg + which * RM_BYTES, op, acc); };
+    auto mmT = [&](int which, const Vec &g, Vec &acc) { gemm_rm<SM, true>(rmimg + which * RM_BYTES, make_operand<SM>(g), acc); };
+    VB2_T0()
+    for (;;) {
+      int u = 0;
+      if (l == 0) u = atomicAdd(&ctrl[VBC_UNIT], 1);
+      u = __builtin_amdgcn_readfirstlane(u);
+      if (u >= n_units) break;
+      int tile, grp, c_lo, c_hi, fslot = 0;
+      if (u < n_coarse) {
+        tile = t_lo + u; grp = 0; c_lo = 0; c_hi = C;
+      } else {
+        const int uf = u - n_coarse;
+        fslot = uf / A.NGF; grp = uf % A.NGF;
+        tile = t_lo + n_coarse + fslot;
+        c_lo = grp * VB_GF; c_hi = min(C, c_lo + VB_GF);
+      }
+      const int n0 = tile * 16, nend = min(a.N, n0 + 16);
+      const int b0 = a.batch[n0], b1 = a.batch[nend - 1];
+      // pools of this unit: 0 = the workgroup's LDS accumulators (the tile lies in graph `cur`), 1 = one global atomic per
+      // (channel, feature) after the sum over the tile (the tile lies in one other graph), 2 = one atomic per row
+      const int pmode = b0 != b1 ? 2 : (b0 == cur ? 0 : 1);
+      const int n = n0 + j;
+      const bool valid = n < nend;
+      const int nc = valid ? n : nend - 1;
+      const int b = a.batch[nc];
+      const unsigned offB = (unsigned)b * C * H + 4u * q;                // [B,C,64] arrays (+ c*H)
+      const unsigned offN = (unsigned)nc * H + 4u * q;                   // [N,64] arrays
+      float gxn[3], xi[3], gx[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gxn[k] = valid ? A.g_x_out[(size_t)nc * 3 + k] : 0.f;
+        xi[k] = a.x[(size_t)nc * 3 + k];
+        gx[k] = grp == 0 ? gxn[k] : 0.f;     // the direct path x' = x + ... is counted once per tile
+      }
+      const unsigned offZ = (unsigned)b * 3u * C;                        // [B,3,C] arrays (+ k*C + c)
+      // where this unit's share of g_A / g_x goes: the arrays themselves, or a part tile (channel groups 1.. of a fine tile)
+      const size_t part = ((size_t)blockIdx.x * VB_FINE_TILES + fslot) * (A.NGF - 1) + (grp - 1);
+      float *dA = grp == 0 ? A.g_A : A.gA_part + part * 16 * H;
+      const unsigned offA = grp == 0 ? offN : (unsigned)j * H + 4u * q;
+#pragma unroll 1
+      for (int c = c_lo; c < c_hi; ++c) {
+        asm volatile("" ::: "memory");
+        VB2_T(0)   // unit / channel bookkeeping
+        const size_t cb = (size_t)c * A.cstride;
+        float vd[3], gpX[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          vd[k] = (a.Z + (k * C + c))[offZ] - xi[k];          // wave-uniform base + 32-bit lane offset (no 64-bit lane pointers)
+          gpX[k] = valid ? (A.g_poolX + (k * C + c))[offZ] : 0.f;
+        }
+        const float vr = sqrt_f(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
+        Vec vp = vload_vec(vec + VV_C2 * H, q);
+        // (requesting these two rows a channel ahead costs 32 registers across the whole body: 57 more spilled registers
+        // at 256 per wave for ~1 k of 31 k cycles -- not done)
+        Vec d_pre = vload_u(a.A, offN);
+        vadd(d_pre, vload_u(a.Bc, offB + (unsigned)c * H));
+        vaxpy(d_pre, vr, vload_vec(vec + VV_WVR * H, q));
+        VB2_T(1)   // rows arrived, pre formed
+        const Vec t = vsilu_keep_d(d_pre);        // d_pre <- silu'(pre)
+        mm(0, make_operand<SM>(t), vp);
+        VB2_T(2)   // silu, split, V2 product
+        const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
+        float att = 1.f;
+        Vec v = v0;
+        if constexpr (ATT) {
+          att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + attb0);
+          v = vscale(v0, att);
+        }
+        if (valid) vstore_u(A.wg_v + cb, offN, v);
+        VB2_T(3)   // silu, v store
+        float sx, sX;
+        Vec g_ux, g_uX;
+        {
+          // both head products first: their shared operand (48 registers in the bf16x3 form) is dead before the activations
+          Vec uxp = vload_vec(vec + VV_BXV0 * H, q), uXp = vload_vec(vec + VV_BXX0 * H, q);
+          {
+            const SOp vs = make_operand<SM>(v);
+            mm(1, vs, uxp);
+            mm(2, vs, uXp);
+          }
+          {  // coord_mlp_r_virtual head: activation, scalar head, adjoint of the activation
+            Vec ux = vsilu_keep_d(uxp);             // uxp <- silu'(uxp)
+            const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
+            sx = tanh_on ? tanh_f(sr) : sr;
+            float g_sx = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g_sx -= vd[k] * invC * gxn[k];
+            const float g_sr = tanh_on ? g_sx * (1.f - sx * sx) : g_sx;
+            vb_accum_items(racc + 0 * H, vscale(ux, g_sr), j, q);
+            g_ux = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
+          }
+          VB2_T(4)   // both head products + head x activation / rank-1 sum
+          {  // coord_mlp_v_virtual head
+            Vec uX = vsilu_keep_d(uXp);
+            const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
+            sX = tanh_on ? tanh_f(sr) : sr;
+            float g_sX = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g_sX += vd[k] * gpX[k];
+            const float g_sr = tanh_on ? g_sX * (1.f - sX * sX) : g_sX;
+            vb_accum_items(racc + 1 * H, vscale(uX, g_sr), j, q);
+            g_uX = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
+          }
+        }
+        VB2_T(5)   // head X forward + rank-1 sum
+        Vec g_v = vload_u(A.Gv + cb, offN);   // (requested ahead of the publish: it arrives under the slot wait)
+        {   // (g_ux, v) and (g_uX, v) to consumers X and XX: one slot of ring A, free once both have drained it
+          int tk = 0;
+          if (l == 0) tk = atomicAdd(&ctrl[VBC_HEAD + 0], 1);
+          tk = __builtin_amdgcn_readfirstlane(tk);
+          const int sl = tk % A.ringA, round = tk / A.ringA;
+          while (vb_ld(&ctrl[VBC_DRAINED + 0 * VB_MAXRING + sl]) != round || vb_ld(&ctrl[VBC_DRAINED + 1 * VB_MAXRING + sl]) != round)
+            __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");   // the tile stores stay behind the flag reads
+          float *slot = ringA + sl * VB_SLOT_A;
+          vb_tile_store(slot, j, q, g_ux);
+          vb_tile_store(slot + VB_TILE, j, q, g_uX);
+          vb_tile_store(slot + 2 * VB_TILE, j, q, v);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // lgkmcnt(0): the tiles are in LDS before the flag
+          if (l == 0) vb_st(&ctrl[VBC_FILLED + sl], round + 1);
+        }
+        VB2_T(6)   // publish to ring A
+        g_v = vb_mask(g_v, valid);
+        mmT(1, g_ux, g_v);
+        mmT(2, g_uX, g_v);
+        VB2_T(7)   // Gv row + two transposed head products
+        float g_vd[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g_vd[k] = -sx * invC * gxn[k] + sX * gpX[k];
+        Vec g_v0 = g_v;
+        if constexpr (ATT) {
+          const float g_a = vdot(g_v, v0);
+          const float g_z = g_a * att * (1.f - att);
+          vb_accum_items(racc + 3 * H, vscale(v0, g_z), j, q);
+          const float sz = jsum(q == 0 ? g_z : 0.f);
+          if (l == 0) atomicAdd(&racc[4 * H], sz);
+          g_v0 = vscale(g_v, att);
+          vaxpy(g_v0, g_z, vload_vec(vec + VV_ATT * H, q));
+        }
+        Vec g_t = vzero(), ga = vzero();
+        {
+          const Vec g_vp = vmul(g_v0, vp);
+          {   // (g_vp, t) to consumer V2
+            int tk = 0;
+            if (l == 0) tk = atomicAdd(&ctrl[VBC_HEAD + 1], 1);
+            tk = __builtin_amdgcn_readfirstlane(tk);
+            const int sl = tk % A.ringB, round = tk / A.ringB;
+            while (vb_ld(&ctrl[VBC_DRAINED + 2 * VB_MAXRING + sl]) != round) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            float *slot = ringB + sl * VB_SLOT_B;
+            vb_tile_store(slot, j, q, g_vp);
+            vb_tile_store(slot + VB_TILE, j, q, t);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (l == 0) vb_st(&ctrl[VBC_FILLED + VB_MAXRING + sl], round + 1);
+          }
+          VB2_T(8)   // g_vp + publish to ring B
+          // requested here, consumed after the product: the tile's running g_A
+          if (c > c_lo) ga = vload_u(dA, offA);
+          mmT(0, g_vp, g_t);
+        }
+        VB2_T(9)   // V2^T product
+        const Vec g_pre = vmul(g_t, d_pre);
+        vadd(ga, g_pre);   // g_A of the tile accumulates through memory (the same lane re-reads its own row)
+        if (valid) vstore_u(dA, offA, ga);
+        vb_accum_items(racc + 2 * H, vscale(g_pre, vr), j, q);
+        const float g_vr = vdot(g_pre, vload_vec(vec + VV_WVR * H, q));
+        const float ivr = vr > 0.f ? g_vr * rcp_f(vr) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          g_vd[k] += ivr * vd[k];
+          gx[k] -= g_vd[k];
+        }
+        // pools over the nodes of the tile: g_Bc[b,c,:] += g_pre, g_Zp[b,:,c] += g_vd (g_pre of a masked lane is zero)
+        if (pmode < 2) {
+          float pz[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pz[k] = jsum((valid && q == 0) ? g_vd[k] : 0.f);
+          vb_accum_items(pmode == 0 ? gBc_l + c * H : A.g_Bc + ((size_t)b0 * C + c) * H, g_pre, j, q);
+          if (l == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              if (pmode == 0) atomicAdd(&gZ_l[k * C + c], pz[k]);
+              else atomicAdd(&A.g_Zp[((size_t)b0 * 3 + k) * C + c], pz[k]);
+            }
+          }
+        } else {
+          if (valid && q == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) atomicAdd(&A.g_Zp[((size_t)b * 3 + k) * C + c], g_vd[k]);
+          }
+          if (valid) {
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                atomicAdd(&A.g_Bc[((size_t)b * C + c) * H + 16 * t2 + 4 * q + r], g_pre.t[t2][r]);
+          }
+        }
+        VB2_T(10)   // g_pre consumers: g_A through memory, w_vr, pools
+      }
+      if (valid && q == 0) {
+        if (grp == 0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) A.g_x[(size_t)n * 3 + k] = gx[k];
+        } else {
+          *reinterpret_cast<f32x4 *>(A.gx_part + (part * 16 + j) * 4) = f32x4{gx[0], gx[1], gx[2], 0.f};
+        }
+      }
+    }
+    VB2_TEND(0)
+  }
+  VB2_T0()
+  __syncthreads();
+  VB2_T(11)   // wait for the rest of the workgroup
+  VB2_TEND(consumer ? 12 : 0)
+  // per-graph pools of graph `cur` and the rank-1 weight gradients: one atomic set per workgroup
+  for (int i = threadIdx.x; i < C * H; i += blockDim.x) atomicAdd(&A.g_Bc[(size_t)cur * C * H + i], gBc_l[i]);
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) atomicAdd(&A.g_Zp[(size_t)cur * 3 * C + i], gZ_l[i]);
+  if (threadIdx.x < H) {
+    const int o = threadIdx.x;
+    float s5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int bk = 0; bk < A.nbank; ++bk) {
+      const float *r = racc0 + bk * VB_RACC;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s5[k] += r[k * H + o];
+      s5[4] += r[4 * H];
+    }
+    atomicAdd(&A.d_wxv2[o], s5[0]);
+    atomicAdd(&A.d_wxx2[o], s5[1]);
+    atomicAdd(&A.d_wvr[(size_t)o * A.ld_v0], s5[2]);   // w_vr is column 2H of edge_mlp_virtual.0.weight
+    if constexpr (ATT) {
+      atomicAdd(&A.d_attw[o], s5[3]);
+      if (o == 0) atomicAdd(A.d_attb, s5[4]);
+    }
+  }
+}
+
+// g_A += parts, g_x += parts over the fine tiles of every workgroup of virt_bwd_pc_kernel (same tile ranges), fixed order
+__global__ __launch_bounds__(256) void virt_bwd_combine_kernel(float *g_A, float *g_x, const float *gA_part, const float *gx_part,
+                                                               int N, int nparts, int grid_pc) {
+  const int wg = (int)blockIdx.x / VB_FINE_TILES, fslot = (int)blockIdx.x % VB_FINE_TILES;
+  const int ntiles = (N + 15) >> 4;
+  const int t_lo = (int)((long)wg * ntiles / grid_pc), t_hi = (int)((long)(wg + 1) * ntiles / grid_pc);
+  const int n_fine = min(t_hi - t_lo, VB_FINE_TILES);
+  if (fslot >= n_fine) return;
+  const int tile = t_hi - n_fine + fslot;
+  const size_t p0 = (size_t)blockIdx.x * nparts;
+  const int row = threadIdx.x >> 4, c4 = threadIdx.x & 15;   // 16 rows x 16 float4
+  const int n = tile * 16 + row;
+  if (n >= N) return;
+  f32x4 s = reinterpret_cast<const f32x4 *>(g_A + (size_t)n * H)[c4];
+  for (int p = 0; p < nparts; ++p) s += reinterpret_cast<const f32x4 *>(gA_part + ((p0 + p) * 16 + row) * H)[c4];
+  reinterpret_cast<f32x4 *>(g_A + (size_t)n * H)[c4] = s;
+  if (c4 < 3) {
+    float sx = g_x[(size_t)n * 3 + c4];
+    for (int p = 0; p < nparts; ++p) sx += gx_part[((p0 + p) * 16 + row) * 4 + c4];
+    g_x[(size_t)n * 3 + c4] = sx;
+  }
+}
+
+bool virt_backward_uses_pc(const fastegnn_layer_t *L) {
+  static const bool off = getenv("FASTEGNN_VIRT_BWD_OLD") && atoi(getenv("FASTEGNN_VIRT_BWD_OLD")) != 0;
+  return !off && L->C >= 1 && L->C <= 32 && !has(L, FASTEGNN_F_RF) && !has(L, FASTEGNN_F_EGNN);
+}
+// floats of wg_virt: v | Gv ([C][N + pad][64] each) | parts of g_A and g_x
+size_t virt_pc_wg_floats(size_t N, size_t C) {
+  const size_t NGF = (C + VB_GF - 1) / VB_GF;
+  return 2 * (N + WGV_PAD) * C * H + (size_t)256 * VB_FINE_TILES * (NGF - 1) * 16 * (H + 4) + (size_t)256 * 3 * IMG;
+}
+
+int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
+  FE_REQUIRE(L->h && L->A && L->x && L->vel && L->aggm && L->npre && L->batch && L->wpack, "virt_backward: null saved buffer");
+  FE_REQUIRE(L->g_h_out && L->g_x_out && L->g_h && L->g_x && L->g_A && L->g_aggm && L->g_aggx && L->g_svel && L->wg_node &&
+                 L->grads && L->wg_slab,
+             "virt_backward: null gradient buffer");
+  FE_REQUIRE(L->Bc && L->Z && L->g_poolV && L->g_poolX && L->g_Bc && L->g_Zp && L->wg_virt, "virt_backward: virtual buffers null");
+  const int N = L->N, C = L->C;
+  (void)hipMemsetAsync(L->g_Bc, 0, (size_t)L->B * C * H * sizeof(float), st);
+  (void)hipMemsetAsync(L->g_Zp, 0, (size_t)L->B * 3 * C * sizeof(float), st);
+  if (N == 0) return check_launch("virt_backward(memset)");
+  const bool bf = has(L, FASTEGNN_F_BF16), att = has(L, FASTEGNN_F_ATTENTION);
+  float *const *g = L->grads;
+  FE_REQUIRE(!att || (g[FASTEGNN_P_ATTV_W] && g[FASTEGNN_P_ATTV_B]), "virt_backward: attention grads null");
+  FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
+  const size_t cstride = ((size_t)N + WGV_PAD) * H;
+  float *wg_v = L->wg_virt, *Gv = L->wg_virt + cstride * C;
+  const int NGF = (C + VB_GF - 1) / VB_GF;
+  float *gA_part = Gv + cstride * C, *gx_part = gA_part + (size_t)256 * VB_FINE_TILES * (NGF - 1) * 16 * H;
+  float *wg_t3 = L->wg_node, *wg_gnp = L->wg_node + (size_t)N * H;
+  const int ntiles = cdiv(N, 16);
+  int rc;
+  {   // B4a
+    VirtNodeArgs a{L->g_h_out, L->npre, L->g_x_out, L->vel, L->aggx, L->wpack, wg_t3, wg_gnp, L->g_h, L->g_aggm, L->g_aggx,
+                   L->g_svel, L->g_sgrav, N, L->flags, {L->gravity[0], L->gravity[1], L->gravity[2]}};
+    int grid = cdiv(ntiles, VB_NODE_WAVES);
+    if (grid > 256) grid = 256;
+    ProfScope ps(K_VIRT_BWD_NODE, st);
+    if (bf) hipLaunchKernelGGL((virt_bwd_node_kernel<true>), dim3(grid), dim3(64 * VB_NODE_WAVES), 3 * IMG * sizeof(float), st, a);
+    else hipLaunchKernelGGL((virt_bwd_node_kernel<false>), dim3(grid), dim3(64 * VB_NODE_WAVES), 3 * IMG * sizeof(float), st, a);
+  }
+  if ((rc = check_launch("virt_bwd_node_kernel"))) return rc;
+  {   // B4b
+    const int ngroups = cdiv(C, VB_GV_CH);
+    int nranges = 256 / ngroups;
+    const int max_ranges = cdiv(ntiles, VB_GV_WAVES);   // at least one tile per wave where possible
+    if (nranges > max_ranges) nranges = max_ranges;
+    if (nranges < 1) nranges = 1;
+    VirtGvArgs a{wg_gnp, L->g_poolV, L->wpack, L->batch, Gv, cstride, N, C, ngroups, nranges};
+    const size_t lds = (size_t)VB_GV_CH * RM_BYTES;
+    ProfScope ps(K_VIRT_BWD_GV, st);
+    if (bf) hipLaunchKernelGGL((virt_bwd_gv_kernel<true>), dim3(ngroups * nranges), dim3(64 * VB_GV_WAVES), lds, st, a);
+    else hipLaunchKernelGGL((virt_bwd_gv_kernel<false>), dim3(ngroups * nranges), dim3(64 * VB_GV_WAVES), lds, st, a);
+  }
+  if ((rc = check_launch("virt_bwd_gv_kernel"))) return rc;
+  // the three in-kernel weight gradients and the per-channel node_mlp.0 blocks: a batch of their own, upper half of the slabs
+  WgradBatch bb(L->wg_slab, st, bf, WG_SLABS / 2, WG_SLABS / 2);
+  VirtBwd2Args A;
+  A.f = make_virt_args(L);
+  A.g_x_out = L->g_x_out; A.g_poolX = L->g_poolX; A.Gv = Gv;
+  A.g_x = L->g_x; A.g_A = L->g_A; A.g_Bc = L->g_Bc; A.g_Zp = L->g_Zp;
+  A.gA_part = gA_part; A.gx_part = gx_part; A.wg_v = wg_v; A.cstride = cstride;
+  A.cons_scratch = gx_part + (size_t)256 * VB_FINE_TILES * (NGF - 1) * 16 * 4;
+  A.ld_v0 = 2 * H + 1 + C;
+  A.d_wxv2 = g[FASTEGNN_P_CRV2_W]; A.d_wxx2 = g[FASTEGNN_P_CVV2_W];
+  A.d_wvr = g[FASTEGNN_P_VIRT0_W] + 2 * H;
+  A.d_attw = g[FASTEGNN_P_ATTV_W]; A.d_attb = g[FASTEGNN_P_ATTV_B];
+  A.NGF = NGF;
+  int grid = ntiles < 256 ? ntiles : 256;   // one workgroup per CU (LDS), each with an equal share of the tiles
+  if ((rc = bb.add_slabs(g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], grid, &A.slab_x))) return rc;
+  if ((rc = bb.add_slabs(g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], grid, &A.slab_X))) return rc;
+  if ((rc = bb.add_slabs(g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], grid, &A.slab_v2))) return rc;
+  A.slab = bb.tab.slab; A.slab_b = bb.tab.slab_b;
+  // rings: as many slots as the 160 KB of LDS leave (three per ring at C <= 32)
+  A.ringA = 3; A.ringB = 3; A.nbank = 1;
+  while (vb_lds_floats(C, A.ringA, A.ringB, 1) * sizeof(float) > 160 * 1024 && A.ringB > 2) --A.ringB;
+  while (vb_lds_floats(C, A.ringA, A.ringB, 1) * sizeof(float) > 160 * 1024 && A.ringA > 2) --A.ringA;
+  while (A.nbank < VB_MAXBANK && vb_lds_floats(C, A.ringA, A.ringB, A.nbank + 1) * sizeof(float) <= 160 * 1024) ++A.nbank;
+  const size_t lds = vb_lds_floats(C, A.ringA, A.ringB, A.nbank) * sizeof(float);
+  FE_REQUIRE(lds <= 160 * 1024, "virt_backward: LDS budget exceeded");
+  {
+    ProfScope ps(K_VIRT_BWD, st);
+    const dim3 g3(grid), b3(64 * VB_WAVES);
+    if (bf) { if (att) hipLaunchKernelGGL((virt_bwd_pc_kernel<true, true>), g3, b3, lds, st, A); else hipLaunchKernelGGL((virt_bwd_pc_kernel<true, false>), g3, b3, lds, st, A); }
+    else { if (att) hipLaunchKernelGGL((virt_bwd_pc_kernel<false, true>), g3, b3, lds, st, A); else hipLaunchKernelGGL((virt_bwd_pc_kernel<false, false>), g3, b3, lds, st, A); }
+  }
+  if ((rc = check_launch("virt_bwd_pc_kernel"))) return rc;
+  if (NGF > 1) {
+    hipLaunchKernelGGL(virt_bwd_combine_kernel, dim3(grid * VB_FINE_TILES), dim3(256), 0, st, L->g_A, L->g_x, gA_part, gx_part, N, NGF - 1, grid);
+    if ((rc = check_launch("virt_bwd_combine_kernel"))) return rc;
+  }
+  const int ld_n0 = 2 * H + H * C + L->na;
+  // node_mlp.0 block of channel c: (g_np, v[:, c]) -- one batch slice per channel
+  if ((rc = bb.add(wg_gnp, H, wg_v, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, (long)cstride, 1))) return rc;
+  if ((rc = bb.finish())) return rc;
+  WgradBatch local(L->wg_slab, st);
+  WgradBatch &wb = shared ? *shared : local;
+  wb.round = bf;
+  // node_mlp.2
+  if ((rc = wb.add(L->g_h_out, H, wg_t3, H, N, g[FASTEGNN_P_NODE2_W], H, 0, 1, g[FASTEGNN_P_NODE2_B]))) return rc;
+  // node_mlp.0: [h | agg | flat(v) | node_attr]
+  if ((rc = wb.add(wg_gnp, H, L->h, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 0, 1, g[FASTEGNN_P_NODE0_B]))) return rc;
+  if ((rc = wb.add(wg_gnp, H, L->aggm, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, H, 1, nullptr))) return rc;
+  if (!shared && (rc = wb.finish())) return rc;
+  if (L->na > 0) {
+    if ((rc = launch_wgrad_small(wg_gnp, H, L->node_attr, L->na, L->na, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H + H * C, st))) return rc;
+    if (L->g_node_attr)
+      if ((rc = launch_dgrad_small(wg_gnp, N, L->na, L->params[FASTEGNN_P_NODE0_W], ld_n0, 2 * H + H * C, L->g_node_attr, 1, st))) return rc;
+  }
+  return FASTEGNN_OK;
+}
+
+}  // namespace fe
+
+#ifdef FE_STAMP
+extern "C" int fastegnn_debug_read_vb2_stamps(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::g_vb2_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(fe::g_vb2_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif

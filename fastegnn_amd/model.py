@@ -347,7 +347,7 @@ class _FastEGNNFunction(torch.autograd.Function):
             g_poolV=(B, Cn, H), g_poolX=(B, 3, Cn), g_Bc=(B, Cn, H), g_Zp=(B, 3, Cn), g_xbar=(B, 4),
             g_A=(N, H), g_P=(N, H), g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,),
             g_QXe=(max(E, 1), K.QX_LD), g_QX_src=(N, K.QX_LD), g_xrow=(N, 3),
-            wg_edge=(lib.fastegnn_wg_edge_floats(E),), wg_virt=(lib.fastegnn_wg_virt_floats(N, Cn),),
+            wg_edge=(lib.fastegnn_wg_edge_floats(E),), wg_virt=(lib.fastegnn_wg_virt_floats_for(N, Cn, spec.flags),),
             wg_node=(lib.fastegnn_wg_node_floats(N, B, Cn),),
             wg_slab=(lib.fastegnn_wg_slab_floats(),)))
         for i in reversed(range(spec.n_layers)):

@@ -206,9 +206,14 @@ size_t fastegnn_wg_slab_floats(void);
 size_t fastegnn_wg_edge_floats(int32_t E);
 size_t fastegnn_wg_virt_floats(int32_t N, int32_t C);
 size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C);
+/* wg_virt for a layer with these FASTEGNN_F_* flags: the FastEGNN wiring with C <= 32 contracts three of the virtual
+ * stage's weight gradients inside the workgroup and keeps two [C][N+16][64] arrays instead of five; the flag-less
+ * query above is the upper bound over all wirings */
+size_t fastegnn_wg_virt_floats_for(int32_t N, int32_t C, int32_t flags);
 /* floats of all backward scratch arrays of fastegnn_layer_t together (g_poolV ... wg_slab), each array rounded up to
  * a multiple of 4 floats so that one allocation can be carved into 16-byte aligned pieces */
 size_t fastegnn_backward_scratch_floats(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C);
+size_t fastegnn_backward_scratch_floats_for(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C, int32_t flags);
 /* struct sizes, so that a foreign-language binding can verify its mirror of the descriptors */
 size_t fastegnn_sizeof_layer(void);
 size_t fastegnn_sizeof_graph(void);
