@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak (= fp32 vector peak)
 PEAK_MFMA_BF16_TFLOPS = 2500.0 # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak
+BF16X3_CEILING_TFLOPS = 224.0  # measured chain of bf16x3 64x64 products (fp32-equivalent FLOPs), DESIGN.md section 4
 H = 64
 UNIT = 2 * H * H               # FLOPs of one 64x64 mat-vec
 
@@ -206,26 +207,42 @@ def loss_fn(loc, vloc, target):
 
 
 def kernel_model(N, E, B, C, L, gravity=True):
-    """Algorithmic (FLOPs, bytes) of each kernel summed over ONE step (L layers, fwd+bwd).
-    FLOPs count the 64x64 contractions actually required (no tile padding); bytes count every
-    operand once (DESIGN.md 'Roofline accounting')."""
+    """Per-LAUNCH algorithmic work of each kernel: name -> (FLOPs, bytes or None).
+
+    FLOPs: the 64x64 contractions the stage requires, no tile padding (UNIT = one 64x64 mat-vec).
+    bytes: SURVEY.md section 8d only -- the edge-scatter formula 280 E + 540 N (forward; the backward counts twice that,
+    'bytes_bwd = 2 bytes_fwd') and the node/virtual figure of 0.82 KB per node and layer (forward; twice for the
+    backward).  Kernels for which section 8d states no byte figure get None: their operand arrays exist because of
+    implementation choices, and a GB/s figure computed from them is not a roofline number (`operand_bytes` below reports
+    what the streaming helper kernels read, separately)."""
     NC = N * C
     heads = 2 if gravity else 1
     f = {}
-    f["edge_fwd_kernel"] = (L * E * 2 * UNIT, L * (280 * E + 540 * N))
+    f["edge_fwd_kernel"] = (E * 2 * UNIT, 280 * E + 540 * N)
     # edge backward: 2 recomputed + 2 transposed layers + the two in-workgroup weight-gradient contractions per edge
-    f["edge_bwd_kernel"] = (L * E * 6 * UNIT, L * (E * (8 + 8 + 272 + 12 + 272 + 32) + N * (256 * 2 + 12 * 2 + 268)))
-    f["virt_fwd_kernel"] = (L * (NC * 4 + N * 3) * UNIT, L * N * (5 * 256 + 60))
-    f["virt_bwd_kernel"] = (L * (NC * 7 + N * 3) * UNIT, L * (NC * 5 * 256 + N * (8 * 256 + 60)))
-    f["node_pre_fwd_kernel"] = (L * N * (3 + heads) * UNIT, L * N * (256 + 12 + 256 + 272 + 256 + 8))
-    f["node_pre_bwd_kernel"] = (L * N * (3 + 2 * heads) * UNIT, L * N * (256 * 6 + 272 + 48))
-    # wgrad launches per layer: virt (3 x NC + C x N for the per-channel node_mlp block),
-    # node-level (N x (3 + 3 + heads)), graph-level (B*C x 5); the edge stage contracts in edge_bwd
-    m_rows = L * (3 * NC + C * N + (6 + heads) * N + 5 * B * C)
-    f["wgrad_tn_kernel"] = (m_rows * UNIT, m_rows * 512)
-    f["wgrad_small_kernel"] = (L * E * 2 * 64 * 3, L * E * (272 + 32))
-    f["edge_col_reduce_kernel"] = (0, L * (E * (272 + 4) + N * 272))
+    f["edge_bwd_kernel"] = (E * 6 * UNIT, 2 * (280 * E + 540 * N))
+    f["virt_fwd_kernel"] = ((NC * 4 + N * 3) * UNIT, 820 * N)
+    # virtual backward (producer/consumer form): 3 recomputed + 3 transposed products + 3 in-workgroup weight gradients
+    # per (node, channel); the W3c^T product and the node-MLP adjoint are kernels of their own
+    f["virt_bwd_kernel"] = (NC * 9 * UNIT, 2 * 820 * N)
+    f["virt_bwd_gv_kernel"] = (NC * UNIT, None)
+    f["virt_bwd_node_kernel"] = (N * 3 * UNIT, None)
+    f["node_pre_fwd_kernel"] = (N * (3 + heads) * UNIT, None)
+    f["node_pre_bwd_kernel"] = (N * (3 + 2 * heads) * UNIT, None)
     return f
+
+
+def operand_bytes(N, E, B, C, gravity=True):
+    """Bytes the streaming helper kernels must read per launch (distinct operand arrays, each counted once)."""
+    heads = 2 if gravity else 1
+    return {
+        # per-edge d/d(Q|x) rows + the inverted index, one output row per node
+        "edge_col_reduce_kernel": E * (272 + 4) + N * (272 + 4),
+        # layer-wide batch: g_h_out t3 g_np h aggm g_P g_A + velocity / gravity operands ([N,64]) and g_QX ([N,68])
+        "wgrad_tn_kernel[layer batch]": N * 256 * (7 + heads) + N * 272 + 5 * B * C * 512,
+        # node_mlp.0 blocks of the C channels: v [C][N][64] once, g_np [N,64] once
+        "wgrad_tn_kernel[v job]": N * 256 * (C + 1),
+    }
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -464,16 +481,26 @@ def main():
     K.profile_collect()
     prof_steps = args.steps
     prof_taken = False
+    eager_ms = None
     if use_graph:
         # per-kernel durations from an eager pass (events cannot be timed inside a captured graph), then the step is
         # captured once and the timed region replays it
         prof_steps = min(args.steps, 20)
+        t0 = time.perf_counter()
         for _ in range(prof_steps):
             step()
         sync()
+        eager_ms = (time.perf_counter() - t0) / prof_steps * 1e3      # eager launches, per-kernel events on (slightly pessimistic)
         K.lib().fastegnn_profile_enable(0)
         prof = K.profile_collect()
         prof_taken = True
+        # the same eager step without the event pairs around every kernel: what a training loop over frames with varying
+        # edge counts pays (a captured graph cannot be replayed for a different E)
+        t0 = time.perf_counter()
+        for _ in range(prof_steps):
+            step()
+        sync()
+        eager_ms = min(eager_ms, (time.perf_counter() - t0) / prof_steps * 1e3)
         gstream = torch.cuda.Stream(dev)
         gstream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(gstream):
@@ -552,25 +579,38 @@ def main():
         # kernel model of what THIS rank ran (sharded: its 1/world share of the rows and edges)
         kN, kE = (shard["plan"].nloc, shard["edge_index"].size(1)) if sharded else (N, E)
         km = kernel_model(kN, kE, B, C, L, gravity=cfg["gravity"] is not None)
+        ob = operand_bytes(kN, kE, B, C, gravity=cfg["gravity"] is not None)
         kernels = {}
         for name, (ms, cnt) in prof.items():
             per_step = ms / prof_steps
+            launch_s = ms / cnt * 1e-3
             ent = {"ms_per_step": round(per_step, 4), "launches_per_step": cnt / prof_steps,
                    "avg_launch_ms": round(ms / cnt, 5)}
             if name in km:
                 fl, by = km[name]
-                ent["tflops"] = round(fl / (per_step * 1e-3) / 1e12, 3)
-                ent["gbs"] = round(by / (per_step * 1e-3) / 1e9, 1)
+                ent["tflops"] = round(fl / launch_s / 1e12, 3)                 # algorithmic FLOPs per launch / launch duration
+                if by is not None:
+                    ent["gbs"] = round(by / launch_s / 1e9, 1)                   # SURVEY 8d algorithmic bytes per launch
+            if name == "edge_col_reduce_kernel":
+                ent["operand_gbs"] = round(ob[name] / launch_s / 1e9, 1)
+            if name == "wgrad_tn_kernel":   # two launches per layer: the layer-wide batch and the per-channel node_mlp.0 job
+                tot = ob["wgrad_tn_kernel[layer batch]"] + ob["wgrad_tn_kernel[v job]"]
+                ent["operand_gbs"] = round(tot / (2 * launch_s) / 1e9, 1)
             kernels[name] = ent
         dom = max((n for n in kernels if n in km), key=lambda n: kernels[n]["ms_per_step"])
         fl, by = km[dom]
         peak_mfma = PEAK_MFMA_BF16_TFLOPS if dtype == "bf16" else PEAK_MFMA_F32_TFLOPS
-        t_mfma, t_hbm = fl / (peak_mfma * 1e12), by / (PEAK_HBM_GBS * 1e9)
+        t_mfma = fl / (peak_mfma * 1e12)
+        t_hbm = (by or 0) / (PEAK_HBM_GBS * 1e9)
         tr, tr_file = latest_traffic()
         traffic = tr.get(dom, {}).get("hbm_bytes_per_launch") if (args.config == "cfg4" and not sharded) else None
         if t_mfma >= t_hbm:
             roof = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak_mfma,
                     "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / peak_mfma, 4), "traffic": traffic}
+            if dtype != "bf16":
+                # the fp32-grade products of this kernel are bf16x3 on the matrix pipe; a bare chain of them reaches
+                # 224 TFLOP/s fp32-equivalent on this part (tools/gpu_bf3.py): the kernel's real ceiling
+                roof["frac_of_bf16x3_ceiling"] = round(kernels[dom]["tflops"] / BF16X3_CEILING_TFLOPS, 4)
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["gbs"], "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic}
@@ -594,7 +634,8 @@ def main():
             "metric": "graphs/sec (fwd+bwd), " + ("Water-3D-like 100k-node frame" if args.config == "cfg4" else args.config),
             "value": round(value, 4),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if sharded else "weak",
+            "ms_per_step": round(ms_per_step, 3), "eager_ms_per_step": round(eager_ms if eager_ms is not None else ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{cfg['text']}; {L}-layer FastEGNN H=64, {what}, CSR build "
                                    + ("cached" if args.cache_graph else "inside the step"),

@@ -420,10 +420,17 @@ __device__ __forceinline__ bf16x8 rm_frag(const char *img, int part, int t, int 
 // The eight (k-step, out-tile) groups of a product are software-pipelined by hand: the three fragments of group g+1 are
 // requested BEFORE the six MFMAs of group g are issued (sched_group_barrier pins the order; the compiler's own schedule was
 // "6 MFMA, 6 reads, wait" -- every group then waited a full LDS round trip with an idle matrix pipe behind it).  Costs 12
-// more live registers; -DFE_NO_GEMM_PIPE restores the compiler's order.
-template <bool TR>
+// more live registers: PIPE = false (edge_bwd_pc_kernel, whose producers are at their register limit: 10 spilled registers
+// and 3.29 instead of 3.21 ms per step with it) or -DFE_NO_GEMM_PIPE restore the compiler's order.  Measured on one box
+// (tools/gpu_ab.sh): virt_bwd 4.15 -> 3.94 ms per step, virt_fwd 1.81 -> 1.77.
+template <bool TR, bool PIPE = true>
 __device__ __forceinline__ void gemm64_x3_rm(const char *img, const Split &in, Vec &acc) {
 #ifdef FE_NO_GEMM_PIPE
+  constexpr bool pipe = false;
+#else
+  constexpr bool pipe = PIPE;
+#endif
+  if constexpr (!pipe) {
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -439,7 +446,7 @@ __device__ __forceinline__ void gemm64_x3_rm(const char *img, const Split &in, V
       acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xm, acc.t[t], 0, 0, 0);
       acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc.t[t], 0, 0, 0);
     }
-#else
+  } else {
   __builtin_amdgcn_sched_barrier(0);
   bf16x8 fr[2][3];
 #pragma unroll
@@ -466,7 +473,7 @@ __device__ __forceinline__ void gemm64_x3_rm(const char *img, const Split &in, V
     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // 6 MFMAs
   }
   __builtin_amdgcn_sched_barrier(0);
-#endif
+  }
 }
 template <bool TR>
 __device__ __forceinline__ void gemm64_b1_rm(const char *img, const BfOp &in, Vec &acc) {
@@ -529,10 +536,10 @@ __device__ __forceinline__ void gemm_op(const void *img, int i, const typename O
 // a product on an fp32 image (fp32-input MFMA) inside a kernel of form MODE: in bf16 mode the activation is rounded
 // (the image already holds bf16-representable weights), so the product has the bf16-mode semantics exactly
 // product (TR = false) or transposed product (TR = true) on a row-major split image, forms GM_X3 / GM_BF16
-template <int MODE, bool TR>
+template <int MODE, bool TR, bool PIPE = true>
 __device__ __forceinline__ void gemm_rm(const char *img, const typename OperandOf<MODE>::type &in, Vec &acc) {
   static_assert(MODE == GM_X3 || MODE == GM_BF16, "row-major images hold bf16 parts");
-  if constexpr (MODE == GM_X3) gemm64_x3_rm<TR>(img, in, acc);
+  if constexpr (MODE == GM_X3) gemm64_x3_rm<TR, PIPE>(img, in, acc);
   else gemm64_b1_rm<TR>(img, in, acc);
 }
 template <int MODE>

@@ -884,7 +884,10 @@ constexpr int PC_PROD = 6;                  // producer waves
 #define FE_PC_RING 4
 #endif
 constexpr int PC_RING = FE_PC_RING;                  // slots per ring; one ring per weight (kind 0: edge_mlp.2, kind 1: coord_mlp_r.0)
-constexpr int PC_FLUSH = 48;                // tickets (16-edge operand sets) a consumer accumulates in registers between two scratch updates
+#ifndef FE_PC_FLUSH
+#define FE_PC_FLUSH 48
+#endif
+constexpr int PC_FLUSH = FE_PC_FLUSH;       // tickets (16-edge operand sets) a consumer accumulates in registers between two scratch updates
 constexpr int PC_RS = 68;                   // row stride of a slot tile
 constexpr int PC_SLOT = 2 * 16 * PC_RS;     // floats per slot: G tile | T tile
 constexpr int PC_IMG_FLOATS = 2 * RM_WORDS;   // W2 | WX1 as row-major split images: each serves the product and its transpose

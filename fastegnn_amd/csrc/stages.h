@@ -107,7 +107,7 @@ __device__ __forceinline__ void gemm_i(const void *img, int i, const Vec &in, Ve
 // two row-major images W2 | WX1 read plain or transposed (RM = true, edge_bwd: half the LDS, which its rings take)
 template <int MODE, int I, bool RM>
 __device__ __forceinline__ void gemm_e(const void *img, const Vec &in, Vec &acc) {
-  if constexpr (RM) gemm_rm<MODE, (I >= 2)>(static_cast<const char *>(img) + (I & 1) * RM_BYTES, make_operand<MODE>(in), acc);
+  if constexpr (RM) gemm_rm<MODE, (I >= 2), false>(static_cast<const char *>(img) + (I & 1) * RM_BYTES, make_operand<MODE>(in), acc);
   else gemm_i<MODE>(img, I, in, acc);
 }
 

@@ -161,7 +161,10 @@ __global__ __launch_bounds__(64 * VB_GV_WAVES) void virt_bwd_gv_kernel(VirtGvArg
 // VB_FINE_TILES tiles of the workgroup's run in units of VB_GF channels, so that the producers finish within a few channels
 // of each other (with whole tiles only, the last tile of the slowest producer was 10 % of the kernel: phase stamps).  The
 // channel groups 1.. of a fine tile write their share of g_A / g_x to a small `part` tile; virt_bwd_combine_kernel adds them.
-constexpr int VB_FLUSH = 48;      // tickets (16-row operand sets) a consumer accumulates in registers between two slab updates
+#ifndef FE_VB_FLUSH
+#define FE_VB_FLUSH 48
+#endif
+constexpr int VB_FLUSH = FE_VB_FLUSH;   // tickets (16-row operand sets) a consumer accumulates in registers between two slab updates
 constexpr int VB_FINE_TILES = 3;
 constexpr int VB_GF = 2;
 constexpr int VB_WAVES = 8;
@@ -283,14 +286,22 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
     // layer-0 sums (test_cfg5_shape_c32_vs_oracle).  The slab is this wave's own: plain read-modify-write, L2 resident.
     // (The running sum lives in a scratch tile of this wave in ACCUMULATOR order -- sixteen 16-byte read-modify-writes per
     // lane off one base address, L2 resident; the [o][k] slab is written once, at the end.)
-    f32x4 *sc = reinterpret_cast<f32x4 *>(A.cons_scratch + ((size_t)blockIdx.x * 3 + role) * IMG) + l;
+    // (wave-uniform base + constant on the scalar side, ONE 32-bit lane offset: per-tile 64-bit lane pointers get hoisted
+    // out of the ticket loop and spilled)
+    char *scb = reinterpret_cast<char *>(A.cons_scratch + ((size_t)blockIdx.x * 3 + role) * IMG);
+    const unsigned sco = (unsigned)l * 16u;
+    auto scp = [&](int ti, int tk) {
+      char *b = scb + (size_t)((ti * 4 + tk) * 64 * 16);
+      asm volatile("" : "+s"(b));
+      return reinterpret_cast<f32x4 *>(b + sco);
+    };
     bool flushed = false;
     auto flush = [&]() {
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
         for (int tk = 0; tk < 4; ++tk) {
-          f32x4 *d = sc + (ti * 4 + tk) * 64;
+          f32x4 *d = scp(ti, tk);
           if (flushed) acc[ti][tk] += *d;
           *d = acc[ti][tk];
           acc[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -386,9 +397,13 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
 #pragma unroll
       for (int tk = 0; tk < 4; ++tk) {
         f32x4 v = acc[ti][tk];
-        if (flushed) v += sc[(ti * 4 + tk) * 64];
+        if (flushed) v += *scp(ti, tk);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sa[(16 * ti + 4 * q + r) * H + 16 * tk + j] = v[r];
+        for (int r = 0; r < 4; ++r) {
+          char *b = reinterpret_cast<char *>(sa) + (size_t)(((16 * ti + r) * H + 16 * tk) * 4);
+          asm volatile("" : "+s"(b));
+          *reinterpret_cast<float *>(b + (unsigned)((4 * q * H + j) * 4)) = v[r];
+        }
       }
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {

@@ -135,6 +135,51 @@ def test_bf16_cfg3_shape_equivariance_and_mirror():
     assert rel_err(loc0.cpu() - x0, lm - x0) < 2e-2
 
 
+def test_bf16_cfg3_shape_backward_vs_mirror():
+    """BASELINE configs[2] shape, BACKWARD: 2 x 3 341-point contact graphs, C=8, L=4, bf16 operands -- every parameter
+    gradient and the input gradients against the mode's mirror (oracle/factored.py, Config.bf16) with the calibrated rule
+    of this file: distance to the fp64 mirror <= 3 x the fp32 mirror's own + 5e-3 of max|g|."""
+    from bench import make_protein_batch
+    batch, target = make_protein_batch(2, 3341, 8, 0.5, 43, "cuda")
+    torch.manual_seed(3)
+    m = fastegnn_amd.FastEGNN(2, 0, 2, 64, 8, device="cuda", n_layers=4, mlp_dtype=torch.bfloat16)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith(("coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
+                p.mul_(50.0)          # trained-like coordinate heads: the coordinate paths carry gradient
+    leaf = {k: batch[k].clone().requires_grad_(True) for k in ("node_loc", "node_vel", "loc_mean")}
+    loc, vloc = m(**dict(batch, **leaf))
+    wv = torch.linspace(-1.0, 1.0, vloc.numel(), device="cuda").view_as(vloc)
+    golden_loss(loc, vloc, target, wv).backward()
+    G = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
+    gin = {k: v.grad.cpu() for k, v in leaf.items()}
+    cfg = R.Config(2, 0, 2, 64, 8, n_layers=4, bf16=True)
+
+    def mirror(dt):
+        p = {k: v.detach().cpu().to(dt) for k, v in m.state_dict().items()}
+        kw = {k: (v.cpu().to(dt) if v.is_floating_point() else v.cpu()) for k, v in batch.items()}
+        lo, vl, ctx = F.model_forward(p, cfg, **kw)
+        l2, v2 = lo.clone().requires_grad_(True), vl.clone().requires_grad_(True)
+        golden_loss(l2, v2, target.cpu().to(dt), wv.cpu().to(dt)).backward()
+        Gm, gim = F.model_backward(p, cfg, ctx, l2.grad, v2.grad)
+        return lo, vl, Gm, gim
+
+    l32, v32, G32, gin32 = mirror(torch.float32)
+    l64, v64, G64, gin64 = mirror(torch.float64)
+    assert rel_err(loc, l32) < OUT_VS_MIRROR and rel_err(vloc, v32) < OUT_VS_MIRROR
+    bad = []
+    pairs = [(k, G[k], G32[k], G64[k]) for k in G64 if k in G]
+    pairs += [("gin/" + k, gin[k], gin32[k], gin64[k]) for k in gin if k in gin64]
+    assert len(pairs) > 100
+    for k, got, m32, m64 in pairs:
+        if float(m64.abs().max()) == 0.0:
+            continue
+        e_got, e_ref = rel_err(got, m64), rel_err(m32, m64)
+        if e_got > GRAD_FACTOR * e_ref + GRAD_FLOOR:
+            bad.append((k, f"{e_got:.2e}", f"mirror32 {e_ref:.2e}"))
+    assert not bad, bad
+
+
 def test_bf16_flag_changes_the_arithmetic_and_fp32_default_does_not():
     """Guards against a silently ignored flag: on the same weights the bf16 mode differs from the fp32 mode by the
     expected 1e-4..1e-2 of the displacement, not by 0 and not by more."""

@@ -309,6 +309,28 @@ def test_cfg5_full_size_properties():
     assert rel_err(loc2, outs[0][0]) < 1e-6 and rel_err(vloc2, outs[0][1]) < 1e-6
 
 
+def test_cfg2_shape_rotation_translation_equivariance():
+    """the reference's acceptance property (equivariant_test.py:62, atol 1e-4) at the cfg2 shape --
+    100-particle fully connected N-body systems (9 900 directed edges per graph), C=3, fp32 -- on a 10-graph batch, with
+    trained-like coordinate heads so that the displacement is not negligible."""
+    from bench import make_nbody_batch
+    batch, _ = make_nbody_batch(10, 100, 3, 0.0, 43, "cuda")
+    torch.manual_seed(5)
+    m = fastegnn_amd.FastEGNN(2, 0, 2, 64, 3, device="cuda", n_layers=4)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith(("coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
+                p.mul_(30.0)
+        loc0, vl0 = m(**batch)
+        Rm, t = _rot(9).cuda(), torch.tensor([1.5, -2.0, 0.7]).cuda()
+        b2 = dict(batch, node_loc=batch["node_loc"] @ Rm + t, node_vel=batch["node_vel"] @ Rm,
+                  loc_mean=(batch["loc_mean"].permute(0, 2, 1) @ Rm + t).permute(0, 2, 1).contiguous())
+        loc1, vl1 = m(**b2)
+    assert (loc0 - batch["node_loc"]).abs().max().item() > 1e-3          # the coordinate path is exercised
+    assert torch.allclose(loc0 @ Rm + t, loc1, atol=1e-4)
+    assert torch.allclose((vl0.permute(0, 2, 1) @ Rm + t).permute(0, 2, 1), vl1, atol=1e-4)
+
+
 def test_hub_rows_and_skewed_degrees_vs_oracle():
     """Rows far longer than a wave's share of the edges (a 4000-edge hub, a 700-edge hub) beside hundreds of rows
     with 0-2 edges: whole rows stay with one wave, the in-workgroup gradient rings see very uneven producers."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # diagnostic: rebuild the library with extra -D flags ($EXTRA) on the GPU box's scratch copy and print the per-kernel table of one bench run
 # usage: EXTRA="-DFE_NT_STORE" TAG=nt bash tools/gpu_variant_bench.sh
-cd fastegnn_amd/csrc && rm -f *.o && make -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include $EXTRA" > /dev/null 2>&1 && cd ../.. || exit 1
+cd fastegnn_amd/csrc && rm -f *.o && make -j8 ../libfastegnn_hip.so EXTRA="$EXTRA" > /dev/null 2>&1 && cd ../.. || exit 1
 mkdir -p gpurun_out/var
 python bench.py --steps 40 --warmup 5 --cpu-baseline none ${BENCH_ARGS} 2>/dev/null | grep '{"metric"' > gpurun_out/var/${TAG:-v}.json
 python - <<PY
