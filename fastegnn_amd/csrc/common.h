@@ -166,6 +166,40 @@ __device__ __forceinline__ float jsum_dpp(float p) {
   p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x121, 0xf, 0xf, false));  // row_ror:1
   return p;
 }
+// Transposing sum over the 16 items of a tile: every lane holds 16 values (index k = 4t + r of a Vec); lane j of each
+// 16-lane row returns the total over the row's 16 lanes of value j.  A butterfly that halves the number of values per
+// step.  Steps 1, 2: partners 8 and 4 lanes away (row shifts); the half a lane keeps depends on lane bits 3 / 2, i.e. on
+// its quad within the row, which is what a DPP bank mask selects (bank = 4 consecutive lanes): two masked
+// v_add_f32_dpp per output, no selects.  Steps 3, 4: partners lane^2 and lane^1 (quad permutes), halves selected by lane
+// bits 1 / 0.  33 vector instructions instead of the 64 of sixteen jsum_dpp() calls, and the result is spread over the
+// lanes: ONE 64-lane LDS atomic adds it to a [64]-feature accumulator (feature of lane (j,q): 16 (j >> 2) + 4 q + (j & 3))
+// instead of sixteen 4-lane ones.  Pinned with integer data by fastegnn_selftest_jreduce (tests/test_gpu_toolkit.py).
+// (The leading s_nop keeps the two wait states a DPP read needs behind the instruction that produced its operand: the
+// hazard recogniser does not look into inline assembly.  EXEC must be all ones.)
+__device__ __forceinline__ float jreduce16(const Vec &u) {
+  float y[8], z[4], w[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {   // lanes 0-7 of a row keep value k (+ lane+8's), lanes 8-15 value k+8 (+ lane-8's)
+    const float a = u.t[k >> 2][k & 3], b = u.t[(k + 8) >> 2][k & 3];
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(y[k]) : "v"(a), "v"(b));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)     // quads 0, 2 keep y[k] (+ lane+4's), quads 1, 3 keep y[k+4] (+ lane-4's)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+        : "=&v"(z[k]) : "v"(y[k]), "v"(y[k + 4]));
+  const int lane = lane_id();
+  const bool b1 = lane & 2, b0 = lane & 1;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float keep = b1 ? z[k + 2] : z[k], send = b1 ? z[k] : z[k + 2];
+    w[k] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x4e, 0xf, 0xf, false));  // quad_perm:[2,3,0,1]
+  }
+  const float keep = b0 ? w[1] : w[0], send = b0 ? w[0] : w[1];
+  return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xb1, 0xf, 0xf, false));  // quad_perm:[1,0,3,2]
+}
 // <v, w> over the hidden dimension; every q-lane of the item gets the full dot product
 __device__ __forceinline__ float vdot(const Vec &v, const Vec &w) {
   float p = 0.f;

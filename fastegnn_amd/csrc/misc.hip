@@ -534,6 +534,13 @@ __global__ __launch_bounds__(64) void selftest_rm_kernel(const float *W, const f
   vstore_row(Y + j * H, q, acc);
 }
 
+// jreduce16 (common.h): out[q*16 + j] = sum over the 16 items of a quarter-row q of X[item][16 (j >> 2) + 4 q + (j & 3)]
+__global__ __launch_bounds__(64) void selftest_jreduce_kernel(const float *X, float *out) {
+  const int l = lane_id(), j = l & 15, q = l >> 4;
+  const Vec v = vload_row(X + j * H, q);
+  out[l] = jreduce16(v);
+}
+
 // bf16x3 counterpart of chain_kernel (mode bit0: SiLU, bit2: single layer written to out for checks)
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void chain_bf3_kernel(const float *W, const float *X, float *out, int iters,
@@ -648,6 +655,12 @@ int fastegnn_selftest_gemm(const float *W, const float *X, float *Y, int32_t tra
   FE_REQUIRE(W && X && Y, "selftest_gemm: null pointer");
   hipLaunchKernelGGL(selftest_gemm_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, W, X, Y, transposed);
   return check_launch("selftest_gemm_kernel");
+}
+
+int fastegnn_selftest_jreduce(const float *X, float *out, void *stream) {
+  FE_REQUIRE(X && out, "selftest_jreduce: null pointer");
+  hipLaunchKernelGGL(selftest_jreduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, X, out);
+  return check_launch("selftest_jreduce_kernel");
 }
 
 int fastegnn_selftest_rm(const float *W, const float *X, float *Y, int32_t transposed, int32_t mode, void *stream) {

@@ -207,19 +207,14 @@ __device__ __forceinline__ void vb_tile_store(float *tile, int j, int q, const V
 #pragma unroll
   for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(tile + j * VB_RS + 16 * t + 4 * q) = v.t[t];
 }
-// row[o] += sum over the 16 items of the tile of u[o][item]: DPP row rotations, then one LDS atomic per feature
+// row[o] += sum over the 16 items of the tile of u[o][item]: transposing DPP butterfly, then ONE 64-lane atomic
 __device__ __forceinline__ void vb_accum_items(float *row, const Vec &u, int j, int q) {
-  float s[4][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s[t][r] = jsum_dpp(u.t[t][r]);
-  if (j == 0) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&row[16 * t + 4 * q + r], s[t][r]);
-  }
+#ifdef VB_DIAG_NOACC   // diagnostic: what do the DPP sums + LDS atomics of the rank-1 gradients and pools cost?
+  if (u.t[0][0] == 12345.678f) row[0] = 1.f;
+  return;
+#endif
+  const float s = jreduce16(u);   // lane j: the sum over the tile of value j
+  atomicAdd(&row[16 * (j >> 2) + 4 * q + (j & 3)], s);
 }
 
 template <bool BF, bool ATT>
@@ -252,7 +247,11 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
   const int t_lo = (int)((long)blockIdx.x * ntiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   const int n_fine = min(t_hi - t_lo, VB_FINE_TILES), n_coarse = t_hi - t_lo - n_fine;
   const int n_units = n_coarse + n_fine * A.NGF;
+#ifdef VB_DIAG_NOPUB   // diagnostic: producers skip the ring hand-offs, consumers have nothing to do
+  const int total = 0;
+#else
   const int total = (t_hi - t_lo) * C;            // (tile, channel) operand sets = tickets per ring
+#endif
   const int cur = a.batch[t_lo * 16];             // graph whose pools this workgroup accumulates in LDS
   const bool tanh_on = a.flags & FASTEGNN_F_TANH;
 
@@ -531,6 +530,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
         }
         VB2_T(5)   // head X forward + rank-1 sum
         Vec g_v = vload_u(A.Gv + cb, offN);   // (requested ahead of the publish: it arrives under the slot wait)
+#ifndef VB_DIAG_NOPUB
         {   // (g_ux, v) and (g_uX, v) to consumers X and XX: one slot of ring A, free once both have drained it
           int tk = 0;
           if (l == 0) tk = atomicAdd(&ctrl[VBC_HEAD + 0], 1);
@@ -546,6 +546,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // lgkmcnt(0): the tiles are in LDS before the flag
           if (l == 0) vb_st(&ctrl[VBC_FILLED + sl], round + 1);
         }
+#endif
         VB2_T(6)   // publish to ring A
         g_v = vb_mask(g_v, valid);
         mmT(1, g_ux, g_v);
@@ -567,6 +568,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
         Vec g_t = vzero(), ga = vzero();
         {
           const Vec g_vp = vmul(g_v0, vp);
+#ifndef VB_DIAG_NOPUB
           {   // (g_vp, t) to consumer V2
             int tk = 0;
             if (l == 0) tk = atomicAdd(&ctrl[VBC_HEAD + 1], 1);
@@ -580,6 +582,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             if (l == 0) vb_st(&ctrl[VBC_FILLED + VB_MAXRING + sl], round + 1);
           }
+#endif
           VB2_T(8)   // g_vp + publish to ring B
           // requested here, consumed after the product: the tile's running g_A
           if (c > c_lo) ga = vload_u(dA, offA);

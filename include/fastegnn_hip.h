@@ -329,6 +329,9 @@ int fastegnn_selftest_gemm(const float *W, const float *X, float *Y, int32_t tra
 /* same through a row-major split image in LDS (one copy serves W and W^T: ds_read_b64 / ds_read_b64_tr_b16);
  * mode 0: bf16x3 products, 1: one bf16 product of the rounded operands */
 int fastegnn_selftest_rm(const float *W, const float *X, float *Y, int32_t transposed, int32_t mode, void *stream);
+/* transposing tile sum of the backward kernels (common.h jreduce16): X one 16x64 tile; out[16 q + j] = sum over the 16
+ * rows of X[row][16 (j >> 2) + 4 q + (j & 3)] */
+int fastegnn_selftest_jreduce(const float *X, float *out, void *stream);
 /* `iters` dependent 64x64 MFMA layers per wave (mode bit0: SiLU between layers, bit1: image from
  * global memory instead of LDS); out receives one 16x64 tile.  Calibrates the MFMA building block. */
 int fastegnn_selftest_chain(const float *wimg, float *out, int32_t iters, int32_t mode, int32_t waves, int32_t grid,

@@ -105,3 +105,15 @@ def test_bf16x3_split_gemm_is_fp32_accurate():
     e_bf3 = (out.cpu().double() - exact).abs().max() / den
     e_f32 = (ref.cpu().double() - exact).abs().max() / den
     assert e_bf3 < 5e-7 and e_bf3 < 3 * e_f32 + 1e-7
+
+
+def test_transposing_tile_sum_jreduce16():
+    """common.h jreduce16 (DPP butterfly with bank masks, inline assembly): exact on integer data, every lane checked."""
+    L = K.lib()
+    g = torch.Generator().manual_seed(5)
+    X = torch.randint(-1000, 1000, (16, 64), generator=g).float().cuda()
+    out = torch.empty(64, device="cuda")
+    K.check(L.fastegnn_selftest_jreduce(K.ptr(X), K.ptr(out), None), "selftest_jreduce")
+    col = X.sum(0).cpu()
+    want = torch.tensor([col[16 * (j >> 2) + 4 * q + (j & 3)] for q in range(4) for j in range(16)])
+    assert torch.equal(out.cpu(), want)
