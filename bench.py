@@ -74,10 +74,35 @@ def spawn_ranks(n: int) -> int:
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, abs(p.wait()))
+    # Poll all ranks: if one dies (before or inside the rendezvous or a collective) the survivors would wait for it
+    # for ever -- the first non-zero exit ends the others and becomes the exit code.  FASTEGNN_BENCH_TIMEOUT bounds the
+    # whole run (default 30 min).
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("FASTEGNN_BENCH_TIMEOUT", "1800"))
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            rc = abs(bad[0]) if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            sys.stderr.write(f"bench: rank exit codes {codes}: " + ("a rank failed" if bad else "timeout") + ", stopped the others\n")
+            break
+        if all(c is not None for c in codes):
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    out = buf[0] if buf else b""
     # stdout carries the ONE JSON line; anything else rank 0 printed there (communicator banners) goes to stderr
     for line in out.decode().splitlines():
         if line.startswith('{"metric"'):
@@ -430,7 +455,9 @@ def main():
     if sharded:
         from fastegnn_amd.sharded import CommStats, ShardedFastEGNN
         smodel = ShardedFastEGNN(model)
-        shard = smodel.shard_inputs(**frame)          # this rank's rows and edges; the full COO is dropped below
+        # nodes sorted along a Morton curve first (a Water-3D loader would do this once per frame): contiguous index
+        # ranges are compact regions, so the halo exchange moves the shell of a region, not the whole table
+        shard = smodel.shard_inputs(**frame, reorder=True)   # this rank's rows and edges; the full COO is dropped below
         tgt_local = shard["plan"].rows(target)
         if world > 1:
             del frame
@@ -650,6 +677,12 @@ def main():
         }
         if stats is not None:
             out["collectives"] = stats.summary(args.steps)
+        if sharded:
+            pl = shard["plan"]
+            out["table_exchange"] = {"mode": pl.mode, "rows_received_per_exchange": pl.exchanged_bytes() // (68 * 4),
+                                     "bytes_received_per_exchange": pl.exchanged_bytes(),
+                                     "all_gather_bytes_for_comparison": (world - 1) * pl.Npad * 68 * 4,
+                                     "node_order": "Morton curve inside each graph (fastegnn_amd.sharded.morton_order)"}
         if dp_leg is not None:
             out["data_parallel_leg"] = dp_leg
         cb = "none" if args.no_cpu_baseline else args.cpu_baseline

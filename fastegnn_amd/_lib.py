@@ -124,6 +124,18 @@ def lib():
     L.fastegnn_selftest_chain_bf3.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
     L.fastegnn_selftest_wgrad.argtypes = [_vp, _vp, _i32, _vp, _vp, _vp, _vp]
     L.fastegnn_selftest_stream.argtypes = [_vp, _vp, C.c_size_t, _i32, _vp]
+    L.fastegnn_comm_unique_id_bytes.restype = _i32
+    L.fastegnn_comm_unique_id.argtypes = [_vp]
+    L.fastegnn_comm_init.argtypes = [C.POINTER(_vp), _vp, _i32, _i32]
+    L.fastegnn_comm_destroy.argtypes = [_vp]
+    L.fastegnn_comm_rank.argtypes = [_vp]
+    L.fastegnn_comm_world.argtypes = [_vp]
+    L.fastegnn_comm_all_reduce.argtypes = [_vp, _vp, C.c_size_t, _vp]
+    L.fastegnn_comm_all_gather.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp]
+    L.fastegnn_comm_reduce_scatter.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp]
+    L.fastegnn_comm_all_to_all_v.argtypes = [_vp, _vp, C.POINTER(C.c_int64), _vp, C.POINTER(C.c_int64), _i32, _vp]
+    L.fastegnn_gather_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
+    L.fastegnn_scatter_add_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_wg_slab_floats.restype = C.c_size_t
     L.fastegnn_sizeof_layer.restype = C.c_size_t
     L.fastegnn_sizeof_graph.restype = C.c_size_t
@@ -159,6 +171,9 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_radius_graph_ws_bytes", "fastegnn_radius_graph_count", "fastegnn_radius_graph_fill",
     "fastegnn_cutoff_tmp_bytes", "fastegnn_cutoff_edges", "fastegnn_nbody_cutoff_edges",
     "fastegnn_profile_enable", "fastegnn_profile_kernels", "fastegnn_profile_name", "fastegnn_profile_collect",
+    "fastegnn_comm_unique_id_bytes", "fastegnn_comm_unique_id", "fastegnn_comm_init", "fastegnn_comm_destroy", "fastegnn_comm_rank",
+    "fastegnn_comm_world", "fastegnn_comm_all_reduce", "fastegnn_comm_all_gather", "fastegnn_comm_reduce_scatter",
+    "fastegnn_comm_all_to_all_v", "fastegnn_gather_rows", "fastegnn_scatter_add_rows",
 ]
 
 

@@ -31,6 +31,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend == "nccl":
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)
+        # a rank that never arrives must not hang the others for the default 10-30 minutes
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("FASTEGNN_DIST_TIMEOUT", "300")))
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 

@@ -3,11 +3,17 @@
 Rank r owns the contiguous node range [r*Npad, (r+1)*Npad) and every edge whose aggregation row lies
 in it, so all segment means are complete locally.  Per layer the ranks exchange exactly:
 
-  forward   all-gather   QX  [Npad,68] -> QX_src [W*Npad,68]   (the gathered source table)
+  forward   table exchange QX [nloc,68] -> QX_src              (the rows of the source table this rank's edges read)
+              "halo" (default): all-to-all-v of the GHOST rows only -- the remote nodes this rank's edges point at,
+                      found once per graph (HaloPlan); QX_src = [own rows | ghost rows], column ids remapped.  With
+                      spatially ordered nodes (shard_inputs(reorder=True): Morton order inside each graph) a rank's
+                      ghosts are the shell of its region: 2-6 % of the all-gather's bytes at cfg4 / cfg5 on 8 ranks
+              "allgather": all-gather of the padded shards, QX_src [W*Npad,68] indexed by global id
             all-reduce   xsum [B,4]                            (centroids / node counts)
             all-reduce   poolV|poolX [B,C,64]+[B,3,C]          (virtual-node accumulators)
   backward  all-reduce   g_Bc|g_Zp                             (adjoint of the broadcast virtual state)
-            reduce-scatter g_QX_src [W*Npad,68] -> g_QX [Npad,68]  (transpose of the all-gather)
+            transpose of the table exchange: ghost-row gradients back to their owners (all-to-all-v + scatter-add),
+              or reduce-scatter g_QX_src [W*Npad,68] -> g_QX [Npad,68]
   once      all-reduce   parameter gradients (fastegnn_amd.dist.allreduce_gradients, by the caller)
 
 The virtual state (Z, Hv) is replicated and updated identically everywhere; the per-graph stages
@@ -19,6 +25,7 @@ it on CPU with the oracle's stage functions (tests/test_sharded_cpu.py).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -106,9 +113,11 @@ class HipBackend:
 # partition
 # ------------------------------------------------------------------------------------------
 class ShardPlan:
-    """Contiguous node ranges of equal padded size Npad = ceil(N / W)."""
+    """Contiguous node ranges of equal padded size Npad = ceil(N / W); table exchange by all-gather."""
 
-    def __init__(self, n_nodes: int, world: int, rank: int):
+    mode = "allgather"
+
+    def __init__(self, n_nodes: int, world: int, rank: int, order: Optional[torch.Tensor] = None):
         self.N, self.world, self.rank = n_nodes, world, rank
         self.Npad = (n_nodes + world - 1) // world
         self.n0 = min(n_nodes, rank * self.Npad)
@@ -117,14 +126,133 @@ class ShardPlan:
         if self.nloc < 1:
             raise ValueError("sharded FastEGNN needs at least one node per rank")
         self.n_src = world * self.Npad      # global ids index the padded, all-gathered table directly
+        self.n_table = self.Npad            # rows of the local table buffer (padded: equal-sized all-gather shards)
+        # order[new] = caller's node id (None: identity): the plan's ranges are ranges of the REORDERED nodes
+        self.order = order
+        self.node_ids = order[self.n0:self.n1] if order is not None else None
 
     def rows(self, t: torch.Tensor) -> torch.Tensor:
+        """This rank's rows of a per-node tensor given in the CALLER's node order."""
+        if self.node_ids is not None:
+            return t.index_select(0, self.node_ids.to(t.device)).contiguous()
         return t[self.n0:self.n1].contiguous()
 
     def edges(self, edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor]):
+        """Edges (in the plan's node numbering) whose aggregation row this rank owns."""
         m = (edge_index[0] >= self.n0) & (edge_index[0] < self.n1)
         ei = edge_index[:, m].contiguous()
         return ei, (edge_attr[m].contiguous() if edge_attr is not None else None)
+
+    # -- table exchange (forward) and its transpose (backward); `t`: the layer's buffers
+    def alloc_tables(self, be):
+        QX = be.zeros(self.Npad, K.QX_LD)                      # padded: equal-sized all-gather shards
+        return QX, be.empty(self.world * self.Npad, K.QX_LD)
+
+    def exchange_forward(self, comm, QX, QX_src):
+        return comm.all_gather("QX", QX_src, QX)
+
+    def alloc_grad_tables(self, be):
+        return be.empty(self.world * self.Npad, K.QX_LD), be.empty(self.Npad, K.QX_LD)
+
+    def exchange_backward(self, comm, g_QX_src, g_QX):
+        return comm.reduce_scatter("g_QX", g_QX, g_QX_src)
+
+    def exchanged_bytes(self):
+        """Bytes this rank receives per table exchange (one layer, one direction)."""
+        return (self.world - 1) * self.Npad * K.QX_LD * 4
+
+
+class _HaloWork:
+    """Completion of a halo exchange: wait for the all-to-all-v, then (backward) add the returned rows to their owners."""
+
+    def __init__(self, work, after=None):
+        self.work, self.after = work, after
+
+    def wait(self):
+        self.work.wait()
+        if self.after is not None:
+            self.after()
+        return True
+
+
+class HaloPlan(ShardPlan):
+    """Same contiguous ownership, but only the GHOST rows travel: the remote nodes this rank's edges point at.
+
+    Built once per graph by `build()` (collective: every rank of the group must call it): the ranks tell each other which
+    of their rows they need (one all-to-all of counts, one all-to-all-v of ids).  Source table of this rank:
+    [own rows (nloc) | ghost rows, grouped by owner rank in ascending id]; the edge columns are remapped to it.
+    Forward: pack the rows each peer asked for, all-to-all-v, the ghosts land behind the own rows.  Backward: the ghost
+    part of the col-keyed gradient goes back the same way and is added to the owners' rows."""
+
+    mode = "halo"
+
+    def build(self, edge_index: torch.Tensor, comm) -> torch.Tensor:
+        """edge_index: this rank's edges (rows in [n0,n1), cols = global ids in the plan's numbering).  Returns the edge
+        index with the columns remapped to the local source table."""
+        W, dev = self.world, edge_index.device
+        cols = edge_index[1]
+        remote = (cols < self.n0) | (cols >= self.n1)
+        ghost = torch.unique(cols[remote])                                 # ascending => grouped by owner (contiguous ranges)
+        owner = torch.div(ghost, self.Npad, rounding_mode="floor")
+        recv_counts = torch.bincount(owner, minlength=W).to(torch.int64)   # rows this rank receives from each owner
+        send_counts = comm.exchange_counts(recv_counts)                    # rows each peer wants from this rank
+        self.recv_splits = [int(v) for v in recv_counts.tolist()]
+        self.send_splits = [int(v) for v in send_counts.tolist()]
+        want = comm.exchange_ids(ghost, self.send_splits, self.recv_splits)   # global ids of MY rows, grouped by asking peer
+        self.send_ids = (want - self.n0).contiguous()
+        if self.send_ids.numel() and (int(self.send_ids.min()) < 0 or int(self.send_ids.max()) >= self.nloc):
+            raise RuntimeError("HaloPlan: a peer asked for a row this rank does not own")
+        self.n_ghost = int(ghost.numel())
+        self.n_send = int(self.send_ids.numel())
+        self.n_src = self.nloc + self.n_ghost
+        self.n_table = self.nloc
+        pos = torch.searchsorted(ghost, cols.clamp(min=0)) if self.n_ghost else torch.zeros_like(cols)
+        new_col = torch.where(remote, self.nloc + pos, cols - self.n0)
+        return torch.stack([edge_index[0], new_col]).contiguous()
+
+    def alloc_tables(self, be):
+        QX_src = be.zeros(max(self.n_src, 1), K.QX_LD)
+        return QX_src[:self.nloc], QX_src          # node_pre writes the own rows in place: no copy
+
+    def exchange_forward(self, comm, QX, QX_src):
+        if self.world == 1:
+            return _Done()
+        send = QX.index_select(0, self.send_ids) if self.n_send else QX.new_zeros(0, K.QX_LD)
+        return _HaloWork(comm.all_to_all_v("QX_halo", QX_src[self.nloc:], send, self.recv_splits, self.send_splits))
+
+    def alloc_grad_tables(self, be):
+        g_src = be.empty(max(self.n_src, 1), K.QX_LD)
+        return g_src, g_src[:self.nloc]            # node_pre_bwd reads the own rows in place
+
+    def exchange_backward(self, comm, g_QX_src, g_QX):
+        if self.world == 1:
+            return _Done()
+        back = g_QX_src.new_empty(self.n_send, K.QX_LD)
+        send = g_QX_src[self.nloc:self.nloc + self.n_ghost].contiguous()
+        work = comm.all_to_all_v("g_QX_halo", back, send, self.send_splits, self.recv_splits)
+
+        def add():
+            if self.n_send:
+                g_QX.index_add_(0, self.send_ids, back)
+        return _HaloWork(work, add)
+
+    def exchanged_bytes(self):
+        return self.n_ghost * K.QX_LD * 4
+
+
+def morton_order(loc: torch.Tensor, data_batch: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """order[new] = old: nodes sorted by (graph, Morton code of their position on a 2^bits grid over the bounding box).
+    data_batch stays ascending; contiguous index ranges become compact regions of space, so a rank's ghosts are the
+    shell of its region instead of almost every remote node."""
+    lo = loc.min(0).values
+    span = (loc.max(0).values - lo).clamp(min=1e-30)
+    g = ((loc - lo) / span * (2 ** bits - 1)).long().clamp(0, 2 ** bits - 1)
+    code = torch.zeros(loc.size(0), dtype=torch.int64, device=loc.device)
+    for b in range(bits):
+        for k in range(3):
+            code |= ((g[:, k] >> b) & 1) << (3 * b + k)
+    key = data_batch.to(torch.int64) * (1 << (3 * bits)) + code
+    return torch.argsort(key, stable=True)
 
 
 class CommStats:
@@ -168,6 +296,9 @@ class _Timed:
         return True
 
 
+_ABI_CACHE: Dict[tuple, object] = {}   # one RCCL communicator per (device, group) and process
+
+
 class _Comm:
     """The three exchange steps of SURVEY 8e as asynchronous collectives (torch.distributed: RCCL on the GPU,
     gloo in the CPU tests).  World size 1 short-circuits to local copies."""
@@ -177,6 +308,25 @@ class _Comm:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # a transport without device support (gloo): device tensors are staged through host memory, synchronously
         self.host_staged = self.world > 1 and dist.get_backend(group) == "gloo"
+        # FASTEGNN_SHARDED_SYNC=1: blocking collectives in program order (async_op=False) -- no overlap, nothing in flight
+        # behind a kernel.  The asynchronous schedule is the default; this is the fallback while RCCL with more than one
+        # rank has not run on the pool's hardware
+        self.sync = os.environ.get("FASTEGNN_SHARDED_SYNC", "0") not in ("", "0")
+        # FASTEGNN_COMM=abi: the data-path collectives go through the C ABI (fastegnn_comm_*: RCCL on the CURRENT stream,
+        # capturable), created lazily on the first device tensor; plan-building exchanges stay on torch.distributed
+        self.use_abi = os.environ.get("FASTEGNN_COMM", "torch") == "abi" and not self.host_staged
+        self._abi = None
+
+    def abi(self, t):
+        """The C-ABI communicator for tensor t's device, or None when this transport is not selected."""
+        if not (self.use_abi and t.is_cuda and self.world > 1):
+            return None
+        if self._abi is None:
+            from .comm import AbiComm
+            self._abi = _ABI_CACHE.get((t.device, id(self.group)))
+            if self._abi is None:
+                self._abi = _ABI_CACHE[(t.device, id(self.group))] = AbiComm(t.device, self.group)
+        return self._abi
 
     def _staged(self, fn, out, *inputs):
         h_in = [t.cpu() for t in inputs]
@@ -201,27 +351,70 @@ class _Comm:
         rec = self._note(name, t)
         if self.world == 1:
             return _Timed(_Done(), rec)
+        if self.abi(t) is not None:
+            return _Timed(self._abi.all_reduce(t), rec)
         if self.host_staged and t.is_cuda:
             return _Timed(self._staged(lambda o: dist.all_reduce(o, group=self.group), t), rec)
-        return _Timed(dist.all_reduce(t, group=self.group, async_op=True), rec)
+        return _Timed(dist.all_reduce(t, group=self.group, async_op=not self.sync) or _Done(), rec)
 
     def all_gather(self, name, out, inp):
         rec = self._note(name, out)
         if self.world == 1:
             out.copy_(inp)
             return _Timed(_Done(), rec)
+        if self.abi(out) is not None:
+            return _Timed(self._abi.all_gather(out, inp), rec)
         if self.host_staged and out.is_cuda:
             return _Timed(self._staged(lambda o, i: dist.all_gather_into_tensor(o, i, group=self.group), out, inp), rec)
-        return _Timed(dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True), rec)
+        return _Timed(dist.all_gather_into_tensor(out, inp, group=self.group, async_op=not self.sync) or _Done(), rec)
+
+    def all_to_all_v(self, name, out, inp, out_splits, in_splits):
+        rec = self._note(name, out)
+        if self.world == 1:
+            return _Timed(_Done(), rec)
+        if self.abi(out) is not None:
+            return _Timed(self._abi.all_to_all_v(out, inp.contiguous(), out_splits, in_splits), rec)
+        if self.host_staged and out.is_cuda:
+            def fn(o, i):
+                dist.all_to_all_single(o, i, out_splits, in_splits, group=self.group)
+            return _Timed(self._staged(fn, out, inp.contiguous()), rec)
+        w = dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group, async_op=not self.sync)
+        return _Timed(w if w is not None else _Done(), rec)
+
+    # plan-building exchanges (once per graph, blocking): int64 counts [W] and id lists
+    def exchange_counts(self, counts):
+        if self.world == 1:
+            return counts.clone()
+        out = torch.empty_like(counts)
+        if self.host_staged and counts.is_cuda:
+            h = counts.cpu()
+            ho = torch.empty_like(h)
+            dist.all_to_all_single(ho, h, group=self.group)
+            return ho.to(counts.device)
+        dist.all_to_all_single(out, counts, group=self.group)
+        return out
+
+    def exchange_ids(self, ids, out_splits, in_splits):
+        out = torch.empty(sum(out_splits), dtype=ids.dtype, device=ids.device)
+        if self.world == 1:
+            return out
+        if self.host_staged and ids.is_cuda:
+            ho = torch.empty(sum(out_splits), dtype=ids.dtype)
+            dist.all_to_all_single(ho, ids.cpu().contiguous(), out_splits, in_splits, group=self.group)
+            return ho.to(ids.device)
+        dist.all_to_all_single(out, ids.contiguous(), out_splits, in_splits, group=self.group)
+        return out
 
     def reduce_scatter(self, name, out, inp):
         rec = self._note(name, inp)
         if self.world == 1:
             out.copy_(inp)
             return _Timed(_Done(), rec)
+        if self.abi(out) is not None:
+            return _Timed(self._abi.reduce_scatter(out, inp), rec)
         if self.host_staged and out.is_cuda:
             return _Timed(self._staged(lambda o, i: dist.reduce_scatter_tensor(o, i, group=self.group), out, inp), rec)
-        return _Timed(dist.reduce_scatter_tensor(out, inp, group=self.group, async_op=True), rec)
+        return _Timed(dist.reduce_scatter_tensor(out, inp, group=self.group, async_op=not self.sync) or _Done(), rec)
 
 
 def _layer_lists(spec: _Spec, params, i):
@@ -256,8 +449,7 @@ class _ShardedFunction(torch.autograd.Function):
             b = dict(h=h, x=x)
             b.update(be.carve(dict(wpack=(be.wpack_floats(Cn),), P=(N, H), A=(N, H), svel=(N,), sgrav=(N,), xsum=(B, 4),
                                    Bc=(B, Cn, H), aggm=(N, H), npre=(N, H), aggx=(N, 3))))
-            b["QX"] = be.zeros(Npad, K.QX_LD)                      # padded: equal-sized all-gather shards
-            b["QX_src"] = be.empty(W * Npad, K.QX_LD)
+            b["QX"], b["QX_src"] = plan.alloc_tables(be)           # own rows | the table the edge kernels gather from
             nV = B * Cn * H
             pools = be.empty(nV + B * 3 * Cn)                      # poolV | poolX adjacent: one all-reduce
             b["poolV"], b["poolX"] = pools[:nV].view(B, Cn, H), pools[nV:].view(B, 3, Cn)
@@ -267,7 +459,7 @@ class _ShardedFunction(torch.autograd.Function):
             be.stage("graph_xsum", spec, N, B, graph, t, lp)
             w_xsum = comm.all_reduce("xsum", b["xsum"])
             be.stage("node_pre_forward", spec, N, B, graph, t, lp)
-            w_qx = comm.all_gather("QX", b["QX_src"], b["QX"])
+            w_qx = plan.exchange_forward(comm, b["QX"], b["QX_src"])
             if pend is not None:                                   # virtual state of this layer <- previous layer's pools
                 pend[0].wait()
                 be.stage("graph_post_forward", spec, N, B, graph, pend[1], pend[2])
@@ -327,8 +519,7 @@ class _ShardedFunction(torch.autograd.Function):
         nV = B * Cn * H
         gpools = be.empty(nV + B * 3 * Cn)                                 # g_Bc | g_Zp adjacent: one all-reduce
         sc["g_Bc"], sc["g_Zp"] = gpools[:nV].view(B, Cn, H), gpools[nV:].view(B, 3, Cn)
-        sc["g_QX_src"] = be.empty(W * Npad, K.QX_LD)
-        sc["g_QX"] = be.empty(Npad, K.QX_LD)
+        sc["g_QX_src"], sc["g_QX"] = plan.alloc_grad_tables(be)
         for i in reversed(range(spec.n_layers)):
             b = saved[i]
             lp = _layer_lists(spec, params, i)
@@ -342,7 +533,7 @@ class _ShardedFunction(torch.autograd.Function):
             w_pools = comm.all_reduce("g_pools", gpools)           # behind the edge backward
             be.stage("edge_backward", spec, N, B, graph, t, lp, lg)
             be.stage("edge_col_reduce", spec, N, B, graph, t, lp, lg)
-            w_qx = comm.reduce_scatter("g_QX", sc["g_QX"], sc["g_QX_src"])   # behind graph_pre_backward
+            w_qx = plan.exchange_backward(comm, sc["g_QX_src"], sc["g_QX"])   # behind graph_pre_backward
             w_pools.wait()
             be.stage("graph_pre_backward", spec, N, B, graph, t, lp, ld)
             w_qx.wait()
@@ -352,6 +543,12 @@ class _ShardedFunction(torch.autograd.Function):
         be.virtual_init_backward(g_HvT, B, Cn, dummy[0])
         g_nf = torch.empty_like(node_feat) if ctx.needs_input_grad[10] else None
         be.embed_backward(node_feat, g_h, spec.nf, params[1], grads[1], grads[2], g_nf)
+        # The last layer's node_mlp / node_mlp_virtual feed nothing: the reference's autograd (and the single-GPU module)
+        # leave their .grad None and torch.optim.Adam / FusedAdam then skip them; the kernels wrote zeros.
+        last = spec.n_layers - 1
+        for s_, suffix in zip(spec.layer_slots[last], K.PARAM_SLOTS):
+            if s_ is not None and suffix.startswith(("node_mlp.", "node_mlp_virtual.")) and not (spec.flags & K.F_RF):
+                grads[s_] = None
         return (None,) * 10 + (g_nf, g_x, g_vel, g_Z, *grads)
 
 
@@ -370,8 +567,14 @@ class ShardedFastEGNN(torch.nn.Module):
     ``loss.backward()`` call ``fastegnn_amd.dist.allreduce_gradients(model.parameters())``.
     """
 
-    def __init__(self, model: FastEGNN, group=None, backend=None, stats: Optional[CommStats] = None):
+    def __init__(self, model: FastEGNN, group=None, backend=None, stats: Optional[CommStats] = None,
+                 exchange: Optional[str] = None):
+        """exchange: "halo" (ghost rows only, all-to-all-v; default) or "allgather" (the whole table); the environment
+        variable FASTEGNN_SHARDED_EXCHANGE overrides the default."""
         super().__init__()
+        self.exchange = exchange or os.environ.get("FASTEGNN_SHARDED_EXCHANGE", "halo")
+        if self.exchange not in ("halo", "allgather"):
+            raise ValueError("ShardedFastEGNN: exchange must be 'halo' or 'allgather'")
         if model.hidden_nf != K.H:   # the zero-padded path of model.py (_pad_param) is single-GPU only
             raise NotImplementedError(f"fastegnn_amd.ShardedFastEGNN: hidden_nf must be {K.H}")
         self.model = model
@@ -386,17 +589,29 @@ class ShardedFastEGNN(torch.nn.Module):
         return dist.get_world_size(self.group), dist.get_rank(self.group)
 
     def shard_inputs(self, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None,
-                     node_attr=None) -> Dict[str, torch.Tensor]:
-        """This rank's share of a batch: its node rows, the edges aggregating into them (global column ids),
-        the replicated per-graph tensors."""
+                     node_attr=None, reorder: bool = False) -> Dict[str, torch.Tensor]:
+        """This rank's share of a batch: its node rows, the edges aggregating into them, the replicated per-graph
+        tensors.  Collective when the exchange is "halo" (the ranks tell each other which rows they need).
+        reorder=True first sorts the nodes of every graph along a Morton curve (`morton_order`), so that a rank owns a
+        compact region of space; `plan.node_ids` / `plan.rows()` map the caller's node order to this rank's rows."""
         for name, t in (("edge_attr", edge_attr), ("node_attr", node_attr)):
             if t is not None and t.requires_grad:   # the single-GPU module returns these; the sharded caller does not (yet)
                 raise NotImplementedError(f"fastegnn_amd.ShardedFastEGNN: gradient w.r.t. {name} is not implemented")
         world, rank = self._world_rank()
-        plan = ShardPlan(node_loc.size(0), world, rank)
+        N = node_loc.size(0)
+        order = None
+        if reorder:
+            order = morton_order(node_loc.detach(), data_batch)
+            inv = torch.empty_like(order)
+            inv[order] = torch.arange(N, device=order.device)
+            edge_index = inv[edge_index]
+        plan = (HaloPlan if self.exchange == "halo" else ShardPlan)(N, world, rank, order)
         ei, ea = plan.edges(edge_index, edge_attr.detach() if edge_attr is not None else None)
+        if plan.mode == "halo":
+            ei = plan.build(ei, _Comm(self.group, None))
+        db = data_batch if order is None else data_batch[order]
         return dict(plan=plan, node_feat=plan.rows(node_feat), node_loc=plan.rows(node_loc), node_vel=plan.rows(node_vel),
-                    edge_index=ei, edge_attr=ea, data_batch=plan.rows(data_batch), loc_mean=loc_mean,
+                    edge_index=ei, edge_attr=ea, data_batch=db[plan.n0:plan.n1].contiguous(), loc_mean=loc_mean,
                     node_attr=plan.rows(node_attr.detach()).float() if node_attr is not None else None)
 
     def forward_local(self, local: Dict[str, torch.Tensor]):

@@ -313,6 +313,31 @@ int fastegnn_cutoff_edges(const int64_t *edge_index, const float *dist, int64_t 
 int fastegnn_nbody_cutoff_edges(const float *loc, int32_t S, int32_t n, int32_t k, int64_t *edge_index, float *dist,
                                 void *stream);
 
+/* ---- exchange steps of the sharded path (the reference has no distributed code) ----
+ * RCCL collectives behind the C ABI: every call is enqueued on `stream` (ordered with the stage kernels, capturable
+ * into a HIP graph) and returns at once.  RCCL is bound at run time (dlopen; FASTEGNN_E_NODEVICE when absent).
+ * Bring-up: rank 0 calls fastegnn_comm_unique_id, the caller distributes the fastegnn_comm_unique_id_bytes() bytes by
+ * any out-of-band means, every rank calls fastegnn_comm_init.  One communicator per process and device. */
+typedef struct fastegnn_comm fastegnn_comm_t;
+int32_t fastegnn_comm_unique_id_bytes(void);
+int fastegnn_comm_unique_id(void *id);
+int fastegnn_comm_init(fastegnn_comm_t **comm, const void *id, int32_t rank, int32_t world);
+int fastegnn_comm_destroy(fastegnn_comm_t *comm);
+int32_t fastegnn_comm_rank(const fastegnn_comm_t *comm);
+int32_t fastegnn_comm_world(const fastegnn_comm_t *comm);
+/* buf <- sum over ranks (xsum [B,4]; poolV|poolX; g_Bc|g_Zp; the flat parameter-gradient buffer) */
+int fastegnn_comm_all_reduce(fastegnn_comm_t *comm, float *buf, size_t n, void *stream);
+/* QX [Npad,68] of every rank -> QX_src [W*Npad,68] ("allgather" table exchange) and its transpose */
+int fastegnn_comm_all_gather(fastegnn_comm_t *comm, const float *in, float *out, size_t n_per_rank, void *stream);
+int fastegnn_comm_reduce_scatter(fastegnn_comm_t *comm, const float *in, float *out, size_t n_per_rank, void *stream);
+/* halo exchange: send_rows[r] rows of row_floats floats go to rank r (from `send`, in rank order), recv_rows[r] rows
+ * arrive from rank r (into `recv`, in rank order); the backward swaps the two count arrays.  HOST arrays [world]. */
+int fastegnn_comm_all_to_all_v(fastegnn_comm_t *comm, const float *send, const int64_t *send_rows, float *recv,
+                               const int64_t *recv_rows, int32_t row_floats, void *stream);
+/* ghost-row pack / unpack of the halo exchange: out[r,:] = table[ids[r],:] (width % 4 == 0);  table[ids[r],:] += rows[r,:] */
+int fastegnn_gather_rows(const float *table, const int64_t *ids, int64_t n, int32_t width, float *out, void *stream);
+int fastegnn_scatter_add_rows(float *table, const int64_t *ids, int64_t n, int32_t width, const float *rows, void *stream);
+
 /* ---- per-kernel timing with HIP events recorded on the launch stream (bench.py) ----
  * enable(1) brackets every kernel launch of this library with two events; collect() waits for
  * them and returns, per kernel id in [0, fastegnn_profile_kernels()), the summed duration in ms

@@ -1,9 +1,11 @@
-"""CPU, world_size 2 over gloo: the graph-sharded path (fastegnn_amd/sharded.py) -- row-owner
-partition, all-gather of the source table, all-reduce of centroid sums / virtual-node pools and
-their adjoints, reduce-scatter of the source-table gradient, rank-0-only gradients of the replicated
-per-graph stages -- driven on CPU with the oracle's stage functions as the compute backend
-(tests/cpu_stage_backend.py).  Every rank's outputs and the all-reduced parameter gradients must
-equal the single-process oracle."""
+"""CPU, world_size 2 and 4 over gloo: the graph-sharded path (fastegnn_amd/sharded.py) -- row-owner
+partition, exchange of the source table (halo: all-to-all-v of the ghost rows found by HaloPlan, or the
+all-gather of the whole table), all-reduce of centroid sums / virtual-node pools and their adjoints, the
+transposed exchange of the source-table gradient, rank-0-only gradients of the replicated per-graph stages,
+optional Morton reordering of the nodes -- driven on CPU with the oracle's stage functions as the compute
+backend (tests/cpu_stage_backend.py).  Uneven shards (23 nodes over 4 ranks: 6, 6, 6, 5) and a graph that
+spans three ranks.  Every rank's outputs and the all-reduced parameter gradients must equal the
+single-process oracle."""
 import os
 import socket
 
@@ -21,7 +23,7 @@ from tests.cpu_stage_backend import CpuOracleBackend
 from tests.helpers import rel_err
 
 CFG = dict(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=4, n_layers=2)
-SIZES = [9, 6, 8]     # 23 nodes: graph 1 straddles the rank boundary (Npad = 12)
+SIZES = [14, 4, 5]    # 23 nodes: W=2 (Npad 12): graph 0 straddles the boundary; W=4 (Npad 6): graph 0 spans ranks 0, 1, 2
 
 
 def _free_port():
@@ -69,7 +71,7 @@ def _loss(loc_rows, vloc, target_rows, n_total):
     return ((loc_rows - target_rows) ** 2).sum() / (3 * n_total) + 0.1 * vloc.pow(2).mean()
 
 
-def _worker(rank, world, port, gravity, q):
+def _worker(rank, world, port, gravity, exchange, reorder, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     init_from_env("gloo")
@@ -78,26 +80,30 @@ def _worker(rank, world, port, gravity, q):
     cfg = R.Config(**CFG, gravity=gravity)
     spec_names = None
     be = CpuOracleBackend(spec_names, CFG["n_layers"], cfg)
-    sm = ShardedFastEGNN(m, backend=be)
-    loc, vloc = sm(**inp)
+    sm = ShardedFastEGNN(m, backend=be, exchange=exchange)
+    loc, vloc = sm.forward_local(sm.shard_inputs(**inp, reorder=reorder))
     plan = sm.plan
-    _loss(loc, vloc, target[plan.n0:plan.n1], target.size(0)).backward()
+    assert plan.mode == exchange
+    _loss(loc, vloc, plan.rows(target), target.size(0)).backward()
     allreduce_gradients(m.parameters())
     grads = {k: (p.grad.numpy().copy() if p.grad is not None else None) for k, p in m.named_parameters()}
-    q.put((rank, plan.n0, plan.n1, loc.detach().numpy().copy(), vloc.detach().numpy().copy(), grads))
+    ids = plan.node_ids.numpy().copy() if plan.node_ids is not None else np.arange(plan.n0, plan.n1)
+    q.put((rank, ids, plan.exchanged_bytes(), loc.detach().numpy().copy(), vloc.detach().numpy().copy(), grads))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gravity", [None, [0, -1, 0]])
-def test_two_rank_sharded_graph_matches_single_process_oracle(gravity):
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world,gravity,exchange,reorder", [
+    (2, None, "halo", False), (2, [0, -1, 0], "allgather", False), (2, [0, -1, 0], "halo", True),
+    (4, [0, -1, 0], "halo", False), (4, None, "halo", True), (4, None, "allgather", True)])
+def test_sharded_graph_matches_single_process_oracle(world, gravity, exchange, reorder):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, gravity, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, gravity, exchange, reorder, q)) for r in range(world)]
     for pr in procs:
         pr.start()
-    res = [q.get(timeout=180) for _ in range(world)]
+    res = [q.get(timeout=240) for _ in range(world)]
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
@@ -108,13 +114,36 @@ def test_two_rank_sharded_graph_matches_single_process_oracle(gravity):
     p = {k: v.detach().clone().requires_grad_(True) for k, v in m.named_parameters()}
     loc, vloc = R.forward(p, cfg, **inp)
     _loss(loc, vloc, target, target.size(0)).backward()
-    for rank, n0, n1, loc_r, vloc_r, grads in res:
-        assert rel_err(loc_r, loc.detach()[n0:n1]) < 1e-5
+    seen = np.concatenate([r[1] for r in res])
+    assert sorted(seen.tolist()) == list(range(target.size(0)))        # every node owned by exactly one rank
+    last = CFG["n_layers"] - 1
+    for rank, ids, xbytes, loc_r, vloc_r, grads in res:
+        assert rel_err(loc_r, loc.detach()[torch.from_numpy(ids)]) < 1e-5
         assert rel_err(vloc_r, vloc.detach()) < 1e-5
+        if exchange == "halo":                                             # ghosts are at most the remote nodes
+            assert xbytes <= (target.size(0) - len(ids)) * 68 * 4
         for k, v in p.items():
-            want = v.grad if v.grad is not None else torch.zeros_like(v)
+            if v.grad is None:      # the last layer's unused heads: None here too (torch.optim.Adam skips them)
+                assert k.startswith(f"gcl_{last}.node_mlp") and (grads[k] is None or not np.any(grads[k])), k
+                continue
             assert grads[k] is not None, k
-            assert rel_err(grads[k], want) < 2e-4, (rank, k, rel_err(grads[k], want))
+            assert rel_err(grads[k], v.grad) < 2e-4, (rank, k, rel_err(grads[k], v.grad))
+
+
+def test_morton_order_keeps_graphs_contiguous_and_localises_neighbours():
+    from fastegnn_amd.sharded import morton_order
+    g = torch.Generator().manual_seed(3)
+    loc = torch.rand(4000, 3, generator=g)
+    batch = torch.cat([torch.zeros(2500, dtype=torch.long), torch.ones(1500, dtype=torch.long)])
+    order = morton_order(loc, batch)
+    assert sorted(order.tolist()) == list(range(4000))
+    assert torch.equal(batch[order], batch)                                # graphs stay contiguous and in place
+    # index distance of spatial neighbours shrinks: a contiguous range is a compact region
+    lo = loc[order][:2500]
+    d = torch.cdist(lo[:300], lo)
+    nn_idx = d.topk(8, largest=False).indices
+    spread = (nn_idx - torch.arange(300).unsqueeze(1)).abs().float().median()
+    assert spread < 400, spread                                            # random order: ~800 for 2500 nodes
 
 
 def test_shard_plan():
