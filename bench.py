@@ -671,6 +671,7 @@ def main():
                        "launch": ("whole step replayed as one captured HIP graph; per-kernel durations from an eager pass of "
                                   f"{prof_steps} steps before the capture") if use_graph else "eager launches"},
             "value_per_gpu": round(value / world, 4),
+            "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
             "roofline": roof,
             "edge_scatter": edge_scatter,
             "kernels": kernels,

@@ -492,8 +492,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
           att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + attb0);
           v = vscale(v0, att);
         }
-        if (valid) vstore_u(A.wg_v + cb, offN, v);
-        VB2_T(3)   // silu, v store
+        VB2_T(3)   // silu
         float sx, sX;
         Vec g_ux, g_uX;
         {
@@ -530,6 +529,9 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
         }
         VB2_T(5)   // head X forward + rank-1 sum
         Vec g_v = vload_u(A.Gv + cb, offN);   // (requested ahead of the publish: it arrives under the slot wait)
+        // v[c][n] takes the place of Gv[c][n]: ONE [C][N][64] array serves both (the row has just been requested by this
+        // very lane; same-address accesses of a lane stay in program order)
+        if (valid) vstore_u(A.wg_v + cb, offN, v);
 #ifndef VB_DIAG_NOPUB
         {   // (g_ux, v) and (g_uX, v) to consumers X and XX: one slot of ring A, free once both have drained it
           int tk = 0;
@@ -692,10 +694,10 @@ bool virt_backward_uses_pc(const fastegnn_layer_t *L) {
   static const bool off = getenv("FASTEGNN_VIRT_BWD_OLD") && atoi(getenv("FASTEGNN_VIRT_BWD_OLD")) != 0;
   return !off && L->C >= 1 && L->C <= 32 && !has(L, FASTEGNN_F_RF) && !has(L, FASTEGNN_F_EGNN);
 }
-// floats of wg_virt: v | Gv ([C][N + pad][64] each) | parts of g_A and g_x
+// floats of wg_virt: Gv, overwritten row by row with v ([C][N + pad][64]) | parts of g_A and g_x | consumer scratch
 size_t virt_pc_wg_floats(size_t N, size_t C) {
   const size_t NGF = (C + VB_GF - 1) / VB_GF;
-  return 2 * (N + WGV_PAD) * C * H + (size_t)256 * VB_FINE_TILES * (NGF - 1) * 16 * (H + 4) + (size_t)256 * 3 * IMG;
+  return (N + WGV_PAD) * C * H + (size_t)256 * VB_FINE_TILES * (NGF - 1) * 16 * (H + 4) + (size_t)256 * 3 * IMG;
 }
 
 int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
@@ -713,7 +715,7 @@ int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shar
   FE_REQUIRE(!att || (g[FASTEGNN_P_ATTV_W] && g[FASTEGNN_P_ATTV_B]), "virt_backward: attention grads null");
   FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
   const size_t cstride = ((size_t)N + WGV_PAD) * H;
-  float *wg_v = L->wg_virt, *Gv = L->wg_virt + cstride * C;
+  float *wg_v = L->wg_virt, *Gv = L->wg_virt;   // one array: virt_bwd_gv writes Gv, virt_bwd_pc replaces each row by v
   const int NGF = (C + VB_GF - 1) / VB_GF;
   float *gA_part = Gv + cstride * C, *gx_part = gA_part + (size_t)256 * VB_FINE_TILES * (NGF - 1) * 16 * H;
   float *wg_t3 = L->wg_node, *wg_gnp = L->wg_node + (size_t)N * H;
