@@ -19,7 +19,7 @@ QX_LD = 68
 FEATW = 8
 
 # flags (fastegnn_hip.h)
-F_ATTENTION, F_NORMALIZE, F_TANH, F_RESIDUAL, F_GRAVITY, F_COORDS_SUM, F_EGNN, F_RF, F_BF16 = 1, 2, 4, 8, 16, 32, 64, 128, 256
+F_ATTENTION, F_NORMALIZE, F_TANH, F_RESIDUAL, F_GRAVITY, F_COORDS_SUM, F_EGNN, F_RF, F_BF16, F_EGNN_NORM = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 # per-layer parameter slots, in header order -> reference state_dict suffix (models/FastEGNN.py:28-99)
 PARAM_SLOTS = [

@@ -376,6 +376,40 @@ __device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Split &in,
 }
 __device__ __forceinline__ void gemm64_x3(const unsigned *img3, const Vec &in, Vec &acc) { gemm64_x3(img3, vsplit(in), acc); }
 
+// Diagnostic lever (-DFE_EDGE_T2, edge_fwd only): the activation operand split into TWO bf16 parts
+// (h, m: 16 mantissa bits) -- 3.5 instead of 5.5 vector instructions per element and five products instead of six (the
+// (h, l) product is gone).  Costs 2^-17 relative on the operand; measured in DESIGN.md section 12, not used by any product path.
+__device__ __forceinline__ void gemm64_x3_t2(const unsigned *img3, const Vec &v, Vec &acc) {
+  const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + lane_id();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float x[8], r1[8];
+    u32x4 ph, pm;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      x[e] = v.t[2 * s + (e >> 2)][e & 3];
+      r1[e] = x[e] - trunc_bf(x[e]);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      ph[w] = pack_hi(x[2 * w], x[2 * w + 1]);
+      pm[w] = pack_hi(r1[2 * w], r1[2 * w + 1]);
+    }
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, ph), xm = __builtin_bit_cast(bf16x8, pm);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, ip[(t * 2 + s) * 64]);
+      const bf16x8 am = __builtin_bit_cast(bf16x8, ip[512 + (t * 2 + s) * 64]);
+      const bf16x8 al = __builtin_bit_cast(bf16x8, ip[1024 + (t * 2 + s) * 64]);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xm, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xh, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xm, acc.t[t], 0, 0, 0);
+      acc.t[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc.t[t], 0, 0, 0);
+    }
+  }
+}
+
 // ---- bf16 operand mode (FASTEGNN_F_BF16): both operands rounded to bf16 (RNE), ONE bf16 product, fp32 accumulate ----
 // The weights are rounded by pack_kernel, so the `h` part of a split image IS the bf16 weight matrix (m = l = 0) and
 // the fp32 images hold bf16-representable values; activations are rounded here (v_cvt_pk_bf16_f32).
@@ -617,13 +651,14 @@ enum ImgId {
 __host__ __device__ inline int img_w3c(int c) { return I_FIXED + c; }
 __host__ __device__ inline int img_w3ct(int C, int c) { return I_FIXED + C + c; }
 // wpack = [fp32 images n x 4096 floats][split images n x IMG3 words (h | m | l)][row-major split images (5 + C) x RM_WORDS]
-// row-major images: slot 0 V2, 1 WXV0, 2 WXX0 (virt_bwd), 3 W2, 4 WX1 (edge_bwd), RM_FIXED + c: W3c[c] (virt_bwd)
-constexpr int RM_FIXED = 5;
+// row-major images: slot 0 V2, 1 WXV0, 2 WXX0 (virt_bwd), 3 W2, 4 WX1 (edge_bwd), 5 WVEL0, 6 WG0 (node_pre_bwd),
+// RM_FIXED + c: W3c[c] (virtual backward)
+constexpr int RM_FIXED = 7;
 __host__ __device__ inline size_t wpack_images(int C) { return (size_t)(I_FIXED + 2 * C); }
 __host__ __device__ inline size_t wpack_rm_images(int C) { return (size_t)(RM_FIXED + (C > 0 ? C : 0)); }
 __host__ __device__ inline size_t wpack_floats(int C) { return wpack_images(C) * (IMG + IMG3) + wpack_rm_images(C) * RM_WORDS; }
 __host__ __device__ inline int rm_slot(int id) {   // -1: the image has no row-major copy
-  return id == I_V2 ? 0 : id == I_WXV0 ? 1 : id == I_WXX0 ? 2 : id == I_W2 ? 3 : id == I_WX1 ? 4 : -1;
+  return id == I_V2 ? 0 : id == I_WXV0 ? 1 : id == I_WXX0 ? 2 : id == I_W2 ? 3 : id == I_WX1 ? 4 : id == I_WVEL0 ? 5 : id == I_WG0 ? 6 : -1;
 }
 __host__ __device__ inline const char *wpack_rm(const float *wpack, int C, int slot) {
   return reinterpret_cast<const char *>(wpack + wpack_images(C) * (IMG + IMG3)) + (size_t)slot * RM_BYTES;

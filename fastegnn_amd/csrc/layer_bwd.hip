@@ -1195,7 +1195,8 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       Vec g_t = vzero();
       gemm_e<MODE, 2, true>(img, g_mp, g_t);
       const Vec g_pre = vmul(g_t, pre);
-      const float g_r = vdot(g_pre, vload_vec(vec + EV_WR * H, q));
+      float g_r = vdot(g_pre, vload_vec(vec + EV_WR * H, q));
+      if (a.flags & FASTEGNN_F_EGNN_NORM) g_r *= S.r >= 1e-12f ? 0.f : 1e12f;   // d normalize(r^2) / d r^2
       float g_d[3];
       const float invn = norm_on ? rcp_f(S.nrm + a.eps) : 1.f;
 #pragma unroll
@@ -1239,7 +1240,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
           accx += xv[ee];
           // d edge_mlp.0.weight[:, 2H + k] += g_pre * [radial | edge_attr][k]   (lane = output row);
           // the per-edge scalars come from the owning lane's registers (v_readlane), not from LDS
-          accW[0] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.r), ee));
+          accW[0] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.rf), ee));
 #pragma unroll
           for (int k = 0; k < EA; ++k)   // slots beyond ea_dim hold zeros
             accW[1 + k] += gp * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S.eav[k]), ee));
@@ -1433,45 +1434,62 @@ struct NodePreBwdArgs {
   int N, gravity, has_vel;
   const float *vel, *wv0;   // FastRF velocity head: coord_mlp_vel(||vel||), wv0 = coord_mlp_vel.0.weight [H,1]
   float *d_wv0, *d_bv0;
-  int bf16;
+  int C;
 };
+// MODE: GM_X3 / GM_BF16 as in node_pre_fwd_kernel.  LDS: three split images W1AT W1BT V1AT (transposed products only) and the
+// ROW-MAJOR split images of WVEL0 and WG0 (common.h), each serving its product and its transpose: 127 KB instead of the
+// 168 KB seven split images would take.
+template <int MODE>
 __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodePreBwdArgs a) {
-  // images WVEL0 WG0 | W1AT W1BT V1AT WVEL0T WG0T (consecutive ids) resident in LDS
   extern __shared__ __attribute__((aligned(16))) float limg[];
-  load_images(limg, a.wpack + (size_t)I_WVEL0 * IMG, 7);
+  unsigned *img3 = reinterpret_cast<unsigned *>(limg);                    // W1AT W1BT V1AT (consecutive ids)
+  char *rmv = reinterpret_cast<char *>(limg + 3 * IMG3), *rmg = rmv + RM_BYTES;   // WVEL0, WG0 (consecutive row-major slots)
+  load_images_x3(img3, wpack_x3(a.wpack, a.C, I_W1AT), 3);
+  if (a.has_vel || a.gravity) {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, a.C, rm_slot(I_WVEL0)));
+    u32x4 *dst = reinterpret_cast<u32x4 *>(rmv);
+    for (int i = threadIdx.x; i < 2 * RM_BYTES / 16; i += blockDim.x) dst[i] = src[i];
+  }
   __syncthreads();
-  auto im = [&](int id) { return limg + (id - I_WVEL0) * IMG; };
-  // one GEMM's operand reads at a time: without the fences the scheduler hoists the LDS reads of all seven
-  // GEMMs of a tile (448 registers) and spills
-  const bool bf = a.bf16;   // bf16 operand mode: the B operand of every product is rounded
-  auto gemm_f = [&](const float *img, const Vec &in, Vec &acc) {
-    __builtin_amdgcn_sched_barrier(0);
-    gemm64(img, bf ? vround(in) : in, acc);
-    __builtin_amdgcn_sched_barrier(0);
-  };
+  typedef typename OperandOf<MODE>::type Op;
+  auto op = [](const Vec &v) -> Op { return make_operand<MODE>(v); };
   const int l = lane_id(), j = l & 15, q = l >> 4;
   const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int ntiles = (a.N + 15) >> 4;
   Vec acc_wv2 = vzero(), acc_wg2 = vzero(), acc_wv0 = vzero(), acc_bv0 = vzero();
-  float acc_bv2 = 0.f, acc_bg2 = 0.f;
+  // the two scalar head biases: sums of N per-node values with cancellation; double accumulators (one add per tile) keep
+  // them at the reference's level (a float chain + float atomics measured 1.07e-6 against a reference at 3e-8)
+  double acc_bv2 = 0.0, acc_bg2 = 0.0;
   for (int tile = wave; tile < ntiles; tile += nwaves) {
     const int n = tile * 16 + j;
     const bool valid = n < a.N;
     const int nc = valid ? n : a.N - 1;
-    const Vec hv = vload_row(a.h + (size_t)nc * H, q);
     Vec g_h = vload_row(a.g_h + (size_t)nc * H, q);
-    gemm_f(im(I_W1AT), vload_row(a.g_P + (size_t)nc * H, q), g_h);
-    gemm_f(im(I_W1BT), vload_row(a.g_QX + (size_t)nc * QXLD, q), g_h);
-    gemm_f(im(I_V1AT), vload_row(a.g_A + (size_t)nc * H, q), g_h);
-    if (a.has_vel) {  // coord_mlp_vel head (:139)
-      Vec z = vload_vec(a.bv0, q);
-      gemm_f(im(I_WVEL0), hv, z);
-      const float gs = valid ? a.g_svel[nc] : 0.f;
-      vaxpy(acc_wv2, gs, vsilu(z));
-      if (q == 0) acc_bv2 += gs;
-      const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z);
-      if (valid) vstore_row(a.wg_gzv + (size_t)n * H, q, g_z);
-      gemm_f(im(I_WVEL0T), g_z, g_h);
+    gemm_op<MODE>(img3, 0, op(vload_row(a.g_P + (size_t)nc * H, q)), g_h);
+    gemm_op<MODE>(img3, 1, op(vload_row(a.g_QX + (size_t)nc * QXLD, q)), g_h);
+    gemm_op<MODE>(img3, 2, op(vload_row(a.g_A + (size_t)nc * H, q)), g_h);
+    if (a.has_vel || a.gravity) {
+      const Op hv = op(vload_row(a.h + (size_t)nc * H, q));   // one split / rounding feeds both heads
+      if (a.has_vel) {  // coord_mlp_vel head (:139)
+        Vec z = vload_vec(a.bv0, q);
+        gemm_rm<MODE, false>(rmv, hv, z);
+        const float gs = valid ? a.g_svel[nc] : 0.f;
+        vaxpy(acc_wv2, gs, vsilu(z));
+        if (q == 0) acc_bv2 += gs;
+        const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z);
+        if (valid) vstore_row(a.wg_gzv + (size_t)n * H, q, g_z);
+        gemm_rm<MODE, true>(rmv, op(g_z), g_h);
+      }
+      if (a.gravity) {  // gravity_mlp head (:142)
+        Vec z = vload_vec(a.bg0, q);
+        gemm_rm<MODE, false>(rmg, hv, z);
+        const float gs = valid ? a.g_sgrav[nc] : 0.f;
+        vaxpy(acc_wg2, gs, vsilu(z));
+        if (q == 0) acc_bg2 += gs;
+        const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wg2, q), gs), z);
+        if (valid) vstore_row(a.wg_gzg + (size_t)n * H, q, g_z);
+        gemm_rm<MODE, true>(rmg, op(g_z), g_h);
+      }
     }
     if (a.wv0) {  // FastRF.py:139: only parameter gradients (the norm of the velocity is detached)
       const float vx = a.vel[(size_t)nc * 3], vy = a.vel[(size_t)nc * 3 + 1], vz = a.vel[(size_t)nc * 3 + 2];
@@ -1484,16 +1502,6 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodeP
       const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z);
       vadd(acc_bv0, g_z);
       vaxpy(acc_wv0, vn, g_z);
-    }
-    if (a.gravity) {  // gravity_mlp head (:142)
-      Vec z = vload_vec(a.bg0, q);
-      gemm_f(im(I_WG0), hv, z);
-      const float gs = valid ? a.g_sgrav[nc] : 0.f;
-      vaxpy(acc_wg2, gs, vsilu(z));
-      if (q == 0) acc_bg2 += gs;
-      const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wg2, q), gs), z);
-      if (valid) vstore_row(a.wg_gzg + (size_t)n * H, q, g_z);
-      gemm_f(im(I_WG0T), g_z, g_h);
     }
     if (valid) {
       vstore_row(a.g_h + (size_t)n * H, q, g_h);
@@ -1509,13 +1517,19 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodeP
     }
   }
   __shared__ float red[4 * H + 2];
+  __shared__ double red_d[2];
   for (int i = threadIdx.x; i < 4 * H + 2; i += blockDim.x) red[i] = 0.f;
+  if (threadIdx.x < 2) red_d[threadIdx.x] = 0.0;
   __syncthreads();
-  float s = 0.f;
+  auto dsum = [&](double v) {   // sum over the 64 lanes of the wave
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+  };
+  double s = 0.0;
   if (a.has_vel || a.wv0) {
     vec_reduce_lds(red, acc_wv2, j, q);
-    s = jsum(acc_bv2);
-    if (l == 0) atomicAdd(&red[2 * H], s);
+    s = dsum(acc_bv2);
+    if (l == 0) atomicAdd(&red_d[0], s);
   }
   if (a.wv0) {
     vec_reduce_lds(red + 2 * H + 2, acc_wv0, j, q);
@@ -1523,14 +1537,14 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodeP
   }
   if (a.gravity) {
     vec_reduce_lds(red + H, acc_wg2, j, q);
-    s = jsum(acc_bg2);
-    if (l == 0) atomicAdd(&red[2 * H + 1], s);
+    s = dsum(acc_bg2);
+    if (l == 0) atomicAdd(&red_d[1], s);
   }
   __syncthreads();
   if (threadIdx.x < H) {
     if (a.has_vel || a.wv0) {
       atomicAdd(&a.d_wv2[threadIdx.x], red[threadIdx.x]);
-      if (threadIdx.x == 0) atomicAdd(a.d_bv2, red[2 * H]);
+      if (threadIdx.x == 0) atomicAdd(a.d_bv2, (float)red_d[0]);
     }
     if (a.wv0) {
       atomicAdd(&a.d_wv0[threadIdx.x], red[2 * H + 2 + threadIdx.x]);
@@ -1538,7 +1552,7 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodeP
     }
     if (a.gravity) {
       atomicAdd(&a.d_wg2[threadIdx.x], red[H + threadIdx.x]);
-      if (threadIdx.x == 0) atomicAdd(a.d_bg2, red[2 * H + 1]);
+      if (threadIdx.x == 0) atomicAdd(a.d_bg2, (float)red_d[1]);
     }
   }
 }
@@ -1559,13 +1573,18 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *sha
                    L->batch, L->g_h, L->g_x, L->g_vel, wg_gzv, wg_gzg,
                    g[FASTEGNN_P_VEL2_W], g[FASTEGNN_P_VEL2_B], g[FASTEGNN_P_GRAV2_W], g[FASTEGNN_P_GRAV2_B], N, grav ? 1 : 0,
                    (p[FASTEGNN_P_VEL0_W] && !rf) ? 1 : 0, L->vel, rf ? p[FASTEGNN_P_VEL0_W] : nullptr,
-                   g[FASTEGNN_P_VEL0_W], g[FASTEGNN_P_VEL0_B], has(L, FASTEGNN_F_BF16) ? 1 : 0};
+                   g[FASTEGNN_P_VEL0_W], g[FASTEGNN_P_VEL0_B], L->C};
   FE_REQUIRE(!rf || (L->vel && p[FASTEGNN_P_VEL0_W] && g[FASTEGNN_P_VEL0_W] && g[FASTEGNN_P_VEL0_B] && g[FASTEGNN_P_VEL2_W] &&
                      g[FASTEGNN_P_VEL2_B]),
              "node_pre_backward: FastRF needs vel and the coord_mlp_vel parameters / gradients");
   int grid = cdiv(cdiv(N, 16), NODE_PRE_WAVES);
   if (grid > 256) grid = 256;
-  { ProfScope _ps_node_pre_bwd_kernel(K_NODE_PRE_BWD, st); hipLaunchKernelGGL(node_pre_bwd_kernel, dim3(grid), dim3(64 * NODE_PRE_WAVES), 7 * IMG * sizeof(float), st, a); }
+  {
+    ProfScope _ps_node_pre_bwd_kernel(K_NODE_PRE_BWD, st);
+    const size_t lds = (size_t)3 * IMG3 * sizeof(float) + 2 * RM_BYTES;
+    if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL(node_pre_bwd_kernel<GM_BF16>, dim3(grid), dim3(64 * NODE_PRE_WAVES), lds, st, a);
+    else hipLaunchKernelGGL(node_pre_bwd_kernel<GM_X3>, dim3(grid), dim3(64 * NODE_PRE_WAVES), lds, st, a);
+  }
   int rc = check_launch("node_pre_bwd_kernel");
   if (rc) return rc;
   const int ld_e0 = 2 * H + 1 + L->ea, ld_v0 = 2 * H + 1 + L->C;

@@ -14,15 +14,19 @@ struct NodePreArgs {
   float *P, *QX, *A, *svel, *sgrav;
   int N, gravity, has_vel;
   const float *vel, *wv0;   // FastRF: velocity scale from ||vel|| through coord_mlp_vel.0.weight [H,1]
-  int bf16;                 // bf16 operand mode: h is rounded (the images hold rounded weights)
+  int C;
 };
 
+// MODE: GM_X3 (bf16x3 products of the split images: fp32-grade, 2.7 x fewer matrix cycles than the fp32-input MFMA these
+// node-level kernels ran on through round 2 -- 2048 -> 768 cycles per 64x64 product and tile, + one operand split per
+// input) or GM_BF16 (bf16 operand mode: one product of the RNE-rounded activation)
+template <int MODE>
 __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodePreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *img = lds;            // 5 images: W1A W1B V1A WVEL0 WG0
-  float *vec = lds + 5 * IMG;  // b1 bv0 wv2 bg0 wg2
+  unsigned *img = reinterpret_cast<unsigned *>(lds);   // 5 split images: W1A W1B V1A WVEL0 WG0
+  float *vec = lds + 5 * IMG3;                         // b1 bv0 wv2 bg0 wg2 wv0
   const int nimg = a.gravity ? 5 : 4;
-  load_images(img, a.wpack + (size_t)I_W1A * IMG, nimg);
+  load_images_x3(img, wpack_x3(a.wpack, a.C, I_W1A), nimg);
   load_floats(vec + 0 * H, a.b1, H);
   load_floats(vec + 1 * H, a.bv0, H);
   load_floats(vec + 2 * H, a.wv2, H);
@@ -39,13 +43,12 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodeP
     const int n = tile * 16 + j;
     const bool valid = n < a.N;
     const int nc = valid ? n : a.N - 1;
-    Vec hv = vload_row(a.h + (size_t)nc * H, q);
-    if (a.bf16) hv = vround(hv);
+    const typename OperandOf<MODE>::type hv = make_operand<MODE>(vload_row(a.h + (size_t)nc * H, q));   // one split / rounding feeds all products
     Vec acc = vload_vec(vec, q);
-    gemm64_f(img + 0 * IMG, hv, acc);
+    gemm_op<MODE>(img, 0, hv, acc);
     if (valid) vstore_row(a.P + (size_t)n * H, q, acc);
     acc = vzero();
-    gemm64_f(img + 1 * IMG, hv, acc);
+    gemm_op<MODE>(img, 1, hv, acc);
     if (valid) {
       vstore_row(a.QX + (size_t)n * QXLD, q, acc);
       if (q == 0) {
@@ -54,12 +57,12 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodeP
       }
     }
     acc = vzero();
-    gemm64_f(img + 2 * IMG, hv, acc);
+    gemm_op<MODE>(img, 2, hv, acc);
     if (valid) vstore_row(a.A + (size_t)n * H, q, acc);
     float s = 0.f;
     if (a.has_vel) {
       acc = vload_vec(vec + 1 * H, q);
-      gemm64_f(img + 3 * IMG, hv, acc);
+      gemm_op<MODE>(img, 3, hv, acc);
       s = vdot(vsilu(acc), vload_vec(vec + 2 * H, q)) + bv2;
     } else if (a.wv0) {   // FastRF.py:139: coord_mlp_vel(||vel||), the norm is detached (:169)
       const float vx = a.vel[(size_t)nc * 3], vy = a.vel[(size_t)nc * 3 + 1], vz = a.vel[(size_t)nc * 3 + 2];
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodeP
     if (valid && q == 0) a.svel[n] = s;
     if (a.gravity) {
       acc = vload_vec(vec + 3 * H, q);
-      gemm64_f(img + 4 * IMG, hv, acc);
+      gemm_op<MODE>(img, 4, hv, acc);
       s = vdot(vsilu(acc), vload_vec(vec + 4 * H, q)) + bg2;
       if (valid && q == 0) a.sgrav[n] = s;
     }
@@ -87,15 +90,19 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
                 p[FASTEGNN_P_VEL2_B], p[FASTEGNN_P_GRAV0_B], p[FASTEGNN_P_GRAV2_W], p[FASTEGNN_P_GRAV2_B],
                 L->P, L->QX, L->A, L->svel, L->sgrav, L->N, grav ? 1 : 0,
                 (p[FASTEGNN_P_VEL0_W] && !has(L, FASTEGNN_F_RF)) ? 1 : 0,
-                L->vel, has(L, FASTEGNN_F_RF) ? p[FASTEGNN_P_VEL0_W] : nullptr, has(L, FASTEGNN_F_BF16) ? 1 : 0};
+                L->vel, has(L, FASTEGNN_F_RF) ? p[FASTEGNN_P_VEL0_W] : nullptr, L->C};
   FE_REQUIRE(!has(L, FASTEGNN_F_RF) || (L->vel && p[FASTEGNN_P_VEL0_W] && p[FASTEGNN_P_VEL0_B] && p[FASTEGNN_P_VEL2_W] &&
                                          p[FASTEGNN_P_VEL2_B]),
              "node_pre_forward: FastRF needs vel and the coord_mlp_vel parameters");
   const int ntiles = (L->N + 15) / 16;
   int grid = cdiv(ntiles, NODE_PRE_WAVES);
   if (grid > 256) grid = 256;
-  const size_t lds = (5 * IMG + 6 * H) * sizeof(float);
-  { ProfScope _ps_node_pre_fwd_kernel(K_NODE_PRE_FWD, st); hipLaunchKernelGGL(node_pre_fwd_kernel, dim3(grid), dim3(64 * NODE_PRE_WAVES), lds, st, a); }
+  const size_t lds = (5 * IMG3 + 6 * H) * sizeof(float);
+  {
+    ProfScope _ps_node_pre_fwd_kernel(K_NODE_PRE_FWD, st);
+    if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL(node_pre_fwd_kernel<GM_BF16>, dim3(grid), dim3(64 * NODE_PRE_WAVES), lds, st, a);
+    else hipLaunchKernelGGL(node_pre_fwd_kernel<GM_X3>, dim3(grid), dim3(64 * NODE_PRE_WAVES), lds, st, a);
+  }
   return check_launch("node_pre_fwd_kernel");
 }
 

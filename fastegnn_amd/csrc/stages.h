@@ -49,7 +49,7 @@ __device__ __forceinline__ void edge_load_vecs(float *vec, const EdgeArgs &a) {
 
 struct EdgeFwdState {
   Vec t, mp, m0, m, up, u;
-  float d[3], dn[3], r, nrm, att, s, eav[8];
+  float d[3], dn[3], r, rf, nrm, att, s, eav[8];   // rf: the radial FEATURE of the message MLP (r, or its normalised form)
   int row, col;
 };
 
@@ -130,7 +130,9 @@ __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *ve
   FE_T(0)   // indices + coordinates arrived
   pre = G.p;
   vadd(pre, G.qv);
-  vaxpy(pre, S.r, vload_vec(vec + EV_WR * H, q));
+  // EGNN(norm=True): F.normalize of the 1x1 Gram (basic.py:271-272, eps 1e-12)
+  S.rf = (a.flags & FASTEGNN_F_EGNN_NORM) ? (S.r >= 1e-12f ? 1.0f : S.r * 1e12f) : S.r;
+  vaxpy(pre, S.rf, vload_vec(vec + EV_WR * H, q));
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     S.eav[k] = I.eav[k];
@@ -145,6 +147,10 @@ __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img
   S.t = KEEP_D ? vsilu_keep_d(pre) : vsilu(pre);
   FE_T(2)   // silu 1
   S.mp = vload_vec(vec + EV_B2 * H, q);
+#ifdef FE_EDGE_T2   // diagnostic lever: two-part split of the first chained layer's operand (forward kernel, fp32 mode)
+  if constexpr (!KEEP_D && MODE == GM_X3 && !RM) gemm64_x3_t2(reinterpret_cast<const unsigned *>(img), S.t, S.mp);
+  else
+#endif
   gemm_e<MODE, 0, RM>(img, S.t, S.mp);
   FE_T(3)   // gemm 1
   S.m0 = KEEP_D ? vsilu_keep_d(S.mp) : vsilu(S.mp);

@@ -52,17 +52,17 @@ __device__ __forceinline__ Vec vb_mask(const Vec &v, bool keep) { return keep ? 
 struct VirtNodeArgs {
   const float *g_h_out, *npre, *g_x_out, *vel, *aggx, *wpack;
   float *wg_t3, *wg_gnp, *g_h, *g_aggm, *g_aggx, *g_svel, *g_sgrav;
-  int N, flags;
+  int N, flags, C;
   float g[3];
 };
 constexpr int VB_NODE_WAVES = 8;
 template <bool BF>
 __global__ __launch_bounds__(64 * VB_NODE_WAVES) void virt_bwd_node_kernel(VirtNodeArgs a) {
-  constexpr int FM = BF ? GM_BF16 : GM_F32;   // fp32 images; bf16 mode rounds the activation operand
+  constexpr int SM = BF ? GM_BF16 : GM_X3;   // split images: bf16x3 products (or one bf16 product of the rounded operand)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  load_images(lds, a.wpack + (size_t)I_W3AT * IMG, 3);   // W3AT, W3BT, W4T (consecutive ids)
+  unsigned *img = reinterpret_cast<unsigned *>(lds);
+  load_images_x3(img, wpack_x3(a.wpack, a.C, I_W3AT), 3);   // W3AT, W3BT, W4T (consecutive ids)
   __syncthreads();
-  const float *w3at = lds, *w3bt = lds + IMG, *w4t = lds + 2 * IMG;
   const int l = lane_id(), j = l & 15, q = l >> 4;
   const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
   const int ntiles = (a.N + 15) >> 4;
@@ -74,21 +74,18 @@ __global__ __launch_bounds__(64 * VB_NODE_WAVES) void virt_bwd_node_kernel(VirtN
     const Vec g_out = vb_mask(vload_row(a.g_h_out + (size_t)nc * H, q), valid);
     const Vec npre = vload_row(a.npre + (size_t)nc * H, q);
     Vec g_t3 = vzero();
-    __builtin_amdgcn_sched_barrier(0);
-    gemm64_m<FM>(w4t, g_out, g_t3);
-    __builtin_amdgcn_sched_barrier(0);
+    gemm_op<SM>(img, 2, make_operand<SM>(g_out), g_t3);
     const Vec g_np = vb_dsilu_mul(g_t3, npre);
     if (valid) {
       vstore_row(a.wg_t3 + (size_t)n * H, q, vsilu(npre));
       vstore_row(a.wg_gnp + (size_t)n * H, q, g_np);
     }
+    const typename OperandOf<SM>::type gop = make_operand<SM>(g_np);   // shared by the two products
     Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
-    gemm64_m<FM>(w3at, g_np, g_h);
-    __builtin_amdgcn_sched_barrier(0);
+    gemm_op<SM>(img, 0, gop, g_h);
     if (valid) vstore_row(a.g_h + (size_t)n * H, q, g_h);
     Vec g_am = vzero();
-    gemm64_m<FM>(w3bt, g_np, g_am);
-    __builtin_amdgcn_sched_barrier(0);
+    gemm_op<SM>(img, 1, gop, g_am);
     if (valid) vstore_row(a.g_aggm + (size_t)n * H, q, g_am);
     if (valid && q == 0) {
       float sv = 0.f, sg = 0.f;
@@ -723,12 +720,12 @@ int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shar
   int rc;
   {   // B4a
     VirtNodeArgs a{L->g_h_out, L->npre, L->g_x_out, L->vel, L->aggx, L->wpack, wg_t3, wg_gnp, L->g_h, L->g_aggm, L->g_aggx,
-                   L->g_svel, L->g_sgrav, N, L->flags, {L->gravity[0], L->gravity[1], L->gravity[2]}};
+                   L->g_svel, L->g_sgrav, N, L->flags, C, {L->gravity[0], L->gravity[1], L->gravity[2]}};
     int grid = cdiv(ntiles, VB_NODE_WAVES);
     if (grid > 256) grid = 256;
     ProfScope ps(K_VIRT_BWD_NODE, st);
-    if (bf) hipLaunchKernelGGL((virt_bwd_node_kernel<true>), dim3(grid), dim3(64 * VB_NODE_WAVES), 3 * IMG * sizeof(float), st, a);
-    else hipLaunchKernelGGL((virt_bwd_node_kernel<false>), dim3(grid), dim3(64 * VB_NODE_WAVES), 3 * IMG * sizeof(float), st, a);
+    if (bf) hipLaunchKernelGGL((virt_bwd_node_kernel<true>), dim3(grid), dim3(64 * VB_NODE_WAVES), 3 * IMG3 * sizeof(float), st, a);
+    else hipLaunchKernelGGL((virt_bwd_node_kernel<false>), dim3(grid), dim3(64 * VB_NODE_WAVES), 3 * IMG3 * sizeof(float), st, a);
   }
   if ((rc = check_launch("virt_bwd_node_kernel"))) return rc;
   {   // B4b

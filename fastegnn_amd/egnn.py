@@ -1,7 +1,8 @@
 """Drop-in ``EGNN`` baseline (reference ``models/basic.py:285-341``; built at ``main_nbody.py:107`` as
 ``EGNN(n_layers, in_node_nf=2, in_edge_nf=2, hidden_nf, device, with_v=True)``) on the same HIP kernels as
 FastEGNN: it is the virtual-channel-free wiring of the stage kernels (``FASTEGNN_F_EGNN``: C = 0, radial
-first in the message MLP's input, coordinate head with bias, +-100 clamp, no residual on h).
+first in the message MLP's input, coordinate head with bias, +-100 clamp, no residual on h; ``norm=True`` --
+the F.normalize of the 1x1 Gram feature, basic.py:271-272 -- is FASTEGNN_F_EGNN_NORM).
 Same constructor / forward signature / state_dict keys as the reference class; GPU only."""
 from __future__ import annotations
 
@@ -133,8 +134,9 @@ class EGNN(nn.Module):
     def __init__(self, n_layers, in_node_nf, in_edge_nf, hidden_nf, activation=nn.SiLU(), device='cpu', with_v=False,
                  flat=False, norm=False):
         super().__init__()
-        if hidden_nf != H or flat or norm or not isinstance(activation, nn.SiLU):
-            raise NotImplementedError("fastegnn_amd.EGNN: hidden_nf=64, SiLU, flat=False, norm=False only")
+        if hidden_nf != H or flat or not isinstance(activation, nn.SiLU):
+            raise NotImplementedError("fastegnn_amd.EGNN: hidden_nf=64, SiLU, flat=False only (flat=True means 256-wide Tanh MLPs)")
+        self.norm = bool(norm)
         if in_edge_nf > 7 or in_node_nf > 8:
             raise NotImplementedError("fastegnn_amd.EGNN: in_edge_nf<=7, in_node_nf<=8")
         self.n_layers, self.with_v = n_layers, with_v
@@ -163,7 +165,8 @@ class EGNN(nn.Module):
             layer_slots.append(slots)
         self._plist = [pidx[n] for n in names]
         self._spec = SimpleNamespace(C=0, ea=self.in_edge_nf, na=0, nf=self.in_node_nf, n_layers=self.n_layers,
-                                     flags=K.F_EGNN, gravity=[0.0, 0.0, 0.0], layer_slots=layer_slots, names=names)
+                                     flags=K.F_EGNN | (K.F_EGNN_NORM if self.norm else 0), gravity=[0.0, 0.0, 0.0],
+                                     layer_slots=layer_slots, names=names)
 
     def forward(self, x, h, edge_index, edge_fea, v=None):
         if not x.is_cuda:

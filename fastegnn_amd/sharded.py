@@ -423,8 +423,12 @@ def _layer_lists(spec: _Spec, params, i):
 
 class _ShardedFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, be, group, stats, spec: _Spec, plan: ShardPlan, graph, batch32, gptr, ea_sorted, node_attr,
+    def forward(ctx, be, group, stats, spec: _Spec, plan: ShardPlan, graph, batch32, gptr, edge_attr, node_attr,
                 node_feat, node_loc, node_vel, loc_mean, *params):
+        # edge_attr / node_attr: this rank's edges / rows; differentiable like in the single-GPU module (their gradients
+        # are accumulated by the edge / virtual backward kernels when asked for)
+        ea_sorted = graph.permute(edge_attr.detach() if edge_attr is not None else None)
+        node_attr = node_attr.detach().contiguous().float() if node_attr is not None else None
         W, rank = plan.world, plan.rank
         N, Npad, B, Cn = plan.nloc, plan.Npad, loc_mean.size(0), spec.C
         params = [p.detach() for p in params]
@@ -520,6 +524,12 @@ class _ShardedFunction(torch.autograd.Function):
         gpools = be.empty(nV + B * 3 * Cn)                                 # g_Bc | g_Zp adjacent: one all-reduce
         sc["g_Bc"], sc["g_Zp"] = gpools[:nV].view(B, Cn, H), gpools[nV:].view(B, 3, Cn)
         sc["g_QX_src"], sc["g_QX"] = plan.alloc_grad_tables(be)
+        want_ea = ctx.needs_input_grad[8] and ea_sorted is not None and E > 0
+        want_na = ctx.needs_input_grad[9] and node_attr is not None
+        if want_ea:
+            sc["g_ea_sorted"] = be.zeros(E, spec.ea)
+        if want_na:
+            sc["g_node_attr"] = be.zeros(N, spec.na)
         for i in reversed(range(spec.n_layers)):
             b = saved[i]
             lp = _layer_lists(spec, params, i)
@@ -549,7 +559,11 @@ class _ShardedFunction(torch.autograd.Function):
         for s_, suffix in zip(spec.layer_slots[last], K.PARAM_SLOTS):
             if s_ is not None and suffix.startswith(("node_mlp.", "node_mlp_virtual.")) and not (spec.flags & K.F_RF):
                 grads[s_] = None
-        return (None,) * 10 + (g_nf, g_x, g_vel, g_Z, *grads)
+        g_ea = None
+        if want_ea:   # back to this rank's edge order: sorted edge k is local edge perm[k]
+            g_ea = torch.empty_like(sc["g_ea_sorted"])
+            g_ea.index_copy_(0, graph.perm[:E].long(), sc["g_ea_sorted"])
+        return (None,) * 8 + (g_ea, sc["g_node_attr"] if want_na else None, g_nf, g_x, g_vel, g_Z, *grads)
 
 
 class ShardedFastEGNN(torch.nn.Module):
@@ -594,9 +608,6 @@ class ShardedFastEGNN(torch.nn.Module):
         tensors.  Collective when the exchange is "halo" (the ranks tell each other which rows they need).
         reorder=True first sorts the nodes of every graph along a Morton curve (`morton_order`), so that a rank owns a
         compact region of space; `plan.node_ids` / `plan.rows()` map the caller's node order to this rank's rows."""
-        for name, t in (("edge_attr", edge_attr), ("node_attr", node_attr)):
-            if t is not None and t.requires_grad:   # the single-GPU module returns these; the sharded caller does not (yet)
-                raise NotImplementedError(f"fastegnn_amd.ShardedFastEGNN: gradient w.r.t. {name} is not implemented")
         world, rank = self._world_rank()
         N = node_loc.size(0)
         order = None
@@ -606,13 +617,15 @@ class ShardedFastEGNN(torch.nn.Module):
             inv[order] = torch.arange(N, device=order.device)
             edge_index = inv[edge_index]
         plan = (HaloPlan if self.exchange == "halo" else ShardPlan)(N, world, rank, order)
-        ei, ea = plan.edges(edge_index, edge_attr.detach() if edge_attr is not None else None)
+        # (edge_attr / node_attr keep their autograd link: the selection below is differentiable, so a gradient computed
+        # for this rank's edges / rows flows back into the caller's full tensors -- zero where another rank owns the edge)
+        ei, ea = plan.edges(edge_index, edge_attr)
         if plan.mode == "halo":
             ei = plan.build(ei, _Comm(self.group, None))
         db = data_batch if order is None else data_batch[order]
         return dict(plan=plan, node_feat=plan.rows(node_feat), node_loc=plan.rows(node_loc), node_vel=plan.rows(node_vel),
                     edge_index=ei, edge_attr=ea, data_batch=db[plan.n0:plan.n1].contiguous(), loc_mean=loc_mean,
-                    node_attr=plan.rows(node_attr.detach()).float() if node_attr is not None else None)
+                    node_attr=plan.rows(node_attr).float() if node_attr is not None else None)
 
     def forward_local(self, local: Dict[str, torch.Tensor]):
         m = self.model
@@ -624,11 +637,13 @@ class ShardedFastEGNN(torch.nn.Module):
             m._plist = [pidx[n] for n in m._spec.names]
         spec = m._spec
         graph = be.build_graph(local["edge_index"], plan.nloc, plan.n_src, plan.n0)
-        ea_sorted = graph.permute(local["edge_attr"])
         B = local["loc_mean"].size(0)
         batch32, gptr = be.build_batch(local["data_batch"], plan.nloc, B)
         self.plan = plan
-        return _ShardedFunction.apply(be, self.group, self.stats, spec, plan, graph, batch32, gptr, ea_sorted,
+        ea = local["edge_attr"]
+        if ea is not None and ea.size(1) == 0:
+            ea = None
+        return _ShardedFunction.apply(be, self.group, self.stats, spec, plan, graph, batch32, gptr, ea,
                                       local["node_attr"], local["node_feat"], local["node_loc"], local["node_vel"],
                                       local["loc_mean"], *m._plist)
 

@@ -65,7 +65,10 @@ enum {
    * (round to nearest even) and multiplied on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Coordinates, radial /
    * vr / Gram terms and their weight columns, edge_attr / node_attr columns, the [1,64] heads, attention gates, biases,
    * activations, segment sums and pools stay fp32.  Mirror: oracle/factored.py with Config.bf16. */
-  FASTEGNN_F_BF16 = 256
+  FASTEGNN_F_BF16 = 256,
+  /* EGNN(norm=True) (models/basic.py:271-272): the 1x1 Gram feature of the message MLP is F.normalize'd -- r^2 / max(r^2, 1e-12),
+   * i.e. 1 for every edge of non-zero length (gradient 0) and r^2 * 1e12 below (gradient 1e12).  With FASTEGNN_F_EGNN only. */
+  FASTEGNN_F_EGNN_NORM = 512
 };
 
 /* Per-layer parameter slots: the reference state_dict tensors of gcl_<i>, untouched

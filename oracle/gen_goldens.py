@@ -321,10 +321,10 @@ def egnn_cases():
     sys.path.insert(0, REF)
     from models.basic import EGNN
 
-    def case(name, seed, with_v, coord_scale=1.0, L=2, loc_scale=2.0):
+    def case(name, seed, with_v, coord_scale=1.0, L=2, loc_scale=2.0, norm=False):
         torch.manual_seed(seed)
         gen = torch.Generator().manual_seed(seed + 100)
-        model = EGNN(n_layers=L, in_node_nf=2, in_edge_nf=2, hidden_nf=64, device="cpu", with_v=with_v)
+        model = EGNN(n_layers=L, in_node_nf=2, in_edge_nf=2, hidden_nf=64, device="cpu", with_v=with_v, norm=norm)
         with torch.no_grad():
             for k, v in model.named_parameters():
                 if "coord_net.mlp.2" in k:
@@ -352,7 +352,7 @@ def egnn_cases():
             rec[f"gp/{k}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
         for k, v in leaf.items():
             rec[f"gin/{k}"] = v.grad.numpy()
-        rec["meta/with_v"], rec["meta/L"] = np.array(int(with_v)), np.array(L)
+        rec["meta/with_v"], rec["meta/L"], rec["meta/norm"] = np.array(int(with_v)), np.array(L), np.array(int(norm))
         path = os.path.join(OUT, f"{name}.npz")
         np.savez_compressed(path, **rec)
         clamped = float((x_out.detach() - inp["x"]).abs().max())
@@ -361,6 +361,7 @@ def egnn_cases():
     case("egnn_with_v", 21, True)
     case("egnn_no_v", 22, False)
     case("egnn_clamped", 23, True, coord_scale=4000.0, loc_scale=6.0)    # tot_f hits the +-100 clamp (:310)
+    case("egnn_norm", 24, True, coord_scale=3.0, norm=True)              # F.normalize of the Gram feature (:271-272); self loops: r = 0
 
 
 def dataset_case(n_systems=6, n_balls=5, seed=43):

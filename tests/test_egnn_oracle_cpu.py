@@ -7,7 +7,7 @@ import torch
 from oracle import egnn_ref as E
 from tests.helpers import GOLDEN_DIR, rel_err
 
-EGNN_NAMES = ["egnn_with_v", "egnn_no_v", "egnn_clamped"]
+EGNN_NAMES = ["egnn_with_v", "egnn_no_v", "egnn_clamped", "egnn_norm"]   # egnn_norm: EGNN(norm=True), basic.py:271-272
 
 
 def load_egnn(name):
@@ -29,7 +29,8 @@ def test_egnn_oracle_matches_reference(name):
     p = {k: v.clone().requires_grad_(True) for k, v in g["p"].items()}
     i = g["in"]
     leaf = {k: i[k].clone().requires_grad_(True) for k in ("x", "h") + (("v",) if "v" in i else ())}
-    x, h = E.forward(p, int(g["meta"]["L"]), leaf["x"], leaf["h"], i["edge_index"], i["edge_fea"], leaf.get("v"))
+    x, h = E.forward(p, int(g["meta"]["L"]), leaf["x"], leaf["h"], i["edge_index"], i["edge_fea"], leaf.get("v"),
+                     norm=bool(int(g["meta"].get("norm", 0))))
     assert rel_err(x, g["out"]["x"]) < 2e-6 and rel_err(h, g["out"]["h"]) < 2e-5
     egnn_loss(x, h, i["target"], i["wh"]).backward()
     for k, v in p.items():

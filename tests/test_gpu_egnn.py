@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 def test_egnn_matches_reference_golden(name):
     g = load_egnn(name)
     with_v = bool(int(g["meta"]["with_v"]))
-    m = fastegnn_amd.EGNN(n_layers=int(g["meta"]["L"]), in_node_nf=2, in_edge_nf=2, hidden_nf=64, device="cuda", with_v=with_v)
+    norm = bool(int(g["meta"].get("norm", 0)))
+    m = fastegnn_amd.EGNN(n_layers=int(g["meta"]["L"]), in_node_nf=2, in_edge_nf=2, hidden_nf=64, device="cuda", with_v=with_v, norm=norm)
     assert list(m.state_dict().keys()) == list(g["p"].keys())
     m.load_state_dict(g["p"], strict=True)
     m = m.cuda()
@@ -31,7 +32,7 @@ def test_egnn_matches_reference_golden(name):
     dt = torch.float64
     p64 = {k: v.to(dt).clone().requires_grad_(True) for k, v in g["p"].items()}
     l64 = {k: g["in"][k].to(dt).clone().requires_grad_(True) for k in leaf}
-    x64, h64 = E.forward(p64, int(g["meta"]["L"]), l64["x"], l64["h"], g["in"]["edge_index"], g["in"]["edge_fea"].to(dt), l64.get("v"))
+    x64, h64 = E.forward(p64, int(g["meta"]["L"]), l64["x"], l64["h"], g["in"]["edge_index"], g["in"]["edge_fea"].to(dt), l64.get("v"), norm=norm)
     egnn_loss(x64, h64, g["in"]["target"].to(dt), g["in"]["wh"].to(dt)).backward()
     bad = []
     for k, p in m.named_parameters():

@@ -65,6 +65,7 @@ def _worker(rank, world, port, exchange, reorder, q, backend="gloo", comm="torch
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     inp, target = _inputs()
     inp = {k: v.cuda() for k, v in inp.items()}
+    inp["edge_attr"].requires_grad_(True)      # d loss / d edge_attr of this rank's edges flows back into the full tensor
     m = _model()
     stats = CommStats()
     sm = ShardedFastEGNN(m, stats=stats, exchange=exchange)
@@ -75,6 +76,7 @@ def _worker(rank, world, port, exchange, reorder, q, backend="gloo", comm="torch
     allreduce_gradients(m.parameters())
     grads = {k: (p.grad.cpu().numpy().copy() if p.grad is not None else None) for k, p in m.named_parameters()}
     ids = plan.node_ids.cpu() if plan.node_ids is not None else torch.arange(plan.n0, plan.n1)
+    grads["__edge_attr__"] = inp["edge_attr"].grad.cpu().numpy().copy()
     q.put((rank, ids.numpy().copy(), plan.exchanged_bytes(), loc.detach().cpu().numpy().copy(),
            vloc.detach().cpu().numpy().copy(), grads, stats.summary()))
     dist.barrier()
@@ -94,8 +96,13 @@ def _run_and_check(exchange, reorder, backend, comm):
         assert pr.exitcode == 0
     inp, target = _inputs()
     m = _model()
-    loc, vloc = m(**{k: v.cuda() for k, v in inp.items()})
+    cin = {k: v.cuda() for k, v in inp.items()}
+    cin["edge_attr"].requires_grad_(True)
+    loc, vloc = m(**cin)
     _loss(loc, vloc, target.cuda(), target.size(0)).backward()
+    # every edge is owned by exactly one rank: the ranks' edge_attr gradients add up to the unsharded one
+    g_ea = sum(torch.from_numpy(r[5].pop("__edge_attr__")) for r in res)
+    assert rel_err(g_ea, cin["edge_attr"].grad.cpu()) < 2e-5, rel_err(g_ea, cin["edge_attr"].grad.cpu())
     loc, vloc = loc.detach().cpu(), vloc.detach().cpu()
     N = target.size(0)
     assert sorted(i for r in res for i in r[1].tolist()) == list(range(N))
