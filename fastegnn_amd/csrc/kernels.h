@@ -63,11 +63,14 @@ struct WgradBatch {
   int min_rows; // smallest row range given to one workgroup (short operands are split that far to fill the chip)
   int max_split; // most workgroups (= partial slabs) one job may take, times its batch count
   int slab_base, slab_cap;   // this batch's share of the slab workspace: [slab_base, slab_base + slab_cap)
+  int slab_top;              // slab jobs (add_slabs) take their ranges downwards from the top of the share
+  bool planned;              // the contraction jobs have their row / workgroup / slab ranges
   WgradBatch(float *slab, hipStream_t st, bool round_bf16 = false, int slab_base = 0, int slab_cap = WG_SLABS / 2);
   int add(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks, float *db,
           int nb = 1, long sG = 0, long sT = 0, long sW = 0, int kmax = 64);
   // a job whose partial slabs (nsplit of them, [64][64] + [64] bias each) are written by the caller's own kernel:
   // only the fixed-order reduction into dW / db runs here.  *slab_begin receives the first slab index.
+  int plan();
   int close_bundle();
   int add_slabs(float *dW, int lddw, int c0, int ks, float *db, int nsplit, int *slab_begin);
   int finish();

@@ -444,12 +444,14 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     if (C > 0 && !rf && !split) fetch_w3c(0);
     const int c_step = split ? VIRT_WAVES : 1;
     for (int c = split ? wv : 0; c < C; c += c_step) {
+#ifndef VF_DIAG_NOSTAGE   // diagnostic: what do the per-channel stage refill and its two barriers cost? (results are wrong without them)
       if (!rf && !split) {
         __syncthreads();          // every wave is done with the previous channel's stage
         commit_w3c();
         __syncthreads();
         if (c + 1 < C) fetch_w3c(c + 1);
       }
+#endif
       if (active) {
         VirtFwdState<MODE> S;
         virt_tile_forward<MODE>(a, img, vec, Ai, xi, b, c, q, S);

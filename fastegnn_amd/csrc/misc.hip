@@ -306,16 +306,22 @@ WgradBatch::WgradBatch(float *slab, hipStream_t st_, bool round_bf16, int slab_b
   n_bundle_wg = 0;
   min_rows = 256;
   // most workgroups (= partial slabs) per job: sweep at cfg4 (contraction + reduction, ms per step) 256: 3.22, 512: 3.17,
-  // 768: 3.23, 1024: 3.28 (FE_WG_CAP overrides it for such sweeps)
+  // 768: 3.23, 1024: 3.28 (FE_WG_CAP overrides it for such sweeps; re-swept in round 3: 256 / 512 within 2 %, 128 and 1024 worse)
   static const int cap_default = getenv("FE_WG_CAP") ? atoi(getenv("FE_WG_CAP")) : 512;
   max_split = cap_default;
   tab.slab = slab;
   tab.slab_b = slab ? slab + (size_t)WG_SLABS * IMG : nullptr;
   n_wg = 0;
   n_slab = slab_base;
+  slab_top = slab_base + slab_cap;
+  planned = false;
   max_nb = 1;
 }
 
+// Slab bookkeeping: jobs whose slabs the caller's own kernel writes (add_slabs) need their slab range at once and take
+// it from the TOP of the batch's share; contraction jobs (add) only record the split they would like -- their ranges are
+// assigned by plan() (from close_bundle() / finish()), scaled down together if the share cannot hold them all (many long
+// jobs in one layer-wide batch: N >= 393 k with B*C >= 30 k overflowed the round-2 budget and failed the backward).
 int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks,
                     float *db, int nb, long sG, long sT, long sW, int kmax) {
   if (M <= 0 || !dW) return FASTEGNN_OK;
@@ -323,6 +329,7 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   FE_REQUIRE(tab.slab, "wgrad: wg_slab workspace is null");
   FE_REQUIRE(tab.n_jobs < WG_MAX_JOBS, "wgrad: too many jobs in one batch");
   FE_REQUIRE((ldg % 4) == 0 && (ldt % 4) == 0, "wgrad: operand rows must be 16-byte aligned");
+  FE_REQUIRE(!planned, "wgrad: add() after the batch has been planned");
   long nsplit = (M + 1023) / 1024;            // 1024 rows per workgroup while that fills the chip ...
   // ... short operands: down to min_rows per workgroup, up to `fill` workgroups per job.  A layer's batch holds ~8 jobs of
   // N rows, so 128 per job already put 4 workgroups on every CU: measured at cfg4 (weight-gradient kernels per step)
@@ -333,28 +340,49 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
   long cap = max_split / nb;
   if (cap < 4) cap = 4;
   if (nsplit > cap) nsplit = cap;
-  long rows = (M + nsplit - 1) / nsplit;
-  rows = (rows + 63) / 64 * 64;
-  nsplit = (M + rows - 1) / rows;
-  // the batch's share of the slab workspace may be nearly used up (many long jobs in one layer-wide batch, large N with
-  // large B*C): the job then takes the slabs that are left -- fewer, longer row ranges -- instead of failing
-  const long left = ((long)slab_base + slab_cap - n_slab) / nb;
-  FE_REQUIRE(left >= 1, "wgrad: slab workspace exhausted");
-  if (nsplit > left) {
-    nsplit = left;
-    rows = (M + nsplit - 1) / nsplit;
-    rows = (rows + 63) / 64 * 64;
-    nsplit = (M + rows - 1) / rows;
-  }
   WgJob &j = tab.job[tab.n_jobs++];
   j.G = G; j.T = T; j.dW = dW; j.db = db; j.M = M; j.sG = sG; j.sT = sT; j.sW = sW;
   j.ldg = ldg; j.ldt = ldt; j.lddw = lddw; j.c0 = c0; j.ks = ks; j.kmax = kmax;
-  j.rows_per_wg = (int)rows; j.nsplit = (int)nsplit; j.nb = nb;
-  j.wg_begin = n_wg; j.slab_begin = n_slab;
+  j.nsplit = (int)nsplit; j.nb = nb; j.rows_per_wg = 0;
+  j.wg_begin = -1; j.slab_begin = -1;
   j.round = round ? 1 : 0;
-  n_wg += (int)(nsplit * nb);
-  n_slab += (int)(nsplit * nb);
   if (nb > max_nb) max_nb = nb;
+  return FASTEGNN_OK;
+}
+
+// assign row ranges, workgroups and slab ranges to the contraction jobs (idempotent)
+int WgradBatch::plan() {
+  if (planned) return FASTEGNN_OK;
+  long want = 0;
+  for (int k = 0; k < tab.n_jobs; ++k)
+    if (tab.job[k].G) want += (long)tab.job[k].nsplit * tab.job[k].nb;
+  const long avail = (long)slab_top - slab_base;
+  long need_min = 0;
+  for (int k = 0; k < tab.n_jobs; ++k)
+    if (tab.job[k].G) need_min += tab.job[k].nb;
+  FE_REQUIRE(need_min <= avail, "wgrad: slab workspace exhausted");
+  n_wg = 0;
+  n_slab = slab_base;
+  for (int k = 0; k < tab.n_jobs; ++k) {
+    WgJob &j = tab.job[k];
+    if (!j.G) { j.wg_begin = n_wg; continue; }   // slab job: contributes no workgroups to wgrad_tn_kernel
+    long nsplit = j.nsplit;
+    if (want > avail) {   // every job gives up the same fraction (at least one slab per batch slice stays)
+      nsplit = nsplit * (avail - need_min) / want;
+      if (nsplit < 1) nsplit = 1;
+    }
+    long rows = (j.M + nsplit - 1) / nsplit;
+    rows = (rows + 63) / 64 * 64;
+    nsplit = (j.M + rows - 1) / rows;
+    j.rows_per_wg = (int)rows;
+    j.nsplit = (int)nsplit;
+    j.wg_begin = n_wg;
+    j.slab_begin = n_slab;
+    n_wg += (int)(nsplit * j.nb);
+    n_slab += (int)(nsplit * j.nb);
+  }
+  FE_REQUIRE(n_slab <= slab_top, "wgrad: slab workspace exhausted");
+  planned = true;
   return FASTEGNN_OK;
 }
 
@@ -363,14 +391,15 @@ int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, fl
 int WgradBatch::close_bundle() {
   FE_REQUIRE(tab.n_bundle == 0 && tab.n_jobs <= 4, "wgrad: a bundle is the first <= 4 jobs of a batch");
   if (tab.n_jobs == 0) return FASTEGNN_OK;
+  int rc = plan();
+  if (rc) return rc;
+  planned = false;                            // jobs may still be added behind the bundle
   for (int k = 1; k < tab.n_jobs; ++k)
     FE_REQUIRE(tab.job[k].M == tab.job[0].M && tab.job[k].nb == tab.job[0].nb && tab.job[k].rows_per_wg == tab.job[0].rows_per_wg &&
                    tab.job[k].nsplit == tab.job[0].nsplit,
                "wgrad: bundle jobs must share their geometry");
   tab.n_bundle = tab.n_jobs;
   n_bundle_wg = tab.job[0].nsplit * tab.job[0].nb;
-  n_wg = 0;                                   // the bundle's workgroups are not part of wgrad_tn_kernel's grid
-  for (int k = 0; k < tab.n_jobs; ++k) tab.job[k].wg_begin = -1;
   return FASTEGNN_OK;
 }
 
@@ -378,22 +407,29 @@ int WgradBatch::add_slabs(float *dW, int lddw, int c0, int ks, float *db, int ns
   FE_REQUIRE(dW && slab_begin && nsplit > 0, "wgrad: add_slabs arguments");
   FE_REQUIRE(tab.slab, "wgrad: wg_slab workspace is null");
   FE_REQUIRE(tab.n_jobs < WG_MAX_JOBS, "wgrad: too many jobs in one batch");
-  FE_REQUIRE(n_slab + nsplit <= slab_base + slab_cap, "wgrad: slab workspace exhausted");
+  FE_REQUIRE(!planned, "wgrad: add_slabs() after the batch has been planned");
+  FE_REQUIRE(slab_top - nsplit >= slab_base, "wgrad: slab workspace exhausted");
+  slab_top -= nsplit;                         // from the top of the share: the range is needed now, by the caller's kernel
   WgJob &j = tab.job[tab.n_jobs++];
   j.G = nullptr; j.T = nullptr; j.dW = dW; j.db = db; j.M = 0; j.sG = j.sT = j.sW = 0;
   j.ldg = j.ldt = H; j.lddw = lddw; j.c0 = c0; j.ks = ks; j.kmax = 64;
   j.rows_per_wg = 0; j.nsplit = nsplit; j.nb = 1;
   j.round = 0;
-  j.wg_begin = n_wg; j.slab_begin = n_slab;   // contributes no workgroups to wgrad_tn_kernel
-  *slab_begin = n_slab;
-  n_slab += nsplit;
+  j.wg_begin = -1; j.slab_begin = slab_top;
+  *slab_begin = slab_top;
   return FASTEGNN_OK;
 }
 
 int WgradBatch::finish() {
   if (tab.n_jobs == 0) return FASTEGNN_OK;
-  int rc = FASTEGNN_OK;
+  int rc = plan();
+  if (rc) return rc;
   if (tab.n_bundle > 0) {
+    // (the bundle's jobs are contracted by wgrad_bundle_kernel: take their workgroups out of wgrad_tn_kernel's grid)
+    int shift = 0;
+    for (int k = 0; k < tab.n_bundle; ++k) shift += tab.job[k].nsplit * tab.job[k].nb;
+    for (int k = 0; k < tab.n_jobs; ++k) tab.job[k].wg_begin = k < tab.n_bundle ? -1 : tab.job[k].wg_begin - shift;
+    n_wg -= shift;
     { ProfScope _ps(K_WGRAD_BUNDLE, st); hipLaunchKernelGGL(wgrad_bundle_kernel, dim3((unsigned)n_bundle_wg), dim3(256), 0, st, tab); }
     rc = check_launch("wgrad_bundle_kernel");
     if (rc) return rc;
@@ -409,6 +445,8 @@ int WgradBatch::finish() {
   n_bundle_wg = 0;
   n_wg = 0;
   n_slab = slab_base;
+  slab_top = slab_base + slab_cap;
+  planned = false;
   max_nb = 1;
   return check_launch("wgrad_reduce_kernel");
 }
@@ -698,6 +736,31 @@ int fastegnn_selftest_stream(const float *src, float *dst, size_t n_floats, int3
   hipLaunchKernelGGL(stream_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4 *>(src),
                      reinterpret_cast<f32x4 *>(dst), n_floats / 4, mode);
   return check_launch("stream_kernel");
+}
+
+// Host-only: the slab planning of a weight-gradient batch (no launch, no device memory touched).  Queues n_jobs jobs of
+// M[k] rows x nb[k] batch slices, then n_slab_jobs caller-written slab jobs of `slabs_each` slabs, into a batch with the
+// given split limit and slab share; nsplit_out[k] receives the partial slabs per batch slice of job k.
+int fastegnn_selftest_wgrad_plan(const int64_t *M, const int32_t *nb, int32_t n_jobs, int32_t n_slab_jobs, int32_t slabs_each,
+                                 int32_t max_split, int32_t slab_cap, int32_t *nsplit_out) {
+  FE_REQUIRE(M && nb && nsplit_out && n_jobs >= 0, "selftest_wgrad_plan: bad arguments");
+  static float dummy[4];
+  WgradBatch wb(dummy, nullptr, false, 0, slab_cap);
+  wb.max_split = max_split;
+  for (int k = 0; k < n_jobs; ++k) {
+    int rc = wb.add(dummy, H, dummy, H, (long)M[k], dummy, H, 0, 1, nullptr, nb[k], 0, 0, 0);
+    if (rc) return rc;
+  }
+  for (int k = 0; k < n_slab_jobs; ++k) {
+    int first = 0;
+    int rc = wb.add_slabs(dummy, H, 0, 1, nullptr, slabs_each, &first);
+    if (rc) return rc;
+  }
+  int rc = wb.plan();
+  if (rc) return rc;
+  for (int k = 0; k < n_jobs; ++k) nsplit_out[k] = wb.tab.job[k].nsplit;
+  FE_REQUIRE(wb.n_slab <= wb.slab_top, "selftest_wgrad_plan: slab budget exceeded");
+  return FASTEGNN_OK;
 }
 
 int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, float *slab,

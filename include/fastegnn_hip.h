@@ -370,6 +370,10 @@ int fastegnn_selftest_chain_bf3(const float *W, const float *X, float *out, int3
                                 int32_t grid, void *stream);
 int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, float *slab,
                             void *stream);
+/* host-only: slab planning of a weight-gradient batch (n_jobs jobs of M[k] rows x nb[k] slices, then n_slab_jobs jobs of
+ * slabs_each caller-written slabs) under a split limit and a slab share; nsplit_out[k] = partial slabs per slice of job k */
+int fastegnn_selftest_wgrad_plan(const int64_t *M, const int32_t *nb, int32_t n_jobs, int32_t n_slab_jobs, int32_t slabs_each,
+                                 int32_t max_split, int32_t slab_cap, int32_t *nsplit_out);
 /* HBM streaming calibration: mode 0 reads src (n_floats, multiple of 4), 1 copies src -> dst, 2 writes dst */
 int fastegnn_selftest_stream(const float *src, float *dst, size_t n_floats, int32_t mode, void *stream);
 

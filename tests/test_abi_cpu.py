@@ -36,7 +36,7 @@ def test_struct_mirrors_and_sizes():
     assert L.fastegnn_sizeof_graph() == C.sizeof(K.GraphT)
     assert L.fastegnn_version() >= 100
     # fp32 + split images of the 34 + 2C matrices, row-major split images (64 rows x 144 B x 3 parts) of V2, WXV0, WXX0, W3c[c]
-    assert L.fastegnn_wpack_floats(16) == (34 + 32) * (4096 + 4096 + 2048) + (5 + 16) * (3 * 64 * 144 // 4)
+    assert L.fastegnn_wpack_floats(16) == (34 + 32) * (4096 + 4096 + 2048) + (7 + 16) * (3 * 64 * 144 // 4)
     assert L.fastegnn_profile_kernels() >= 15
 
 
@@ -104,3 +104,25 @@ def test_product_does_not_import_oracle():
                 elif isinstance(node, ast.ImportFrom):
                     mods = [node.module or ""]
                 assert not any(m == "oracle" or m.startswith("oracle.") or m.startswith("tests") for m in mods), (f, mods)
+
+
+def test_weight_gradient_slab_planning_never_exhausts_its_share():
+    """the layer-wide weight-gradient batch (8 jobs of N rows, 5 of B*C rows, the edge stage's 2 x 256
+    slabs; 4096 slabs, at most 384 per job) overflowed for N >= 393 k with B*C >= 30 k.  The contraction jobs are now
+    planned together when the batch closes: if the share cannot hold the splits they ask for, all of them give up the
+    same fraction (fewer, longer row ranges) instead of failing.  Host-only planning, no GPU."""
+    import ctypes as C
+    from fastegnn_amd import _lib
+    L = _lib.lib()
+    for N, BC in ((100000, 16), (393216, 32000), (600000, 64000), (1000000, 32), (4000000, 4096 * 64)):
+        M = [N] * 3 + [BC] * 5 + [N] * 5          # virt (3 node-level jobs), graph_post + graph_pre (5), node_pre (5)
+        nb = [1] * len(M)
+        out = (C.c_int32 * len(M))()
+        rc = L.fastegnn_selftest_wgrad_plan((C.c_int64 * len(M))(*M), (C.c_int32 * len(M))(*nb), len(M), 2, 256, 384, 4096, out)
+        assert rc == 0, (N, BC, L.fastegnn_last_error())
+        assert all(1 <= v <= 384 for v in out)
+        assert sum(out) + 512 <= 4096
+    # a share that cannot hold even one slab per job fails loudly instead of overrunning
+    out = (C.c_int32 * 3)()
+    rc = L.fastegnn_selftest_wgrad_plan((C.c_int64 * 3)(10 ** 6, 10 ** 6, 10 ** 6), (C.c_int32 * 3)(1, 1, 1), 3, 0, 0, 384, 2, out)
+    assert rc != 0

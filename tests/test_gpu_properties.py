@@ -309,6 +309,40 @@ def test_cfg5_full_size_properties():
     assert rel_err(loc2, outs[0][0]) < 1e-6 and rel_err(vloc2, outs[0][1]) < 1e-6
 
 
+def test_many_graphs_large_total_is_sum_of_half_batches():
+    """1 024 graphs x 400 nodes (N = 409 600, B*C = 32 768): the layer-wide weight-gradient batch asks for more partial
+    slabs than its share holds (the round-2 planner failed here with 'slab workspace exhausted'); the jobs are scaled
+    down together instead.  Size-independent property: graphs are independent, so the whole batch's weight gradients are
+    the sum of the two half batches' (each of which fits the share unscaled), and its outputs their concatenation."""
+    B, n, C = 1024, 400, 32
+    torch.manual_seed(9)
+    m = fastegnn_amd.FastEGNN(2, 0, 2, 64, C, device="cuda", n_layers=2, gravity=[0, -1, 0])
+    inp = {k: v.cuda() for k, v in _batch([n] * B, 8, C, seed=91).items()}
+    tgt = inp["node_loc"] + 0.5
+
+    def run(sel_graphs):
+        lo, hi = sel_graphs
+        nodes = slice(lo * n, hi * n)
+        em = (inp["data_batch"][inp["edge_index"][0]] >= lo) & (inp["data_batch"][inp["edge_index"][0]] < hi)
+        f = dict(node_feat=inp["node_feat"][nodes], node_loc=inp["node_loc"][nodes], node_vel=inp["node_vel"][nodes],
+                 edge_index=(inp["edge_index"][:, em] - lo * n).contiguous(), data_batch=inp["data_batch"][nodes] - lo,
+                 loc_mean=inp["loc_mean"][lo:hi].contiguous(), edge_attr=inp["edge_attr"][em].contiguous())
+        for p in m.parameters():
+            p.grad = None
+        loc, vloc = m(**f)
+        ((loc - tgt[nodes]).pow(2).sum() / (B * n) + 0.05 * vloc.pow(2).sum() / (B * C)).backward()
+        g = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        return loc.detach(), vloc.detach(), g
+
+    loc, vloc, g = run((0, B))
+    la, va, ga = run((0, B // 2))
+    lb, vb, gb = run((B // 2, B))
+    assert torch.isfinite(loc).all() and torch.isfinite(vloc).all()
+    assert rel_err(loc, torch.cat([la, lb])) < 1e-6 and rel_err(vloc, torch.cat([va, vb])) < 1e-6
+    bad = [(k, rel_err(g[k], ga[k] + gb[k])) for k in g if rel_err(g[k], ga[k] + gb[k]) > 2e-5]
+    assert not bad, bad
+
+
 def test_cfg2_shape_rotation_translation_equivariance():
     """the reference's acceptance property (equivariant_test.py:62, atol 1e-4) at the cfg2 shape --
     100-particle fully connected N-body systems (9 900 directed edges per graph), C=3, fp32 -- on a 10-graph batch, with
