@@ -125,6 +125,10 @@ GRAD_EXCEPTIONS = [
      "different association of the same cancelling sum: 1.26e-5 / 1.36e-5 on two builds against ref 3.95e-6 "
      "(ragged3_tanh, gcl_1.coord_mlp_v_virtual.2.weight, 17 nodes); one Newton step on the reciprocal would cost 5 % of "
      "the producers' vector issue time in virt_bwd_pc_kernel and was not taken"),
+    (r"cfg5_shape", r"gcl_0\.coord_mlp_r_virtual\.0\.bias", 3.0, 1e-6,
+     "a column sum over N*C = 640 k rows that cancels to ~1e-3 of its terms (the reference's own fp32 result is 1.18e-4 "
+     "from fp64): five runs on one box (tools/gpu_tolrepeat.sh) measured 2.31e-4 .. 2.63e-4 = 1.96 .. 2.23 x the "
+     "reference's draw -- the run-to-run spread (summation order follows the ticket order) straddles the 2 x line"),
 ]
 
 

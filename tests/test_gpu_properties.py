@@ -339,7 +339,11 @@ def test_many_graphs_large_total_is_sum_of_half_batches():
     lb, vb, gb = run((B // 2, B))
     assert torch.isfinite(loc).all() and torch.isfinite(vloc).all()
     assert rel_err(loc, torch.cat([la, lb])) < 1e-6 and rel_err(vloc, torch.cat([va, vb])) < 1e-6
-    bad = [(k, rel_err(g[k], ga[k] + gb[k])) for k in g if rel_err(g[k], ga[k] + gb[k]) > 2e-5]
+    # 2e-5 holds for every tensor but the first-layer virtual-head biases (measured 6.6e-5 on gcl_0.coord_mlp_v_virtual.0.bias):
+    # column sums over N*C = 13 M rows that cancel -- the reference's fp32 result for that tensor is 2.9e-3 from fp64 at
+    # the cfg5 shape -- in two different summation orders
+    bad = [(k, rel_err(g[k], ga[k] + gb[k])) for k in g
+           if rel_err(g[k], ga[k] + gb[k]) > (3e-4 if k.endswith("_virtual.0.bias") else 2e-5)]
     assert not bad, bad
 
 
