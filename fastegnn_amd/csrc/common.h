@@ -210,6 +210,25 @@ __device__ __forceinline__ float vdot(const Vec &v, const Vec &w) {
   return qsum(p);
 }
 
+// ---- phase stamps of virt_fwd_kernel (diagnostic builds only: -DFE_STAMP_VF) ----
+#ifdef FE_STAMP_VF
+__device__ unsigned long long g_vf_stamps[16];
+struct VfStamp {
+  unsigned long long prev, acc[12];
+};
+#define VF_TP , VfStamp &_vst
+#define VF_TA , _vst
+#define VF_T0() VfStamp _vst; for (int _k = 0; _k < 12; ++_k) _vst.acc[_k] = 0; _vst.prev = __builtin_amdgcn_s_memtime();
+#define VF_T(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+                  _vst.acc[i] += _t - _vst.prev; _vst.prev = _t; __builtin_amdgcn_sched_barrier(0); }
+#define VF_TEND() if (lane_id() == 0) { for (int _k = 0; _k < 12; ++_k) atomicAdd(&g_vf_stamps[_k], _vst.acc[_k]); }
+#else
+#define VF_TP
+#define VF_TA
+#define VF_T0()
+#define VF_T(i)
+#define VF_TEND()
+#endif
 // ---- in-kernel phase stamps (diagnostic builds only: -DFE_STAMP; never in the shipped library) ----
 #ifdef FE_STAMP
 __device__ unsigned long long g_stamps[16];

@@ -385,6 +385,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;   // basic.py:310
   const bool rf = a.flags & FASTEGNN_F_RF;             // FastRF.py:155-186: no node_model / node_model_virtual
   int cur = -1;  // graph the LDS pool accumulators belong to
+  VF_T0()
   auto flush_pools = [&]() {
     if (!rf)
       for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     Vec nodeacc = own ? vload_vec(vec + VV_B3 * H, q) : vzero();
     if (C > 0 && !rf && !split) fetch_w3c(0);
     const int c_step = split ? VIRT_WAVES : 1;
+    VF_T(8)   // tile head: row loads, bookkeeping
     for (int c = split ? wv : 0; c < C; c += c_step) {
 #ifndef VF_DIAG_NOSTAGE   // diagnostic: what do the per-channel stage refill and its two barriers cost? (results are wrong without them)
       if (!rf && !split) {
@@ -452,9 +454,10 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
         if (c + 1 < C) fetch_w3c(c + 1);
       }
 #endif
+      VF_T(0)   // per-channel barriers + stage refill
       if (active) {
         VirtFwdState<MODE> S;
-        virt_tile_forward<MODE>(a, img, vec, Ai, xi, b, c, q, S);
+        virt_tile_forward<MODE>(a, img, vec, Ai, xi, b, c, q, S VF_TA);
         transv[0] -= S.vd[0] * S.sx;
         transv[1] -= S.vd[1] * S.sx;
         transv[2] -= S.vd[2] * S.sx;
@@ -492,10 +495,12 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
             }
           }
         }
+        VF_T(6)   // pools
         if (!rf) {
           if (split) gemm_op<MODE>(wpack_x3(a.wpack, C, img_w3c(c)), 0, S.vs, nodeacc);   // the stage serves one channel at a time
           else gemm_op<MODE>(stage, 0, S.vs, nodeacc);
         }
+        VF_T(7)   // node-MLP block product
       }
     }
     if (split) {   // sum the waves' channel shares ([16][68] floats in the idle W3c stage)
@@ -573,6 +578,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
         if (valid) vstore_row(a.h_out + (size_t)n * H, q, out);
       }
     }
+    VF_T(9)   // tile tail: node-level products through the stage
     if (active && own) {
       if (valid) {
         if (q == 0) {
@@ -590,6 +596,8 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   }
   __syncthreads();
   if (cur >= 0) flush_pools();
+  VF_T(10)
+  VF_TEND()
 }
 
 int virt_forward(const fastegnn_layer_t *L, hipStream_t st) {
@@ -673,6 +681,16 @@ int graph_post_forward(const fastegnn_layer_t *L, hipStream_t st) {
 
 }  // namespace fe
 
+#ifdef FE_STAMP_VF
+extern "C" int fastegnn_debug_read_stamps_vf(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::g_vf_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(fe::g_vf_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 #ifdef FE_STAMP
 extern "C" int fastegnn_debug_read_stamps(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;

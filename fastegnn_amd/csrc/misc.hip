@@ -170,7 +170,16 @@ __global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_tn_kernel(WgTable tab) {
   const WgJob &a = tab.job[jb];
   const int local = blockIdx.x - a.wg_begin;
   // batch index varies fastest: co-resident workgroups read the same row range of every batch slice
-  const int bidx = local % a.nb, split = local / a.nb;
+  int bidx = local % a.nb, split = local / a.nb;
+#ifdef FE_WG_XCD
+  // ... and the nb workgroups of one row range sit on ONE XCD (workgroup i runs on XCD i % 8): the G rows they share are
+  // then served by that XCD's L2 instead of being fetched once per XCD
+  if (a.nb > 1 && (a.nsplit & 7) == 0 && (a.wg_begin & 7) == 0) {
+    const int xcd = local & 7, slot = local >> 3;
+    bidx = slot % a.nb;
+    split = xcd + 8 * (slot / a.nb);
+  }
+#endif
   const int l = lane_id(), i = l & 15, q = l >> 4, w = wave_id();
   const float *G = a.G + (size_t)bidx * a.sG;
   const float *T = a.T + (size_t)bidx * a.sT;

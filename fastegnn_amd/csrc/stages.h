@@ -226,7 +226,7 @@ __device__ __forceinline__ void virt_load_vecs(float *vec, const VirtArgs &a) {
 // forward math of one (16-node tile, channel c); img = resident V2, WXV0, WXX0
 template <int MODE = GM_F32>
 __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void *img, const float *vec, const Vec &Ai,
-                                                  const float xi[3], int b, int c, int q, VirtFwdState<MODE> &S) {
+                                                  const float xi[3], int b, int c, int q, VirtFwdState<MODE> &S VF_TP) {
   const int C = a.C;
   const float *Zb = a.Z + (size_t)b * 3 * C;
   S.vd[0] = Zb[c] - xi[0];
@@ -237,8 +237,10 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void 
   vadd(S.pre, vload_row(a.Bc + ((size_t)b * C + c) * H, q));
   vaxpy(S.pre, S.vr, vload_vec(vec + VV_WVR * H, q));
   S.t = vsilu(S.pre);
+  VF_T(1)   // geometry, pre-activation, silu 1
   S.vp = vload_vec(vec + VV_C2 * H, q);
   gemm_i<MODE>(img, 0, S.t, S.vp);
+  VF_T(2)   // split + product 1
   S.v0 = vsilu(S.vp);
   if (a.flags & FASTEGNN_F_ATTENTION) {
     S.att = sigmoid_f(vdot(S.v0, vload_vec(vec + VV_ATT * H, q)) + a.attb[0]);
@@ -249,13 +251,18 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void 
   }
   S.uxp = vload_vec(vec + VV_BXV0 * H, q);
   S.vs = make_operand<MODE>(S.v);   // one split / rounding feeds both coordinate heads and the node MLP
+  VF_T(3)   // silu 2 + split
   gemm_op<MODE>(img, 1, S.vs, S.uxp);
+  VF_T(4)   // product 2
   float sr = vdot(vsilu(S.uxp), vload_vec(vec + VV_WXV2 * H, q));
   S.sx = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;
+  VF_T(5)   // silu + head dot
   S.uXp = vload_vec(vec + VV_BXX0 * H, q);
   gemm_op<MODE>(img, 2, S.vs, S.uXp);
+  VF_T(4)
   sr = vdot(vsilu(S.uXp), vload_vec(vec + VV_WXX2 * H, q));
   S.sX = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;
+  VF_T(5)
 }
 
 inline VirtArgs make_virt_args(const fastegnn_layer_t *L) {
