@@ -20,6 +20,12 @@ FEATW = 8
 
 # flags (fastegnn_hip.h)
 F_ATTENTION, F_NORMALIZE, F_TANH, F_RESIDUAL, F_GRAVITY, F_COORDS_SUM, F_EGNN, F_RF, F_BF16, F_EGNN_NORM = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+F_DETERMINISTIC = 1024   # backward: per-edge rows + CSC reduce instead of the atomic scatter (include/fastegnn_hip.h)
+
+
+def deterministic_default() -> bool:
+    """FASTEGNN_DETERMINISTIC=1 selects the bit-reproducible backward for every model that does not say otherwise."""
+    return os.environ.get("FASTEGNN_DETERMINISTIC", "0") == "1"
 
 # per-layer parameter slots, in header order -> reference state_dict suffix (models/FastEGNN.py:28-99)
 PARAM_SLOTS = [

@@ -200,6 +200,11 @@ __device__ __forceinline__ float jreduce16(const Vec &u) {
   const float keep = b0 ? w[1] : w[0], send = b0 ? w[0] : w[1];
   return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xb1, 0xf, 0xf, false));  // quad_perm:[1,0,3,2]
 }
+// row[f] += sum over the 16 items of the tile of u (feature f); `row` is an LDS or global [64] accumulator.  All lanes active.
+__device__ __forceinline__ void tile_sum_add(float *row, const Vec &u, int j, int q) {
+  const float s = jreduce16(u);   // lane j: the sum over the tile of value j
+  atomicAdd(&row[16 * (j >> 2) + 4 * q + (j & 3)], s);
+}
 // <v, w> over the hidden dimension; every q-lane of the item gets the full dot product
 __device__ __forceinline__ float vdot(const Vec &v, const Vec &w) {
   float p = 0.f;

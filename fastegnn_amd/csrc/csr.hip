@@ -71,8 +71,10 @@ int fastegnn_build_csr(const int64_t *edge_index, int32_t E, int32_t row_begin, 
                        int32_t *rowptr, int32_t *erow, int32_t *col, int32_t *perm, int32_t *cscptr,
                        int32_t *csc_eid, int32_t *chunk_row, int32_t *n_chunks, void *tmp, size_t tmp_bytes,
                        void *stream) {
-  FE_REQUIRE(rowptr && cscptr && chunk_row && n_chunks, "build_csr: null output");
-  FE_REQUIRE(E == 0 || (edge_index && erow && col && perm && csc_eid && tmp), "build_csr: null pointer");
+  FE_REQUIRE(rowptr && chunk_row && n_chunks, "build_csr: null output");
+  FE_REQUIRE(E == 0 || (edge_index && erow && col && perm && tmp), "build_csr: null pointer");
+  FE_REQUIRE((cscptr == nullptr) == (csc_eid == nullptr), "build_csr: cscptr and csc_eid are given or omitted together");
+  const bool want_csc = cscptr != nullptr;   // only the deterministic backward (FASTEGNN_F_DETERMINISTIC) reads the CSC index
   FE_REQUIRE(tmp_bytes >= fastegnn_csr_tmp_bytes(E, n_rows, n_src), "build_csr: tmp too small");
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps(K_CSR, st);
@@ -101,13 +103,15 @@ int fastegnn_build_csr(const int64_t *edge_index, int32_t E, int32_t row_begin, 
     e = rocprim::radix_sort_pairs(rp_tmp, need, keys_in, erow, vals_in, perm, (size_t)E, 0, row_bits, st);
     if (e != hipSuccess) { set_error(std::string("build_csr: row sort: ") + hipGetErrorString(e)); return FASTEGNN_E_LAUNCH; }
     hipLaunchKernelGGL(csr_col_kernel, dim3(g), dim3(256), 0, st, edge_index, E, perm, col, vals_in);
-    e = rocprim::radix_sort_pairs(rp_tmp, need, col, keys_out, vals_in, csc_eid, (size_t)E, 0, col_bits, st);
-    if (e != hipSuccess) { set_error(std::string("build_csr: col sort: ") + hipGetErrorString(e)); return FASTEGNN_E_LAUNCH; }
     hipLaunchKernelGGL(lower_bound_kernel, dim3(cdiv(n_rows + 1, 256)), dim3(256), 0, st, erow, E, n_rows, rowptr);
-    hipLaunchKernelGGL(lower_bound_kernel, dim3(cdiv(n_src + 1, 256)), dim3(256), 0, st, keys_out, E, n_src, cscptr);
+    if (want_csc) {
+      e = rocprim::radix_sort_pairs(rp_tmp, need, col, keys_out, vals_in, csc_eid, (size_t)E, 0, col_bits, st);
+      if (e != hipSuccess) { set_error(std::string("build_csr: col sort: ") + hipGetErrorString(e)); return FASTEGNN_E_LAUNCH; }
+      hipLaunchKernelGGL(lower_bound_kernel, dim3(cdiv(n_src + 1, 256)), dim3(256), 0, st, keys_out, E, n_src, cscptr);
+    }
   } else {
     (void)hipMemsetAsync(rowptr, 0, (size_t)(n_rows + 1) * 4, st);
-    (void)hipMemsetAsync(cscptr, 0, (size_t)(n_src + 1) * 4, st);
+    if (want_csc) (void)hipMemsetAsync(cscptr, 0, (size_t)(n_src + 1) * 4, st);
   }
   hipLaunchKernelGGL(chunk_kernel, dim3(cdiv(nch + 1, 256)), dim3(256), 0, st, rowptr, n_rows, nch, chunk_row);
   return check_launch("build_csr");

@@ -853,6 +853,7 @@ struct EdgeBwdArgs {
   EdgeArgs f;
   const float *g_aggm, *g_aggx;
   float *g_P, *g_xrow, *g_QXe;
+  float *g_QXs_atomic;   // non-null: scatter d/d(Q|x) straight into the source table with float atomics (no g_QXe, no CSC reduce)
   float *g_ea;   // [E,ea] d loss / d edge_attr (sorted-edge order, +=) or null
   float *d_wx2, *d_attw, *d_attb, *d_bx2;
   float *d_wr, *d_we;   // edge_mlp.0.weight grad: radial column and first edge_attr column (row stride ld_e0)
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       const float invn = norm_on ? rcp_f(S.nrm + a.eps) : 1.f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) g_d[k] = g_dn[k] * invn + 2.f * g_r * S.d[k];
-      if (valid) {
+      if (valid && !A.g_QXs_atomic) {
         float *qe = A.g_QXe + (size_t)e * QXLD;
         vstore_row(qe, q, g_pre);
         if (q == 0) *reinterpret_cast<f32x4 *>(qe + H) = f32x4{-g_d[0], -g_d[1], -g_d[2], 0.f};
@@ -1224,6 +1225,17 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         xv[ee] = pt[ee * TS + H + (l & 3)];
       }
       const int rowv = S.row;
+      if (A.g_QXs_atomic) {   // default (no FASTEGNN_F_DETERMINISTIC): one coalesced 272-byte atomic row per edge
+        const int colv = S.col;
+#pragma unroll
+        for (int ee = 0; ee < 16; ++ee) {
+          if (ee < nvalid) {
+            float *dst = A.g_QXs_atomic + (size_t)__builtin_amdgcn_readlane(colv, ee) * QXLD;
+            atomicAdd(dst + l, mv[ee]);
+            if (l < 3) atomicAdd(dst + H + l, -xv[ee]);
+          }
+        }
+      }
 #pragma unroll
       for (int ee = 0; ee < 16; ++ee) {
         if (ee < nvalid) {
@@ -1285,10 +1297,12 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
 }
 
 int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
-  FE_REQUIRE(L->P && L->QX && L->g_aggm && L->g_aggx && L->g_P && L->g_xrow && L->g_QXe && L->grads &&
-                 L->wpack,
+  FE_REQUIRE(L->P && L->QX && L->g_aggm && L->g_aggx && L->g_P && L->g_xrow && L->grads && L->wpack,
              "edge_backward: null buffer");
+  const bool det = has(L, FASTEGNN_F_DETERMINISTIC);   // store + CSC reduce instead of the atomic scatter
+  FE_REQUIRE(det ? L->g_QXe != nullptr : L->g_QX_src != nullptr, "edge_backward: g_QXe (deterministic) / g_QX_src null");
   const fastegnn_graph_t &gr = L->graph;
+  if (!det && gr.n_src > 0) (void)hipMemsetAsync(L->g_QX_src, 0, (size_t)gr.n_src * QXLD * sizeof(float), st);
   if (gr.n_edges == 0 || L->N == 0) {   // nothing to walk (with edges the kernel writes every row of g_P / g_xrow)
     (void)hipMemsetAsync(L->g_P, 0, (size_t)L->N * H * sizeof(float), st);
     (void)hipMemsetAsync(L->g_xrow, 0, (size_t)L->N * 3 * sizeof(float), st);
@@ -1298,6 +1312,7 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
   EdgeBwdArgs A;
   A.f = make_edge_args(L);
   A.g_aggm = L->g_aggm; A.g_aggx = L->g_aggx; A.g_P = L->g_P; A.g_xrow = L->g_xrow; A.g_QXe = L->g_QXe;
+  A.g_QXs_atomic = det ? nullptr : L->g_QX_src;
   A.g_ea = L->ea > 0 ? L->g_ea_sorted : nullptr;
   A.ld_e0 = 2 * H + 1 + L->ea;
   A.d_wr = g[FASTEGNN_P_EDGE0_W] + (has(L, FASTEGNN_F_EGNN) ? 0 : 2 * H);   // basic.py:313: radial is column 0
@@ -1362,13 +1377,13 @@ extern "C" size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C) {
 }
 // floats of ALL backward scratch arrays of fastegnn_layer_t (g_poolV .. wg_slab), each rounded up to a multiple of 4
 // floats (16-byte aligned carving of one allocation)
-static size_t scratch_floats(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C, size_t wg_virt) {
+static size_t scratch_floats(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C, size_t wg_virt, bool per_edge_rows = true) {
   auto r4 = [](size_t n) { return (n + 3) / 4 * 4; };
   const size_t n = N > 0 ? N : 0, e = E > 0 ? E : 1, s = n_src > 0 ? n_src : 0, bc = (size_t)(B > 0 ? B : 0) * (size_t)(C > 0 ? C : 0);
   size_t t = 0;
   t += 2 * r4(bc * fe::H) + 2 * r4(bc * 3) + r4((size_t)B * 4);          // g_poolV g_Bc | g_poolX g_Zp | g_xbar
   t += 3 * r4(n * fe::H) + 2 * r4(n * 3) + 2 * r4(n);                    // g_A g_P g_aggm | g_aggx g_xrow | g_svel g_sgrav
-  t += r4(e * fe::QXLD) + r4(s * fe::QXLD);                              // g_QXe | g_QX_src
+  t += (per_edge_rows ? r4(e * fe::QXLD) : 4) + r4(s * fe::QXLD);        // g_QXe (FASTEGNN_F_DETERMINISTIC only) | g_QX_src
   t += r4(fastegnn_wg_edge_floats(E)) + r4(wg_virt) + r4(fastegnn_wg_node_floats(N, B, C)) + r4(fastegnn_wg_slab_floats());
   return t;
 }
@@ -1376,7 +1391,7 @@ extern "C" size_t fastegnn_backward_scratch_floats(int32_t N, int32_t E, int32_t
   return scratch_floats(N, E, n_src, B, C, fastegnn_wg_virt_floats(N, C));
 }
 extern "C" size_t fastegnn_backward_scratch_floats_for(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C, int32_t flags) {
-  return scratch_floats(N, E, n_src, B, C, fastegnn_wg_virt_floats_for(N, C, flags));
+  return scratch_floats(N, E, n_src, B, C, fastegnn_wg_virt_floats_for(N, C, flags), (flags & FASTEGNN_F_DETERMINISTIC) != 0);
 }
 namespace fe {
 
@@ -1409,6 +1424,7 @@ __global__ __launch_bounds__(256) void edge_col_reduce_kernel(const float *g_QXe
 }
 int edge_col_reduce(const fastegnn_layer_t *L, hipStream_t st) {
   const fastegnn_graph_t &gr = L->graph;
+  if (!has(L, FASTEGNN_F_DETERMINISTIC)) return FASTEGNN_OK;   // edge_backward has zeroed g_QX_src and scattered into it
   FE_REQUIRE(L->g_QX_src && (gr.n_edges == 0 || (L->g_QXe && gr.cscptr && gr.csc_eid)), "edge_col_reduce: null buffer");
   if (gr.n_src == 0) return FASTEGNN_OK;
   if (gr.n_edges == 0) {

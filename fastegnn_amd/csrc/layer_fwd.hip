@@ -359,24 +359,27 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // contraction of node_mlp.0 accumulates in MFMA registers, v [N,C,H] never reaches HBM.
 // =====================================================================================
 
-// LDS: images V2, WXV0, WXX0 | W3c[c] stage (split mode) | vectors | per-wave transpose tiles | pools
-constexpr int VIRT_FWD_IMG_FLOATS = 4 * IMG3;
+// LDS: images V2, WXV0, WXX0 | two W3c[c] stage slots | vectors | pools | Bc / Z rows of the graph in flight
+constexpr int VIRT_FWD_IMG_FLOATS = 5 * IMG3;
+inline size_t virt_fwd_lds_bytes(int C) {
+  return (size_t)(VIRT_FWD_IMG_FLOATS + VV_COUNT * H + 2 * (C * H + ((3 * C + 3) & ~3))) * sizeof(float);
+}
 template <int MODE>
 __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C;
-  float *img = lds;                              // V2, WXV0, WXX0 (fp32 or split images)
-  unsigned *stage = reinterpret_cast<unsigned *>(lds) + 3 * IMG3;   // split mode: W3c[c] of the channel in flight
+  float *img = lds;                              // V2, WXV0, WXX0 (split images)
+  unsigned *stage = reinterpret_cast<unsigned *>(lds) + 3 * IMG3;   // W3c[c] of the channel in flight (slot c & 1) and of the next
   float *vec = lds + VIRT_FWD_IMG_FLOATS;        // VV_COUNT vectors
-  float *tiles = vec + VV_COUNT * H;             // per wave [16][TS]
-  float *poolV_l = tiles + VIRT_WAVES * 16 * TS; // [C][64]
+  float *poolV_l = vec + VV_COUNT * H;           // [C][64]
   float *poolX_l = poolV_l + C * H;              // [3][C]
+  float *Bc_l = poolX_l + ((3 * C + 3) & ~3);    // [C][64]: Bc rows of the graph the workgroup is in
+  float *Z_l = Bc_l + C * H;                     // [3][C]: its virtual coordinates
   load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, C, I_V2), 3);
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) poolV_l[i] = 0.f;
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
-  float *tile = tiles + wv * 16 * TS;
   // a workgroup owns a contiguous run of 16-node tiles and walks it VIRT_WAVES tiles at a time; the runs differ by
   // at most one tile, so the last, partial step of a workgroup is a single wave that has its SIMD to itself
   const int ntiles = (a.N + 15) >> 4;
@@ -397,9 +400,9 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       poolX_l[i] = 0.f;
     }
   };
-  // split mode: the K = H*C contraction of node_mlp.0 reads W3c[c] from an LDS stage that the whole
-  // workgroup refills once per channel (all waves walk the channels in step); the next channel's
-  // image is fetched into registers while the current one is being used.
+  // the K = H*C contraction of node_mlp.0 reads W3c[c] from an LDS stage of two slots that the whole workgroup refills (all
+  // waves walk the channels in step): channel c + 1 is written into the other slot while channel c is in use, channel
+  // c + 2 is on its way into registers -- ONE workgroup barrier per channel.
   constexpr int STG = IMG3 / 4 / (64 * VIRT_WAVES);   // 16-byte pieces per thread
   static_assert(STG * 4 * 64 * VIRT_WAVES == IMG3, "stage copy must tile the image");
   u32x4 pre_w[STG];
@@ -408,8 +411,8 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
 #pragma unroll
     for (int i = 0; i < STG; ++i) pre_w[i] = src[threadIdx.x + i * 64 * VIRT_WAVES];
   };
-  auto commit_w3c = [&]() {
-    u32x4 *dst = reinterpret_cast<u32x4 *>(stage);
+  auto commit_w3c = [&](int slot) {
+    u32x4 *dst = reinterpret_cast<u32x4 *>(stage + slot * IMG3);
 #pragma unroll
     for (int i = 0; i < STG; ++i) dst[threadIdx.x + i * 64 * VIRT_WAVES] = pre_w[i];
   };
@@ -420,12 +423,16 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     const bool own = !split || wv == 0;
     const int n0 = tb * 16, nend = min(a.N, min(t_hi, tb + VIRT_WAVES) * 16);
     const int bfirst = a.batch[n0], blast = a.batch[nend - 1];
-    const bool fast = bfirst == blast;
+    const bool fast = bfirst == blast;   // every node of this step in ONE graph: its pools, Bc rows and Z sit in LDS
+    const bool staged = C > 0 && !rf && !split;
+    if (staged) fetch_w3c(0);
     if (fast && bfirst != cur) {
       __syncthreads();
       if (cur >= 0) flush_pools();
-      __syncthreads();
       cur = bfirst;
+      for (int i = threadIdx.x; i < C * H; i += blockDim.x) Bc_l[i] = a.Bc[(size_t)cur * C * H + i];
+      for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) Z_l[i] = a.Z[(size_t)cur * 3 * C + i];
+      __syncthreads();
     }
     const int nb = split ? n0 : n0 + wv * 16;
     const int nvalid = max(0, min(16, nend - nb));
@@ -442,63 +449,58 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     }
     float transv[3] = {0.f, 0.f, 0.f};
     Vec nodeacc = own ? vload_vec(vec + VV_B3 * H, q) : vzero();
-    if (C > 0 && !rf && !split) fetch_w3c(0);
+    if (staged) {
+      __syncthreads();            // every wave is done with the stage (the previous step's node-level images)
+      commit_w3c(0);
+      if (C > 1) fetch_w3c(1);
+    }
     const int c_step = split ? VIRT_WAVES : 1;
     VF_T(8)   // tile head: row loads, bookkeeping
     for (int c = split ? wv : 0; c < C; c += c_step) {
-#ifndef VF_DIAG_NOSTAGE   // diagnostic: what do the per-channel stage refill and its two barriers cost? (results are wrong without them)
-      if (!rf && !split) {
-        __syncthreads();          // every wave is done with the previous channel's stage
-        commit_w3c();
-        __syncthreads();
-        if (c + 1 < C) fetch_w3c(c + 1);
+#ifndef VF_DIAG_NOSTAGE   // diagnostic: what do the per-channel stage refill and its barrier cost? (results are wrong without them)
+      if (staged) {
+        __syncthreads();          // W3c[c] is in slot c & 1; every wave is done with channel c - 1, i.e. with the other slot
+        if (c + 1 < C) {
+          commit_w3c((c + 1) & 1);
+          if (c + 2 < C) fetch_w3c(c + 2);
+        }
       }
 #endif
-      VF_T(0)   // per-channel barriers + stage refill
+      VF_T(0)   // per-channel barrier + stage refill
       if (active) {
         VirtFwdState<MODE> S;
-        virt_tile_forward<MODE>(a, img, vec, Ai, xi, b, c, q, S VF_TA);
+        virt_tile_forward<MODE>(a, img, vec, Ai, xi, b, c, q, fast ? Bc_l : nullptr, fast ? Z_l : nullptr, S VF_TA);
         transv[0] -= S.vd[0] * S.sx;
         transv[1] -= S.vd[1] * S.sx;
         transv[2] -= S.vd[2] * S.sx;
-        // pools: sum over the nodes of the tile
-        if (!rf) {
-          __builtin_amdgcn_wave_barrier();
-          tile_store(tile, j, q, valid ? S.v : vzero());
-          __builtin_amdgcn_wave_barrier();
-        }
+        // pools: sums over the nodes of the tile (transposing DPP butterfly, then one 64-lane atomic per accumulator)
         if (fast) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            float pv = (valid && q == 0) ? S.vd[k] * S.sX : 0.f;
-            pv = jsum(pv);
-            if (l == 0) atomicAdd(&poolX_l[k * C + c], pv);
-          }
-          if (!rf) {
-            float s = 0.f;
-#pragma unroll
-            for (int ee = 0; ee < 16; ++ee) s += tile[ee * TS + l];
-            atomicAdd(&poolV_l[c * H + l], s);
-          }
+          if (!rf) tile_sum_add(poolV_l + c * H, nvalid == 16 ? S.v : (valid ? S.v : vzero()), j, q);
+          // (lane k < 3 adds component k: per-lane addresses, so the compiler's uniform-address atomic combiner stays out)
+          const float p0 = jsum_dpp(valid ? S.vd[0] * S.sX : 0.f), p1 = jsum_dpp(valid ? S.vd[1] * S.sX : 0.f),
+                      p2 = jsum_dpp(valid ? S.vd[2] * S.sX : 0.f);
+          if (l < 3) atomicAdd(&poolX_l[l * C + c], l == 0 ? p0 : (l == 1 ? p1 : p2));
         } else {
-          if (valid && q == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) atomicAdd(&a.poolX[((size_t)b * 3 + k) * C + c], S.vd[k] * S.sX);
-          }
-          if (!rf) {
-#pragma unroll
-            for (int ee = 0; ee < 16; ++ee) {
-              if (ee < nvalid) {
-                const int be = __builtin_amdgcn_readlane(b, ee);
-                atomicAdd(&a.poolV[((size_t)be * C + c) * H + l], tile[ee * TS + l]);
-              }
-            }
+          // the step spans graphs: straight to the global pools, one pass per graph present in this tile
+          const int g_lo = __builtin_amdgcn_readlane(b, 0), g_hi = __builtin_amdgcn_readlane(b, nvalid - 1);
+          for (int g = g_lo; g <= g_hi; ++g) {
+            const bool in_g = valid && b == g;
+            if (!rf) tile_sum_add(a.poolV + ((size_t)g * C + c) * H, in_g ? S.v : vzero(), j, q);
+            const float p0 = jsum_dpp(in_g ? S.vd[0] * S.sX : 0.f), p1 = jsum_dpp(in_g ? S.vd[1] * S.sX : 0.f),
+                        p2 = jsum_dpp(in_g ? S.vd[2] * S.sX : 0.f);
+            if (l < 3) atomicAdd(&a.poolX[((size_t)g * 3 + l) * C + c], l == 0 ? p0 : (l == 1 ? p1 : p2));
           }
         }
         VF_T(6)   // pools
         if (!rf) {
-          if (split) gemm_op<MODE>(wpack_x3(a.wpack, C, img_w3c(c)), 0, S.vs, nodeacc);   // the stage serves one channel at a time
-          else gemm_op<MODE>(stage, 0, S.vs, nodeacc);
+#ifdef VF_DIAG_NODE_IMG0      // diagnostic: the node-MLP block product from a resident image instead of the stage (wrong results)
+          gemm_op<MODE>(img, 0, S.vs, nodeacc);
+#elif defined(VF_DIAG_NONODE)  // diagnostic: no node-MLP block product (wrong results)
+          if (S.vs.p[0][0][0] == 0x12345678u) nodeacc = S.v;
+#else
+          if (split) gemm_op<MODE>(wpack_x3(a.wpack, C, img_w3c(c)), 0, S.vs, nodeacc);   // the stage serves the stepped walk only
+          else gemm_op<MODE>(stage + (c & 1) * IMG3, 0, S.vs, nodeacc);
+#endif
         }
         VF_T(7)   // node-MLP block product
       }
@@ -618,7 +620,7 @@ int virt_forward(const fastegnn_layer_t *L, hipStream_t st) {
   int grid = ntg < 256 ? ntg : 256;   // one workgroup per CU (LDS), each with an equal share of the tiles
   {
     ProfScope _ps_virt_fwd_kernel(K_VIRT_FWD, st);
-    const size_t lds = virt_lds_bytes(L->C, 3) + (VIRT_FWD_IMG_FLOATS - 3 * IMG) * sizeof(float);
+    const size_t lds = virt_fwd_lds_bytes(L->C);
     if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL(virt_fwd_kernel<GM_BF16>, dim3(grid), dim3(64 * VIRT_WAVES), lds, st, a);
     else hipLaunchKernelGGL(virt_fwd_kernel<GM_X3>, dim3(grid), dim3(64 * VIRT_WAVES), lds, st, a);
   }

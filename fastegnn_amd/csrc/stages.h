@@ -226,15 +226,25 @@ __device__ __forceinline__ void virt_load_vecs(float *vec, const VirtArgs &a) {
 // forward math of one (16-node tile, channel c); img = resident V2, WXV0, WXX0
 template <int MODE = GM_F32>
 __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void *img, const float *vec, const Vec &Ai,
-                                                  const float xi[3], int b, int c, int q, VirtFwdState<MODE> &S VF_TP) {
+                                                  const float xi[3], int b, int c, int q, const float *BcL,
+                                                  const float *ZL, VirtFwdState<MODE> &S VF_TP) {
+  // BcL / ZL (wave-uniform, LDS): the Bc rows [C][64] and virtual coordinates [3][C] of the graph when the whole tile
+  // lies in one graph and the workgroup has staged them; null: read per node from global memory
   const int C = a.C;
-  const float *Zb = a.Z + (size_t)b * 3 * C;
-  S.vd[0] = Zb[c] - xi[0];
-  S.vd[1] = Zb[C + c] - xi[1];
-  S.vd[2] = Zb[2 * C + c] - xi[2];
+  if (ZL) {
+    S.vd[0] = ZL[c] - xi[0];
+    S.vd[1] = ZL[C + c] - xi[1];
+    S.vd[2] = ZL[2 * C + c] - xi[2];
+  } else {
+    const float *Zb = a.Z + (size_t)b * 3 * C;
+    S.vd[0] = Zb[c] - xi[0];
+    S.vd[1] = Zb[C + c] - xi[1];
+    S.vd[2] = Zb[2 * C + c] - xi[2];
+  }
   S.vr = sqrt_f(S.vd[0] * S.vd[0] + S.vd[1] * S.vd[1] + S.vd[2] * S.vd[2]);
   S.pre = Ai;
-  vadd(S.pre, vload_row(a.Bc + ((size_t)b * C + c) * H, q));
+  if (BcL) vadd(S.pre, vload_vec(BcL + c * H, q));
+  else vadd(S.pre, vload_row(a.Bc + ((size_t)b * C + c) * H, q));
   vaxpy(S.pre, S.vr, vload_vec(vec + VV_WVR * H, q));
   S.t = vsilu(S.pre);
   VF_T(1)   // geometry, pre-activation, silu 1
@@ -263,6 +273,9 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void 
   sr = vdot(vsilu(S.uXp), vload_vec(vec + VV_WXX2 * H, q));
   S.sX = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;
   VF_T(5)
+  // (measured in round 3: the two head products and the node-MLP block product issued back to back, activations and
+  // dot products after them -- two pipeline drains per channel instead of four -- was slower: 1.71 vs 1.62 ms per step,
+  // 42 spilled registers)
 }
 
 inline VirtArgs make_virt_args(const fastegnn_layer_t *L) {

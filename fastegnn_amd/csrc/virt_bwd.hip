@@ -210,8 +210,7 @@ __device__ __forceinline__ void vb_accum_items(float *row, const Vec &u, int j, 
   if (u.t[0][0] == 12345.678f) row[0] = 1.f;
   return;
 #endif
-  const float s = jreduce16(u);   // lane j: the sum over the tile of value j
-  atomicAdd(&row[16 * (j >> 2) + 4 * q + (j & 3)], s);
+  tile_sum_add(row, u, j, q);
 }
 
 template <bool BF, bool ATT>

@@ -104,7 +104,7 @@ class _EGNNFunction(torch.autograd.Function):
         g_x = (g_x if g_x is not None else torch.zeros(N, 3, **f32)).contiguous().float()
         g_vel = torch.zeros(N, 3, **f32)
         sc = _carve(dev, dict(g_A=(N, H), g_P=(N, H), g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,),
-                              g_QXe=(max(E, 1), K.QX_LD), g_QX_src=(N, K.QX_LD), g_xrow=(N, 3),
+                              g_QXe=(max(E, 1) if spec.flags & K.F_DETERMINISTIC else 1, K.QX_LD), g_QX_src=(N, K.QX_LD), g_xrow=(N, 3),
                               wg_edge=(lib.fastegnn_wg_edge_floats(E),), wg_node=(lib.fastegnn_wg_node_floats(N, 1, 0),), wg_slab=(lib.fastegnn_wg_slab_floats(),)))
         sc["g_xbar"] = torch.zeros(1, 4, **f32)
         for i in reversed(range(spec.n_layers)):
@@ -147,6 +147,7 @@ class EGNN(nn.Module):
             self.layers.append(EGNN_Layer(in_edge_nf, hidden_nf, activation, with_v))
         self._spec = None
         self._graph_cache = {}
+        self.deterministic = K.deterministic_default()   # see fastegnn_amd.FastEGNN.deterministic (set before the first call)
         self.to(device)
 
     def _build_spec(self):
@@ -165,7 +166,8 @@ class EGNN(nn.Module):
             layer_slots.append(slots)
         self._plist = [pidx[n] for n in names]
         self._spec = SimpleNamespace(C=0, ea=self.in_edge_nf, na=0, nf=self.in_node_nf, n_layers=self.n_layers,
-                                     flags=K.F_EGNN | (K.F_EGNN_NORM if self.norm else 0), gravity=[0.0, 0.0, 0.0],
+                                     flags=K.F_EGNN | (K.F_EGNN_NORM if self.norm else 0) | (K.F_DETERMINISTIC if self.deterministic else 0),
+                                     gravity=[0.0, 0.0, 0.0],
                                      layer_slots=layer_slots, names=names)
 
     def forward(self, x, h, edge_index, edge_fea, v=None):
@@ -179,7 +181,7 @@ class EGNN(nn.Module):
         key = (edge_index.data_ptr(), edge_index.size(1), edge_index._version, N)
         graph = self._graph_cache.get(key)
         if graph is None:
-            graph = SortedGraph(edge_index, N)
+            graph = SortedGraph(edge_index, N, csc=bool(self._spec.flags & K.F_DETERMINISTIC))
             graph._keepalive = edge_index
             if len(self._graph_cache) >= 8:
                 self._graph_cache.pop(next(iter(self._graph_cache)))

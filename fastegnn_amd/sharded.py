@@ -71,8 +71,8 @@ class HipBackend:
     def wg_node_floats(self, N, B, Cn):
         return self.lib.fastegnn_wg_node_floats(N, B, Cn)
 
-    def build_graph(self, edge_index, n_rows, n_src, row_begin):
-        return SortedGraph(edge_index, n_rows, n_src, row_begin)
+    def build_graph(self, edge_index, n_rows, n_src, row_begin, csc=True):
+        return SortedGraph(edge_index, n_rows, n_src, row_begin, csc=csc)
 
     def build_batch(self, data_batch, N, B):
         b32 = torch.empty(N, dtype=torch.int32, device=self.dev)
@@ -517,7 +517,7 @@ class _ShardedFunction(torch.autograd.Function):
         g_HvT = be.zeros(B, Cn, H)
         g_vel = be.zeros(N, 3)
         sc = be.carve(dict(g_poolV=(B, Cn, H), g_poolX=(B, 3, Cn), g_xbar=(B, 4), g_A=(N, H), g_P=(N, H),
-                           g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,), g_QXe=(max(E, 1), K.QX_LD),
+                           g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,), g_QXe=(max(E, 1) if spec.flags & K.F_DETERMINISTIC else 1, K.QX_LD),
                            g_xrow=(N, 3), wg_edge=(be.wg_edge_floats(E),), wg_virt=(be.wg_virt_floats(N, Cn),),
                            wg_node=(be.wg_node_floats(N, B, Cn),), wg_slab=(be.wg_slab_floats(),)))
         nV = B * Cn * H
@@ -636,7 +636,7 @@ class ShardedFastEGNN(torch.nn.Module):
             pidx = m._param_index
             m._plist = [pidx[n] for n in m._spec.names]
         spec = m._spec
-        graph = be.build_graph(local["edge_index"], plan.nloc, plan.n_src, plan.n0)
+        graph = be.build_graph(local["edge_index"], plan.nloc, plan.n_src, plan.n0, csc=bool(m._spec.flags & K.F_DETERMINISTIC))
         B = local["loc_mean"].size(0)
         batch32, gptr = be.build_batch(local["data_batch"], plan.nloc, B)
         self.plan = plan

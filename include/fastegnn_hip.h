@@ -68,7 +68,14 @@ enum {
   FASTEGNN_F_BF16 = 256,
   /* EGNN(norm=True) (models/basic.py:271-272): the 1x1 Gram feature of the message MLP is F.normalize'd -- r^2 / max(r^2, 1e-12),
    * i.e. 1 for every edge of non-zero length (gradient 0) and r^2 * 1e12 below (gradient 1e12).  With FASTEGNN_F_EGNN only. */
-  FASTEGNN_F_EGNN_NORM = 512
+  FASTEGNN_F_EGNN_NORM = 512,
+  /* Backward only.  By default the col-side adjoint of the edge stage -- d loss / d (Q | x)[col], the transpose of the
+   * forward gather -- is scattered into g_QX_src with fp32 atomics (one coalesced 272-byte row per edge): g_QXe, the CSC
+   * index of the graph (cscptr / csc_eid may then be NULL, also in fastegnn_build_csr) and fastegnn_edge_col_reduce's
+   * kernel are not used, and the sums depend on the order the atomics land in (rounding-level run-to-run differences,
+   * like torch's scatter_add_ on a GPU).  With this flag the rows are stored per edge in g_QXe [E,68] and summed in CSC
+   * order by fastegnn_edge_col_reduce: bit-reproducible, 0.26 ms per step slower at cfg4 and 272 bytes of scratch per edge. */
+  FASTEGNN_F_DETERMINISTIC = 1024
 };
 
 /* Per-layer parameter slots: the reference state_dict tensors of gcl_<i>, untouched

@@ -54,7 +54,7 @@ class CpuOracleBackend:
         return 4
 
     # ---- prologue / epilogue ----
-    def build_graph(self, ei, n_rows, n_src, row_begin):
+    def build_graph(self, ei, n_rows, n_src, row_begin, csc=True):
         return CpuGraph(ei, n_rows, n_src, row_begin)
 
     def build_batch(self, data_batch, N, B):

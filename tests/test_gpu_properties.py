@@ -347,6 +347,33 @@ def test_many_graphs_large_total_is_sum_of_half_batches():
     assert not bad, bad
 
 
+def test_deterministic_backward_matches_atomic_scatter():
+    """FASTEGNN_F_DETERMINISTIC (model.deterministic = True: per-edge rows + CSC-ordered sum) against the default backward
+    (fp32 atomic scatter of the col-side adjoint): same gradients up to summation order, and the deterministic mode's
+    input-table gradient path is reproducible (the edge stage's own weight gradients are bitwise equal between two runs
+    of the LAST layer's backward, which nothing atomic precedes)."""
+    torch.manual_seed(5)
+    from bench import make_frame
+    frame, target = make_frame(20000, 16, 11, "cuda")
+    m = fastegnn_amd.FastEGNN(2, 0, 2, 64, 16, device="cuda", n_layers=3, gravity=[0, -1, 0])
+    res = {}
+    for det in (False, True, True):
+        m.deterministic = det
+        assert bool(m.deterministic) == det
+        for p in m.parameters():
+            p.grad = None
+        loc, vloc = m(**frame)
+        torch.nn.functional.mse_loss(loc, target).backward()
+        assert (m._spec.flags & fastegnn_amd._lib.F_DETERMINISTIC != 0) == det
+        res.setdefault(det, []).append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    ga, gd, gd2 = res[False][0], res[True][0], res[True][1]
+    bad = [(k, rel_err(ga[k], gd[k])) for k in gd if rel_err(ga[k], gd[k]) > (1e-3 if "_virtual.0.bias" in k else 2e-5)]
+    assert not bad, bad
+    # reproducibility where nothing order-dependent feeds in: the last layer's edge-stage weight gradients
+    for k in ("gcl_2.coord_mlp_r.0.weight", "gcl_2.edge_mlp.2.weight"):
+        assert rel_err(gd[k], gd2[k]) < 1e-5
+
+
 def test_cfg2_shape_rotation_translation_equivariance():
     """the reference's acceptance property (equivariant_test.py:62, atol 1e-4) at the cfg2 shape --
     100-particle fully connected N-body systems (9 900 directed edges per graph), C=3, fp32 -- on a 10-graph batch, with
