@@ -220,7 +220,19 @@ def make_protein_batch(n_graphs, n, C, cutoff_rate, seed, device, radius=10.0, b
 def make_workload(cfg, seed, device, nodes=None, channels=None):
     C = channels or cfg["C"]
     if cfg["kind"] == "water":
-        return make_frame(nodes or cfg["nodes"], C, seed, device)
+        frame, target = make_frame(nodes or cfg["nodes"], C, seed, device)
+        if os.environ.get("FASTEGNN_BENCH_NODE_ORDER") == "morton":
+            # DIAGNOSTIC ONLY (never the reported configuration): the same frame with its nodes relabelled along a Morton
+            # curve -- what spatial locality of the node order is worth to the gather / scatter kernels
+            import torch
+            from fastegnn_amd.sharded import morton_order
+            order = morton_order(frame["node_loc"], frame["data_batch"])
+            inv = torch.empty_like(order)
+            inv[order] = torch.arange(order.numel(), device=order.device)
+            frame = dict(frame, node_feat=frame["node_feat"][order], node_loc=frame["node_loc"][order],
+                         node_vel=frame["node_vel"][order], edge_index=inv[frame["edge_index"]])
+            target = target[order]
+        return frame, target
     if cfg["kind"] == "nbody":
         return make_nbody_batch(cfg["graphs"], nodes or cfg["nodes"], C, cfg["cutoff"], seed, device)
     return make_protein_batch(cfg["graphs"], nodes or cfg["nodes"], C, cfg["cutoff"], seed, device)

@@ -1225,16 +1225,23 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         xv[ee] = pt[ee * TS + H + (l & 3)];
       }
       const int rowv = S.row;
-      if (A.g_QXs_atomic) {   // default (no FASTEGNN_F_DETERMINISTIC): one coalesced 272-byte atomic row per edge
+      if (A.g_QXs_atomic) {   // default (no FASTEGNN_F_DETERMINISTIC): one coalesced 256-byte atomic row per edge ...
         const int colv = S.col;
+        char *gb = reinterpret_cast<char *>(A.g_QXs_atomic);   // wave-uniform base + 32-bit lane offsets (tables < 2^30 floats)
+        const unsigned lo = 4u * (unsigned)l;
+        if (nvalid == 16) {
 #pragma unroll
-        for (int ee = 0; ee < 16; ++ee) {
-          if (ee < nvalid) {
-            float *dst = A.g_QXs_atomic + (size_t)__builtin_amdgcn_readlane(colv, ee) * QXLD;
-            atomicAdd(dst + l, mv[ee]);
-            if (l < 3) atomicAdd(dst + H + l, -xv[ee]);
-          }
+          for (int ee = 0; ee < 16; ++ee)
+            atomicAdd(reinterpret_cast<float *>(gb + ((unsigned)__builtin_amdgcn_readlane(colv, ee) * (QXLD * 4u) + lo)), mv[ee]);
+        } else {
+          for (int ee = 0; ee < nvalid; ++ee)
+            atomicAdd(reinterpret_cast<float *>(gb + ((unsigned)__shfl(colv, ee) * (QXLD * 4u) + lo)), pt[ee * TS + l]);
         }
+        // ... and ONE atomic for the tile's coordinate parts: lane l < 3 * nvalid adds component l % 3 of edge l / 3
+        const int ex = min(l / 3, 15), kx = l - 3 * ex;
+        const unsigned cx = (unsigned)__shfl(colv, ex);   // lane ex (q = 0) holds edge ex
+        const float gx = pt[ex * TS + H + (kx & 3)];
+        if (l < 3 * nvalid) atomicAdd(reinterpret_cast<float *>(gb + (cx * (QXLD * 4u) + 4u * (unsigned)(H + kx))), -gx);
       }
 #pragma unroll
       for (int ee = 0; ee < 16; ++ee) {
