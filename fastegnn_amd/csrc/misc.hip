@@ -158,6 +158,199 @@ __device__ __forceinline__ void wg_accumulate(const float *G, const float *T, in
   }
 }
 
+// The same contraction with the MFMA fragments loaded straight from global memory (lane l = i + 16 k reads element
+// (row m + 4 s + k, column 16 t + i): exactly the 16x16x4 operand layout, 64-byte segments of four rows per instruction), no
+// LDS staging: nothing to write, read back or fence, and DEPTH tiles of loads in flight per wave instead of one.
+#ifndef FE_WG_DEPTH
+#define FE_WG_DEPTH 2
+#endif
+__device__ __forceinline__ void wg_accumulate_direct(const float *G, const float *T, int ldg, int ldt, long m_first, long m1,
+                                                     int step, bool want_bias, bool rnd, f32x4 (&acc)[4][4], float (&bsum)[4]) {
+  constexpr int D = FE_WG_DEPTH;
+  const int l = lane_id(), i = l & 15, k = l >> 4;
+  float gv[D][16], tv[D][16];
+  unsigned og[4], ot[4];   // byte offsets of (row 4 s + k, column i); + 64 t bytes per column tile
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    og[s] = ((unsigned)(4 * s + k) * (unsigned)ldg + (unsigned)i) * 4u;
+    ot[s] = ((unsigned)(4 * s + k) * (unsigned)ldt + (unsigned)i) * 4u;
+  }
+  auto issue = [&](int slot, long m) {
+    const char *gb = reinterpret_cast<const char *>(G + (size_t)m * ldg);
+    const char *tb = reinterpret_cast<const char *>(T + (size_t)m * ldt);
+    const bool full = m + 16 <= m1;   // wave-uniform; a ragged tail reads row m (always valid) and is zeroed at use
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool ok = full || m + 4 * s + k < m1;
+      const unsigned a = ok ? og[s] : (unsigned)i * 4u, b = ok ? ot[s] : (unsigned)i * 4u;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        gv[slot][4 * s + t] = *reinterpret_cast<const float *>(gb + a + 64u * t);
+        tv[slot][4 * s + t] = *reinterpret_cast<const float *>(tb + b + 64u * t);
+      }
+    }
+  };
+  auto consume = [&](int slot, long m) {
+    const bool full = m + 16 <= m1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float av[4], bv[4];
+      const bool ok = full || m + 4 * s + k < m1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        av[t] = ok ? gv[slot][4 * s + t] : 0.f;
+        bv[t] = ok ? tv[slot][4 * s + t] : 0.f;
+      }
+      if (rnd) {   // bf16 operand mode (wave-uniform): products of bf16 values are exact in fp32-input MFMA
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (want_bias) bsum[t] += av[t];   // the bias gradient sums the unrounded rows
+          av[t] = round_bf(av[t]);
+          bv[t] = round_bf(bv[t]);
+        }
+      }
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        if (want_bias && !rnd) bsum[ti] += av[ti];
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+          acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti], bv[tk], acc[ti][tk], 0, 0, 0);
+      }
+    }
+  };
+  long m = m_first;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (m + (long)d * step < m1) issue(d, m + (long)d * step);
+  while (m < m1) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {   // static slots: the ring is the unrolled loop body
+      if (m < m1) {
+        consume(d, m);
+        if (m + (long)D * step < m1) issue(d, m + (long)D * step);
+        m += step;
+      }
+    }
+  }
+}
+
+// The contraction on the bf16 matrix pipe: 32 rows per step, fragments straight from global memory in the 16x16x32 operand
+// layout (lane l = i + 16 q holds rows m + 8 q .. + 7 of column 16 t + i: eight 64-byte-segment loads per fragment), each
+// fp32 operand split in registers into bf16 parts h | m | l (truncation, as the stage kernels' activations) and six
+// products per (ti, tk) tile -- 96 matrix instructions of 16 cycles per 32 rows against 128 of 32 cycles on the fp32-input
+// form.  BF (bf16 operand mode): both operands rounded to bf16 (RNE) and ONE product -- the mode's weight gradients on
+// the bf16 instruction itself.  The next step's G fragments are requested while this step's T fragments are split, the
+// next T fragment of a column tile as soon as the current one has been split.
+struct WgParts { u32x4 p[3]; };
+template <bool BF>
+__device__ __forceinline__ WgParts wg_split8(const float (&x)[8]) {
+  WgParts P;
+  if constexpr (BF) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) P.p[0][w] = pack_rne(x[2 * w], x[2 * w + 1]);
+    P.p[1] = P.p[2] = u32x4{0u, 0u, 0u, 0u};
+  } else {
+    float r1[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      r1[e] = x[e] - trunc_bf(x[e]);
+      r2[e] = r1[e] - trunc_bf(r1[e]);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      P.p[0][w] = pack_hi(x[2 * w], x[2 * w + 1]);
+      P.p[1][w] = pack_hi(r1[2 * w], r1[2 * w + 1]);
+      P.p[2][w] = pack_hi(r2[2 * w], r2[2 * w + 1]);
+    }
+  }
+  return P;
+}
+template <bool BF>
+__device__ __forceinline__ void wg_accumulate_x3(const float *G, const float *T, int ldg, int ldt, long m_first, long m1,
+                                                 int step, bool want_bias, f32x4 (&acc)[4][4], float (&bsum)[4]) {
+  const int l = lane_id(), i = l & 15, q = l >> 4;
+  float gr[4][8], tr[4][8];   // raw fragments [column tile][row e]
+  unsigned og[8], ot[8];      // byte offsets of (row 8 q + e, column i); + 64 t bytes per column tile
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    og[e] = ((unsigned)(8 * q + e) * (unsigned)ldg + (unsigned)i) * 4u;
+    ot[e] = ((unsigned)(8 * q + e) * (unsigned)ldt + (unsigned)i) * 4u;
+  }
+  // rows at or beyond m1 read row m (always valid) and are zeroed at use
+  auto load_g = [&](long m) {
+    const char *gb = reinterpret_cast<const char *>(G + (size_t)m * ldg);
+    const bool full = m + 32 <= m1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned a = (full || m + 8 * q + e < m1) ? og[e] : (unsigned)i * 4u;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) gr[t][e] = *reinterpret_cast<const float *>(gb + a + 64u * t);
+    }
+  };
+  auto load_t = [&](long m, int t) {
+    const char *tb = reinterpret_cast<const char *>(T + (size_t)m * ldt);
+    const bool full = m + 32 <= m1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned a = (full || m + 8 * q + e < m1) ? ot[e] : (unsigned)i * 4u;
+      tr[t][e] = *reinterpret_cast<const float *>(tb + a + 64u * t);
+    }
+  };
+  long m = m_first;
+  if (m < m1) {
+    load_g(m);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) load_t(m, t);
+  }
+  for (; m < m1; m += step) {
+    const bool full = m + 32 <= m1;
+    const bool more = m + step < m1;
+    WgParts gp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (!full) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (m + 8 * q + e >= m1) gr[t][e] = 0.f;
+      }
+      if (want_bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[t] += gr[t][e];   // the bias gradient sums the unrounded rows
+      }
+      gp[t] = wg_split8<BF>(gr[t]);
+    }
+    if (more) load_g(m + step);
+#pragma unroll
+    for (int tk = 0; tk < 4; ++tk) {
+      if (!full) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (m + 8 * q + e >= m1) tr[tk][e] = 0.f;
+      }
+      const WgParts tp = wg_split8<BF>(tr[tk]);
+      if (more) load_t(m + step, tk);
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, tp.p[0]), bm = __builtin_bit_cast(bf16x8, tp.p[1]),
+                   bl = __builtin_bit_cast(bf16x8, tp.p[2]);
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, gp[ti].p[0]);
+        if constexpr (BF) {
+          acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[ti][tk], 0, 0, 0);
+        } else {
+          const bf16x8 am = __builtin_bit_cast(bf16x8, gp[ti].p[1]), al = __builtin_bit_cast(bf16x8, gp[ti].p[2]);
+          // smallest terms first
+          acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[ti][tk], 0, 0, 0);
+          acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[ti][tk], 0, 0, 0);
+          acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[ti][tk], 0, 0, 0);
+          acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[ti][tk], 0, 0, 0);
+          acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[ti][tk], 0, 0, 0);
+          acc[ti][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[ti][tk], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_tn_kernel(WgTable tab) {
   // 40 KB of staging tiles; the 64x64 reduction buffer aliases them after the main loop
   __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 16 * WTS];
@@ -195,7 +388,16 @@ __global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_tn_kernel(WgTable tab) {
 #pragma unroll
     for (int tk = 0; tk < 4; ++tk) acc[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool want_bias = a.db != nullptr;
+#if defined(FE_WG_STAGED)
   wg_accumulate(G, T, a.ldg, a.ldt, m0 + 16 * w, m1, 64, want_bias, a.round != 0, gt, tt, acc, bsum);
+#elif defined(FE_WG_F32)
+  (void)gt; (void)tt;
+  wg_accumulate_direct(G, T, a.ldg, a.ldt, m0 + 16 * w, m1, 64, want_bias, a.round != 0, acc, bsum);
+#else
+  (void)gt; (void)tt;
+  if (a.round) wg_accumulate_x3<true>(G, T, a.ldg, a.ldt, m0 + 32 * w, m1, 128, want_bias, acc, bsum);
+  else wg_accumulate_x3<false>(G, T, a.ldg, a.ldt, m0 + 32 * w, m1, 128, want_bias, acc, bsum);
+#endif
   __syncthreads();   // all waves are done with their staging tiles
   for (int k = threadIdx.x; k < IMG; k += 256) red[k] = 0.f;
   __syncthreads();
