@@ -43,7 +43,13 @@ __device__ __forceinline__ float dsilu_f(float z) {
 }
 // silu(z) and its derivative from ONE sigmoid: d = s*(1 + z*(1-s)) = s + y*(1-s) with y = z*s
 __device__ __forceinline__ void silu_both(float z, float &y, float &d) {
+#ifdef FE_SIGMOID_NEWTON   // measured lever (round-2 verdict item 7): one Newton step on the reciprocal of the backward recompute
+  const float den = 1.0f + __expf(-z);
+  float s = __builtin_amdgcn_rcpf(den);
+  s = fmaf(fmaf(-den, s, 1.0f), s, s);
+#else
   const float s = sigmoid_f(z);
+#endif
   y = z * s;
   d = s + y * (1.0f - s);
 }
