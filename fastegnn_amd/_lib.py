@@ -54,6 +54,12 @@ class GraphT(C.Structure):
                 ("cscptr", _vp), ("csc_eid", _vp), ("chunk_row", _vp)]
 
 
+class PadDesc(C.Structure):
+    """fastegnn_pad_desc_t (include/fastegnn_hip.h)"""
+    _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i32), ("cols", _i32), ("rows_dst", _i32), ("cols_dst", _i32),
+                ("nblk", _i32), ("blk", _i32 * 3)]
+
+
 _LAYER_PTRS_A = ["batch", "gptr", "ea_sorted", "vel", "node_attr", "params", "grads", "wpack",
                  "h", "x", "Z", "HvT", "h_out", "x_out", "Z_out", "HvT_out",
                  "P", "QX", "QX_src", "A", "svel", "sgrav", "xsum", "Bc", "aggm", "aggx", "npre", "poolV", "poolX",
@@ -103,6 +109,7 @@ def lib():
     L.fastegnn_backward_scratch_floats.argtypes = [_i32, _i32, _i32, _i32, _i32]
     L.fastegnn_chunk_edges.restype = _i32
     L.fastegnn_chunk_edges.argtypes = []
+    L.fastegnn_pad_params.argtypes = [C.POINTER(PadDesc), _i32, _i32, _i32, _vp]
     L.fastegnn_build_csr.argtypes = [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      C.POINTER(_i32), _vp, C.c_size_t, _vp]
     L.fastegnn_permute_rows.argtypes = [_vp, _vp, _i32, _i32, _vp, _vp]
@@ -171,7 +178,7 @@ STAGE_FUNCS = [
 # every symbol include/fastegnn_hip.h declares (checked by tests/test_abi_cpu.py)
 EXPORTED = STAGE_FUNCS + [
     "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_wg_edge_floats", "fastegnn_wg_virt_floats", "fastegnn_wg_virt_floats_for", "fastegnn_backward_scratch_floats_for", "fastegnn_wg_node_floats", "fastegnn_backward_scratch_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes", "fastegnn_chunk_rows", "fastegnn_chunk_edges",
-    "fastegnn_build_csr", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
+    "fastegnn_build_csr", "fastegnn_pad_params", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_rm", "fastegnn_selftest_jreduce", "fastegnn_selftest_wgrad", "fastegnn_selftest_wgrad_plan", "fastegnn_selftest_stream", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
     "fastegnn_augment_edge_attr", "fastegnn_loss_mse_mmd", "fastegnn_adam_step",

@@ -43,6 +43,47 @@ __global__ void virtual_init_bwd_kernel(const float *g_HvT, int B, int C, float 
   g_vnf[hh * C + c] += acc;
 }
 
+// ---------------------------------------------------------------- hidden_nf < 64: zero-padded parameter images
+constexpr int PAD_MAX_DESC = 64;
+struct PadTable {
+  fastegnn_pad_desc_t d[PAD_MAX_DESC];
+  int n, h;
+};
+// source column of padded column c (or -1: a zero of the padding)
+__device__ __forceinline__ int pad_src_col(const fastegnn_pad_desc_t &d, int h, int c) {
+  int os = 0, od = 0;
+  for (int b = 0; b < d.nblk; ++b) {
+    const int wd = d.blk[b] / h * H;
+    if (c < od + wd) return c - od < d.blk[b] ? os + (c - od) : -1;
+    os += d.blk[b];
+    od += wd;
+  }
+  return os + (c - od);
+}
+__device__ __forceinline__ int pad_dst_col(const fastegnn_pad_desc_t &d, int h, int c) {
+  int os = 0, od = 0;
+  for (int b = 0; b < d.nblk; ++b) {
+    if (c < os + d.blk[b]) return od + (c - os);
+    os += d.blk[b];
+    od += d.blk[b] / h * H;
+  }
+  return od + (c - os);
+}
+__global__ __launch_bounds__(256) void pad_params_kernel(PadTable tab, int reverse) {
+  const fastegnn_pad_desc_t &d = tab.d[blockIdx.y];
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (!reverse) {
+    if (i >= (long)d.rows_dst * d.cols_dst) return;
+    const int r = (int)(i / d.cols_dst), c = (int)(i % d.cols_dst);
+    const int cs = r < d.rows ? pad_src_col(d, tab.h, c) : -1;
+    d.dst[i] = cs >= 0 ? d.src[(size_t)r * d.cols + cs] : 0.f;
+  } else {
+    if (i >= (long)d.rows * d.cols) return;
+    const int r = (int)(i / d.cols), c = (int)(i % d.cols);
+    const_cast<float *>(d.src)[i] = d.dst[(size_t)r * d.cols_dst + pad_dst_col(d, tab.h, c)];
+  }
+}
+
 __global__ void permute_rows_kernel(const float *in, const int32_t *perm, int E, int w, float *out) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)E * w) return;
@@ -883,6 +924,36 @@ int fastegnn_virtual_init_backward(const float *g_HvT, int32_t B, int32_t C, flo
   hipLaunchKernelGGL(virtual_init_bwd_kernel, dim3(cdiv((long)C * H, 256)), dim3(256), 0, (hipStream_t)stream, g_HvT, B,
                      C, g_vnf);
   return check_launch("virtual_init_bwd_kernel");
+}
+
+int fastegnn_pad_params(const fastegnn_pad_desc_t *desc, int32_t n, int32_t h, int32_t reverse, void *stream) {
+  FE_REQUIRE(n == 0 || desc, "pad_params: null descriptors");
+  FE_REQUIRE(h >= 1 && h <= fe::H, "pad_params: hidden_nf must be in [1,64]");
+  for (int k0 = 0; k0 < n; k0 += fe::PAD_MAX_DESC) {
+    fe::PadTable tab;
+    tab.n = n - k0 < fe::PAD_MAX_DESC ? n - k0 : fe::PAD_MAX_DESC;
+    tab.h = h;
+    long most = 0;
+    for (int k = 0; k < tab.n; ++k) {
+      const fastegnn_pad_desc_t &d = desc[k0 + k];
+      FE_REQUIRE(d.src && d.dst && d.rows >= 0 && d.cols >= 0 && d.rows_dst >= d.rows && d.nblk >= 0 && d.nblk <= 3,
+                 "pad_params: bad descriptor");
+      int cs = 0, cd = 0;
+      for (int b = 0; b < d.nblk; ++b) {
+        FE_REQUIRE(d.blk[b] >= 0 && d.blk[b] % h == 0, "pad_params: a block must be a multiple of hidden_nf columns");
+        cs += d.blk[b];
+        cd += d.blk[b] / h * fe::H;
+      }
+      FE_REQUIRE(cs <= d.cols && d.cols_dst == cd + (d.cols - cs), "pad_params: column blocks do not add up");
+      tab.d[k] = d;
+      const long elems = reverse ? (long)d.rows * d.cols : (long)d.rows_dst * d.cols_dst;
+      if (elems > most) most = elems;
+    }
+    if (most == 0) continue;
+    hipLaunchKernelGGL(fe::pad_params_kernel, dim3((unsigned)cdiv(most, 256), (unsigned)tab.n), dim3(256), 0, (hipStream_t)stream,
+                       tab, reverse);
+  }
+  return check_launch("pad_params_kernel");
 }
 
 int fastegnn_permute_rows(const float *in, const int32_t *perm, int32_t E, int32_t width, float *out, void *stream) {

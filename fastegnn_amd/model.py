@@ -10,6 +10,7 @@ C ABI of ``include/fastegnn_hip.h``; there is no CPU path -- CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from typing import Dict, List, Optional
 
@@ -232,34 +233,89 @@ _HIDDEN_OUT = ("edge_mlp.0", "edge_mlp.2", "edge_mlp_virtual.0", "edge_mlp_virtu
                "node_mlp.2", "node_mlp_virtual.0", "node_mlp_virtual.2", "embedding_in")
 
 
-def _pad_param(name: str, p: torch.Tensor, h: int, C_: int, rf: bool) -> torch.Tensor:
+def _pad_layout(name: str, shape, h: int, C_: int, rf: bool):
     """The 64-wide image of a parameter of a ``hidden_nf = h < 64`` model: every hidden-sized row / column block is
     zero-extended to 64.  A zero row of a Linear gives a zero pre-activation, SiLU(0) = 0, and a zero column ignores
     its input, so the padded model computes exactly the reference's function (models/FastEGNN.py:28-99 with
-    hidden_nf = h); built from differentiable torch ops, so autograd slices the gradients back."""
-    pad = torch.nn.functional.pad
+    hidden_nf = h).  Returns (rows, cols, rows_dst, blocks, out_shape): the parameter seen as a [rows, cols] matrix, the
+    padded row count, the source-column blocks that are widened to 64 per h columns (the hidden-sized pieces of the
+    reference's torch.cat inputs, FastEGNN.py:104,114,157,171; the remaining columns follow unchanged) and the shape
+    of the image.  tests/test_pad_cpu.py evaluates the oracle on images built from this layout."""
+    shape = tuple(shape)
     if name == "virtual_node_feat":                       # [1, h, C]
-        return pad(p, (0, 0, 0, H - h))
+        return h, shape[2], H, [], (1, H, shape[2])
     mod, kind = name.rsplit(".", 1)
     mod = mod.split(".", 1)[1] if mod.startswith("gcl_") else mod
     if kind == "bias":
-        return pad(p, (0, H - h)) if mod in _HIDDEN_OUT else p
-    # input columns: the blocks of the reference's torch.cat, hidden-sized ones first (FastEGNN.py:104,114,157,171)
+        if mod in _HIDDEN_OUT:
+            return 1, shape[0], 1, [h], (H,)
+        return 1, shape[0], 1, [], shape
     if mod in ("edge_mlp.0", "edge_mlp_virtual.0", "node_mlp_virtual.0"):
-        sizes = [h, h]
+        blocks = [h, h]
     elif mod == "node_mlp.0":
-        sizes = [h, h, h * C_]                            # flat(v) is feature-major: column 2h + i*C + c
+        blocks = [h, h, h * C_]                           # flat(v) is feature-major: column 2h + i*C + c
     elif mod == "embedding_in" or (rf and mod == "coord_mlp_vel.0"):
-        sizes = []                                        # inputs that are not hidden features
+        blocks = []                                       # inputs that are not hidden features
     else:
-        sizes = [h]
-    blocks, at = [], 0
-    for sz in sizes:
-        blocks.append(pad(p[:, at:at + sz], (0, sz // h * (H - h))))
-        at += sz
-    blocks.append(p[:, at:])
-    w = torch.cat(blocks, dim=1) if len(blocks) > 1 else blocks[0]
-    return pad(w, (0, 0, 0, H - h)) if mod in _HIDDEN_OUT else w
+        blocks = [h]
+    rows, cols = shape
+    rows_dst = H if mod in _HIDDEN_OUT else rows
+    cols_dst = cols + sum(b // h * (H - h) for b in blocks)
+    return rows, cols, rows_dst, blocks, (rows_dst, cols_dst)
+
+
+class _PadParams(torch.autograd.Function):
+    """All parameters of a narrow model -> their 64-wide images, one HIP launch per 64 parameters
+    (fastegnn_pad_params); the backward slices the padded gradients back with the same kernel in reverse."""
+
+    @staticmethod
+    def _table(layouts, narrow, wide):
+        tab = (K.PadDesc * len(layouts))()
+        for d, (rows, cols, rows_dst, blocks, out_shape), a, b in zip(tab, layouts, narrow, wide):
+            d.src, d.dst = a.data_ptr(), b.data_ptr()
+            d.rows, d.cols, d.rows_dst = rows, cols, rows_dst
+            d.cols_dst = b.numel() // max(rows_dst, 1)
+            d.nblk = len(blocks)
+            for i, blk in enumerate(blocks):
+                d.blk[i] = blk
+        return tab
+
+    @staticmethod
+    def forward(ctx, names, h, C_, rf, *params):
+        lib = K.lib()
+        dev = params[0].device
+        layouts = [_pad_layout(n, p.shape, h, C_, rf) for n, p in zip(names, params)]
+        sizes = [(math.prod(l[4]) + 3) // 4 * 4 for l in layouts]      # 16-byte aligned pieces of one buffer
+        flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        outs, off = [], 0
+        for l, sz in zip(layouts, sizes):
+            outs.append(flat[off:off + math.prod(l[4])].view(l[4]))
+            off += sz
+        src = [p.detach().contiguous().float() for p in params]
+        tab = _PadParams._table(layouts, src, outs)
+        K.check(lib.fastegnn_pad_params(tab, len(layouts), h, 0, _stream(dev)), "fastegnn_pad_params")
+        ctx.layouts, ctx.h, ctx.shapes = layouts, h, [p.shape for p in params]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        lib = K.lib()
+        idx = [i for i, g in enumerate(gouts) if g is not None]
+        grads = [None] * len(gouts)
+        if idx:
+            dev = gouts[idx[0]].device
+            wide = [gouts[i].contiguous().float() for i in idx]
+            sizes = [(math.prod(ctx.shapes[i]) + 3) // 4 * 4 for i in idx]
+            flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+            narrow, off = [], 0
+            for i, sz in zip(idx, sizes):
+                narrow.append(flat[off:off + math.prod(ctx.shapes[i])].view(ctx.shapes[i]))
+                off += sz
+            tab = _PadParams._table([ctx.layouts[i] for i in idx], narrow, wide)
+            K.check(lib.fastegnn_pad_params(tab, len(idx), ctx.h, 1, _stream(dev)), "fastegnn_pad_params")
+            for i, g in zip(idx, narrow):
+                grads[i] = g
+        return (None, None, None, None, *grads)
 
 
 class _FastEGNNFunction(torch.autograd.Function):
@@ -508,6 +564,6 @@ class FastEGNN(nn.Module):
         plist = self._plist
         if self.hidden_nf < H:
             rf = bool(spec.flags & K.F_RF)
-            plist = [_pad_param(n, p, self.hidden_nf, spec.C, rf) for n, p in zip(spec.names, plist)]
+            plist = list(_PadParams.apply(tuple(spec.names), self.hidden_nf, spec.C, rf, *plist))
         return _FastEGNNFunction.apply(spec, graph, batch32, gptr, edge_attr, node_attr, node_feat, node_loc, node_vel,
                                        loc_mean, *plist)

@@ -32,7 +32,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as K
-from .model import FastEGNN, SortedGraph, _PtrTable, _Spec, _carve, _fill, _new_layer, _stream
+from .model import FastEGNN, SortedGraph, _PadParams, _PtrTable, _Spec, _carve, _fill, _new_layer, _stream
 
 H = K.H
 
@@ -73,6 +73,10 @@ class HipBackend:
 
     def build_graph(self, edge_index, n_rows, n_src, row_begin, csc=True):
         return SortedGraph(edge_index, n_rows, n_src, row_begin, csc=csc)
+
+    def pad_params(self, names, h, C_, rf, params):
+        """hidden_nf < 64: the parameters' 64-wide images (fastegnn_pad_params, differentiable)"""
+        return list(_PadParams.apply(tuple(names), h, C_, rf, *params))
 
     def build_batch(self, data_batch, N, B):
         b32 = torch.empty(N, dtype=torch.int32, device=self.dev)
@@ -589,8 +593,6 @@ class ShardedFastEGNN(torch.nn.Module):
         self.exchange = exchange or os.environ.get("FASTEGNN_SHARDED_EXCHANGE", "halo")
         if self.exchange not in ("halo", "allgather"):
             raise ValueError("ShardedFastEGNN: exchange must be 'halo' or 'allgather'")
-        if model.hidden_nf != K.H:   # the zero-padded path of model.py (_pad_param) is single-GPU only
-            raise NotImplementedError(f"fastegnn_amd.ShardedFastEGNN: hidden_nf must be {K.H}")
         self.model = model
         self.group = group
         self.backend = backend
@@ -643,9 +645,12 @@ class ShardedFastEGNN(torch.nn.Module):
         ea = local["edge_attr"]
         if ea is not None and ea.size(1) == 0:
             ea = None
+        plist = m._plist
+        if m.hidden_nf < K.H:
+            plist = be.pad_params(spec.names, m.hidden_nf, spec.C, bool(spec.flags & K.F_RF), plist)
         return _ShardedFunction.apply(be, self.group, self.stats, spec, plan, graph, batch32, gptr, ea,
                                       local["node_attr"], local["node_feat"], local["node_loc"], local["node_vel"],
-                                      local["loc_mean"], *m._plist)
+                                      local["loc_mean"], *plist)
 
     def forward(self, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None,
                 node_attr=None):

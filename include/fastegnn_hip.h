@@ -248,6 +248,23 @@ int fastegnn_build_csr(const int64_t *edge_index, int32_t E, int32_t row_begin, 
 /* out[k,:] = in[perm[k],:]   (edge_attr into sorted order) */
 int fastegnn_permute_rows(const float *in, const int32_t *perm, int32_t E, int32_t width, float *out,
                           void *stream);
+/* hidden_nf < 64: the kernels work on 64-wide tiles, a narrower model runs zero-padded (a zero row of a Linear gives a
+ * zero pre-activation, SiLU(0) = 0, a zero column ignores its input: the padded model computes the reference's function,
+ * models/FastEGNN.py:28-99 with hidden_nf = h).  One descriptor per parameter: `src` [rows, cols] row-major is copied into
+ * `dst` [rows_dst, cols_dst] (zero elsewhere); the first `nblk` column blocks of blk[i] source columns each -- the
+ * hidden-sized pieces of the reference's torch.cat inputs, FastEGNN.py:104,114,157,171 -- are widened to
+ * blk[i] / h * 64 columns (zeros appended to the block), the remaining columns follow unchanged.  reverse != 0 runs the
+ * adjoint: src[r, c] = dst[r, map(c)] (the gradient of the narrow parameter is the matching slice of the padded one).
+ * `desc` is a HOST array; at most 64 descriptors travel per launch (kernel arguments, capturable into a HIP graph). */
+typedef struct {
+  const float *src;        /* reverse: written */
+  float *dst;              /* reverse: read */
+  int32_t rows, cols;      /* of src */
+  int32_t rows_dst, cols_dst;
+  int32_t nblk;
+  int32_t blk[3];
+} fastegnn_pad_desc_t;
+int fastegnn_pad_params(const fastegnn_pad_desc_t *desc, int32_t n, int32_t h, int32_t reverse, void *stream);
 /* batch int64 [N] (ascending) -> batch int32 [N], gptr int32 [B+1] */
 int fastegnn_build_batch(const int64_t *batch64, int32_t N, int32_t B, int32_t *batch, int32_t *gptr,
                          void *stream);

@@ -57,6 +57,10 @@ class CpuOracleBackend:
     def build_graph(self, ei, n_rows, n_src, row_begin, csc=True):
         return CpuGraph(ei, n_rows, n_src, row_begin)
 
+    def pad_params(self, names, h, C_, rf, params):
+        from tests.helpers import pad_reference
+        return [pad_reference(n, p, h, C_, rf) for n, p in zip(names, params)]
+
     def build_batch(self, data_batch, N, B):
         return data_batch.clone(), F.graph_ptr(data_batch, B)
 

@@ -183,3 +183,21 @@ def check_parity(g, loc, vloc, G=None, gin=None, truth=None):
                 continue
             grad_check(g.name, f"{tag}/{k}", got[k], ref[k], tru[k], msgs)
     return msgs
+
+
+def pad_reference(name, p, h, C_, rf):
+    """Differentiable torch statement of the zero-padded 64-wide image of a narrow model's parameter, built from the
+    layout the product uses (fastegnn_amd.model._pad_layout; the product's own implementation is the HIP kernel behind
+    fastegnn_pad_params).  Checker for tests/test_pad_cpu.py and tests/test_gpu_properties.py."""
+    import torch
+    from fastegnn_amd.model import _pad_layout
+    rows, cols, rows_dst, blocks, out_shape = _pad_layout(name, p.shape, h, C_, rf)
+    w = p.reshape(rows, cols)
+    pieces, at = [], 0
+    for b in blocks:
+        pieces.append(torch.nn.functional.pad(w[:, at:at + b], (0, b // h * (64 - h))))
+        at += b
+    pieces.append(w[:, at:])
+    w = torch.cat(pieces, dim=1) if len(pieces) > 1 else pieces[0]
+    w = torch.nn.functional.pad(w, (0, 0, 0, rows_dst - rows))
+    return w.reshape(out_shape)

@@ -378,6 +378,29 @@ def test_deterministic_backward_matches_atomic_scatter():
         assert rel_err(gd[k], gd2[k]) < 1e-5
 
 
+@pytest.mark.parametrize("h,C,rf", [(20, 3, False), (1, 2, False), (24, 2, True)])
+def test_pad_params_kernel_matches_the_layout_reference(h, C, rf):
+    """fastegnn_pad_params (one launch per 64 parameters) against the torch statement of the same layout: images
+    bitwise, and its reverse mode returns exactly the slices of the padded gradients."""
+    from fastegnn_amd.model import _PadParams
+    from tests.helpers import pad_reference
+    torch.manual_seed(h)
+    cls = fastegnn_amd.FastRF if rf else fastegnn_amd.FastEGNN
+    m = cls(2, 0 if rf else 2, 2, h, C, device="cuda", n_layers=3, attention=True, gravity=[0, -1, 0])
+    names = [k for k, _ in m.named_parameters()]
+    params = [p.detach().clone().requires_grad_(True) for _, p in m.named_parameters()]
+    assert len(params) > 64          # more than one launch
+    outs = _PadParams.apply(tuple(names), h, C, rf, *params)
+    ref = [pad_reference(n, p, h, C, rf) for n, p in zip(names, params)]
+    for n, a, b in zip(names, outs, ref):
+        assert a.shape == b.shape and torch.equal(a, b), n
+    gs = [torch.randn_like(o) for o in outs]
+    got = torch.autograd.grad(outs, params, gs)
+    want = torch.autograd.grad(ref, params, gs)
+    for n, a, b in zip(names, got, want):
+        assert torch.equal(a, b), n
+
+
 def test_cfg2_shape_rotation_translation_equivariance():
     """the reference's acceptance property (equivariant_test.py:62, atol 1e-4) at the cfg2 shape --
     100-particle fully connected N-body systems (9 900 directed edges per graph), C=3, fp32 -- on a 10-graph batch, with

@@ -40,9 +40,9 @@ def _inputs():
     return inp, target
 
 
-def _model():
+def _model(hidden=64):
     torch.manual_seed(9)
-    m = fastegnn_amd.FastEGNN(2, 0, 2, 64, C, device="cuda", n_layers=L, gravity=[0, -1, 0], attention=True)
+    m = fastegnn_amd.FastEGNN(2, 0, 2, hidden, C, device="cuda", n_layers=L, gravity=[0, -1, 0], attention=True)
     with torch.no_grad():
         for k, v in m.named_parameters():
             if k.endswith((".coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
@@ -54,7 +54,7 @@ def _loss(loc_rows, vloc, target_rows, n_total):
     return ((loc_rows - target_rows) ** 2).sum() / (3 * n_total) + 0.1 * vloc.pow(2).mean()
 
 
-def _worker(rank, world, port, exchange, reorder, q, backend="gloo", comm="torch"):
+def _worker(rank, world, port, exchange, reorder, q, backend="gloo", comm="torch", hidden=64):
     from fastegnn_amd.dist import allreduce_gradients
     from fastegnn_amd.sharded import CommStats, ShardedFastEGNN
     dev = rank if backend == "nccl" else 0           # RCCL: one device per rank; gloo: the ranks share cuda:0
@@ -66,7 +66,7 @@ def _worker(rank, world, port, exchange, reorder, q, backend="gloo", comm="torch
     inp, target = _inputs()
     inp = {k: v.cuda() for k, v in inp.items()}
     inp["edge_attr"].requires_grad_(True)      # d loss / d edge_attr of this rank's edges flows back into the full tensor
-    m = _model()
+    m = _model(hidden)
     stats = CommStats()
     sm = ShardedFastEGNN(m, stats=stats, exchange=exchange)
     local = sm.shard_inputs(**inp, reorder=reorder)
@@ -83,11 +83,11 @@ def _worker(rank, world, port, exchange, reorder, q, backend="gloo", comm="torch
     dist.destroy_process_group()
 
 
-def _run_and_check(exchange, reorder, backend, comm):
+def _run_and_check(exchange, reorder, backend, comm, hidden=64):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, reorder, q, backend, comm)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, reorder, q, backend, comm, hidden)) for r in range(world)]
     for pr in procs:
         pr.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -95,7 +95,7 @@ def _run_and_check(exchange, reorder, backend, comm):
         pr.join(timeout=120)
         assert pr.exitcode == 0
     inp, target = _inputs()
-    m = _model()
+    m = _model(hidden)
     cin = {k: v.cuda() for k, v in inp.items()}
     cin["edge_attr"].requires_grad_(True)
     loc, vloc = m(**cin)
@@ -131,6 +131,12 @@ def _run_and_check(exchange, reorder, backend, comm):
 @pytest.mark.parametrize("exchange,reorder", [("allgather", False), ("halo", False), ("halo", True)])
 def test_two_ranks_on_one_gpu_match_the_unsharded_model(exchange, reorder):
     _run_and_check(exchange, reorder, "gloo", "torch")
+
+
+def test_two_ranks_narrow_hidden_nf_match_the_unsharded_model():
+    """hidden_nf = 24 under sharding: every rank pads the parameters with fastegnn_pad_params, the padded gradients are
+    sliced back by its reverse mode and all-reduced in the reference's shapes."""
+    _run_and_check("halo", True, "gloo", "torch", hidden=24)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank; this box has one GPU")

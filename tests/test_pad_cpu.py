@@ -1,10 +1,10 @@
-"""CPU: the zero-padding that lets a hidden_nf < 64 model run on the 64-wide kernels (fastegnn_amd/model.py:_pad_param)
+"""CPU: the zero-padding that lets a hidden_nf < 64 model run on the 64-wide kernels (layout: fastegnn_amd/model.py:_pad_layout; the product pads with the HIP kernel behind fastegnn_pad_params)
 preserves the reference function -- the oracle evaluated with the true hidden_nf equals the oracle evaluated at
 hidden_nf = 64 on the padded parameters (models/FastEGNN.py:28-99 block layouts), and gradients slice back."""
 import pytest
 import torch
 
-from fastegnn_amd.model import _pad_param
+from tests.helpers import pad_reference as _pad_param
 from oracle import fastegnn_ref as R
 
 
