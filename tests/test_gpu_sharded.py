@@ -42,7 +42,8 @@ def _inputs():
 
 def _model(hidden=64):
     torch.manual_seed(9)
-    m = fastegnn_amd.FastEGNN(2, 0, 2, hidden, C, device="cuda", n_layers=L, gravity=[0, -1, 0], attention=True)
+    cls = fastegnn_amd.FastRF if os.environ.get("FASTEGNN_TEST_SHARDED_MODEL") == "FastRF" else fastegnn_amd.FastEGNN
+    m = cls(2, 0, 2, abs(hidden), C, device="cuda", n_layers=L, gravity=[0, -1, 0], attention=True)
     with torch.no_grad():
         for k, v in m.named_parameters():
             if k.endswith((".coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
@@ -137,6 +138,13 @@ def test_two_ranks_narrow_hidden_nf_match_the_unsharded_model():
     """hidden_nf = 24 under sharding: every rank pads the parameters with fastegnn_pad_params, the padded gradients are
     sliced back by its reverse mode and all-reduced in the reference's shapes."""
     _run_and_check("halo", True, "gloo", "torch", hidden=24)
+
+
+def test_two_ranks_fastrf_sibling_match_the_unsharded_model(monkeypatch):
+    """The FastRF sibling (FASTEGNN_F_RF: no node model, velocity scale from the detached speed) through the same sharded
+    stages.  The model class travels to the spawned ranks through the environment."""
+    monkeypatch.setenv("FASTEGNN_TEST_SHARDED_MODEL", "FastRF")
+    _run_and_check("halo", True, "gloo", "torch")
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank; this box has one GPU")
