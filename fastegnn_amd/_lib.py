@@ -70,23 +70,32 @@ _LAYER_PTRS_A = ["batch", "gptr", "ea_sorted", "vel", "node_attr", "params", "gr
 
 class LayerT(C.Structure):
     _fields_ = ([("N", _i32), ("B", _i32), ("C", _i32), ("ea", _i32), ("na", _i32), ("flags", _i32),
-                 ("gravity", C.c_float * 3), ("epsilon", C.c_float), ("graph", GraphT)]
+                 ("gravity", C.c_float * 3), ("epsilon", C.c_float), ("act_param", C.c_float),
+                 ("graph", GraphT)]
                 + [(n, _vp) for n in _LAYER_PTRS_A])
 
 
-_lib = None
+_libs = {}
+ACT_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfastegnn_hip_act.so")
+# activation kinds of the FASTEGNN_F_ACT bits (include/fastegnn_hip.h)
+F_ACT_SHIFT = 11
+ACT_SILU, ACT_RELU, ACT_LEAKY_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU, ACT_GELU, ACT_SOFTPLUS = range(8)
 
 
-def lib():
-    """Load the HIP library; raises (never falls back) when it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def lib(act: bool = False):
+    """Load the HIP library; raises (never falls back) when it is missing.  act=True: the generic-activation build
+    (libfastegnn_hip_act.so, -DFE_ACT_GENERIC) -- the layer / stage calls of a model whose act_fn is not SiLU go there;
+    the default library rejects their flags."""
+    path = ACT_LIB_PATH if act else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"fastegnn_amd: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"fastegnn_amd: {path} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C fastegnn_amd/csrc`. There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
+    if bool(L.fastegnn_generic_activations()) != act:
+        raise RuntimeError(f"fastegnn_amd: {path} is not the {'generic-activation' if act else 'SiLU'} build")
     L.fastegnn_last_error.restype = C.c_char_p
     L.fastegnn_version.restype = C.c_int
     L.fastegnn_wpack_floats.restype = C.c_size_t
@@ -164,7 +173,7 @@ def lib():
         f = getattr(L, name)
         f.argtypes = [C.POINTER(LayerT), _vp]
         f.restype = C.c_int
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -178,7 +187,7 @@ STAGE_FUNCS = [
 # every symbol include/fastegnn_hip.h declares (checked by tests/test_abi_cpu.py)
 EXPORTED = STAGE_FUNCS + [
     "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_wg_edge_floats", "fastegnn_wg_virt_floats", "fastegnn_wg_virt_floats_for", "fastegnn_backward_scratch_floats_for", "fastegnn_wg_node_floats", "fastegnn_backward_scratch_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes", "fastegnn_chunk_rows", "fastegnn_chunk_edges",
-    "fastegnn_build_csr", "fastegnn_pad_params", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
+    "fastegnn_build_csr", "fastegnn_pad_params", "fastegnn_generic_activations", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_rm", "fastegnn_selftest_jreduce", "fastegnn_selftest_wgrad", "fastegnn_selftest_wgrad_plan", "fastegnn_selftest_stream", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
     "fastegnn_augment_edge_attr", "fastegnn_loss_mse_mmd", "fastegnn_adam_step",

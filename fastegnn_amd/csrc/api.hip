@@ -58,12 +58,39 @@ static int check_layer(const fastegnn_layer_t *L, const char *who) {
     set_error(std::string(who) + ": params null");
     return FASTEGNN_E_INVALID;
   }
+  {
+    const int act = (L->flags >> FASTEGNN_F_ACT_SHIFT) & FASTEGNN_F_ACT_MASK;
+#ifdef FE_ACT_GENERIC
+    if (act > FASTEGNN_ACT_SOFTPLUS) {
+      set_error(std::string(who) + ": unknown activation kind in the flags");
+      return FASTEGNN_E_INVALID;
+    }
+    if ((L->flags & (FASTEGNN_F_BF16 | FASTEGNN_F_EGNN)) && act != FASTEGNN_ACT_SILU) {
+      set_error(std::string(who) + ": activations other than SiLU are not combined with the bf16 operand mode / the EGNN wiring");
+      return FASTEGNN_E_INVALID;
+    }
+#else
+    if (act != FASTEGNN_ACT_SILU) {   // never a silent SiLU in place of what the caller asked for
+      set_error(std::string(who) + ": this library is compiled for SiLU only; activations selected by the FASTEGNN_F_ACT bits "
+                                   "need libfastegnn_hip_act.so (same sources, -DFE_ACT_GENERIC)");
+      return FASTEGNN_E_INVALID;
+    }
+#endif
+  }
   return FASTEGNN_OK;
 }
 
 }  // namespace fe
 
 using namespace fe;
+
+extern "C" int fastegnn_generic_activations(void) {
+#ifdef FE_ACT_GENERIC
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 #define STAGE(name, fn)                                               \
   int name(const fastegnn_layer_t *L, void *stream) {                 \

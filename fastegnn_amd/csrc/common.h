@@ -104,6 +104,68 @@ __device__ __forceinline__ Vec vsilu_keep_d(Vec &z) {
     }
   return y;
 }
+// ---- activation functions other than SiLU (act_fn of the reference constructor, models/FastEGNN.py:227) ----
+// Only the library built with -DFE_ACT_GENERIC (libfastegnn_hip_act.so) carries them: there every activation site takes
+// an Act (kind from the FASTEGNN_F_ACT bits of the layer flags, parameter from fastegnn_layer_t.act_param) through the
+// FE_ACT(args) macro, which expands to nothing in the default build -- the SiLU kernels are untouched.
+struct Act {
+  int kind;      // FASTEGNN_ACT_*
+  float p;       // negative_slope (LeakyReLU), alpha (ELU), beta (Softplus)
+};
+#ifdef FE_ACT_GENERIC
+#define FE_ACT(a) , fe::Act{((a).flags >> FASTEGNN_F_ACT_SHIFT) & FASTEGNN_F_ACT_MASK, (a).act_param}
+#define FE_ACT_P , Act act
+#define FE_ACT_A , act
+__device__ __forceinline__ float expm1_f(float z) {   // exp(z) - 1 without cancellation near 0
+  const float p = z * (1.0f + z * (0.5f + z * (0.16666667f + z * (0.041666668f + z * (0.008333334f + z * 0.0013888889f)))));
+  return fabsf(z) < 0.3f ? p : __expf(z) - 1.0f;
+}
+// y = f(z), d = f'(z)
+__device__ __forceinline__ void act_both(float z, Act a, float &y, float &d) {
+  switch (a.kind) {
+    case FASTEGNN_ACT_RELU: y = fmaxf(z, 0.f); d = z > 0.f ? 1.f : 0.f; break;
+    case FASTEGNN_ACT_LEAKY_RELU: y = z > 0.f ? z : a.p * z; d = z > 0.f ? 1.f : a.p; break;
+    case FASTEGNN_ACT_TANH: y = tanh_f(z); d = 1.0f - y * y; break;
+    case FASTEGNN_ACT_SIGMOID: y = sigmoid_f(z); d = y * (1.0f - y); break;
+    case FASTEGNN_ACT_ELU: { const float e = a.p * expm1_f(fminf(z, 0.f)); y = z > 0.f ? z : e; d = z > 0.f ? 1.f : e + a.p; break; }
+    case FASTEGNN_ACT_GELU: {
+      const float c = 0.5f * (1.0f + erff(z * 0.70710678f));
+      y = z * c;
+      d = c + z * 0.3989422804f * __expf(-0.5f * z * z);
+      break;
+    }
+    case FASTEGNN_ACT_SOFTPLUS: {   // torch.nn.Softplus(beta, threshold = 20)
+      const float bz = a.p * z;
+      const float s = sigmoid_f(bz);
+      y = bz > 20.f ? z : log1pf(__expf(fminf(bz, 20.f))) / a.p;
+      d = bz > 20.f ? 1.f : s;
+      break;
+    }
+    default: silu_both(z, y, d); break;
+  }
+}
+__device__ __forceinline__ float act_f(float z, Act a) { float y, d; act_both(z, a, y, d); return y; }
+__device__ __forceinline__ float dact_f(float z, Act a) { float y, d; act_both(z, a, y, d); return d; }
+__device__ __forceinline__ Vec vsilu(const Vec &v, Act a) { return vmap(v, [a](float z) { return act_f(z, a); }); }
+__device__ __forceinline__ Vec vsilu_keep_d(Vec &z, Act a) {
+  Vec y;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float yy, dd;
+      act_both(z.t[t][r], a, yy, dd);
+      y.t[t][r] = yy;
+      z.t[t][r] = dd;
+    }
+  return y;
+}
+__device__ __forceinline__ float dsilu_f(float z, Act a) { return dact_f(z, a); }
+#else
+#define FE_ACT(a)
+#define FE_ACT_P
+#define FE_ACT_A
+#endif
 __device__ __forceinline__ Vec vmul(const Vec &a, const Vec &b) {
   return vmap2(a, b, [](float x, float y) { return x * y; });
 }

@@ -25,8 +25,8 @@ __device__ unsigned long long g_vb_stamps[16];
 #define VB_TEND()
 #endif
 
-__device__ __forceinline__ Vec vdsilu_mul(const Vec &g, const Vec &z) {
-  return vmap2(g, z, [](float a, float b) { return a * dsilu_f(b); });
+__device__ __forceinline__ Vec vdsilu_mul(const Vec &g, const Vec &z FE_ACT_P) {
+  return vmap2(g, z, [=](float a, float b) { return a * dsilu_f(b FE_ACT_A); });
 }
 __device__ __forceinline__ Vec vmask(const Vec &v, bool keep) { return keep ? v : vzero(); }
 
@@ -50,6 +50,7 @@ struct GraphPostBwdArgs {
   const float *xsum, *HvT, *poolV, *g_Z_out, *g_HvT_out, *wpack, *b5;
   float *g_Z, *g_HvT, *g_poolV, *g_poolX, *wg_u, *wg_gz5, *wg_pm;
   int B, C, flags;
+  float act_param = 0.f;
 };
 __global__ __launch_bounds__(256) void graph_post_bwd_kernel(GraphPostBwdArgs a) {
   const bool bf = a.flags & FASTEGNN_F_BF16;   // bf16 operand mode: the B operand of every product is rounded
@@ -84,13 +85,13 @@ __global__ __launch_bounds__(256) void graph_post_bwd_kernel(GraphPostBwdArgs a)
     const Vec g_out = vload_row(a.g_HvT_out + (size_t)mc * H, q);
     Vec g_u = vzero();
     gemm64(a.wpack + (size_t)I_W6T * IMG, rb(g_out), g_u);
-    const Vec g_z5 = vdsilu_mul(g_u, z5);
+    const Vec g_z5 = vdsilu_mul(g_u, z5 FE_ACT(a));
     Vec g_hv = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
     gemm64(a.wpack + (size_t)I_W5AT * IMG, rb(g_z5), g_hv);
     Vec g_pm = vzero();
     gemm64(a.wpack + (size_t)I_W5BT * IMG, rb(g_z5), g_pm);
     if (valid) {
-      vstore_row(a.wg_u + (size_t)m * H, q, vsilu(z5));
+      vstore_row(a.wg_u + (size_t)m * H, q, vsilu(z5 FE_ACT(a)));
       vstore_row(a.wg_gz5 + (size_t)m * H, q, g_z5);
       vstore_row(a.wg_pm + (size_t)m * H, q, pm);
       vstore_row(a.g_HvT + (size_t)m * H, q, g_hv);
@@ -107,7 +108,7 @@ int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *s
   float *wg_gp = L->wg_node + 4 * wg_node_rows(L) * H;   // this stage's operand region of wg_node (kernels.h)
   float *wg_u = wg_gp, *wg_gz5 = wg_gp + M * H, *wg_pm = wg_gp + 2 * M * H;
   GraphPostBwdArgs a{L->xsum, L->HvT, L->poolV, L->g_Z_out, L->g_HvT_out, L->wpack, L->params[FASTEGNN_P_NODEV0_B],
-                     L->g_Z, L->g_HvT, L->g_poolV, L->g_poolX, wg_u, wg_gz5, wg_pm, L->B, L->C, L->flags};
+                     L->g_Z, L->g_HvT, L->g_poolV, L->g_poolX, wg_u, wg_gz5, wg_pm, L->B, L->C, L->flags, L->act_param};
   int grid = cdiv(cdiv(M, 16), 4);
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
           Vec g_t3 = vzero();
           stage_image(I_W4T);
           gemm64_m<FM>(w3ct_l, g_out, g_t3);
-          g_np = vdsilu_mul(g_t3, npre);
-          if (valid && own) vstore_u(b_t3, offN, vsilu(npre));
+          g_np = vdsilu_mul(g_t3, npre FE_ACT(a));
+          if (valid && own) vstore_u(b_t3, offN, vsilu(npre FE_ACT(a)));
         }
         if (valid && own) vstore_u(b_gnp, offN, g_np);
         {
@@ -474,11 +475,11 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         Vec vp = vload_vec(vec + VV_C2 * H, q);
         Vec d_pre = make_pre();
         {
-          const Vec t = vsilu_keep_d(d_pre);      // d_pre <- silu'(pre)
+          const Vec t = vsilu_keep_d(d_pre FE_ACT(a));      // d_pre <- silu'(pre)
           WG_STORE(vstore_u(b_t + cb, oc, t);)
           mm(0, sop(t), vp);
         }
-        const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
+        const Vec v0 = vsilu_keep_d(vp FE_ACT(a));          // vp <- silu'(vp)
         float att = 1.f;
         Vec v = v0;
         if (att_on) {
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {  // coord_mlp_r_virtual head: forward, then its adjoint
           Vec uxp = vload_vec(vec + VV_BXV0 * H, q);
           mm(1, vs, uxp);
-          const Vec ux = vsilu_keep_d(uxp);       // uxp <- silu'(uxp)
+          const Vec ux = vsilu_keep_d(uxp FE_ACT(a));       // uxp <- silu'(uxp)
           const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
           sx = tanh_on ? tanh_f(sr) : sr;
           float g_sx = 0.f;
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdAr
         {  // coord_mlp_v_virtual head
           Vec uXp = vload_vec(vec + VV_BXX0 * H, q);
           mm(2, vs, uXp);
-          const Vec uX = vsilu_keep_d(uXp);
+          const Vec uX = vsilu_keep_d(uXp FE_ACT(a));
           const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
           sX = tanh_on ? tanh_f(sr) : sr;
           float g_sX = 0.f;
@@ -1458,6 +1459,8 @@ struct NodePreBwdArgs {
   const float *vel, *wv0;   // FastRF velocity head: coord_mlp_vel(||vel||), wv0 = coord_mlp_vel.0.weight [H,1]
   float *d_wv0, *d_bv0;
   int C;
+  int flags = 0;
+  float act_param = 0.f;
 };
 // MODE: GM_X3 / GM_BF16 as in node_pre_fwd_kernel.  LDS: three split images W1AT W1BT V1AT (transposed products only) and the
 // ROW-MAJOR split images of WVEL0 and WG0 (common.h), each serving its product and its transpose: 127 KB instead of the
@@ -1497,9 +1500,9 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodeP
         Vec z = vload_vec(a.bv0, q);
         gemm_rm<MODE, false>(rmv, hv, z);
         const float gs = valid ? a.g_svel[nc] : 0.f;
-        vaxpy(acc_wv2, gs, vsilu(z));
+        vaxpy(acc_wv2, gs, vsilu(z FE_ACT(a)));
         if (q == 0) acc_bv2 += gs;
-        const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z);
+        const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z FE_ACT(a));
         if (valid) vstore_row(a.wg_gzv + (size_t)n * H, q, g_z);
         gemm_rm<MODE, true>(rmv, op(g_z), g_h);
       }
@@ -1507,9 +1510,9 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodeP
         Vec z = vload_vec(a.bg0, q);
         gemm_rm<MODE, false>(rmg, hv, z);
         const float gs = valid ? a.g_sgrav[nc] : 0.f;
-        vaxpy(acc_wg2, gs, vsilu(z));
+        vaxpy(acc_wg2, gs, vsilu(z FE_ACT(a)));
         if (q == 0) acc_bg2 += gs;
-        const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wg2, q), gs), z);
+        const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wg2, q), gs), z FE_ACT(a));
         if (valid) vstore_row(a.wg_gzg + (size_t)n * H, q, g_z);
         gemm_rm<MODE, true>(rmg, op(g_z), g_h);
       }
@@ -1520,9 +1523,9 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_bwd_kernel(NodeP
       Vec z = vload_vec(a.bv0, q);
       vaxpy(z, vn, vload_vec(a.wv0, q));
       const float gs = valid ? a.g_svel[nc] : 0.f;
-      vaxpy(acc_wv2, gs, vsilu(z));
+      vaxpy(acc_wv2, gs, vsilu(z FE_ACT(a)));
       if (q == 0) acc_bv2 += gs;
-      const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z);
+      const Vec g_z = vdsilu_mul(vscale(vload_vec(a.wv2, q), gs), z FE_ACT(a));
       vadd(acc_bv0, g_z);
       vaxpy(acc_wv0, vn, g_z);
     }
@@ -1596,7 +1599,7 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *sha
                    L->batch, L->g_h, L->g_x, L->g_vel, wg_gzv, wg_gzg,
                    g[FASTEGNN_P_VEL2_W], g[FASTEGNN_P_VEL2_B], g[FASTEGNN_P_GRAV2_W], g[FASTEGNN_P_GRAV2_B], N, grav ? 1 : 0,
                    (p[FASTEGNN_P_VEL0_W] && !rf) ? 1 : 0, L->vel, rf ? p[FASTEGNN_P_VEL0_W] : nullptr,
-                   g[FASTEGNN_P_VEL0_W], g[FASTEGNN_P_VEL0_B], L->C};
+                   g[FASTEGNN_P_VEL0_W], g[FASTEGNN_P_VEL0_B], L->C, L->flags, L->act_param};
   FE_REQUIRE(!rf || (L->vel && p[FASTEGNN_P_VEL0_W] && g[FASTEGNN_P_VEL0_W] && g[FASTEGNN_P_VEL0_B] && g[FASTEGNN_P_VEL2_W] &&
                      g[FASTEGNN_P_VEL2_B]),
              "node_pre_backward: FastRF needs vel and the coord_mlp_vel parameters / gradients");

@@ -15,6 +15,8 @@ struct NodePreArgs {
   int N, gravity, has_vel;
   const float *vel, *wv0;   // FastRF: velocity scale from ||vel|| through coord_mlp_vel.0.weight [H,1]
   int C;
+  int flags = 0;
+  float act_param = 0.f;
 };
 
 // MODE: GM_X3 (bf16x3 products of the split images: fp32-grade, 2.7 x fewer matrix cycles than the fp32-input MFMA these
@@ -63,18 +65,18 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodeP
     if (a.has_vel) {
       acc = vload_vec(vec + 1 * H, q);
       gemm_op<MODE>(img, 3, hv, acc);
-      s = vdot(vsilu(acc), vload_vec(vec + 2 * H, q)) + bv2;
+      s = vdot(vsilu(acc FE_ACT(a)), vload_vec(vec + 2 * H, q)) + bv2;
     } else if (a.wv0) {   // FastRF.py:139: coord_mlp_vel(||vel||), the norm is detached (:169)
       const float vx = a.vel[(size_t)nc * 3], vy = a.vel[(size_t)nc * 3 + 1], vz = a.vel[(size_t)nc * 3 + 2];
       acc = vload_vec(vec + 1 * H, q);
       vaxpy(acc, sqrt_f(vx * vx + vy * vy + vz * vz), vload_vec(vec + 5 * H, q));
-      s = vdot(vsilu(acc), vload_vec(vec + 2 * H, q)) + bv2;
+      s = vdot(vsilu(acc FE_ACT(a)), vload_vec(vec + 2 * H, q)) + bv2;
     }
     if (valid && q == 0) a.svel[n] = s;
     if (a.gravity) {
       acc = vload_vec(vec + 3 * H, q);
       gemm_op<MODE>(img, 4, hv, acc);
-      s = vdot(vsilu(acc), vload_vec(vec + 4 * H, q)) + bg2;
+      s = vdot(vsilu(acc FE_ACT(a)), vload_vec(vec + 4 * H, q)) + bg2;
       if (valid && q == 0) a.sgrav[n] = s;
     }
   }
@@ -90,7 +92,7 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
                 p[FASTEGNN_P_VEL2_B], p[FASTEGNN_P_GRAV0_B], p[FASTEGNN_P_GRAV2_W], p[FASTEGNN_P_GRAV2_B],
                 L->P, L->QX, L->A, L->svel, L->sgrav, L->N, grav ? 1 : 0,
                 (p[FASTEGNN_P_VEL0_W] && !has(L, FASTEGNN_F_RF)) ? 1 : 0,
-                L->vel, has(L, FASTEGNN_F_RF) ? p[FASTEGNN_P_VEL0_W] : nullptr, L->C};
+                L->vel, has(L, FASTEGNN_F_RF) ? p[FASTEGNN_P_VEL0_W] : nullptr, L->C, L->flags, L->act_param};
   FE_REQUIRE(!has(L, FASTEGNN_F_RF) || (L->vel && p[FASTEGNN_P_VEL0_W] && p[FASTEGNN_P_VEL0_B] && p[FASTEGNN_P_VEL2_W] &&
                                          p[FASTEGNN_P_VEL2_B]),
              "node_pre_forward: FastRF needs vel and the coord_mlp_vel parameters");
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       stage_image(I_W4);
       if (mine) {
         Vec out = vload_vec(vec + VV_B4 * H, q);
-        gemm64_m<MODE>(fstage, vsilu(nodeacc), out);
+        gemm64_m<MODE>(fstage, vsilu(nodeacc FE_ACT(a)), out);
         if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
         if (valid) vstore_row(a.h_out + (size_t)n * H, q, out);
       }
@@ -635,6 +637,7 @@ struct GraphPostArgs {
   const float *xsum, *Z, *HvT, *poolV, *poolX, *wpack, *b5, *b6;
   float *Z_out, *HvT_out;
   int B, C, flags;
+  float act_param = 0.f;
 };
 __global__ __launch_bounds__(256) void graph_post_fwd_kernel(GraphPostArgs a) {
   const bool bf = a.flags & FASTEGNN_F_BF16;   // bf16 operand mode: activations rounded, images hold rounded weights
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(256) void graph_post_fwd_kernel(GraphPostArgs a) {
     gemm64(a.wpack + (size_t)I_W5A * IMG, bf ? vround(hv) : hv, z5);
     gemm64(a.wpack + (size_t)I_W5B * IMG, bf ? vround(pm) : pm, z5);
     Vec out = vload_vec(a.b6, q);
-    const Vec u5 = vsilu(z5);
+    const Vec u5 = vsilu(z5 FE_ACT(a));
     gemm64(a.wpack + (size_t)I_W6 * IMG, bf ? vround(u5) : u5, out);
     if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
     if (valid) vstore_row(a.HvT_out + (size_t)m * H, q, out);
@@ -673,7 +676,7 @@ int graph_post_forward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(L->xsum && L->Z && L->HvT && L->poolV && L->poolX && L->Z_out && L->HvT_out && L->wpack,
              "graph_post_forward: null buffer");
   GraphPostArgs a{L->xsum, L->Z, L->HvT, L->poolV, L->poolX, L->wpack, L->params[FASTEGNN_P_NODEV0_B],
-                  L->params[FASTEGNN_P_NODEV2_B], L->Z_out, L->HvT_out, L->B, L->C, L->flags};
+                  L->params[FASTEGNN_P_NODEV2_B], L->Z_out, L->HvT_out, L->B, L->C, L->flags, L->act_param};
   int grid = cdiv(cdiv((long)L->B * L->C, 16), 4);
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;

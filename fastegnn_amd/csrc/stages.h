@@ -31,6 +31,7 @@ struct EdgeArgs {
   float *aggm, *aggx;
   int n_chunks, ea_dim, flags;
   float eps;
+  float act_param = 0.f;   // parameter of the activation kind in the flags (generic-activation build only)
 };
 
 constexpr int EV_WR = 0, EV_WE = 1, EV_B2 = 9, EV_BX1 = 10, EV_WX2 = 11, EV_ATT = 12, EV_COUNT = 13;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *ve
 template <bool KEEP_D, int MODE = GM_F32, bool RM = false>
 __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img, const float *vec, int q, EdgeFwdState &S,
                                               Vec &pre FE_TP) {
-  S.t = KEEP_D ? vsilu_keep_d(pre) : vsilu(pre);
+  S.t = KEEP_D ? vsilu_keep_d(pre FE_ACT(a)) : vsilu(pre FE_ACT(a));
   FE_T(2)   // silu 1
   S.mp = vload_vec(vec + EV_B2 * H, q);
 #ifdef FE_EDGE_T2   // diagnostic lever: two-part split of the first chained layer's operand (forward kernel, fp32 mode)
@@ -153,7 +154,7 @@ __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img
 #endif
   gemm_e<MODE, 0, RM>(img, S.t, S.mp);
   FE_T(3)   // gemm 1
-  S.m0 = KEEP_D ? vsilu_keep_d(S.mp) : vsilu(S.mp);
+  S.m0 = KEEP_D ? vsilu_keep_d(S.mp FE_ACT(a)) : vsilu(S.mp FE_ACT(a));
   if (a.flags & FASTEGNN_F_ATTENTION) {
     S.att = sigmoid_f(vdot(S.m0, vload_vec(vec + EV_ATT * H, q)) + a.attb[0]);
     S.m = vscale(S.m0, S.att);
@@ -165,7 +166,7 @@ __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img
   S.up = vload_vec(vec + EV_BX1 * H, q);
   gemm_e<MODE, 1, RM>(img, S.m, S.up);
   FE_T(3)
-  S.u = KEEP_D ? vsilu_keep_d(S.up) : vsilu(S.up);
+  S.u = KEEP_D ? vsilu_keep_d(S.up FE_ACT(a)) : vsilu(S.up FE_ACT(a));
   const float sraw = vdot(S.u, vload_vec(vec + EV_WX2 * H, q)) + (a.bx2 ? a.bx2[0] : 0.f);
   S.s = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sraw) : sraw;
   FE_T(4)   // silu 3 + head dot
@@ -186,6 +187,7 @@ inline EdgeArgs make_edge_args(const fastegnn_layer_t *L) {
              p[FASTEGNN_P_EDGE0_W], p[FASTEGNN_P_EDGE2_B], p[FASTEGNN_P_CR0_B], p[FASTEGNN_P_CR2_W],
              p[FASTEGNN_P_ATT_W], p[FASTEGNN_P_ATT_B], p[FASTEGNN_P_CR2_B], g.rowptr, g.erow, g.col, g.chunk_row, L->aggm, L->aggx,
              g.n_chunks, L->ea, L->flags, L->epsilon};
+  a.act_param = L->act_param;
   return a;
 }
 
@@ -196,6 +198,7 @@ struct VirtArgs {
   float *h_out, *x_out, *npre, *poolV, *poolX;
   int N, B, C, na, flags;
   float g[3];
+  float act_param = 0.f;
 };
 constexpr int VV_WVR = 0, VV_C2 = 1, VV_BXV0 = 2, VV_WXV2 = 3, VV_BXX0 = 4, VV_WXX2 = 5, VV_ATT = 6, VV_B3 = 7,
               VV_B4 = 8, VV_COUNT = 9;
@@ -246,12 +249,12 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void 
   if (BcL) vadd(S.pre, vload_vec(BcL + c * H, q));
   else vadd(S.pre, vload_row(a.Bc + ((size_t)b * C + c) * H, q));
   vaxpy(S.pre, S.vr, vload_vec(vec + VV_WVR * H, q));
-  S.t = vsilu(S.pre);
+  S.t = vsilu(S.pre FE_ACT(a));
   VF_T(1)   // geometry, pre-activation, silu 1
   S.vp = vload_vec(vec + VV_C2 * H, q);
   gemm_i<MODE>(img, 0, S.t, S.vp);
   VF_T(2)   // split + product 1
-  S.v0 = vsilu(S.vp);
+  S.v0 = vsilu(S.vp FE_ACT(a));
   if (a.flags & FASTEGNN_F_ATTENTION) {
     S.att = sigmoid_f(vdot(S.v0, vload_vec(vec + VV_ATT * H, q)) + a.attb[0]);
     S.v = vscale(S.v0, S.att);
@@ -264,13 +267,13 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void 
   VF_T(3)   // silu 2 + split
   gemm_op<MODE>(img, 1, S.vs, S.uxp);
   VF_T(4)   // product 2
-  float sr = vdot(vsilu(S.uxp), vload_vec(vec + VV_WXV2 * H, q));
+  float sr = vdot(vsilu(S.uxp FE_ACT(a)), vload_vec(vec + VV_WXV2 * H, q));
   S.sx = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;
   VF_T(5)   // silu + head dot
   S.uXp = vload_vec(vec + VV_BXX0 * H, q);
   gemm_op<MODE>(img, 2, S.vs, S.uXp);
   VF_T(4)
-  sr = vdot(vsilu(S.uXp), vload_vec(vec + VV_WXX2 * H, q));
+  sr = vdot(vsilu(S.uXp FE_ACT(a)), vload_vec(vec + VV_WXX2 * H, q));
   S.sX = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;
   VF_T(5)
   // (measured in round 3: the two head products and the node-MLP block product issued back to back, activations and
@@ -286,6 +289,7 @@ inline VirtArgs make_virt_args(const fastegnn_layer_t *L) {
              p[FASTEGNN_P_NODE0_W], p[FASTEGNN_P_NODE0_B], p[FASTEGNN_P_NODE2_B], L->batch,
              L->h_out, L->x_out, L->npre, L->poolV, L->poolX, L->N, L->B, L->C, L->na, L->flags,
              {L->gravity[0], L->gravity[1], L->gravity[2]}};
+  a.act_param = L->act_param;
   return a;
 }
 inline size_t virt_lds_bytes(int C, int n_img, int waves = VIRT_WAVES) {

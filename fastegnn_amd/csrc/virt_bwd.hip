@@ -41,8 +41,8 @@ __device__ unsigned long long g_vb2_stamps[32];
 #define VB2_TEND(base)
 #endif
 
-__device__ __forceinline__ Vec vb_dsilu_mul(const Vec &g, const Vec &z) {
-  return vmap2(g, z, [](float a, float b) { return a * dsilu_f(b); });
+__device__ __forceinline__ Vec vb_dsilu_mul(const Vec &g, const Vec &z FE_ACT_P) {
+  return vmap2(g, z, [=](float a, float b) { return a * dsilu_f(b FE_ACT_A); });
 }
 __device__ __forceinline__ Vec vb_mask(const Vec &v, bool keep) { return keep ? v : vzero(); }
 
@@ -54,6 +54,7 @@ struct VirtNodeArgs {
   float *wg_t3, *wg_gnp, *g_h, *g_aggm, *g_aggx, *g_svel, *g_sgrav;
   int N, flags, C;
   float g[3];
+  float act_param = 0.f;
 };
 constexpr int VB_NODE_WAVES = 8;
 template <bool BF>
@@ -75,9 +76,9 @@ __global__ __launch_bounds__(64 * VB_NODE_WAVES) void virt_bwd_node_kernel(VirtN
     const Vec npre = vload_row(a.npre + (size_t)nc * H, q);
     Vec g_t3 = vzero();
     gemm_op<SM>(img, 2, make_operand<SM>(g_out), g_t3);
-    const Vec g_np = vb_dsilu_mul(g_t3, npre);
+    const Vec g_np = vb_dsilu_mul(g_t3, npre FE_ACT(a));
     if (valid) {
-      vstore_row(a.wg_t3 + (size_t)n * H, q, vsilu(npre));
+      vstore_row(a.wg_t3 + (size_t)n * H, q, vsilu(npre FE_ACT(a)));
       vstore_row(a.wg_gnp + (size_t)n * H, q, g_np);
     }
     const typename OperandOf<SM>::type gop = make_operand<SM>(g_np);   // shared by the two products
@@ -478,10 +479,10 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
         vadd(d_pre, vload_u(a.Bc, offB + (unsigned)c * H));
         vaxpy(d_pre, vr, vload_vec(vec + VV_WVR * H, q));
         VB2_T(1)   // rows arrived, pre formed
-        const Vec t = vsilu_keep_d(d_pre);        // d_pre <- silu'(pre)
+        const Vec t = vsilu_keep_d(d_pre FE_ACT(a));        // d_pre <- silu'(pre)
         mm(0, make_operand<SM>(t), vp);
         VB2_T(2)   // silu, split, V2 product
-        const Vec v0 = vsilu_keep_d(vp);          // vp <- silu'(vp)
+        const Vec v0 = vsilu_keep_d(vp FE_ACT(a));          // vp <- silu'(vp)
         float att = 1.f;
         Vec v = v0;
         if constexpr (ATT) {
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
             mm(2, vs, uXp);
           }
           {  // coord_mlp_r_virtual head: activation, scalar head, adjoint of the activation
-            Vec ux = vsilu_keep_d(uxp);             // uxp <- silu'(uxp)
+            Vec ux = vsilu_keep_d(uxp FE_ACT(a));             // uxp <- silu'(uxp)
             const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
             sx = tanh_on ? tanh_f(sr) : sr;
             float g_sx = 0.f;
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
           }
           VB2_T(4)   // both head products + head x activation / rank-1 sum
           {  // coord_mlp_v_virtual head
-            Vec uX = vsilu_keep_d(uXp);
+            Vec uX = vsilu_keep_d(uXp FE_ACT(a));
             const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
             sX = tanh_on ? tanh_f(sr) : sr;
             float g_sX = 0.f;
@@ -719,7 +720,7 @@ int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shar
   int rc;
   {   // B4a
     VirtNodeArgs a{L->g_h_out, L->npre, L->g_x_out, L->vel, L->aggx, L->wpack, wg_t3, wg_gnp, L->g_h, L->g_aggm, L->g_aggx,
-                   L->g_svel, L->g_sgrav, N, L->flags, C, {L->gravity[0], L->gravity[1], L->gravity[2]}};
+                   L->g_svel, L->g_sgrav, N, L->flags, C, {L->gravity[0], L->gravity[1], L->gravity[2]}, L->act_param};
     int grid = cdiv(ntiles, VB_NODE_WAVES);
     if (grid > 256) grid = 256;
     ProfScope ps(K_VIRT_BWD_NODE, st);

@@ -198,6 +198,8 @@ class _Spec:
         flags |= K.F_GRAVITY if model.gravity is not None else 0
         flags |= K.F_BF16 if getattr(model, "mlp_dtype", torch.float32) == torch.bfloat16 else 0
         flags |= K.F_DETERMINISTIC if getattr(model, "deterministic", False) else 0
+        self.act_kind, self.act_param = getattr(model, "_act", (K.ACT_SILU, 0.0))
+        flags |= self.act_kind << K.F_ACT_SHIFT
         self.flags = flags | model._extra_flags
         self.gravity = [float(v) for v in model.gravity] if model.gravity is not None else [0.0, 0.0, 0.0]
         # parameter order handed to the autograd function
@@ -221,6 +223,7 @@ def _new_layer(spec: _Spec, N: int, B: int, graph: SortedGraph) -> K.LayerT:
     L.N, L.B, L.C, L.ea, L.na, L.flags = N, B, spec.C, spec.ea, spec.na, spec.flags
     L.gravity = (C.c_float * 3)(*spec.gravity)
     L.epsilon = 1e-8
+    L.act_param = getattr(spec, "act_param", 0.0)
     L.graph = graph.struct()
     return L
 
@@ -262,6 +265,28 @@ def _pad_layout(name: str, shape, h: int, C_: int, rf: bool):
     rows_dst = H if mod in _HIDDEN_OUT else rows
     cols_dst = cols + sum(b // h * (H - h) for b in blocks)
     return rows, cols, rows_dst, blocks, (rows_dst, cols_dst)
+
+
+def _activation_kind(act_fn: nn.Module):
+    """(FASTEGNN_ACT_* kind, parameter) of the reference constructor's ``act_fn`` (models/FastEGNN.py:227)."""
+    if isinstance(act_fn, nn.SiLU):
+        return K.ACT_SILU, 0.0
+    if isinstance(act_fn, nn.ReLU):
+        return K.ACT_RELU, 0.0
+    if isinstance(act_fn, nn.LeakyReLU):
+        return K.ACT_LEAKY_RELU, float(act_fn.negative_slope)
+    if isinstance(act_fn, nn.Tanh):
+        return K.ACT_TANH, 0.0
+    if isinstance(act_fn, nn.Sigmoid):
+        return K.ACT_SIGMOID, 0.0
+    if isinstance(act_fn, nn.ELU):
+        return K.ACT_ELU, float(act_fn.alpha)
+    if isinstance(act_fn, nn.GELU) and getattr(act_fn, "approximate", "none") == "none":
+        return K.ACT_GELU, 0.0
+    if isinstance(act_fn, nn.Softplus) and float(act_fn.threshold) == 20.0:
+        return K.ACT_SOFTPLUS, float(act_fn.beta)
+    raise NotImplementedError("fastegnn_amd: act_fn must be one of SiLU, ReLU, LeakyReLU, Tanh, Sigmoid, ELU, GELU "
+                              f"(exact) or Softplus(threshold=20); got {act_fn!r}")
 
 
 class _PadParams(torch.autograd.Function):
@@ -324,7 +349,7 @@ class _FastEGNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec: _Spec, graph: SortedGraph, batch32, gptr, edge_attr, node_attr,
                 node_feat, node_loc, node_vel, loc_mean, *params):
-        lib = K.lib()
+        lib = K.lib(act=spec.act_kind != K.ACT_SILU)
         # edge_attr / node_attr are differentiable inputs (the reference harness detaches them, utils/train.py:33,46-47,
         # but the module itself is differentiable in them): their gradients are accumulated by the edge / virtual backward
         # kernels when asked for
@@ -378,7 +403,7 @@ class _FastEGNNFunction(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_loc, g_vloc):
-        lib = K.lib()
+        lib = K.lib(act=ctx.spec.act_kind != K.ACT_SILU)
         spec, graph, saved = ctx.spec, ctx.graph, ctx.saved
         if saved is None or any(b is None for b in saved):
             raise RuntimeError("fastegnn_amd: backward through the graph a second time: the saved stage products are "
@@ -475,8 +500,11 @@ class FastEGNN(nn.Module):
         assert virtual_channels > 0, f'Channels of virtual node must greater than 0 (got {virtual_channels})'
         if not 1 <= hidden_nf <= H:   # (< 64 runs zero-padded on the 64-wide tiles, see _pad_param)
             raise NotImplementedError(f"fastegnn_amd: hidden_nf must be at most {H} in this build (got {hidden_nf})")
-        if not isinstance(act_fn, nn.SiLU):
-            raise NotImplementedError("fastegnn_amd: the HIP kernels implement SiLU (the reference default) only")
+        self._act = _activation_kind(act_fn)
+        if self._act[0] in (K.ACT_SIGMOID, K.ACT_SOFTPLUS) and hidden_nf < H:
+            raise NotImplementedError("fastegnn_amd: hidden_nf < 64 runs zero-padded, which needs act_fn(0) = 0")
+        if self._act[0] != K.ACT_SILU and mlp_dtype != torch.float32:
+            raise NotImplementedError("fastegnn_amd: the bf16 operand mode is built for SiLU only")
         if virtual_channels > 64 or edge_attr_nf > 7 or node_feat_nf > 8:
             raise NotImplementedError("fastegnn_amd: supports virtual_channels<=64, edge_attr_nf<=7, node_feat_nf<=8")
         self.hidden_nf = hidden_nf

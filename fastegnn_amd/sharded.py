@@ -43,9 +43,9 @@ H = K.H
 class HipBackend:
     """Stage calls on libfastegnn_hip.so (the product path)."""
 
-    def __init__(self, device):
+    def __init__(self, device, act: bool = False):
         self.dev = device
-        self.lib = K.lib()
+        self.lib = K.lib(act)   # act: the generic-activation build (a model whose act_fn is not SiLU)
 
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.dev)
@@ -632,11 +632,11 @@ class ShardedFastEGNN(torch.nn.Module):
     def forward_local(self, local: Dict[str, torch.Tensor]):
         m = self.model
         plan: ShardPlan = local["plan"]
-        be = self.backend or HipBackend(local["node_loc"].device)
         if m._spec is None:
             m._spec = _Spec(m)
             pidx = m._param_index
             m._plist = [pidx[n] for n in m._spec.names]
+        be = self.backend or HipBackend(local["node_loc"].device, act=m._spec.act_kind != K.ACT_SILU)
         spec = m._spec
         graph = be.build_graph(local["edge_index"], plan.nloc, plan.n_src, plan.n0, csc=bool(m._spec.flags & K.F_DETERMINISTIC))
         B = local["loc_mean"].size(0)

@@ -77,6 +77,21 @@ enum {
    * order by fastegnn_edge_col_reduce: bit-reproducible, 0.26 ms per step slower at cfg4 and 272 bytes of scratch per edge. */
   FASTEGNN_F_DETERMINISTIC = 1024
 };
+/* Activation of every MLP (the reference's act_fn, models/FastEGNN.py:227): bits 11..14 of the flags hold one of the
+ * FASTEGNN_ACT_* kinds, fastegnn_layer_t.act_param its parameter.  libfastegnn_hip.so is compiled for SiLU and rejects
+ * any other kind (FASTEGNN_E_ARG); libfastegnn_hip_act.so (same sources, -DFE_ACT_GENERIC) evaluates all of them. */
+#define FASTEGNN_F_ACT_SHIFT 11
+#define FASTEGNN_F_ACT_MASK 15
+enum {
+  FASTEGNN_ACT_SILU = 0,
+  FASTEGNN_ACT_RELU = 1,
+  FASTEGNN_ACT_LEAKY_RELU = 2,   /* act_param = negative_slope */
+  FASTEGNN_ACT_TANH = 3,
+  FASTEGNN_ACT_SIGMOID = 4,
+  FASTEGNN_ACT_ELU = 5,          /* act_param = alpha */
+  FASTEGNN_ACT_GELU = 6,         /* exact (erf) form */
+  FASTEGNN_ACT_SOFTPLUS = 7      /* act_param = beta; threshold 20 as torch.nn.Softplus */
+};
 
 /* Per-layer parameter slots: the reference state_dict tensors of gcl_<i>, untouched
  * ([out,in] row-major as torch stores them).  models/FastEGNN.py:28-99. */
@@ -145,6 +160,7 @@ typedef struct {
   int32_t N, B, C, ea, na, flags;
   float gravity[3];
   float epsilon;           /* models/FastEGNN.py:21 */
+  float act_param;         /* parameter of the activation kind in the flags (FASTEGNN_ACT_*); 0 for SiLU */
   fastegnn_graph_t graph;
   const int32_t *batch;    /* [N] graph id per node, ascending */
   const int32_t *gptr;     /* [B+1] node range of each graph */
@@ -265,6 +281,8 @@ typedef struct {
   int32_t blk[3];
 } fastegnn_pad_desc_t;
 int fastegnn_pad_params(const fastegnn_pad_desc_t *desc, int32_t n, int32_t h, int32_t reverse, void *stream);
+/* 1 when the library evaluates every FASTEGNN_ACT_* kind (libfastegnn_hip_act.so), 0 for the SiLU-only build */
+int fastegnn_generic_activations(void);
 /* batch int64 [N] (ascending) -> batch int32 [N], gptr int32 [B+1] */
 int fastegnn_build_batch(const int64_t *batch64, int32_t N, int32_t B, int32_t *batch, int32_t *gptr,
                          void *stream);

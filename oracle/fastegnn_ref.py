@@ -44,6 +44,8 @@ class Config:
     bf16: bool = False                # bf16 operand mode of the product (BASELINE configs[2]); honoured by
                                       # oracle/factored.py only -- the reference itself has no reduced-precision mode
     epsilon: float = 1e-8             # FastEGNN.py:21
+    act: str = "silu"                 # the constructor's act_fn (FastEGNN.py:227): silu | relu | leaky_relu | tanh | sigmoid | elu |
+    act_param: float = 0.0            # gelu | softplus; negative_slope / alpha / beta where the module has one
 
 
 # --------------------------------------------------------------------------
@@ -143,14 +145,22 @@ def _lin(p, name, x):
     return F.linear(x, p[name + ".weight"], p.get(name + ".bias"))
 
 
-def _mlp2(p, name, x, act_last):
-    """Linear -> SiLU -> Linear [-> SiLU]."""
-    y = _lin(p, name + ".2", F.silu(_lin(p, name + ".0", x)))
-    return F.silu(y) if act_last else y
+def act_of(cfg):
+    """The activation module of the reference constructor as a function (default nn.SiLU(), FastEGNN.py:227)."""
+    a, q = getattr(cfg, "act", "silu"), getattr(cfg, "act_param", 0.0)
+    return {"silu": F.silu, "relu": F.relu, "leaky_relu": lambda z: F.leaky_relu(z, q), "tanh": torch.tanh,
+            "sigmoid": torch.sigmoid, "elu": lambda z: F.elu(z, q), "gelu": F.gelu,
+            "softplus": lambda z: F.softplus(z, beta=q, threshold=20.0)}[a]
 
 
-def _coord_head(p, name, x, tanh):
-    y = _mlp2(p, name, x, act_last=False)
+def _mlp2(p, name, x, act_last, act=F.silu):
+    """Linear -> act -> Linear [-> act]."""
+    y = _lin(p, name + ".2", act(_lin(p, name + ".0", x)))
+    return act(y) if act_last else y
+
+
+def _coord_head(p, name, x, tanh, act=F.silu):
+    y = _mlp2(p, name, x, act_last=False, act=act)
     return torch.tanh(y) if tanh else y
 
 
@@ -160,6 +170,7 @@ def _coord_head(p, name, x, tanh):
 def layer_forward(p: Params, L: str, cfg: Config, h, edge_index, x, vel, Z, Hv, batch,
                   edge_attr=None, node_attr=None, gravity=None):
     row, col = edge_index[0], edge_index[1]
+    act = act_of(cfg)
     N, C, H = h.size(0), cfg.virtual_channels, cfg.hidden_nf
 
     # coord2radial, :180-189
@@ -173,7 +184,7 @@ def layer_forward(p: Params, L: str, cfg: Config, h, edge_index, x, vel, Z, Hv, 
     vr = torch.norm(vd, p=2, dim=1, keepdim=True)         # [N,1,C]
 
     # edge_model, :102-108
-    m = _mlp2(p, f"{L}.edge_mlp", torch.cat([h[row], h[col], radial, edge_attr], dim=1), act_last=True)
+    m = _mlp2(p, f"{L}.edge_mlp", torch.cat([h[row], h[col], radial, edge_attr], dim=1), act_last=True, act=act)
     if cfg.attention:
         m = m * torch.sigmoid(_lin(p, f"{L}.att_mlp.0", m))
 
@@ -184,13 +195,13 @@ def layer_forward(p: Params, L: str, cfg: Config, h, edge_index, x, vel, Z, Hv, 
 
     # edge_mode_virtual, :111-119
     inp = torch.cat([h.unsqueeze(-1).repeat(1, 1, C), Hv[batch], vr, mX[batch]], dim=1)  # [N,2H+1+C,C]
-    v = _mlp2(p, f"{L}.edge_mlp_virtual", inp.permute(0, 2, 1), act_last=True)           # [N,C,H]
+    v = _mlp2(p, f"{L}.edge_mlp_virtual", inp.permute(0, 2, 1), act_last=True, act=act)           # [N,C,H]
     if cfg.attention:
         v = v * torch.sigmoid(_lin(p, f"{L}.att_mlp_virtual.0", v))
     v_hc = v.permute(0, 2, 1)                                                             # [N,H,C]
 
     # coord_model_vel, :122-144
-    trans = d * _coord_head(p, f"{L}.coord_mlp_r", m, cfg.tanh)
+    trans = d * _coord_head(p, f"{L}.coord_mlp_r", m, cfg.tanh, act)
     if cfg.coords_agg == "sum":
         agg = segment_sum(trans, row, N)
     elif cfg.coords_agg == "mean":
@@ -198,14 +209,14 @@ def layer_forward(p: Params, L: str, cfg: Config, h, edge_index, x, vel, Z, Hv, 
     else:
         raise Exception("Wrong coords_agg parameter")
     x_new = x + agg
-    phi_xv = _coord_head(p, f"{L}.coord_mlp_r_virtual", v, cfg.tanh).permute(0, 2, 1)     # [N,1,C]
+    phi_xv = _coord_head(p, f"{L}.coord_mlp_r_virtual", v, cfg.tanh, act).permute(0, 2, 1)     # [N,1,C]
     x_new = x_new + torch.mean(-vd * phi_xv, dim=-1)
-    x_new = x_new + _mlp2(p, f"{L}.coord_mlp_vel", h, act_last=False) * vel
+    x_new = x_new + _mlp2(p, f"{L}.coord_mlp_vel", h, act_last=False, act=act) * vel
     if gravity is not None:
-        x_new = x_new + _mlp2(p, f"{L}.gravity_mlp", h, act_last=False) * gravity
+        x_new = x_new + _mlp2(p, f"{L}.gravity_mlp", h, act_last=False, act=act) * gravity
 
     # coord_model_virtual, :146-150
-    phi_X = _coord_head(p, f"{L}.coord_mlp_v_virtual", v, cfg.tanh).permute(0, 2, 1)      # [N,1,C]
+    phi_X = _coord_head(p, f"{L}.coord_mlp_v_virtual", v, cfg.tanh, act).permute(0, 2, 1)      # [N,1,C]
     Z_new = Z + graph_mean_pool((vd * phi_X).reshape(N, -1), batch).reshape(-1, 3, C)
 
     # node_model, :153-166
@@ -213,13 +224,13 @@ def layer_forward(p: Params, L: str, cfg: Config, h, edge_index, x, vel, Z, Hv, 
     parts = [h, agg_m, v_hc.reshape(N, -1)]
     if node_attr is not None:
         parts.append(node_attr)
-    out = _mlp2(p, f"{L}.node_mlp", torch.cat(parts, dim=1), act_last=False)
+    out = _mlp2(p, f"{L}.node_mlp", torch.cat(parts, dim=1), act_last=False, act=act)
     h_new = h + out if cfg.residual else out
 
     # node_model_virtual, :168-177
     pool = graph_mean_pool(v_hc.reshape(N, -1), batch).reshape(-1, H, C)
     outv = _mlp2(p, f"{L}.node_mlp_virtual", torch.cat([Hv, pool], dim=1).permute(0, 2, 1),
-                 act_last=False).permute(0, 2, 1)
+                 act_last=False, act=act).permute(0, 2, 1)
     Hv_new = Hv + outv if cfg.residual else outv
     return h_new, x_new, Hv_new, Z_new
 

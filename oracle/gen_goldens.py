@@ -85,14 +85,20 @@ def _loc_mean(loc, batch, C):
 def run_case(FastEGNN, name, *, sizes, edges, nf, na, ea, C, H=64, L=4, seed=0,
              attention=False, normalize=False, tanh=False, gravity=None, residual=True,
              coord_scale=1.0, loc_scale=3.0, isolate=None, dtype=torch.float32,
-             explicit=None):
+             explicit=None, act=None, act_param=0.0):
     torch.manual_seed(seed)
     random.seed(seed)
     np.random.seed(seed)
     gen = torch.Generator().manual_seed(seed + 1000)
+    act_kw = {}
+    if act is not None:   # the reference constructor's act_fn (models/FastEGNN.py:227); default nn.SiLU()
+        act_kw["act_fn"] = {"relu": lambda: torch.nn.ReLU(), "leaky_relu": lambda: torch.nn.LeakyReLU(act_param),
+                            "tanh": lambda: torch.nn.Tanh(), "sigmoid": lambda: torch.nn.Sigmoid(),
+                            "elu": lambda: torch.nn.ELU(act_param), "gelu": lambda: torch.nn.GELU(),
+                            "softplus": lambda: torch.nn.Softplus(beta=act_param)}[act]()
     model = FastEGNN(node_feat_nf=nf, node_attr_nf=na, edge_attr_nf=ea, hidden_nf=H,
                      virtual_channels=C, device="cpu", n_layers=L, residual=residual,
-                     attention=attention, normalize=normalize, tanh=tanh, gravity=gravity)
+                     attention=attention, normalize=normalize, tanh=tanh, gravity=gravity, **act_kw)
     with torch.no_grad():
         for k, v in model.named_parameters():
             if k.endswith("coord_mlp_r.2.weight") or k.endswith("coord_mlp_r_virtual.2.weight") \
@@ -173,6 +179,9 @@ def run_case(FastEGNN, name, *, sizes, edges, nf, na, ea, C, H=64, L=4, seed=0,
     for k, v in meta.items():
         rec[f"meta/{k}"] = np.array(v)
     rec["meta/gravity"] = np.array(gravity if gravity is not None else [0, 0, 0], dtype=np.float64)
+    if act is not None:
+        rec["meta/act"] = np.array(act)
+        rec["meta/act_param"] = np.array(float(act_param))
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, f"{name}.npz")
     np.savez_compressed(path, **rec)
@@ -492,6 +501,19 @@ def main():
                   node_vel=torch.randn(sum(sizes), 3, generator=gen) * 0.3, edge_index=ei, data_batch=batch,
                   loc_mean=_loc_mean(loc, batch, 3), edge_attr=torch.rand(ei.size(1), 2, generator=gen))
         train_case(FastEGNN, "train_ragged_simulation", rg, sigma=1.0, ragged_sizes=sizes)
+        return
+    if "--act" in sys.argv:   # act_fn other than the default SiLU: only these files are (re)written
+        common = dict(sizes=[7, 4, 9], edges=[25, 10, 25], nf=2, na=0, ea=2, C=4, isolate=(2, 3), L=2, coord_scale=300.0,
+                      gravity=[0, -1, 0])
+        run_case(FastEGNN, "act_relu", seed=21, act="relu", **common)
+        run_case(FastEGNN, "act_leaky_relu", seed=22, act="leaky_relu", act_param=0.2, attention=True, **common)
+        run_case(FastEGNN, "act_tanh", seed=23, act="tanh", **common)
+        # (sigmoid / softplus are positive at 0: the coordinate heads see 64 inputs of one sign -- a smaller head scale keeps
+        # the layer-0 virtual-head gradients out of the fp32 rounding noise of two differently ordered evaluations)
+        run_case(FastEGNN, "act_sigmoid", seed=24, act="sigmoid", **{**common, "coord_scale": 30.0})
+        run_case(FastEGNN, "act_elu", seed=25, act="elu", act_param=1.0, tanh=True, **common)
+        run_case(FastEGNN, "act_gelu", seed=26, act="gelu", **common)
+        run_case(FastEGNN, "act_softplus", seed=27, act="softplus", act_param=1.5, **{**common, "coord_scale": 30.0})
         return
     # equivariant_test.py shape: 10 nodes, 20 random directed edges, nf=1, ea=1, C=3
     run_case(FastEGNN, "equiv10", sizes=[10], edges=[20], nf=1, na=0, ea=1, C=3, seed=1,

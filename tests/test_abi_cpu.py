@@ -29,6 +29,14 @@ def test_library_exports_every_declared_symbol():
     assert set(K.EXPORTED) == set(names)
 
 
+def test_generic_activation_library_exports_the_same_interface():
+    """libfastegnn_hip_act.so (-DFE_ACT_GENERIC): same symbols, says what it is; the default library is the SiLU build."""
+    A, L = K.lib(act=True), K.lib()
+    assert A.fastegnn_generic_activations() == 1 and L.fastegnn_generic_activations() == 0
+    assert not [n for n in _declared_symbols() if not hasattr(A, n)]
+    assert A.fastegnn_sizeof_layer() == L.fastegnn_sizeof_layer()
+
+
 def test_struct_mirrors_and_sizes():
     L = K.lib()
     import ctypes as C
@@ -80,7 +88,10 @@ def test_error_behaviour():
     with pytest.raises(NotImplementedError):
         fastegnn_amd.FastEGNN(2, 0, 2, 128, 3)                # wider than the 64-wide tiles (narrower runs zero-padded)
     with pytest.raises(NotImplementedError):
-        fastegnn_amd.FastEGNN(2, 0, 2, 64, 3, act_fn=torch.nn.ReLU())
+        fastegnn_amd.FastEGNN(2, 0, 2, 64, 3, act_fn=torch.nn.Hardswish())      # not one of the eight kinds of the C ABI
+    with pytest.raises(NotImplementedError):
+        fastegnn_amd.FastEGNN(2, 0, 2, 32, 3, act_fn=torch.nn.Sigmoid())        # zero padding needs act_fn(0) = 0
+    assert fastegnn_amd.FastEGNN(2, 0, 2, 64, 3, act_fn=torch.nn.LeakyReLU(0.2))._act == (K.ACT_LEAKY_RELU, 0.2)
     g = Golden("equiv10")
     m = fastegnn_amd.FastEGNN(1, 0, 1, 64, 3)
     kw, _, _ = g.model_kwargs()
