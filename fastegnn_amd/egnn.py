@@ -147,7 +147,7 @@ class EGNN(nn.Module):
             self.layers.append(EGNN_Layer(in_edge_nf, hidden_nf, activation, with_v))
         self._spec = None
         self._graph_cache = {}
-        self.deterministic = K.deterministic_default()   # see fastegnn_amd.FastEGNN.deterministic (set before the first call)
+        self.deterministic = bool(K.deterministic_default())   # see fastegnn_amd.FastEGNN.deterministic (set before the first call)
         self.to(device)
 
     def _build_spec(self):
