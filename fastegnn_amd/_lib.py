@@ -29,6 +29,53 @@ def deterministic_default():
     v = os.environ.get("FASTEGNN_DETERMINISTIC")
     return None if v is None or v == "" else v == "1"
 
+# per-layer parameter slots, in header order -> reference state_dict suffix (models/FastEGNN.py:28-99)
+PARAM_SLOTS = [
+    "edge_mlp.0.weight", "edge_mlp.0.bias", "edge_mlp.2.weight", "edge_mlp.2.bias",
+    "edge_mlp_virtual.0.weight", "edge_mlp_virtual.0.bias", "edge_mlp_virtual.2.weight", "edge_mlp_virtual.2.bias",
+    "att_mlp.0.weight", "att_mlp.0.bias", "att_mlp_virtual.0.weight", "att_mlp_virtual.0.bias",
+    "coord_mlp_r.0.weight", "coord_mlp_r.0.bias", "coord_mlp_r.2.weight",
+    "coord_mlp_r_virtual.0.weight", "coord_mlp_r_virtual.0.bias", "coord_mlp_r_virtual.2.weight",
+    "coord_mlp_v_virtual.0.weight", "coord_mlp_v_virtual.0.bias", "coord_mlp_v_virtual.2.weight",
+    "coord_mlp_vel.0.weight", "coord_mlp_vel.0.bias", "coord_mlp_vel.2.weight", "coord_mlp_vel.2.bias",
+    "gravity_mlp.0.weight", "gravity_mlp.0.bias", "gravity_mlp.2.weight", "gravity_mlp.2.bias",
+    "node_mlp.0.weight", "node_mlp.0.bias", "node_mlp.2.weight", "node_mlp.2.bias",
+    "node_mlp_virtual.0.weight", "node_mlp_virtual.0.bias", "node_mlp_virtual.2.weight", "node_mlp_virtual.2.bias",
+    "coord_mlp_r.2.bias",     # EGNN baseline only (FastEGNN's coordinate heads have no bias)
+]
+P_COUNT = len(PARAM_SLOTS)
+assert P_COUNT == 38
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+
+
+class GraphT(C.Structure):
+    _fields_ = [("n_rows", _i32), ("n_src", _i32), ("n_edges", _i32), ("n_chunks", _i32),
+                ("rowptr", _vp), ("erow", _vp), ("col", _vp), ("perm", _vp),
+                ("cscptr", _vp), ("csc_eid", _vp), ("chunk_row", _vp)]
+
+
+class PadDesc(C.Structure):
+    """fastegnn_pad_desc_t (include/fastegnn_hip.h)"""
+    _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i32), ("cols", _i32), ("rows_dst", _i32), ("cols_dst", _i32),
+                ("nblk", _i32), ("blk", _i32 * 3)]
+
+
+_LAYER_PTRS_A = ["batch", "gptr", "ea_sorted", "vel", "node_attr", "params", "grads", "wpack",
+                 "h", "x", "Z", "HvT", "h_out", "x_out", "Z_out", "HvT_out",
+                 "P", "QX", "QX_src", "A", "svel", "sgrav", "xsum", "Bc", "aggm", "aggx", "npre", "poolV", "poolX",
+                 "g_h_out", "g_x_out", "g_Z_out", "g_HvT_out", "g_h", "g_x", "g_Z", "g_HvT", "g_vel", "g_ea_sorted", "g_node_attr",
+                 "g_poolV", "g_poolX", "g_Bc", "g_Zp", "g_xbar", "g_A", "g_P", "g_aggm", "g_aggx",
+                 "g_svel", "g_sgrav", "g_QXe", "g_QX_src", "g_QX", "g_xrow", "wg_edge", "wg_virt", "wg_node", "wg_slab"]
+
+
+class LayerT(C.Structure):
+    _fields_ = ([("N", _i32), ("B", _i32), ("C", _i32), ("ea", _i32), ("na", _i32), ("flags", _i32),
+                 ("gravity", C.c_float * 3), ("epsilon", C.c_float), ("act_param", C.c_float),
+                 ("graph", GraphT)]
+                + [(n, _vp) for n in _LAYER_PTRS_A])
+
 
 _libs = {}
 ACT_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfastegnn_hip_act.so")

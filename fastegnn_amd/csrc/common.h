@@ -43,10 +43,19 @@ __device__ __forceinline__ float dsilu_f(float z) {
 }
 // silu(z) and its derivative from ONE sigmoid: d = s*(1 + z*(1-s)) = s + y*(1-s) with y = z*s
 __device__ __forceinline__ void silu_both(float z, float &y, float &d) {
-#ifdef FE_SIGMOID_NEWTON   // measured lever (round-2 verdict item 7): one Newton step on the reciprocal of the backward recompute
+#if defined(FE_SIGMOID_NEWTON) || defined(FE_EXP_ACCURATE)   // measured levers (round-2 verdict item 7), backward recompute only
+#ifdef FE_EXP_ACCURATE   // exp(-z) with the rounding error of the exp2 argument corrected (two fma + one fma)
+  const float t = -z * 1.44269504f;
+  const float lo = fmaf(-z, 1.44269504f, -t) + (-z) * 1.92596299e-8f;
+  const float e0 = __builtin_amdgcn_exp2f(t);
+  const float den = 1.0f + fmaf(e0, lo * 0.69314718f, e0);
+#else
   const float den = 1.0f + __expf(-z);
+#endif
   float s = __builtin_amdgcn_rcpf(den);
+#ifdef FE_SIGMOID_NEWTON   // one Newton step on the reciprocal
   s = fmaf(fmaf(-den, s, 1.0f), s, s);
+#endif
 #else
   const float s = sigmoid_f(z);
 #endif
