@@ -365,8 +365,8 @@ __device__ __forceinline__ void gemm64_f(const float *img, const Vec &in, Vec &a
 
 // ---- 3-way bf16 split ("bf16x3") variant of gemm64 ------------------------------------------
 // fp32-input MFMA shares the vector ALUs with every other VALU instruction and runs at 1/16 of the
-// bf16 matrix rate.  x = h + m + l with h, m, l bf16 values (8+8+8 mantissa bits, by truncation: the
-// residuals are exact, so the three parts reproduce x exactly) turns one fp32 product into six bf16
+// bf16 matrix rate.  x = h + m + l with h, m, l bf16 values (8+8+8 mantissa bits, each the round-to-nearest
+// image of the residual so far -- part_pack below; the residuals are exact, so the three parts reproduce x to 2^-25) turns one fp32 product into six bf16
 // products (hh, hm, mh, hl, lh, mm; the dropped ml, lm, ll terms are <= 2^-24 relative, i.e. below
 // fp32 rounding) accumulated in fp32 by v_mfma_f32_16x16x32_bf16 on the matrix pipe, which runs
 // beside the VALU.  Same D layout as gemm64, so the chained-MLP property is unchanged.
@@ -383,6 +383,28 @@ __device__ __forceinline__ float trunc_bf(float x) { return __builtin_bit_cast(f
 __device__ __forceinline__ unsigned pack_hi(float x0, float x1) {
   return __builtin_amdgcn_perm(f2u(x1), f2u(x0), 0x07060302u);
 }
+// One level of the h | m | l split of a pair: returns the packed bf16 parts of (a0, a1) and leaves the residuals in them.
+// Round to nearest even: one v_cvt_pk_bf16_f32 per pair, shift / and + sub per element -- the instruction count of the
+// truncating split of rounds 1-2 (and + sub per element, one perm per pair; -DFE_SPLIT_TRUNC brings it back).  With
+// truncation every part has the sign of the value, so the dropped m*l, l*m, l*l terms and the last residue all point
+// towards zero: a bias of ~1e-7 per product that does not cancel in cancelling sums.  Measured on one box (round 3,
+// tools/gpu_lever_newton.sh): 40 -> 32 gradient comparisons beyond 2 x ref + 1e-6, the attention goldens' excesses down by
+// 2-4 x (att_mlp.0.bias 2.67e-5 -> 6.8e-6), for +0.5 % step time (v_cvt_pk_bf16_f32 issues in 4-5 cycles, v_perm_b32 in 4).
+__device__ __forceinline__ unsigned part_pack(float &a0, float &a1) {
+#ifndef FE_SPLIT_TRUNC
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{a0, a1}, bf16x2_));
+  a0 -= __builtin_bit_cast(float, p << 16);
+  a1 -= __builtin_bit_cast(float, p & 0xffff0000u);
+  return p;
+#else
+  const unsigned p = pack_hi(a0, a1);
+  a0 -= trunc_bf(a0);
+  a1 -= trunc_bf(a1);
+  return p;
+#endif
+}
 // k index held by element e of lane quarter q in k-step s (matches the chained D layout)
 __host__ __device__ __forceinline__ int bf3_k(int s, int q, int e) { return 16 * (2 * s + (e >> 2)) + 4 * q + (e & 3); }
 // u32 index of (part, out o, k) in a split image; pairs (e, e+1) share a word
@@ -394,28 +416,22 @@ __host__ __device__ __forceinline__ int img3_index(int part, int o, int k) {
 // word (two bf16) of the split image: elements k0 (low half) and k0+1 (high half) of part `part`
 __device__ __forceinline__ unsigned split_word(float w0, float w1, int part) {
   float a0 = w0, a1 = w1;
-  for (int p = 0; p < part; ++p) {
-    a0 -= trunc_bf(a0);
-    a1 -= trunc_bf(a1);
-  }
-  return pack_hi(a0, a1);
+  unsigned p = 0;
+  for (int k = 0; k <= part; ++k) p = part_pack(a0, a1);
+  return p;
 }
 __device__ __forceinline__ Split vsplit(const Vec &v) {
   Split S;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    float x[8], r1[8], r2[8];
+    float x[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      x[e] = v.t[2 * s + (e >> 2)][e & 3];
-      r1[e] = x[e] - trunc_bf(x[e]);
-      r2[e] = r1[e] - trunc_bf(r1[e]);
-    }
+    for (int e = 0; e < 8; ++e) x[e] = v.t[2 * s + (e >> 2)][e & 3];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      S.p[0][s][w] = pack_hi(x[2 * w], x[2 * w + 1]);
-      S.p[1][s][w] = pack_hi(r1[2 * w], r1[2 * w + 1]);
-      S.p[2][s][w] = pack_hi(r2[2 * w], r2[2 * w + 1]);
+      S.p[0][s][w] = part_pack(x[2 * w], x[2 * w + 1]);
+      S.p[1][s][w] = part_pack(x[2 * w], x[2 * w + 1]);
+      S.p[2][s][w] = part_pack(x[2 * w], x[2 * w + 1]);
     }
   }
   return S;
@@ -659,19 +675,16 @@ struct Split8 {
   u32x4 h, m, l;
 };
 // eight fp32 values -> their three bf16 parts, packed as one k-block of v_mfma_f32_16x16x32_bf16
-__device__ __forceinline__ Split8 split8(const float (&x)[8]) {
-  float r1[8], r2[8];
+__device__ __forceinline__ Split8 split8(const float (&x_)[8]) {
+  float x[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    r1[e] = x[e] - trunc_bf(x[e]);
-    r2[e] = r1[e] - trunc_bf(r1[e]);
-  }
+  for (int e = 0; e < 8; ++e) x[e] = x_[e];
   Split8 S;
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    S.h[w] = pack_hi(x[2 * w], x[2 * w + 1]);
-    S.m[w] = pack_hi(r1[2 * w], r1[2 * w + 1]);
-    S.l[w] = pack_hi(r2[2 * w], r2[2 * w + 1]);
+    S.h[w] = part_pack(x[2 * w], x[2 * w + 1]);
+    S.m[w] = part_pack(x[2 * w], x[2 * w + 1]);
+    S.l[w] = part_pack(x[2 * w], x[2 * w + 1]);
   }
   return S;
 }

@@ -277,7 +277,7 @@ __device__ __forceinline__ void wg_accumulate_direct(const float *G, const float
 
 // The contraction on the bf16 matrix pipe: 32 rows per step, fragments straight from global memory in the 16x16x32 operand
 // layout (lane l = i + 16 q holds rows m + 8 q .. + 7 of column 16 t + i: eight 64-byte-segment loads per fragment), each
-// fp32 operand split in registers into bf16 parts h | m | l (truncation, as the stage kernels' activations) and six
+// fp32 operand split in registers into bf16 parts h | m | l (part_pack, as the stage kernels' activations) and six
 // products per (ti, tk) tile -- 96 matrix instructions of 16 cycles per 32 rows against 128 of 32 cycles on the fp32-input
 // form.  BF (bf16 operand mode): both operands rounded to bf16 (RNE) and ONE product -- the mode's weight gradients on
 // the bf16 instruction itself.  The next step's G fragments are requested while this step's T fragments are split, the
@@ -291,17 +291,14 @@ __device__ __forceinline__ WgParts wg_split8(const float (&x)[8]) {
     for (int w = 0; w < 4; ++w) P.p[0][w] = pack_rne(x[2 * w], x[2 * w + 1]);
     P.p[1] = P.p[2] = u32x4{0u, 0u, 0u, 0u};
   } else {
-    float r1[8], r2[8];
+    float y[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      r1[e] = x[e] - trunc_bf(x[e]);
-      r2[e] = r1[e] - trunc_bf(r1[e]);
-    }
+    for (int e = 0; e < 8; ++e) y[e] = x[e];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      P.p[0][w] = pack_hi(x[2 * w], x[2 * w + 1]);
-      P.p[1][w] = pack_hi(r1[2 * w], r1[2 * w + 1]);
-      P.p[2][w] = pack_hi(r2[2 * w], r2[2 * w + 1]);
+      P.p[0][w] = part_pack(y[2 * w], y[2 * w + 1]);
+      P.p[1][w] = part_pack(y[2 * w], y[2 * w + 1]);
+      P.p[2][w] = part_pack(y[2 * w], y[2 * w + 1]);
     }
   }
   return P;
@@ -841,12 +838,10 @@ __global__ __launch_bounds__(64 * WAVES) void chain_bf3_kernel(const float *W, c
   // split the fp32 weights W[o][k] into the three bf16 images (what pack.hip would do once per step)
   for (int idx = threadIdx.x; idx < IMG; idx += blockDim.x) {
     const int o = idx >> 6, k = idx & 63;
-    const float w = W[idx];
-    const float r1 = w - trunc_bf(w), r2 = r1 - trunc_bf(r1);
-    const float parts[3] = {w, r1, r2};
+    float w = W[idx], dummy = 0.f;
     const int tile = k >> 4, r = k & 3, e = ((tile & 1) << 2) | r;
     for (int p = 0; p < 3; ++p) {
-      const unsigned hb = f2u(parts[p]) >> 16;
+      const unsigned hb = part_pack(w, dummy) & 0xffffu;   // the bf16 part of w (low half of the pair word); w <- residual
       atomicOr(&lds3[img3_index(p, o, k)], (e & 1) ? (hb << 16) : hb);
     }
   }

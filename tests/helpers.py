@@ -100,47 +100,51 @@ GRAD_FLOOR = 1e-6
 # each entry states what was measured.  A tensor lands here when its gradient is a short or strongly cancelling
 # sum, for which two fp32 evaluations in different summation orders (the reference's ATen kernels, these HIP
 # kernels) each sit at a random point of the same rounding-noise band, so "2 x the reference's own draw" is not a
-# bound; the floor granted is the measured band, never more than 2.5e-5.
+# bound; the floor granted is the measured band, never more than 1.5e-5.
 GRAD_EXCEPTIONS = [
-    # (case regex, tensor regex, factor, floor, why) -- measured on an MI355X with FASTEGNN_TOL_DUMP (2 500 comparisons over
-    # 31 cases, 52 beyond 2 x ref + 1e-6; gpurun_out/a1/tol_report.txt of round 2) unless a CPU measurement is named
-    (r"ragged3_(allflags|normalize)|fastrf_allflags", r".", 8.0, 1e-6,
+    # (case regex, tensor regex, factor, floor, why) -- re-measured at the end of round 3 on an MI355X with FASTEGNN_TOL_DUMP
+    # over the whole -m gpu suite (4 054 comparisons over 45 cases, 29 beyond 2 x ref + 1e-6; the operand split of the
+    # bf16x3 products rounds to nearest since then, which took the attention goldens' excesses down 2-4 x): every entry
+    # states what was measured and grants ~1.3-1.5 x that
+    (r"ragged3_(allflags|normalize)|fastrf_allflags", r".", 3.0, 1e-6,
      "normalize=True on graphs with self loops / coincident points: d/(|d|+1e-8) at d = 0 amplifies rounding noise by "
      "1e8, the reference's own gradients are 5e-4..5e-3 from exact arithmetic there, and a mathematically identical "
      "fp32 re-association run on the SAME torch CPU kernels (oracle/factored.py in tests/test_factored_cpu.py) "
-     "measures 2.1-5.7x the reference's draw on 13 tensors; HIP: <= 2.4x (gin/node_vel 1.1e-2 vs 4.8e-3)"),
-    (r"ragged3_attention|ragged3_allflags", r".", 8.0, 1e-6,
+     "measures 2.1-5.7x the reference's draw on 13 tensors; HIP: <= 2.36x (gin/node_vel 1.13e-2 vs 4.81e-3; factor 8 "
+     "until round 3)"),
+    (r"ragged3_attention|ragged3_allflags", r".", 4.0, 1e-6,
      "the attention goldens are moderately ill-conditioned (reference 1e-5 from exact arithmetic on the layer-1 edge "
-     "stage, 10x its usual level): HIP measures 2.5-6.0x the reference's draw on the edge-stage tensors of that layer"),
-    (r"attention|allflags", r"att_mlp(_virtual)?\.0\.(weight|bias)", 40.0, 1e-6,
-     "attention gates: scalar / 64-vector gradients that are cancelling sums over ~100 edges; the CPU re-association "
-     "above measures 10.8x the reference's draw on att_mlp.0.bias (9.1e-6 vs 8.4e-7), HIP 23.5x (2.0e-5) in round 2 and "
-     "33.4x (2.82e-5, ragged3_attention gcl_1) once the library is compiled without SLP vectorisation in round 3 -- the "
-     "same arithmetic in another instruction order; the per-edge term g_a = <g_m, m0> is itself a cancelling 64-term dot "
-     "product, so no summation order of the ~100 edges removes the band"),
-    (r".", r"(edge_mlp|coord_mlp_r|edge_message_net\.scalar_net\.mlp|coord_net\.mlp)\.", 2.0, 2e-5,
-     "parameter gradients of the edge stage: every per-edge operand passes three SiLU activations whose sigmoid is "
-     "v_exp_f32 + v_rcp_f32 (about 2-4 ulp; torch's CPU sigmoid is < 1 ulp) and the sums run over up to 370 k edges "
-     "with cancellation (max|g| ~1e-8 on the last layers of the radius-graph cases): measured <= 1.5e-5 "
-     "(cfg5 shape at 20 k nodes, gcl_3.edge_mlp.0.bias) where the reference sits at 1e-6..6e-6"),
+     "stage, 10x its usual level): HIP measures <= 3.3x the reference's draw on the edge-stage tensors of that layer "
+     "(gcl_1.coord_mlp_r.0.bias 3.59e-6 vs 1.09e-6; 2.5-6.0x and factor 8 with the truncating split of rounds 1-2)"),
+    (r"attention|allflags", r"att_mlp(_virtual)?\.0\.(weight|bias)", 12.0, 8e-6,
+     "attention gates: scalar / 64-vector gradients that are cancelling sums over ~100 edges whose per-edge term "
+     "g_a = <g_m, m0> is itself a cancelling 64-term dot product; the CPU re-association above measures 10.8x the "
+     "reference's draw on att_mlp.0.bias (9.1e-6 vs 8.4e-7); HIP: 8.0x (6.77e-6, ragged3_attention gcl_1), 5.65e-6 "
+     "against a reference draw of 1.4e-8 on the 4 000-node GELU case (23.5-33x and factor 40 with the truncating split)"),
+    (r".", r"(edge_mlp|coord_mlp_r|edge_message_net\.scalar_net\.mlp|coord_net\.mlp)\.", 2.0, 1.5e-5,
+     "parameter gradients of the edge stage: sums over up to 370 k edges with cancellation (max|g| ~1e-8 on the last "
+     "layers of the radius-graph cases): measured <= 1.02e-5 over 2 x ref (cfg5 shape at 20 k nodes, "
+     "gcl_3.edge_mlp.0.bias 1.39e-5 vs ref 1.87e-6) where the reference sits at 1e-6..6e-6.  NOT the transcendentals: one "
+     "Newton step on the sigmoid's reciprocal and an exp2 argument corrected to < 1 ulp, in the backward recompute, were "
+     "both measured (profiles/r03_lever_*.txt) and move this figure by < 5 %; the bf16x3 split's rounding mode moves it "
+     "by 10 % -- what remains is the order of the fp32 sums (floor 2e-5 until round 3)"),
     (r".", r"embedding_in\.bias", 2.0, 3e-6,
      "the column sum of the gradient that leaves the first layer -- every rounding of the whole backward chain ends in "
      "it: 3.4e-6 / 2.7e-6 against the reference's 1.1e-6 / 7.9e-7 (nbody5_cfg1_trained, train_ragged_simulation)"),
-    (r".", r"coord_mlp_v_virtual\.|att_mlp_virtual\.", 2.0, 1e-5,
-     "same activation floor on the virtual coordinate head (v_exp_f32 + v_rcp_f32 sigmoid, ~3 ulp with the rounded exp2 "
-     "argument, against < 1 ulp on the CPU): round 2 measured an excess <= 1.6e-6 over 2 x ref with per-lane accumulators; "
-     "round 3 sums these [1,64] gradients per (tile, channel) over the tile first (DPP) and then across tiles in LDS -- a "
-     "different association of the same cancelling sum: 1.26e-5 / 1.36e-5 on two builds against ref 3.95e-6 "
-     "(ragged3_tanh, gcl_1.coord_mlp_v_virtual.2.weight, 17 nodes); one Newton step on the reciprocal would cost 5 % of "
-     "the producers' vector issue time in virt_bwd_pc_kernel and was not taken"),
-    (r"act_", r"(gravity_mlp|coord_mlp_vel)\.2\.bias", 2.0, 3e-6,
-     "activation goldens (act_fn other than SiLU; libfastegnn_hip_act.so): the scalar head biases are sums of 20 per-node "
-     "terms behind log1p / exp / erf evaluations of 2-4 ulp: 3.28e-6 against the reference's 1.10e-6 "
-     "(act_softplus, gcl_0.gravity_mlp.2.bias), the same floor as embedding_in.bias"),
+    (r".", r"(gravity_mlp|coord_mlp_vel)\.2\.bias", 2.0, 3e-6,
+     "scalar head biases: one number, the sum of N per-node terms: 2.44e-6 against the reference's 3.7e-7 "
+     "(nbody5_cfg1_trained, gcl_1.coord_mlp_vel.2.bias), 3.28e-6 against 1.10e-6 (act_softplus, gcl_0.gravity_mlp.2.bias)"),
+    (r".", r"coord_mlp_v_virtual\.|att_mlp_virtual\.", 2.0, 8e-6,
+     "the virtual coordinate head and gate: [1,64] / scalar gradients summed per (tile, channel) over the tile first (DPP) and "
+     "then across tiles in LDS -- a different association of a cancelling sum: 5.81e-6 over 2 x ref "
+     "(ragged3_attention, gcl_0.att_mlp_virtual.0.bias 9.60e-6 vs 1.89e-6; 1.26e-5 / 1.36e-5 and floor 1e-5 with the "
+     "truncating split)"),
     (r"act_mid", r"\.bias$", 2.0, 5e-6,
      "activations other than SiLU at 4 000 nodes: bias gradients are column sums over 32 k - 48 k rows behind erf / exp / "
      "log1p evaluations of 2-4 ulp; measured 4.64e-6 against 2 x ref + 1e-6 = 2.96e-6 (act_mid_gelu, "
      "gcl_1.edge_mlp_virtual.0.bias)"),
+    (r"no_edges", r"edge_mlp_virtual\.2\.bias", 2.0, 2e-6,
+     "4.67e-6 against 2 x ref + 1e-6 = 4.58e-6 (test_no_edges_and_isolated_nodes, gcl_1): a column sum over N*C rows"),
     (r"cfg5_shape", r"gcl_0\.coord_mlp_r_virtual\.0\.bias", 3.0, 1e-6,
      "a column sum over N*C = 640 k rows that cancels to ~1e-3 of its terms (the reference's own fp32 result is 1.18e-4 "
      "from fp64): five runs on one box (tools/gpu_tolrepeat.sh) measured 2.31e-4 .. 2.63e-4 = 1.96 .. 2.23 x the "
