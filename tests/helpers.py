@@ -112,6 +112,12 @@ GRAD_EXCEPTIONS = [
      "fp32 re-association run on the SAME torch CPU kernels (oracle/factored.py in tests/test_factored_cpu.py) "
      "measures 2.1-5.7x the reference's draw on 13 tensors; HIP: <= 2.36x (gin/node_vel 1.13e-2 vs 4.81e-3; factor 8 "
      "until round 3)"),
+    (r"cpu_reassociation:.*(ragged3_(allflags|normalize|attention)|fastrf_allflags)", r".", 8.0, 1e-6,
+     "tests/test_factored_cpu.py only: the mathematically identical fp32 re-association on the torch CPU kernels "
+     "(oracle/factored.py) itself measures 2.1-5.7x the reference's draw on 13 tensors of the normalize goldens and up "
+     "to 10.8x on att_mlp.0.bias -- the yardstick that says these goldens are ill-conditioned, not a product tolerance"),
+    (r"cpu_reassociation:.*(attention|allflags)", r"att_mlp(_virtual)?\.0\.(weight|bias)", 25.0, 1e-6,
+     "same, attention gates (10.8x measured)"),
     (r"ragged3_attention|ragged3_allflags", r".", 4.0, 1e-6,
      "the attention goldens are moderately ill-conditioned (reference 1e-5 from exact arithmetic on the layer-1 edge "
      "stage, 10x its usual level): HIP measures <= 3.3x the reference's draw on the edge-stage tensors of that layer "
@@ -179,7 +185,7 @@ def grad_check(case, name, got, ref32, truth, bad):
         bad.append(f"{name} {e_got:.2e} (ref {e_ref:.2e}, tol {tol:.2e})")
 
 
-def check_parity(g, loc, vloc, G=None, gin=None, truth=None):
+def check_parity(g, loc, vloc, G=None, gin=None, truth=None, case_prefix=""):
     """loc/vloc: <=1e-5 rel of the reference golden.  Displacement and gradients: the fp32
     reference itself is 1e-7..1e-3 away from exact arithmetic depending on the tensor, so the
     build's error against the fp64 oracle must stay within GRAD_FACTOR x the reference's own
@@ -189,7 +195,7 @@ def check_parity(g, loc, vloc, G=None, gin=None, truth=None):
     e = rel_err(loc, g.out["loc"]); msgs += [f"loc {e:.2e}"] if e >= OUT_TOL else []
     e = rel_err(vloc, g.out["vloc"]); msgs += [f"vloc {e:.2e}"] if e >= OUT_TOL else []
     x0 = torch.from_numpy(g.inp["node_loc"]).double()
-    grad_check(g.name, "displacement", torch.as_tensor(loc).double().cpu() - x0,
+    grad_check(case_prefix + g.name, "displacement", torch.as_tensor(loc).double().cpu() - x0,
                torch.from_numpy(g.out["loc"]).double() - x0, t_loc - x0, msgs)
     for got, ref, tru, tag in ((G, g.gp, t_G, "gp"), (gin, g.gin, t_gin, "gin")):
         if got is None:
@@ -198,7 +204,7 @@ def check_parity(g, loc, vloc, G=None, gin=None, truth=None):
             if k not in got or got[k] is None:
                 msgs.append(f"{tag}/{k} missing")
                 continue
-            grad_check(g.name, f"{tag}/{k}", got[k], ref[k], tru[k], msgs)
+            grad_check(case_prefix + g.name, f"{tag}/{k}", got[k], ref[k], tru[k], msgs)
     return msgs
 
 

@@ -42,5 +42,5 @@ def test_factored_fp64_matches_autograd(name):
 def test_factored_fp32_matches_reference_golden(name):
     g = Golden(name)
     p, leaf, loc, vloc, loc2, vloc2, G, gin = _run_pair(g, torch.float32)
-    msgs = check_parity(g, loc2, vloc2, G, gin)
+    msgs = check_parity(g, loc2, vloc2, G, gin, case_prefix="cpu_reassociation:")
     assert not msgs, msgs
