@@ -104,12 +104,37 @@ template <int MODE>
 __device__ __forceinline__ void gemm_i(const void *img, int i, const Vec &in, Vec &acc) {
   gemm_op<MODE>(img, i, make_operand<MODE>(in), acc);
 }
+// The products of virt_tile_forward are issued at wave priority 3 (0 elsewhere): of the two waves of a SIMD the one that has
+// matrix work gets the issue port first and the other fills the gaps with its vector work -- virt_fwd 1.64 -> 1.58 ms per
+// step on one box (priority 1: 1.59).  -DVF_PRIO=0 switches it off; -DEF_PRIO=n / -DVB_PRIO=n: the same experiment in the
+// edge kernels / the producers of virt_bwd_pc (measured, not adopted: edge_bwd 3.44 -> 3.61 ms at priority 2, edge_fwd and
+// virt_bwd_pc unchanged at priorities 1 and 2).
+#ifndef VF_PRIO
+#define VF_PRIO 3
+#endif
+#if VF_PRIO > 0
+#define VF_PRIO_ON() __builtin_amdgcn_s_setprio(VF_PRIO)
+#define VF_PRIO_OFF() __builtin_amdgcn_s_setprio(0)
+#else
+#define VF_PRIO_ON()
+#define VF_PRIO_OFF()
+#endif
+#ifdef EF_PRIO
+#define EF_PRIO_ON() __builtin_amdgcn_s_setprio(EF_PRIO)
+#define EF_PRIO_OFF() __builtin_amdgcn_s_setprio(0)
+#else
+#define EF_PRIO_ON()
+#define EF_PRIO_OFF()
+#endif
 // the edge stage's four products I = 0 W2, 1 WX1, 2 W2^T, 3 WX1^T: from four split images (RM = false: img + I) or from the
 // two row-major images W2 | WX1 read plain or transposed (RM = true, edge_bwd: half the LDS, which its rings take)
 template <int MODE, int I, bool RM>
 __device__ __forceinline__ void gemm_e(const void *img, const Vec &in, Vec &acc) {
-  if constexpr (RM) gemm_rm<MODE, (I >= 2), false>(static_cast<const char *>(img) + (I & 1) * RM_BYTES, make_operand<MODE>(in), acc);
-  else gemm_i<MODE>(img, I, in, acc);
+  const auto op = make_operand<MODE>(in);
+  EF_PRIO_ON();
+  if constexpr (RM) gemm_rm<MODE, (I >= 2), false>(static_cast<const char *>(img) + (I & 1) * RM_BYTES, op, acc);
+  else gemm_op<MODE>(img, I, op, acc);
+  EF_PRIO_OFF();
 }
 
 // part 1: consumes the gathered operands (geometry + first-layer pre-activation)
@@ -252,7 +277,9 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void 
   S.t = vsilu(S.pre FE_ACT(a));
   VF_T(1)   // geometry, pre-activation, silu 1
   S.vp = vload_vec(vec + VV_C2 * H, q);
+  VF_PRIO_ON();
   gemm_i<MODE>(img, 0, S.t, S.vp);
+  VF_PRIO_OFF();
   VF_T(2)   // split + product 1
   S.v0 = vsilu(S.vp FE_ACT(a));
   if (a.flags & FASTEGNN_F_ATTENTION) {
@@ -265,13 +292,17 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void 
   S.uxp = vload_vec(vec + VV_BXV0 * H, q);
   S.vs = make_operand<MODE>(S.v);   // one split / rounding feeds both coordinate heads and the node MLP
   VF_T(3)   // silu 2 + split
+  VF_PRIO_ON();
   gemm_op<MODE>(img, 1, S.vs, S.uxp);
+  VF_PRIO_OFF();
   VF_T(4)   // product 2
   float sr = vdot(vsilu(S.uxp FE_ACT(a)), vload_vec(vec + VV_WXV2 * H, q));
   S.sx = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;
   VF_T(5)   // silu + head dot
   S.uXp = vload_vec(vec + VV_BXX0 * H, q);
+  VF_PRIO_ON();
   gemm_op<MODE>(img, 2, S.vs, S.uXp);
+  VF_PRIO_OFF();
   VF_T(4)
   sr = vdot(vsilu(S.uXp FE_ACT(a)), vload_vec(vec + VV_WXX2 * H, q));
   S.sX = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sr) : sr;

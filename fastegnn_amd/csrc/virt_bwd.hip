@@ -420,8 +420,20 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
     const float invC = 1.0f / (float)C;
     const float attb0 = ATT ? a.attb[0] : 0.f;
     float *racc = racc0 + ((wv > 3 ? wv - 1 : wv) % A.nbank) * VB_RACC;   // this producer's bank (producers: waves 0,1,2,4,5)
-    auto mm = [&](int which, const SOp &op, Vec &acc) { gemm_rm<SM, false>(rmimg + which * RM_BYTES, op, acc); };
-    auto mmT = [&](int which, const Vec &g, Vec &acc) { gemm_rm<SM, true>(rmimg + which * RM_BYTES, make_operand<SM>(g), acc); };
+#ifdef VB_PRIO
+#define VB_PRIO_ON() __builtin_amdgcn_s_setprio(VB_PRIO)
+#define VB_PRIO_OFF() __builtin_amdgcn_s_setprio(0)
+#else
+#define VB_PRIO_ON()
+#define VB_PRIO_OFF()
+#endif
+    auto mm = [&](int which, const SOp &op, Vec &acc) { VB_PRIO_ON(); gemm_rm<SM, false>(rmimg + which * RM_BYTES, op, acc); VB_PRIO_OFF(); };
+    auto mmT = [&](int which, const Vec &g, Vec &acc) {
+      const auto op = make_operand<SM>(g);
+      VB_PRIO_ON();
+      gemm_rm<SM, true>(rmimg + which * RM_BYTES, op, acc);
+      VB_PRIO_OFF();
+    };
     VB2_T0()
     for (;;) {
       int u = 0;
