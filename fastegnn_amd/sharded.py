@@ -312,10 +312,11 @@ class _Comm:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # a transport without device support (gloo): device tensors are staged through host memory, synchronously
         self.host_staged = self.world > 1 and dist.get_backend(group) == "gloo"
-        # FASTEGNN_SHARDED_SYNC=1: blocking collectives in program order (async_op=False) -- no overlap, nothing in flight
-        # behind a kernel.  The asynchronous schedule is the default; this is the fallback while RCCL with more than one
-        # rank has not run on the pool's hardware
-        self.sync = os.environ.get("FASTEGNN_SHARDED_SYNC", "0") not in ("", "0")
+        # Blocking collectives in program order (async_op=False: no overlap, nothing in flight behind a kernel) are the DEFAULT
+        # while RCCL with more than one rank has never run on the hardware this was built on: the
+        # asynchronous schedule (each exchange waited for at its first consumer) is exercised only through gloo, where the
+        # staged transport is synchronous anyway.  FASTEGNN_SHARDED_SYNC=0 selects it.
+        self.sync = os.environ.get("FASTEGNN_SHARDED_SYNC", "1") not in ("", "0")
         # FASTEGNN_COMM=abi: the data-path collectives go through the C ABI (fastegnn_comm_*: RCCL on the CURRENT stream,
         # capturable), created lazily on the first device tensor; plan-building exchanges stay on torch.distributed
         self.use_abi = os.environ.get("FASTEGNN_COMM", "torch") == "abi" and not self.host_staged
