@@ -695,7 +695,11 @@ def main():
             out["table_exchange"] = {"mode": pl.mode, "rows_received_per_exchange": pl.exchanged_bytes() // (68 * 4),
                                      "bytes_received_per_exchange": pl.exchanged_bytes(),
                                      "all_gather_bytes_for_comparison": (world - 1) * pl.Npad * 68 * 4,
-                                     "node_order": "Morton curve inside each graph (fastegnn_amd.sharded.morton_order)"}
+                                     "node_order": "Morton curve inside each graph (fastegnn_amd.sharded.morton_order)",
+                                     "collective_schedule": ("blocking, program order (default until RCCL with N > 1 has been "
+                                                             "verified; FASTEGNN_SHARDED_SYNC=0 overlaps)"
+                                                             if os.environ.get("FASTEGNN_SHARDED_SYNC", "1") not in ("", "0")
+                                                             else "asynchronous, waited for at the first consumer")}
         if dp_leg is not None:
             out["data_parallel_leg"] = dp_leg
         cb = "none" if args.no_cpu_baseline else args.cpu_baseline
