@@ -24,7 +24,7 @@ F_DETERMINISTIC = 1024   # backward: per-edge rows + CSC reduce instead of the a
 
 
 def deterministic_default():
-    """FASTEGNN_DETERMINISTIC=1 / =0 selects the bit-reproducible backward / the atomic scatter for every model that does
+    """FASTEGNN_DETERMINISTIC=1 / =0 selects the order-independent col-side sums (store + CSC reduce) / the atomic scatter for every model that does
     not say otherwise; unset (None): each model picks the faster one for its operand mode (FastEGNN.deterministic)."""
     v = os.environ.get("FASTEGNN_DETERMINISTIC")
     return None if v is None or v == "" else v == "1"

@@ -74,7 +74,9 @@ enum {
    * index of the graph (cscptr / csc_eid may then be NULL, also in fastegnn_build_csr) and fastegnn_edge_col_reduce's
    * kernel are not used, and the sums depend on the order the atomics land in (rounding-level run-to-run differences,
    * like torch's scatter_add_ on a GPU).  With this flag the rows are stored per edge in g_QXe [E,68] and summed in CSC
-   * order by fastegnn_edge_col_reduce: bit-reproducible, 0.26 ms per step slower at cfg4 and 272 bytes of scratch per edge. */
+   * order by fastegnn_edge_col_reduce: that sum is then order-independent (the rest of the backward keeps its
+   * rounding-level run-to-run differences: pools and ticket-ordered in-workgroup sums); 0.26 ms per step slower at cfg4 in
+   * fp32, faster than the atomics with bf16 operands; 272 bytes of scratch per edge. */
   FASTEGNN_F_DETERMINISTIC = 1024
 };
 /* Activation of every MLP (the reference's act_fn, models/FastEGNN.py:227): bits 11..14 of the flags hold one of the

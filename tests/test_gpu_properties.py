@@ -355,9 +355,9 @@ def test_many_graphs_large_total_is_sum_of_half_batches():
 
 def test_deterministic_backward_matches_atomic_scatter():
     """FASTEGNN_F_DETERMINISTIC (model.deterministic = True: per-edge rows + CSC-ordered sum) against the default backward
-    (fp32 atomic scatter of the col-side adjoint): same gradients up to summation order, and the deterministic mode's
-    input-table gradient path is reproducible (the edge stage's own weight gradients are bitwise equal between two runs
-    of the LAST layer's backward, which nothing atomic precedes)."""
+    (fp32 atomic scatter of the col-side adjoint): same gradients up to summation order; two runs of the deterministic mode
+    agree to 1e-5 on the last layer's edge-stage weight gradients (nothing atomic precedes them; what is left is the ticket
+    order of the in-workgroup weight-gradient sums)."""
     torch.manual_seed(5)
     from bench import make_frame
     frame, target = make_frame(20000, 16, 11, "cuda")
