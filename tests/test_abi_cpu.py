@@ -37,6 +37,25 @@ def test_generic_activation_library_exports_the_same_interface():
     assert A.fastegnn_sizeof_layer() == L.fastegnn_sizeof_layer()
 
 
+def test_silu_library_refuses_other_activation_kinds_before_any_device_call():
+    """The layer check runs on the host: the default library returns FASTEGNN_E_INVALID for any FASTEGNN_ACT_* kind but SiLU,
+    the generic-activation build for kinds it does not know and for kinds combined with the bf16 operand mode."""
+    import ctypes as C
+    table = (C.c_void_p * K.P_COUNT)()
+    def layer(flags):
+        L = K.LayerT()
+        L.N, L.B, L.C, L.ea, L.na, L.flags = 32, 1, 2, 2, 0, flags
+        L.params = C.cast(table, C.c_void_p)
+        return L
+    lib, act = K.lib(), K.lib(act=True)
+    assert lib.fastegnn_pack_weights(layer(K.ACT_RELU << K.F_ACT_SHIFT), None) == -1
+    assert b"SiLU only" in lib.fastegnn_last_error()
+    assert act.fastegnn_pack_weights(layer(9 << K.F_ACT_SHIFT), None) == -1
+    assert b"unknown activation" in act.fastegnn_last_error()
+    assert act.fastegnn_pack_weights(layer((K.ACT_GELU << K.F_ACT_SHIFT) | K.F_BF16), None) == -1
+    assert b"bf16" in act.fastegnn_last_error()
+
+
 def test_struct_mirrors_and_sizes():
     L = K.lib()
     import ctypes as C
