@@ -1,6 +1,7 @@
 // extern "C" surface of libfastegnn_hip.so (declared in include/fastegnn_hip.h).
 #include <vector>
 #include "kernels.h"
+#include <initializer_list>
 
 namespace fe {
 
@@ -182,18 +183,53 @@ int fastegnn_layer_backward(const fastegnn_layer_t *L, void *stream) {
   // up to eight node-level jobs of N rows + the edge stage's 2 x 256 slabs share the lower half of the slab workspace
   // (4096 slabs): 384 partial slabs per job at most (at cfg4 sizes a job takes 256 anyway)
   wb.max_split = 384;
+  // The jobs queued by a stage are contracted at wb.finish(): no later stage may write what they still have to read.  The
+  // arrays each stage writes (its outputs in fastegnn_layer_t and its region of the wg_* workspaces, kernels.h) are checked
+  // against the operands queued so far -- host-side pointer arithmetic, no device work.
+  const size_t N = (size_t)L->N, BC = (size_t)L->B * L->C, rows = wg_node_rows(L), E = (size_t)L->graph.n_edges;
+  struct W { const float *p; size_t n; const char *what; };
+  auto guard = [&](std::initializer_list<W> ws) {
+    for (const W &w : ws) {
+      const int r = wb.guard_write(w.p, w.n, w.what);
+      if (r) return r;
+    }
+    return (int)FASTEGNN_OK;
+  };
+  const bool det = has(L, FASTEGNN_F_DETERMINISTIC);
+  auto guard_virt = [&]() {
+    return guard({{L->g_h, N * H, "g_h"}, {L->g_x, N * 3, "g_x"}, {L->g_A, N * H, "g_A"}, {L->g_aggm, N * H, "g_aggm"},
+                  {L->g_aggx, N * 3, "g_aggx"}, {L->g_svel, N, "g_svel"}, {L->g_sgrav, N, "g_sgrav"}, {L->g_Bc, BC * H, "g_Bc"},
+                  {L->g_Zp, BC * 3, "g_Zp"}, {L->wg_node, 2 * rows * H, "wg_node[0..2)"},
+                  {L->wg_virt, L->wg_virt ? fastegnn_wg_virt_floats_for(L->N, L->C, L->flags) : 0, "wg_virt"}});
+  };
+  auto guard_edge = [&]() {
+    return guard({{L->g_P, N * H, "g_P"}, {L->g_xrow, N * 3, "g_xrow"}, {det ? L->g_QXe : nullptr, E * QXLD, "g_QXe"},
+                  {L->g_QX_src, (size_t)L->graph.n_src * QXLD, "g_QX_src"}, {L->wg_edge, fastegnn_wg_edge_floats(L->graph.n_edges), "wg_edge"}});
+  };
+  auto guard_node_pre = [&]() {
+    return guard({{L->g_h, N * H, "g_h"}, {L->g_x, N * 3, "g_x"}, {L->g_vel, N * 3, "g_vel"},
+                  {L->wg_node ? L->wg_node + 2 * rows * H : nullptr, 2 * rows * H, "wg_node[2..4)"}});
+  };
   if (has(L, FASTEGNN_F_EGNN)) {
+    if ((rc = guard_virt())) return rc;
     if ((rc = virt_backward(L, st, &wb))) return rc;
+    if ((rc = guard_edge())) return rc;
     if ((rc = edge_backward(L, st, &wb))) return rc;
     if ((rc = edge_col_reduce(L, st))) return rc;
+    if ((rc = guard_node_pre())) return rc;
     if ((rc = node_pre_backward(L, st, &wb))) return rc;
     return wb.finish();
   }
   if ((rc = graph_post_backward(L, st, &wb))) return rc;
+  if ((rc = guard_virt())) return rc;
   if ((rc = virt_backward(L, st, &wb))) return rc;
+  if ((rc = guard({{L->g_HvT, BC * H, "g_HvT"}, {L->g_Z, BC * 3, "g_Z"}, {L->g_xbar, (size_t)L->B * 4, "g_xbar"},
+                   {L->wg_node ? L->wg_node + 7 * rows * H : nullptr, rows * H, "wg_node[7..8)"}}))) return rc;
   if ((rc = graph_pre_backward(L, st, &wb))) return rc;
+  if ((rc = guard_edge())) return rc;
   if ((rc = edge_backward(L, st, &wb))) return rc;
   if ((rc = edge_col_reduce(L, st))) return rc;
+  if ((rc = guard_node_pre())) return rc;
   if ((rc = node_pre_backward(L, st, &wb))) return rc;
   return wb.finish();
 }

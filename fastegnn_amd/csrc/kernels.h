@@ -74,6 +74,10 @@ struct WgradBatch {
   int close_bundle();
   int add_slabs(float *dW, int lddw, int c0, int ks, float *db, int nsplit, int *slab_begin);
   int finish();
+  // The contractions are deferred to finish(): a job's operand rows must stay untouched until then.  A stage that is about
+  // to write `n` floats at `p` while the batch is open declares it here; an overlap with an operand of a queued job is an
+  // error (host-side check, no device work).
+  int guard_write(const float *p, size_t n, const char *what) const;
 };
 inline size_t wg_slab_floats() { return (size_t)WG_SLABS * (IMG + H); }
 //   dW[o*lddw + c0 + a] += sum_m G[m*ldg + o] * F[m*ldf + a],  a < kf <= 8

@@ -635,6 +635,25 @@ int WgradBatch::plan() {
   return FASTEGNN_OK;
 }
 
+int WgradBatch::guard_write(const float *p, size_t n, const char *what) const {
+  if (!p || n == 0) return FASTEGNN_OK;
+  const char *w0 = reinterpret_cast<const char *>(p), *w1 = w0 + n * sizeof(float);
+  for (int k = 0; k < tab.n_jobs; ++k) {
+    const WgJob &j = tab.job[k];
+    if (!j.G || j.M <= 0) continue;   // slab jobs have no operands
+    const size_t span_g = (size_t)(j.nb - 1) * (size_t)(j.sG > 0 ? j.sG : 0) + (size_t)(j.M - 1) * j.ldg + H;
+    const size_t span_t = (size_t)(j.nb - 1) * (size_t)(j.sT > 0 ? j.sT : 0) + (size_t)(j.M - 1) * j.ldt + H;
+    const char *g0 = reinterpret_cast<const char *>(j.G), *t0 = reinterpret_cast<const char *>(j.T);
+    const bool hit = (w0 < g0 + span_g * sizeof(float) && g0 < w1) || (w0 < t0 + span_t * sizeof(float) && t0 < w1);
+    if (hit) {
+      set_error(std::string("wgrad: a stage is about to overwrite ") + what + " while queued weight-gradient job " +
+                std::to_string(k) + " still has to read it (the contractions run at finish())");
+      return FASTEGNN_E_INVALID;
+    }
+  }
+  return FASTEGNN_OK;
+}
+
 // The FIRST jobs added to a batch may form the wave-parallel bundle (wgrad_bundle_kernel): <= 4 jobs with identical
 // M / nb / row split whose operands overlap.  Call after adding them, before any other add().
 int WgradBatch::close_bundle() {
@@ -1038,6 +1057,17 @@ int fastegnn_selftest_wgrad_plan(const int64_t *M, const int32_t *nb, int32_t n_
   for (int k = 0; k < n_jobs; ++k) nsplit_out[k] = wb.tab.job[k].nsplit;
   FE_REQUIRE(wb.n_slab <= wb.slab_top, "selftest_wgrad_plan: slab budget exceeded");
   return FASTEGNN_OK;
+}
+
+// Host-only: the overwrite guard of an open batch.  A job reading M rows of 64 floats at `base` (G) and at
+// base + 64 M (T) is queued; returns guard_write(base + probe_off, probe_n): 0 = disjoint, FASTEGNN_E_INVALID = overlap.
+int fastegnn_selftest_wgrad_guard(int64_t M, int64_t probe_off, int64_t probe_n) {
+  static float arena[4];
+  WgradBatch wb(arena, nullptr, false, 0, 64);
+  const float *base = reinterpret_cast<const float *>((uintptr_t)1 << 32);   // never dereferenced
+  int rc = wb.add(base, H, base + M * H, H, (long)M, arena, H, 0, 1, nullptr);
+  if (rc) return rc;
+  return wb.guard_write(base + probe_off, (size_t)probe_n, "the probe range");
 }
 
 int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW, float *db, float *slab,

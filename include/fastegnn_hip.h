@@ -418,6 +418,8 @@ int fastegnn_selftest_wgrad(const float *G, const float *T, int32_t M, float *dW
  * slabs_each caller-written slabs) under a split limit and a slab share; nsplit_out[k] = partial slabs per slice of job k */
 int fastegnn_selftest_wgrad_plan(const int64_t *M, const int32_t *nb, int32_t n_jobs, int32_t n_slab_jobs, int32_t slabs_each,
                                  int32_t max_split, int32_t slab_cap, int32_t *nsplit_out);
+/* Host-only self-test of the open batch's overwrite guard (a stage must not write what a queued, not yet contracted job reads) */
+int fastegnn_selftest_wgrad_guard(int64_t M, int64_t probe_off, int64_t probe_n);
 /* HBM streaming calibration: mode 0 reads src (n_floats, multiple of 4), 1 copies src -> dst, 2 writes dst */
 int fastegnn_selftest_stream(const float *src, float *dst, size_t n_floats, int32_t mode, void *stream);
 

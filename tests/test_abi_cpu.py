@@ -56,6 +56,22 @@ def test_silu_library_refuses_other_activation_kinds_before_any_device_call():
     assert b"bf16" in act.fastegnn_last_error()
 
 
+def test_open_weight_gradient_batch_guards_its_operands():
+    """the contractions of a layer run when the batch closes, so no later stage may write what a queued job
+    still reads.  The layer driver declares every stage's writes to the open batch; here the overlap test itself (host-only:
+    a job over rows [0, M) of G at `base` and of T at base + 64 M, probes around both)."""
+    L = K.lib()
+    M = 1000
+    assert L.fastegnn_selftest_wgrad_guard(M, 0, 1) == -1                      # first float of G
+    assert b"still has to read" in L.fastegnn_last_error()
+    assert L.fastegnn_selftest_wgrad_guard(M, 64 * M - 1, 1) == -1             # last float of G
+    assert L.fastegnn_selftest_wgrad_guard(M, 64 * M, 4) == -1                 # first floats of T
+    assert L.fastegnn_selftest_wgrad_guard(M, 2 * 64 * M - 1, 1) == -1         # last float of T
+    assert L.fastegnn_selftest_wgrad_guard(M, 2 * 64 * M, 1024) == 0           # just behind T
+    assert L.fastegnn_selftest_wgrad_guard(M, -4096, 4096) == 0                # just in front of G
+    assert L.fastegnn_selftest_wgrad_guard(M, -1, 2) == -1                     # straddles the start
+
+
 def test_struct_mirrors_and_sizes():
     L = K.lib()
     import ctypes as C
