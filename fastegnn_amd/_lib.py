@@ -59,7 +59,7 @@ class GraphT(C.Structure):
 class PadDesc(C.Structure):
     """fastegnn_pad_desc_t (include/fastegnn_hip.h)"""
     _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i32), ("cols", _i32), ("rows_dst", _i32), ("cols_dst", _i32),
-                ("nblk", _i32), ("blk", _i32 * 3)]
+                ("nblk", _i32), ("blk", _i32 * 3), ("lead", _i32), ("reserved", _i32)]
 
 
 _LAYER_PTRS_A = ["batch", "gptr", "ea_sorted", "vel", "node_attr", "params", "grads", "wpack",

@@ -51,7 +51,8 @@ struct PadTable {
 };
 // source column of padded column c (or -1: a zero of the padding)
 __device__ __forceinline__ int pad_src_col(const fastegnn_pad_desc_t &d, int h, int c) {
-  int os = 0, od = 0;
+  if (c < d.lead) return c;
+  int os = d.lead, od = d.lead;
   for (int b = 0; b < d.nblk; ++b) {
     const int wd = d.blk[b] / h * H;
     if (c < od + wd) return c - od < d.blk[b] ? os + (c - od) : -1;
@@ -61,7 +62,8 @@ __device__ __forceinline__ int pad_src_col(const fastegnn_pad_desc_t &d, int h, 
   return os + (c - od);
 }
 __device__ __forceinline__ int pad_dst_col(const fastegnn_pad_desc_t &d, int h, int c) {
-  int os = 0, od = 0;
+  if (c < d.lead) return c;
+  int os = d.lead, od = d.lead;
   for (int b = 0; b < d.nblk; ++b) {
     if (c < os + d.blk[b]) return od + (c - os);
     os += d.blk[b];
@@ -950,9 +952,9 @@ int fastegnn_pad_params(const fastegnn_pad_desc_t *desc, int32_t n, int32_t h, i
     long most = 0;
     for (int k = 0; k < tab.n; ++k) {
       const fastegnn_pad_desc_t &d = desc[k0 + k];
-      FE_REQUIRE(d.src && d.dst && d.rows >= 0 && d.cols >= 0 && d.rows_dst >= d.rows && d.nblk >= 0 && d.nblk <= 3,
+      FE_REQUIRE(d.src && d.dst && d.rows >= 0 && d.cols >= 0 && d.rows_dst >= d.rows && d.nblk >= 0 && d.nblk <= 3 && d.lead >= 0,
                  "pad_params: bad descriptor");
-      int cs = 0, cd = 0;
+      int cs = d.lead, cd = d.lead;
       for (int b = 0; b < d.nblk; ++b) {
         FE_REQUIRE(d.blk[b] >= 0 && d.blk[b] % h == 0, "pad_params: a block must be a multiple of hidden_nf columns");
         cs += d.blk[b];

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import _lib as K
-from .model import SortedGraph, _PtrTable, _carve, _fill, _new_layer, _stream
+from .model import SortedGraph, _PadParams, _PtrTable, _carve, _fill, _new_layer, _stream
 
 H = K.H
 
@@ -48,6 +48,29 @@ _SLOT_OF = {   # FASTEGNN_P_* slot name -> reference key suffix inside layers.<i
     "coord_mlp_vel.0.weight": "node_v_net.mlp.0.weight", "coord_mlp_vel.0.bias": "node_v_net.mlp.0.bias",
     "coord_mlp_vel.2.weight": "node_v_net.mlp.2.weight", "coord_mlp_vel.2.bias": "node_v_net.mlp.2.bias",
 }
+
+
+def _egnn_pad_layout(name: str, shape, h: int):
+    """64-wide image of a parameter of a ``hidden_nf = h < 64`` EGNN (same algebra as fastegnn_amd.model._pad_layout: zero
+    rows give zero pre-activations, SiLU(0) = 0, zero columns ignore their input).  Input blocks per models/basic.py:
+    message MLP on [radial | h_row | h_col | edge_fea] (:313, one leading non-hidden column), node_net on [h | agg] (:317),
+    the other first layers on one hidden vector; every first / second layer but the [1,H] heads has hidden-sized outputs."""
+    shape = tuple(shape)
+    mod, kind = name.rsplit(".", 1)
+    head = mod.endswith(("coord_net.mlp.2", "node_v_net.mlp.2"))           # [1, H] -> scalar
+    if kind == "bias":
+        return (1, shape[0], 1, [], shape) if head else (1, shape[0], 1, [h], (H,))
+    rows, cols = shape
+    if mod == "embedding":
+        blocks, lead = [], 0
+    elif mod.endswith("scalar_net.mlp.0"):
+        blocks, lead = [h, h], 1
+    elif mod.endswith("node_net.mlp.0"):
+        blocks, lead = [h, h], 0
+    else:
+        blocks, lead = [h], 0
+    rows_dst = rows if head else H
+    return rows, cols, rows_dst, blocks, (rows_dst, cols + sum(b // h * (H - h) for b in blocks)), lead
 
 
 class _EGNNFunction(torch.autograd.Function):
@@ -134,8 +157,10 @@ class EGNN(nn.Module):
     def __init__(self, n_layers, in_node_nf, in_edge_nf, hidden_nf, activation=nn.SiLU(), device='cpu', with_v=False,
                  flat=False, norm=False):
         super().__init__()
-        if hidden_nf != H or flat or not isinstance(activation, nn.SiLU):
-            raise NotImplementedError("fastegnn_amd.EGNN: hidden_nf=64, SiLU, flat=False only (flat=True means 256-wide Tanh MLPs)")
+        if not 1 <= hidden_nf <= H or flat or not isinstance(activation, nn.SiLU):
+            raise NotImplementedError("fastegnn_amd.EGNN: hidden_nf<=64 (narrower runs zero-padded), SiLU, flat=False only "
+                                      "(flat=True means 256-wide Tanh MLPs)")
+        self.hidden_nf = hidden_nf
         self.norm = bool(norm)
         if in_edge_nf > 7 or in_node_nf > 8:
             raise NotImplementedError("fastegnn_amd.EGNN: in_edge_nf<=7, in_node_nf<=8")
@@ -188,5 +213,10 @@ class EGNN(nn.Module):
             self._graph_cache[key] = graph
         ea_sorted = graph.permute(edge_fea.detach() if edge_fea is not None else None)
         vv = v if v is not None else torch.zeros_like(x)
-        x_out, h_out = _EGNNFunction.apply(self._spec, graph, ea_sorted, x, h, vv, *self._plist)
+        plist = self._plist
+        if self.hidden_nf < H:   # 64-wide images of the parameters (fastegnn_pad_params; the reverse mode slices the gradients back)
+            plist = list(_PadParams.apply(tuple(self._spec.names), self.hidden_nf, 0, _egnn_pad_layout, *plist))
+        x_out, h_out = _EGNNFunction.apply(self._spec, graph, ea_sorted, x, h, vv, *plist)
+        if self.hidden_nf < H:
+            h_out = h_out[:, :self.hidden_nf]     # the padded features are identically zero
         return (x_out, v, h_out) if v is not None else (x_out, h_out)

@@ -240,10 +240,11 @@ def _pad_layout(name: str, shape, h: int, C_: int, rf: bool):
     """The 64-wide image of a parameter of a ``hidden_nf = h < 64`` model: every hidden-sized row / column block is
     zero-extended to 64.  A zero row of a Linear gives a zero pre-activation, SiLU(0) = 0, and a zero column ignores
     its input, so the padded model computes exactly the reference's function (models/FastEGNN.py:28-99 with
-    hidden_nf = h).  Returns (rows, cols, rows_dst, blocks, out_shape): the parameter seen as a [rows, cols] matrix, the
-    padded row count, the source-column blocks that are widened to 64 per h columns (the hidden-sized pieces of the
-    reference's torch.cat inputs, FastEGNN.py:104,114,157,171; the remaining columns follow unchanged) and the shape
-    of the image.  tests/test_pad_cpu.py evaluates the oracle on images built from this layout."""
+    hidden_nf = h).  Returns (rows, cols, rows_dst, blocks, out_shape[, lead]): the parameter seen as a [rows, cols]
+    matrix, the padded row count, the source-column blocks that are widened to 64 per h columns (the hidden-sized pieces
+    of the reference's torch.cat inputs, FastEGNN.py:104,114,157,171; the remaining columns follow unchanged), the shape
+    of the image and -- EGNN only -- the unchanged columns in front of the blocks.  tests/test_pad_cpu.py evaluates the
+    oracle on images built from this layout."""
     shape = tuple(shape)
     if name == "virtual_node_feat":                       # [1, h, C]
         return h, shape[2], H, [], (1, H, shape[2])
@@ -296,7 +297,9 @@ class _PadParams(torch.autograd.Function):
     @staticmethod
     def _table(layouts, narrow, wide):
         tab = (K.PadDesc * len(layouts))()
-        for d, (rows, cols, rows_dst, blocks, out_shape), a, b in zip(tab, layouts, narrow, wide):
+        for d, lay, a, b in zip(tab, layouts, narrow, wide):
+            rows, cols, rows_dst, blocks, out_shape = lay[:5]
+            d.lead = lay[5] if len(lay) > 5 else 0
             d.src, d.dst = a.data_ptr(), b.data_ptr()
             d.rows, d.cols, d.rows_dst = rows, cols, rows_dst
             d.cols_dst = b.numel() // max(rows_dst, 1)
@@ -309,7 +312,8 @@ class _PadParams(torch.autograd.Function):
     def forward(ctx, names, h, C_, rf, *params):
         lib = K.lib()
         dev = params[0].device
-        layouts = [_pad_layout(n, p.shape, h, C_, rf) for n, p in zip(names, params)]
+        # rf: FastRF flag, or a layout function (name, shape, h) -> layout for another parameter naming (fastegnn_amd.egnn)
+        layouts = [(rf(n, p.shape, h) if callable(rf) else _pad_layout(n, p.shape, h, C_, rf)) for n, p in zip(names, params)]
         sizes = [(math.prod(l[4]) + 3) // 4 * 4 for l in layouts]      # 16-byte aligned pieces of one buffer
         flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
         outs, off = [], 0

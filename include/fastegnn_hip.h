@@ -271,7 +271,9 @@ int fastegnn_permute_rows(const float *in, const int32_t *perm, int32_t E, int32
  * models/FastEGNN.py:28-99 with hidden_nf = h).  One descriptor per parameter: `src` [rows, cols] row-major is copied into
  * `dst` [rows_dst, cols_dst] (zero elsewhere); the first `nblk` column blocks of blk[i] source columns each -- the
  * hidden-sized pieces of the reference's torch.cat inputs, FastEGNN.py:104,114,157,171 -- are widened to
- * blk[i] / h * 64 columns (zeros appended to the block), the remaining columns follow unchanged.  reverse != 0 runs the
+ * blk[i] / h * 64 columns (zeros appended to the block), the remaining columns follow unchanged; `lead` source columns
+ * in front of the first block are copied as they are (the radial column of the EGNN baseline's message MLP, basic.py:313).
+ * reverse != 0 runs the
  * adjoint: src[r, c] = dst[r, map(c)] (the gradient of the narrow parameter is the matching slice of the padded one).
  * `desc` is a HOST array; at most 64 descriptors travel per launch (kernel arguments, capturable into a HIP graph). */
 typedef struct {
@@ -281,6 +283,8 @@ typedef struct {
   int32_t rows_dst, cols_dst;
   int32_t nblk;
   int32_t blk[3];
+  int32_t lead;            /* unchanged columns in front of the blocks */
+  int32_t reserved;
 } fastegnn_pad_desc_t;
 int fastegnn_pad_params(const fastegnn_pad_desc_t *desc, int32_t n, int32_t h, int32_t reverse, void *stream);
 /* 1 when the library evaluates every FASTEGNN_ACT_* kind (libfastegnn_hip_act.so), 0 for the SiLU-only build */

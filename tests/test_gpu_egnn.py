@@ -65,3 +65,32 @@ def test_egnn_mid_size_vs_oracle():
     for k, prm in m.named_parameters():
         grad_check("egnn_mid_size", k, prm.grad, p[k].grad, p64[k].grad, bad)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("hidden", [24, 40])
+def test_egnn_narrow_hidden_nf_vs_oracle(hidden):
+    """--dim_hidden below 64 on the EGNN sibling (main_nbody.py:107): the parameters run zero-padded on the 64-wide tiles
+    (fastegnn_pad_params with the EGNN block layout: one leading radial column in the message MLP's input), the returned h
+    has the reference's width, gradients arrive in the reference's shapes."""
+    g = torch.Generator().manual_seed(11)
+    N, Ed = 900, 9000
+    torch.manual_seed(6)
+    m = fastegnn_amd.EGNN(n_layers=2, in_node_nf=2, in_edge_nf=2, hidden_nf=hidden, device="cuda", with_v=True)
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.named_parameters()}
+    x = torch.randn(N, 3, generator=g); h = torch.rand(N, 2, generator=g); v = torch.randn(N, 3, generator=g) * 0.2
+    ei = torch.randint(0, N, (2, Ed), generator=g); ea = torch.rand(Ed, 2, generator=g)
+    xo, vo, ho = m(x=x.cuda(), h=h.cuda(), edge_index=ei.cuda(), edge_fea=ea.cuda(), v=v.cuda())
+    assert ho.shape == (N, hidden)
+    (xo.pow(2).mean() + ho.pow(2).mean()).backward()
+    xr, hr = E.forward(p, 2, x, h, ei, ea, v)
+    (xr.pow(2).mean() + hr.pow(2).mean()).backward()
+    assert rel_err(xo, xr) < 1e-5 and rel_err(ho, hr) < 2e-5
+    dt = torch.float64
+    p64 = {k: t.detach().to(dt).clone().requires_grad_(True) for k, t in p.items()}
+    x64, h64 = E.forward(p64, 2, x.to(dt), h.to(dt), ei, ea.to(dt), v.to(dt))
+    (x64.pow(2).mean() + h64.pow(2).mean()).backward()
+    bad = []
+    for k, prm in m.named_parameters():
+        assert prm.grad is not None and prm.grad.shape == prm.shape, k
+        grad_check("egnn_narrow", k, prm.grad, p[k].grad, p64[k].grad, bad)
+    assert not bad, bad
