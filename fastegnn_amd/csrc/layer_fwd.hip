@@ -364,7 +364,7 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // LDS: images V2, WXV0, WXX0 | two W3c[c] stage slots | vectors | pools | Bc / Z rows of the graph in flight
 constexpr int VIRT_FWD_IMG_FLOATS = 5 * IMG3;
 inline size_t virt_fwd_lds_bytes(int C) {
-  return (size_t)(VIRT_FWD_IMG_FLOATS + VV_COUNT * H + 2 * (C * H + ((3 * C + 3) & ~3))) * sizeof(float);
+  return (size_t)(VIRT_FWD_IMG_FLOATS + VV_COUNT * H + 2 * (C * H + ((3 * C + 3) & ~3)) + 4) * sizeof(float);   // + 4 control words
 }
 template <int MODE>
 __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
@@ -377,6 +377,21 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   float *poolX_l = poolV_l + C * H;              // [3][C]
   float *Bc_l = poolX_l + ((3 * C + 3) & ~3);    // [C][64]: Bc rows of the graph the workgroup is in
   float *Z_l = Bc_l + C * H;                     // [3][C]: its virtual coordinates
+#ifdef VF_SPLIT_BARRIER
+  // measured alternative to the per-channel workgroup barrier: per stage slot a count of committed image shares and a count
+  // of waves that are done with the image (monotonic; a wave waits only for what it needs, at most one channel of skew)
+  int *ctl = reinterpret_cast<int *>(Z_l + ((3 * C + 3) & ~3));   // filled[2] | done[2]
+  if (threadIdx.x < 4) ctl[threadIdx.x] = 0;
+  int vf_steps = 0;   // staged steps this workgroup has completed (the same in every wave)
+  auto vf_signal = [&](int k) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane_id() == 0) atomicAdd(&ctl[k], 1);
+  };
+  auto vf_wait = [&](int k, int need) {
+    while (__atomic_load_n(&ctl[k], __ATOMIC_RELAXED) < need) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+#endif
   load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, C, I_V2), 3);
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) poolV_l[i] = 0.f;
@@ -454,12 +469,27 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
     if (staged) {
       __syncthreads();            // every wave is done with the stage (the previous step's node-level images)
       commit_w3c(0);
+#ifdef VF_SPLIT_BARRIER
+      vf_signal(0);
+#endif
       if (C > 1) fetch_w3c(1);
     }
     const int c_step = split ? VIRT_WAVES : 1;
     VF_T(8)   // tile head: row loads, bookkeeping
     for (int c = split ? wv : 0; c < C; c += c_step) {
-#ifndef VF_DIAG_NOSTAGE   // diagnostic: what do the per-channel stage refill and its barrier cost? (results are wrong without them)
+#if defined(VF_SPLIT_BARRIER)
+      if (staged) {
+        const int sl = c & 1, s1 = sl ^ 1, per0 = (C + 1) >> 1, per1 = C >> 1;
+        if (c + 1 < C) {
+          // every wave is done with channel c - 1 (the previous image of slot s1) ...
+          vf_wait(2 + s1, VIRT_WAVES * (vf_steps * (s1 ? per1 : per0) + ((c + 2 - s1) >> 1)));
+          commit_w3c(s1);           // ... this wave's share of W3c[c + 1]
+          vf_signal(s1);
+          if (c + 2 < C) fetch_w3c(c + 2);
+        }
+        vf_wait(sl, VIRT_WAVES * (vf_steps * (sl ? per1 : per0) + (c >> 1) + 1));   // every share of W3c[c] is in slot c & 1
+      }
+#elif !defined(VF_DIAG_NOSTAGE)   // diagnostic: what do the per-channel stage refill and its barrier cost? (results are wrong without them)
       if (staged) {
         __syncthreads();          // W3c[c] is in slot c & 1; every wave is done with channel c - 1, i.e. with the other slot
         if (c + 1 < C) {
@@ -506,7 +536,13 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
         }
         VF_T(7)   // node-MLP block product
       }
+#ifdef VF_SPLIT_BARRIER
+      if (staged) vf_signal(2 + (c & 1));   // this wave is done with the image of channel c
+#endif
     }
+#ifdef VF_SPLIT_BARRIER
+    if (staged) ++vf_steps;
+#endif
     if (split) {   // sum the waves' channel shares ([16][68] floats in the idle W3c stage)
       float *comb = reinterpret_cast<float *>(stage);
       __syncthreads();
