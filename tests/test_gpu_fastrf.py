@@ -124,3 +124,35 @@ def test_fastrf_narrow_hidden_nf_vs_oracle():
         assert got.shape == g64[k].shape
         grad_check("test_fastrf_narrow_hidden_nf_vs_oracle", k, got, g32[k], g64[k], bad)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("act,q,h", [("elu", 1.0, 64), ("tanh", 0.0, 24)])
+def test_fastrf_other_activation_vs_oracle(act, q, h):
+    """act_fn other than SiLU on the FastRF sibling (generic-activation library, FASTEGNN_F_RF wiring incl. its velocity head
+    on the 1-wide speed input), once together with zero-padded narrow parameters (Tanh(0) = 0)."""
+    from oracle import fastegnn_ref as R
+    from tests.gpu_util import act_module
+    from tests.test_gpu_properties import _batch
+    C = 3
+    cfg = R.Config(2, 0, 2, h, C, n_layers=2, gravity=[0, -1, 0], attention=True, act=act, act_param=q)
+    inp = _batch([300, 141], 5, C, seed=33)
+    torch.manual_seed(10)
+    m = fastegnn_amd.FastRF(2, 0, 2, h, C, device="cuda", n_layers=2, gravity=[0, -1, 0], attention=True, act_fn=act_module(cfg))
+    tgt = inp["node_loc"] + 0.5
+    loc, vloc = m(**{k: v.cuda() for k, v in inp.items()})
+    (torch.nn.functional.mse_loss(loc, tgt.cuda()) + 0.05 * vloc.pow(2).mean()).backward()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        p = {k: v.detach().cpu().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+        ii = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in inp.items()}
+        l, v = RF.forward(p, cfg, **ii)
+        (torch.nn.functional.mse_loss(l, tgt.to(dt)) + 0.05 * v.pow(2).mean()).backward()
+        res[dt] = (l.detach(), v.detach(), {k: (t.grad if t.grad is not None else torch.zeros_like(t)) for k, t in p.items()})
+    l32, v32, g32 = res[torch.float32]
+    _, _, g64 = res[torch.float64]
+    assert rel_err(loc, l32) < OUT_TOL and rel_err(vloc, v32) < OUT_TOL
+    bad = []
+    for k, prm in m.named_parameters():
+        got = prm.grad.cpu() if prm.grad is not None else torch.zeros_like(prm).cpu()
+        grad_check(f"act_mid_fastrf_{act}_attention", k, got, g32[k], g64[k], bad)
+    assert not bad, bad
