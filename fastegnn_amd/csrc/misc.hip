@@ -392,8 +392,13 @@ __device__ __forceinline__ void wg_accumulate_x3(const float *G, const float *T,
 }
 
 __global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_tn_kernel(WgTable tab) {
-  // 40 KB of staging tiles; the 64x64 reduction buffer aliases them after the main loop
+  // staged form: 40 KB of staging tiles, the 64x64 reduction buffer aliases them after the main loop; default form: the
+  // four waves' partial tiles (64 KB)
+#if defined(FE_WG_STAGED)
   __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 16 * WTS];
+#else
+  __shared__ __attribute__((aligned(16))) float smem[4 * IMG];
+#endif
   __shared__ float redb[H];
   float *red = smem;
   // locate the job of this workgroup (the wave-parallel bundle, if any, is served by wgrad_bundle_kernel)
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_tn_kernel(WgTable tab) {
   if (a.round) wg_accumulate_x3<true>(G, T, a.ldg, a.ldt, m0 + 32 * w, m1, 128, want_bias, acc, bsum);
   else wg_accumulate_x3<false>(G, T, a.ldg, a.ldt, m0 + 32 * w, m1, 128, want_bias, acc, bsum);
 #endif
+#if defined(FE_WG_STAGED) || defined(FE_WG_ATOMIC_EPILOGUE)
   __syncthreads();   // all waves are done with their staging tiles
   for (int k = threadIdx.x; k < IMG; k += 256) red[k] = 0.f;
   __syncthreads();
@@ -459,6 +465,37 @@ __global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_tn_kernel(WgTable tab) {
   const f32x4 *src = reinterpret_cast<const f32x4 *>(red);
   for (int k = threadIdx.x; k < IMG / 4; k += 256) dst[k] = src[k];
   if (threadIdx.x < H) tab.slab_b[sidx * H + threadIdx.x] = redb[threadIdx.x];
+#else
+  // The four waves' 64x64 partials are added in a FIXED order (wave 0 + 1 + 2 + 3): every wave parks its accumulator in
+  // LDS in register order (sixteen 16-byte stores per lane, conflict-free), then thread t sums fragment tiles 4 (t / 64) ..
+  // + 3 of lane t % 64 and stores them into the slab.  (Until late round 3 every lane added its 256 values to one shared
+  // tile with LDS float atomics -- 1 024 64-lane atomics per workgroup, a third of the kernel's wave time by the counters,
+  // and an order-dependent sum.)
+  (void)red;
+  f32x4 *part = reinterpret_cast<f32x4 *>(smem) + (size_t)w * (IMG / 4);
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tk = 0; tk < 4; ++tk) part[(ti * 4 + tk) * 64 + l] = acc[ti][tk];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    float s = qsum(bsum[ti]);
+    if (q == 0) atomicAdd(&redb[16 * ti + i], s);   // 64 values per wave: the bias sums keep their atomics
+  }
+  __syncthreads();
+  // slab order: [job slabs][batch][split] so that the reducer walks splits contiguously
+  const size_t sidx = (size_t)a.slab_begin + (size_t)bidx * a.nsplit + split;
+  float *dst = tab.slab + sidx * IMG;
+  const f32x4 *p0 = reinterpret_cast<const f32x4 *>(smem);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = w * 4 + u, ti = k >> 2, tk = k & 3;
+    const f32x4 v = ((p0[k * 64 + l] + p0[IMG / 4 + k * 64 + l]) + p0[2 * (IMG / 4) + k * 64 + l]) + p0[3 * (IMG / 4) + k * 64 + l];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(16 * ti + 4 * q + r) * H + 16 * tk + i] = v[r];
+  }
+  if (threadIdx.x < H) tab.slab_b[sidx * H + threadIdx.x] = redb[threadIdx.x];
+#endif
 }
 
 // Wave-parallel bundle: up to four jobs of the SAME geometry (M, nb, strides, row split) that share operand rows --
