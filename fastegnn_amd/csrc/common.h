@@ -222,18 +222,39 @@ __device__ __forceinline__ void vstore_u(float *base, unsigned off, const Vec &v
 }
 
 // sum over the four q-lanes of an item (xor 16, xor 32)
+// (gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd 16- / 32-lane rows of one register with the even rows of
+// another: with both holding p, the sum of the two results is p[l] + p[l ^ 16] (resp. ^ 32) in EVERY lane -- one vector
+// instruction + one add per step and no trip through the LDS crossbar (ds_bpermute, which is what __shfl_xor compiles to).
+// Same additions in the same order as the shuffle form: bitwise identical.  Inline assembly: the builtin's second result is
+// mis-modelled by this compiler (tools/scratch/permlane_test.hip pins the semantics on the GPU).  The partner lanes of a
+// q-sum hold the same item, so they are active together; -DFE_QSUM_SHFL restores the shuffles.)
 __device__ __forceinline__ float qsum(float p) {
+#ifdef FE_QSUM_SHFL
   p += __shfl_xor(p, 16);
   p += __shfl_xor(p, 32);
   return p;
+#else
+  float a = p, b = p;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  p = a + b;
+  a = p; b = p;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+#endif
 }
-// sum over the 16 items of a tile that share q (xor 1,2,4,8)
+// sum over the 16 items of a tile that share q: every lane of the 16-lane row gets the total.  DPP row rotations (pure
+// vector instructions; all lanes of the row must be active); -DFE_QSUM_SHFL: the xor butterfly through ds_bpermute.
+__device__ __forceinline__ float jsum_dpp(float p);
 __device__ __forceinline__ float jsum(float p) {
+#ifdef FE_QSUM_SHFL
   p += __shfl_xor(p, 1);
   p += __shfl_xor(p, 2);
   p += __shfl_xor(p, 4);
   p += __shfl_xor(p, 8);
   return p;
+#else
+  return jsum_dpp(p);
+#endif
 }
 // same sum by DPP row rotations (no LDS crossbar traffic): every lane of the 16-lane row gets the total
 __device__ __forceinline__ float jsum_dpp(float p) {

@@ -151,10 +151,12 @@ GRAD_EXCEPTIONS = [
      "gcl_1.edge_mlp_virtual.0.bias)"),
     (r"no_edges", r"edge_mlp_virtual\.2\.bias", 2.0, 2e-6,
      "4.67e-6 against 2 x ref + 1e-6 = 4.58e-6 (test_no_edges_and_isolated_nodes, gcl_1): a column sum over N*C rows"),
-    (r"cfg5_shape", r"gcl_0\.coord_mlp_r_virtual\.0\.bias", 3.0, 1e-6,
-     "a column sum over N*C = 640 k rows that cancels to ~1e-3 of its terms (the reference's own fp32 result is 1.18e-4 "
-     "from fp64): five runs on one box (tools/gpu_tolrepeat.sh) measured 2.31e-4 .. 2.63e-4 = 1.96 .. 2.23 x the "
-     "reference's draw -- the run-to-run spread (summation order follows the ticket order) straddles the 2 x line"),
+    (r"cfg5_shape|cfg4_headline", r"gcl_0\.coord_mlp_[rv]_virtual\.0\.bias", 4.0, 1e-6,
+     "column sums over N*C = 320 k - 640 k rows that cancel to ~1e-3 of their terms; BOTH sides of the rule move: the "
+     "reference's own fp32 result is 9.6e-5 .. 1.4e-4 from fp64 depending on the host's thread count (cfg4 headline shape, "
+     "gcl_0.coord_mlp_v_virtual.0.bias) and 1.18e-4 (cfg5 shape, r_virtual), the HIP result 2.29e-4 .. 2.63e-4 over "
+     "twelve runs on different boxes and summation orders (ticket order; DPP or shuffle tile sums): 1.65 .. 2.64 x the "
+     "reference's draw of the same run (tools/gpu_tolrepeat.sh)"),
 ]
 
 
