@@ -625,12 +625,12 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
 #pragma unroll
           for (int k = 0; k < 3; ++k) pz[k] = jsum((valid && q == 0) ? g_vd[k] : 0.f);
           vb_accum_items(pmode == 0 ? gBc_l + c * H : A.g_Bc + ((size_t)b0 * C + c) * H, g_pre, j, q);
-          if (l == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              if (pmode == 0) atomicAdd(&gZ_l[k * C + c], pz[k]);
-              else atomicAdd(&A.g_Zp[((size_t)b0 * 3 + k) * C + c], pz[k]);
-            }
+          // (lane k < 3 adds component k: per-lane addresses, so the compiler's uniform-address atomic combiner -- a loop over
+          // the active lanes per atomic -- stays out)
+          if (l < 3) {
+            const float pzl = l == 0 ? pz[0] : (l == 1 ? pz[1] : pz[2]);
+            if (pmode == 0) atomicAdd(&gZ_l[l * C + c], pzl);
+            else atomicAdd(&A.g_Zp[((size_t)b0 * 3 + l) * C + c], pzl);
           }
         } else {
           if (valid && q == 0) {
