@@ -144,6 +144,7 @@ def lib(act: bool = False):
     L.fastegnn_selftest_gemm.argtypes = [_vp, _vp, _vp, _i32, _vp]
     L.fastegnn_selftest_rm.argtypes = [_vp, _vp, _vp, _i32, _i32, _vp]
     L.fastegnn_selftest_jreduce.argtypes = [_vp, _vp, _vp]
+    L.fastegnn_selftest_lane_sums.argtypes = [_vp, _vp, _vp]
     L.fastegnn_selftest_chain.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _vp]
     L.fastegnn_selftest_chain_bf3.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
     L.fastegnn_selftest_wgrad.argtypes = [_vp, _vp, _i32, _vp, _vp, _vp, _vp]
@@ -192,7 +193,7 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_wg_edge_floats", "fastegnn_wg_virt_floats", "fastegnn_wg_virt_floats_for", "fastegnn_backward_scratch_floats_for", "fastegnn_wg_node_floats", "fastegnn_backward_scratch_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes", "fastegnn_chunk_rows", "fastegnn_chunk_edges",
     "fastegnn_build_csr", "fastegnn_pad_params", "fastegnn_generic_activations", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
-    "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_rm", "fastegnn_selftest_jreduce", "fastegnn_selftest_wgrad", "fastegnn_selftest_wgrad_plan", "fastegnn_selftest_wgrad_guard", "fastegnn_selftest_stream", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
+    "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_rm", "fastegnn_selftest_jreduce", "fastegnn_selftest_lane_sums", "fastegnn_selftest_wgrad", "fastegnn_selftest_wgrad_plan", "fastegnn_selftest_wgrad_guard", "fastegnn_selftest_stream", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
     "fastegnn_augment_edge_attr", "fastegnn_loss_mse_mmd", "fastegnn_adam_step",
     "fastegnn_radius_graph_ws_bytes", "fastegnn_radius_graph_count", "fastegnn_radius_graph_fill",
     "fastegnn_cutoff_tmp_bytes", "fastegnn_cutoff_edges", "fastegnn_nbody_cutoff_edges",

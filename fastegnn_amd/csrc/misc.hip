@@ -880,6 +880,12 @@ __global__ __launch_bounds__(64) void selftest_rm_kernel(const float *W, const f
 }
 
 // jreduce16 (common.h): out[q*16 + j] = sum over the 16 items of a quarter-row q of X[item][16 (j >> 2) + 4 q + (j & 3)]
+// lane l: out[l] = qsum(X[l]) (over the four lanes l % 16 + 16 q), out[64 + l] = jsum(X[l]) (over the 16 lanes of its row)
+__global__ __launch_bounds__(64) void selftest_lane_sums_kernel(const float *X, float *out) {
+  const float x = X[threadIdx.x];
+  out[threadIdx.x] = qsum(x);
+  out[64 + threadIdx.x] = jsum(x);
+}
 __global__ __launch_bounds__(64) void selftest_jreduce_kernel(const float *X, float *out) {
   const int l = lane_id(), j = l & 15, q = l >> 4;
   const Vec v = vload_row(X + j * H, q);
@@ -1028,6 +1034,12 @@ int fastegnn_selftest_gemm(const float *W, const float *X, float *Y, int32_t tra
   FE_REQUIRE(W && X && Y, "selftest_gemm: null pointer");
   hipLaunchKernelGGL(selftest_gemm_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, W, X, Y, transposed);
   return check_launch("selftest_gemm_kernel");
+}
+
+int fastegnn_selftest_lane_sums(const float *X, float *out, void *stream) {
+  FE_REQUIRE(X && out, "selftest_lane_sums: null pointer");
+  hipLaunchKernelGGL(selftest_lane_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, X, out);
+  return check_launch("selftest_lane_sums_kernel");
 }
 
 int fastegnn_selftest_jreduce(const float *X, float *out, void *stream) {

@@ -408,6 +408,9 @@ int fastegnn_selftest_rm(const float *W, const float *X, float *Y, int32_t trans
 /* transposing tile sum of the backward kernels (common.h jreduce16): X one 16x64 tile; out[16 q + j] = sum over the 16
  * rows of X[row][16 (j >> 2) + 4 q + (j & 3)] */
 int fastegnn_selftest_jreduce(const float *X, float *out, void *stream);
+/* X [64] -> out [128]: the kernels' cross-lane sums of one wave: out[l] = sum over the lanes l % 16 + 16 q (v_permlane16_swap /
+ * v_permlane32_swap), out[64 + l] = sum over the 16 lanes of l's row (DPP rotations) */
+int fastegnn_selftest_lane_sums(const float *X, float *out, void *stream);
 /* `iters` dependent 64x64 MFMA layers per wave (mode bit0: SiLU between layers, bit1: image from
  * global memory instead of LDS); out receives one 16x64 tile.  Calibrates the MFMA building block. */
 int fastegnn_selftest_chain(const float *wimg, float *out, int32_t iters, int32_t mode, int32_t waves, int32_t grid,

@@ -117,3 +117,17 @@ def test_transposing_tile_sum_jreduce16():
     col = X.sum(0).cpu()
     want = torch.tensor([col[16 * (j >> 2) + 4 * q + (j & 3)] for q in range(4) for j in range(16)])
     assert torch.equal(out.cpu(), want)
+
+
+def test_cross_lane_sums_of_a_wave():
+    """common.h qsum (v_permlane16_swap / v_permlane32_swap, inline assembly) and jsum (DPP row rotations): exact on integer
+    data, every lane checked -- the <v, w> of every fused kernel ends in them."""
+    L = K.lib()
+    g = torch.Generator().manual_seed(6)
+    X = torch.randint(-100000, 100000, (64,), generator=g).float()
+    out = torch.empty(128, device="cuda")
+    K.check(L.fastegnn_selftest_lane_sums(K.ptr(X.cuda()), K.ptr(out), None), "selftest_lane_sums")
+    q = X.view(4, 16).sum(0)                    # lanes l % 16 + 16 q
+    j = X.view(4, 16).sum(1)                    # the 16 lanes of a row
+    want = torch.cat([q.repeat(4), j.repeat_interleave(16)])
+    assert torch.equal(out.cpu(), want)
