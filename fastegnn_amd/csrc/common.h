@@ -618,8 +618,19 @@ __device__ __forceinline__ bf16x8 rm_frag(const char *img, int part, int t, int 
     hi = lds_tr_read(p + 16 * RM_RS);
   } else {
     const char *p = img + part * RM_PART + (16 * t + i) * RM_RS + (32 * s + 4 * q) * 2;
+#ifdef FE_RM_READ2
     lo = *reinterpret_cast<const u32x2 *>(p);
     hi = *reinterpret_cast<const u32x2 *>(p + 32);
+#else
+    // Two ds_read_b64 (conflict-free on the 144-byte rows, 2 LDS cycles each).  As plain loads the compiler fuses them --
+    // and the loads of neighbouring fragments -- into ds_read2_b64, which is banked modulo 32 dwords: rows i and i + 8 of
+    // a 16-lane group then collide (2-way) and the instruction runs at half the rate; the counters showed a third of the
+    // backward kernels' LDS cycles as bank conflicts.  Volatile accesses are not merged (and stay under the compiler's
+    // own s_waitcnt bookkeeping, unlike inline assembly).
+    typedef __attribute__((address_space(3))) const volatile u32x2 *lds_vu32x2;
+    lo = *(lds_vu32x2)(p);
+    hi = *(lds_vu32x2)(p + 32);
+#endif
   }
   return __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
 }
