@@ -56,9 +56,9 @@ def _inputs():
     return inp, target
 
 
-def _model(gravity):
+def _model(gravity, hidden=64):
     torch.manual_seed(7)
-    m = fastegnn_amd.FastEGNN(CFG["node_feat_nf"], 0, CFG["edge_attr_nf"], 64, CFG["virtual_channels"],
+    m = fastegnn_amd.FastEGNN(CFG["node_feat_nf"], 0, CFG["edge_attr_nf"], hidden, CFG["virtual_channels"],
                               n_layers=CFG["n_layers"], gravity=gravity)
     with torch.no_grad():
         for k, v in m.named_parameters():
@@ -71,13 +71,13 @@ def _loss(loc_rows, vloc, target_rows, n_total):
     return ((loc_rows - target_rows) ** 2).sum() / (3 * n_total) + 0.1 * vloc.pow(2).mean()
 
 
-def _worker(rank, world, port, gravity, exchange, reorder, q):
+def _worker(rank, world, port, gravity, exchange, reorder, q, hidden=64):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     init_from_env("gloo")
     inp, target = _inputs()
-    m = _model(gravity)
-    cfg = R.Config(**CFG, gravity=gravity)
+    m = _model(gravity, hidden)
+    cfg = R.Config(**CFG, gravity=gravity)      # the stages see the 64-wide (zero-padded) parameters
     spec_names = None
     be = CpuOracleBackend(spec_names, CFG["n_layers"], cfg)
     sm = ShardedFastEGNN(m, backend=be, exchange=exchange)
@@ -93,14 +93,17 @@ def _worker(rank, world, port, gravity, exchange, reorder, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,gravity,exchange,reorder", [
-    (2, None, "halo", False), (2, [0, -1, 0], "allgather", False), (2, [0, -1, 0], "halo", True),
-    (4, [0, -1, 0], "halo", False), (4, None, "halo", True), (4, None, "allgather", True)])
-def test_sharded_graph_matches_single_process_oracle(world, gravity, exchange, reorder):
+@pytest.mark.parametrize("world,gravity,exchange,reorder,hidden", [
+    (2, None, "halo", False, 64), (2, [0, -1, 0], "allgather", False, 64), (2, [0, -1, 0], "halo", True, 64),
+    (4, [0, -1, 0], "halo", False, 64), (4, None, "halo", True, 64), (4, None, "allgather", True, 64),
+    (2, [0, -1, 0], "halo", True, 24)])
+def test_sharded_graph_matches_single_process_oracle(world, gravity, exchange, reorder, hidden):
+    """(hidden 24: the ranks pad the parameters to the stages' 64-wide tiles -- the pad op of the backend -- and the padded
+    gradients are sliced back before the all-reduce; the single-process oracle runs at the true width)"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, gravity, exchange, reorder, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, gravity, exchange, reorder, q, hidden)) for r in range(world)]
     for pr in procs:
         pr.start()
     res = [q.get(timeout=240) for _ in range(world)]
@@ -109,8 +112,8 @@ def test_sharded_graph_matches_single_process_oracle(world, gravity, exchange, r
         assert pr.exitcode == 0
     # single-process oracle
     inp, target = _inputs()
-    m = _model(gravity)
-    cfg = R.Config(**CFG, gravity=gravity)
+    m = _model(gravity, hidden)
+    cfg = R.Config(**{**CFG, "hidden_nf": hidden}, gravity=gravity)
     p = {k: v.detach().clone().requires_grad_(True) for k, v in m.named_parameters()}
     loc, vloc = R.forward(p, cfg, **inp)
     _loss(loc, vloc, target, target.size(0)).backward()
