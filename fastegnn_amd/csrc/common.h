@@ -521,17 +521,14 @@ __device__ __forceinline__ void gemm64_x3_t2(const unsigned *img3, const Vec &v,
   const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + lane_id();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    float x[8], r1[8];
+    float x[8];
     u32x4 ph, pm;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      x[e] = v.t[2 * s + (e >> 2)][e & 3];
-      r1[e] = x[e] - trunc_bf(x[e]);
-    }
+    for (int e = 0; e < 8; ++e) x[e] = v.t[2 * s + (e >> 2)][e & 3];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      ph[w] = pack_hi(x[2 * w], x[2 * w + 1]);
-      pm[w] = pack_hi(r1[2 * w], r1[2 * w + 1]);
+    for (int w = 0; w < 4; ++w) {   // (part_pack: the rounding mode of the three-part split, nearest since late round 3)
+      ph[w] = part_pack(x[2 * w], x[2 * w + 1]);
+      pm[w] = part_pack(x[2 * w], x[2 * w + 1]);
     }
     const bf16x8 xh = __builtin_bit_cast(bf16x8, ph), xm = __builtin_bit_cast(bf16x8, pm);
 #pragma unroll
