@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SAFE_WAITS = os.environ.get("FASTEGNN_SAFE_WAITS", "0") not in ("", "0")
 LIB_PATH = os.path.join(_HERE, "libfastegnn_hip_safe.so" if SAFE_WAITS else "libfastegnn_hip.so")
 
+ABI_VERSION = 101   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
 H = 64
 QX_LD = 68
 FEATW = 8
@@ -100,6 +101,9 @@ def lib(act: bool = False):
         raise RuntimeError(f"fastegnn_amd: {path} is not the {'generic-activation' if act else 'SiLU'} build")
     L.fastegnn_last_error.restype = C.c_char_p
     L.fastegnn_version.restype = C.c_int
+    if L.fastegnn_version() != ABI_VERSION:
+        raise RuntimeError(f"fastegnn_amd: {path} has ABI revision {L.fastegnn_version()}, this binding expects "
+                           f"{ABI_VERSION} -- rebuild with `make -C fastegnn_amd/csrc`")
     L.fastegnn_wpack_floats.restype = C.c_size_t
     L.fastegnn_wpack_floats.argtypes = [_i32]
     L.fastegnn_csr_tmp_bytes.restype = C.c_size_t

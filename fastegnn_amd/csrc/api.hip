@@ -111,7 +111,7 @@ extern "C" int fastegnn_generic_activations(void) {
 extern "C" {
 
 const char *fastegnn_last_error(void) { return g_last_error.c_str(); }
-int fastegnn_version(void) { return 100; }
+int fastegnn_version(void) { return FASTEGNN_ABI_VERSION; }
 size_t fastegnn_wpack_floats(int32_t C) { return wpack_floats(C); }
 size_t fastegnn_wg_slab_floats(void) { return wg_slab_floats(); }
 size_t fastegnn_sizeof_layer(void) { return sizeof(fastegnn_layer_t); }

@@ -1369,7 +1369,13 @@ extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { (void)E; return (size_t)2
 // largest size any wiring needs (the FastRF / C > 32 form of B4 materialises five operand arrays); the _for variants
 // take the layer's flags: the FastEGNN wiring with C <= 32 keeps v and Gv only (+ the per-group parts of g_A / g_x).
 extern "C" size_t fastegnn_wg_virt_floats(int32_t N, int32_t C) {
-  const size_t n = (size_t)5 * ((size_t)(N > 0 ? N : 0) + fe::WGV_PAD) * (size_t)(C > 0 ? C : 0) * fe::H;
+  size_t n = (size_t)5 * ((size_t)(N > 0 ? N : 0) + fe::WGV_PAD) * (size_t)(C > 0 ? C : 0) * fe::H;
+  // the producer / consumer form carries constant terms (part tiles, consumer scratch: ~36 MB at C = 16) that exceed the
+  // five-array size on small shards: the flag-less query is the maximum over both forms
+  if (C >= 1 && C <= 32) {
+    const size_t pc = fe::virt_pc_wg_floats((size_t)(N > 0 ? N : 0), (size_t)C);
+    if (pc > n) n = pc;
+  }
   return n > 4 ? n : 4;
 }
 extern "C" size_t fastegnn_wg_virt_floats_for(int32_t N, int32_t C, int32_t flags) {

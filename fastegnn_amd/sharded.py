@@ -65,8 +65,8 @@ class HipBackend:
     def wg_edge_floats(self, E):
         return self.lib.fastegnn_wg_edge_floats(E)
 
-    def wg_virt_floats(self, N, Cn):
-        return self.lib.fastegnn_wg_virt_floats(N, Cn)
+    def wg_virt_floats(self, N, Cn, flags=0):
+        return self.lib.fastegnn_wg_virt_floats_for(N, Cn, flags)
 
     def wg_node_floats(self, N, B, Cn):
         return self.lib.fastegnn_wg_node_floats(N, B, Cn)
@@ -523,7 +523,7 @@ class _ShardedFunction(torch.autograd.Function):
         g_vel = be.zeros(N, 3)
         sc = be.carve(dict(g_poolV=(B, Cn, H), g_poolX=(B, 3, Cn), g_xbar=(B, 4), g_A=(N, H), g_P=(N, H),
                            g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,), g_QXe=(max(E, 1) if spec.flags & K.F_DETERMINISTIC else 1, K.QX_LD),
-                           g_xrow=(N, 3), wg_edge=(be.wg_edge_floats(E),), wg_virt=(be.wg_virt_floats(N, Cn),),
+                           g_xrow=(N, 3), wg_edge=(be.wg_edge_floats(E),), wg_virt=(be.wg_virt_floats(N, Cn, spec.flags),),
                            wg_node=(be.wg_node_floats(N, B, Cn),), wg_slab=(be.wg_slab_floats(),)))
         nV = B * Cn * H
         gpools = be.empty(nV + B * 3 * Cn)                                 # g_Bc | g_Zp adjacent: one all-reduce

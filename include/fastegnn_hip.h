@@ -219,13 +219,18 @@ typedef struct {
   float *g_xrow;              /* [N,3]   row-side d/dx of the edge stage */
   float *wg_edge;             /* [fastegnn_wg_edge_floats(E)] weight-gradient operands of the edge stage (none when the
                                * edge backward contracts them inside the workgroup: 4 floats then) */
-  float *wg_virt;             /* [fastegnn_wg_virt_floats(N,C)]   weight-gradient operands of the virtual stage */
+  float *wg_virt;             /* [fastegnn_wg_virt_floats_for(N,C,flags)] weight-gradient operands of the virtual stage */
   float *wg_node;             /* [fastegnn_wg_node_floats(N,B,C)] node-level weight-gradient operands */
   float *wg_slab;             /* [fastegnn_wg_slab_floats()] partial 64x64 slabs of the weight-gradient GEMMs */
 } fastegnn_layer_t;
 
 /* ---- library ---- */
 const char *fastegnn_last_error(void);
+/* ABI revision: FASTEGNN_ABI_VERSION of the header the library was built from.  It changes whenever the layout of
+ * fastegnn_layer_t / fastegnn_graph_t or the meaning of an argument changes (round 3 inserted act_param: 100 -> 101).
+ * A binding MUST compare it with the FASTEGNN_ABI_VERSION it was written against AND check fastegnn_sizeof_layer() /
+ * fastegnn_sizeof_graph() against its own mirror of the descriptors before the first call (fastegnn_amd/_lib.py does). */
+#define FASTEGNN_ABI_VERSION 101
 int fastegnn_version(void);
 /* floats of the packed weight-image buffer for C virtual channels */
 size_t fastegnn_wpack_floats(int32_t C);
@@ -235,8 +240,9 @@ size_t fastegnn_wg_edge_floats(int32_t E);
 size_t fastegnn_wg_virt_floats(int32_t N, int32_t C);
 size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C);
 /* wg_virt for a layer with these FASTEGNN_F_* flags: the FastEGNN wiring with C <= 32 contracts three of the virtual
- * stage's weight gradients inside the workgroup and keeps two [C][N+16][64] arrays instead of five; the flag-less
- * query above is the upper bound over all wirings */
+ * stage's weight gradients inside the workgroup and keeps ONE [C][N+16][64] array plus constant-size part tiles and
+ * consumer scratch (~36 MB at C = 16) instead of five arrays; the flag-less query above returns the maximum over both
+ * forms, i.e. an upper bound for every wiring and every N (on small shards the constant terms dominate) */
 size_t fastegnn_wg_virt_floats_for(int32_t N, int32_t C, int32_t flags);
 /* floats of all backward scratch arrays of fastegnn_layer_t together (g_poolV ... wg_slab), each array rounded up to
  * a multiple of 4 floats so that one allocation can be carved into 16-byte aligned pieces */
