@@ -393,6 +393,12 @@ def main():
                     help="N>1: 'sharded' = ONE batch partitioned over the ranks (strong scaling; default for cfg4/cfg5), "
                          "'dp' = one batch per rank + gradient all-reduce (weak scaling; default for cfg1..cfg3)")
     ap.add_argument("--sharded", action="store_true", help="same as --mode sharded (also at 1 GPU: the staged C entry points)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="1 GPU only: this process plays ONE rank (--emulate-rank) of a W-rank partition of the frame -- its rows and "
+                         "edges, the interior / boundary split, the pack / unpack kernels and byte counts of its halo, device copies "
+                         "in the place of the xGMI transfers: the compute and fixed costs of a 1/W shard, measured (implies --sharded; "
+                         "`value` is then the rate of THAT shard's step, an upper bound of the W-GPU job's rate)")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--dtype", choices=["auto", "f32", "bf16"], default="auto",
                     help="MLP operand type: bf16 = bf16 operands / fp32 accumulate (default for cfg3), f32 otherwise")
     ap.add_argument("--cpu-baseline", choices=["auto", "full", "scaled", "none"], default="auto",
@@ -435,6 +441,10 @@ def main():
     cfg = CONFIGS[args.config]
     C, L = args.channels or cfg["C"], args.layers
     mode = args.mode
+    if args.emulate_world:
+        if world != 1:
+            raise SystemExit("--emulate-world needs --gpus 1")
+        args.sharded = True
     if args.sharded:
         mode = "sharded"
     if mode == "auto":
@@ -466,7 +476,7 @@ def main():
     stats = None
     if sharded:
         from fastegnn_amd.sharded import CommStats, ShardedFastEGNN
-        smodel = ShardedFastEGNN(model)
+        smodel = ShardedFastEGNN(model, emulate=(args.emulate_world, args.emulate_rank) if args.emulate_world else None)
         # nodes sorted along a Morton curve first (a Water-3D loader would do this once per frame): contiguous index
         # ranges are compact regions, so the halo exchange moves the shell of a region, not the whole table
         shard = smodel.shard_inputs(**frame, reorder=True)   # this rank's rows and edges; the full COO is dropped below
@@ -692,6 +702,13 @@ def main():
             out["collectives"] = stats.summary(args.steps)
         if sharded:
             pl = shard["plan"]
+            out["launches_per_step"] = sum(v["launches_per_step"] for v in kernels.values())
+            out["shard"] = {"rows": pl.nloc, "edges": kE, "edge_stage_launch_ranges": [
+                {"first_row": r0, "rows": n, "waits_for_halo": bool(h)} for r0, n, h in pl.parts],
+                "transport": os.environ.get("FASTEGNN_COMM", "torch"),
+                "emulated_rank_of_world": [args.emulate_rank, args.emulate_world] if args.emulate_world else None}
+            if args.emulate_world:
+                out["metric"] += f" -- ONE emulated rank of {args.emulate_world} (its shard's step on one GPU, no xGMI transfers)"
             out["table_exchange"] = {"mode": pl.mode, "rows_received_per_exchange": pl.exchanged_bytes() // (68 * 4),
                                      "bytes_received_per_exchange": pl.exchanged_bytes(),
                                      "all_gather_bytes_for_comparison": (world - 1) * pl.Npad * 68 * 4,

@@ -14,13 +14,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SAFE_WAITS = os.environ.get("FASTEGNN_SAFE_WAITS", "0") not in ("", "0")
 LIB_PATH = os.path.join(_HERE, "libfastegnn_hip_safe.so" if SAFE_WAITS else "libfastegnn_hip.so")
 
-ABI_VERSION = 101   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
+ABI_VERSION = 102   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
 H = 64
 QX_LD = 68
 FEATW = 8
 
 # flags (fastegnn_hip.h)
 F_ATTENTION, F_NORMALIZE, F_TANH, F_RESIDUAL, F_GRAVITY, F_COORDS_SUM, F_EGNN, F_RF, F_BF16, F_EGNN_NORM = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+F_GQX_ACCUM = 32768   # edge_backward scatters into g_QX_src without zeroing it (second launch of a layer; include/fastegnn_hip.h)
 F_DETERMINISTIC = 1024   # backward: per-edge rows + CSC reduce instead of the atomic scatter (include/fastegnn_hip.h)
 
 
@@ -68,7 +69,7 @@ _LAYER_PTRS_A = ["batch", "gptr", "ea_sorted", "vel", "node_attr", "params", "gr
                  "P", "QX", "QX_src", "A", "svel", "sgrav", "xsum", "Bc", "aggm", "aggx", "npre", "poolV", "poolX",
                  "g_h_out", "g_x_out", "g_Z_out", "g_HvT_out", "g_h", "g_x", "g_Z", "g_HvT", "g_vel", "g_ea_sorted", "g_node_attr",
                  "g_poolV", "g_poolX", "g_Bc", "g_Zp", "g_xbar", "g_A", "g_P", "g_aggm", "g_aggx",
-                 "g_svel", "g_sgrav", "g_QXe", "g_QX_src", "g_QX", "g_xrow", "wg_edge", "wg_virt", "wg_node", "wg_slab"]
+                 "g_svel", "g_sgrav", "g_QXe", "g_QX_src", "g_QX", "g_xrow", "wg_edge", "wg_virt", "wg_node", "wg_slab", "wgrad_batch"]
 
 
 class LayerT(C.Structure):
@@ -168,6 +169,8 @@ def lib(act: bool = False):
     L.fastegnn_gather_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_scatter_add_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_wg_slab_floats.restype = C.c_size_t
+    L.fastegnn_wgrad_batch_open.argtypes = [C.POINTER(LayerT), _vp, C.POINTER(_vp)]
+    L.fastegnn_wgrad_batch_close.argtypes = [_vp]
     L.fastegnn_sizeof_layer.restype = C.c_size_t
     L.fastegnn_sizeof_graph.restype = C.c_size_t
     if L.fastegnn_sizeof_layer() != C.sizeof(LayerT) or L.fastegnn_sizeof_graph() != C.sizeof(GraphT):
@@ -205,6 +208,7 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_comm_unique_id_bytes", "fastegnn_comm_unique_id", "fastegnn_comm_init", "fastegnn_comm_destroy", "fastegnn_comm_rank",
     "fastegnn_comm_world", "fastegnn_comm_all_reduce", "fastegnn_comm_all_gather", "fastegnn_comm_reduce_scatter",
     "fastegnn_comm_all_to_all_v", "fastegnn_gather_rows", "fastegnn_scatter_add_rows",
+    "fastegnn_wgrad_batch_open", "fastegnn_wgrad_batch_close",
 ]
 
 

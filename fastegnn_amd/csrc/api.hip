@@ -81,6 +81,43 @@ static int check_layer(const fastegnn_layer_t *L, const char *who) {
   return FASTEGNN_OK;
 }
 
+
+// The jobs a backward stage queues into a shared batch are contracted when the batch closes: no later stage may write what
+// they still have to read.  The arrays each stage writes (its outputs in fastegnn_layer_t and its region of the wg_*
+// workspaces, kernels.h) are checked against the operands queued so far -- host-side pointer arithmetic, no device work
+// (ADVICE round 2).  Used by fastegnn_layer_backward and by the staged entry points when L->wgrad_batch is set.
+enum GuardStage { G_GRAPH_POST, G_VIRT, G_GRAPH_PRE, G_EDGE, G_NODE_PRE };
+static int guard_stage(const fastegnn_layer_t *L, const WgradBatch &wb, int stage) {
+  const size_t N = (size_t)L->N, BC = (size_t)L->B * L->C, rows = wg_node_rows(L), E = (size_t)L->graph.n_edges;
+  const bool det = has(L, FASTEGNN_F_DETERMINISTIC);
+  struct W { const float *p; size_t n; const char *what; };
+  auto guard = [&](std::initializer_list<W> ws) {
+    for (const W &w : ws) {
+      const int r = wb.guard_write(w.p, w.n, w.what);
+      if (r) return r;
+    }
+    return (int)FASTEGNN_OK;
+  };
+  switch (stage) {
+    case G_VIRT:
+      return guard({{L->g_h, N * H, "g_h"}, {L->g_x, N * 3, "g_x"}, {L->g_A, N * H, "g_A"}, {L->g_aggm, N * H, "g_aggm"},
+                    {L->g_aggx, N * 3, "g_aggx"}, {L->g_svel, N, "g_svel"}, {L->g_sgrav, N, "g_sgrav"}, {L->g_Bc, BC * H, "g_Bc"},
+                    {L->g_Zp, BC * 3, "g_Zp"}, {L->wg_node, 2 * rows * H, "wg_node[0..2)"},
+                    {L->wg_virt, L->wg_virt ? fastegnn_wg_virt_floats_for(L->N, L->C, L->flags) : 0, "wg_virt"}});
+    case G_GRAPH_PRE:
+      return guard({{L->g_HvT, BC * H, "g_HvT"}, {L->g_Z, BC * 3, "g_Z"}, {L->g_xbar, (size_t)L->B * 4, "g_xbar"},
+                    {L->wg_node ? L->wg_node + 7 * rows * H : nullptr, rows * H, "wg_node[7..8)"}});
+    case G_EDGE:
+      return guard({{L->g_P, N * H, "g_P"}, {L->g_xrow, N * 3, "g_xrow"}, {det ? L->g_QXe : nullptr, E * QXLD, "g_QXe"},
+                    {L->g_QX_src, (size_t)L->graph.n_src * QXLD, "g_QX_src"},
+                    {L->wg_edge, fastegnn_wg_edge_floats(L->graph.n_edges), "wg_edge"}});
+    case G_NODE_PRE:
+      return guard({{L->g_h, N * H, "g_h"}, {L->g_x, N * 3, "g_x"}, {L->g_vel, N * 3, "g_vel"},
+                    {L->wg_node ? L->wg_node + 2 * rows * H : nullptr, 2 * rows * H, "wg_node[2..4)"}});
+    default: return FASTEGNN_OK;
+  }
+}
+
 }  // namespace fe
 
 using namespace fe;
@@ -101,11 +138,13 @@ extern "C" int fastegnn_generic_activations(void) {
   }
 
 // backward stages with weight gradients: the staged entry point contracts and reduces its own jobs
-#define STAGE_B(name, fn)                                             \
+#define STAGE_B(name, fn, gid)                                        \
   int name(const fastegnn_layer_t *L, void *stream) {                 \
     int rc = check_layer(L, #name);                                   \
     if (rc) return rc;                                                \
-    return fn(L, (hipStream_t)stream, nullptr);                       \
+    WgradBatch *wb = static_cast<WgradBatch *>(L->wgrad_batch);       \
+    if (wb && (rc = guard_stage(L, *wb, gid))) return rc;             \
+    return fn(L, (hipStream_t)stream, wb);                            \
   }
 
 extern "C" {
@@ -124,12 +163,27 @@ STAGE(fastegnn_graph_pre_forward, graph_pre_forward)
 STAGE(fastegnn_edge_forward, edge_forward)
 STAGE(fastegnn_virt_forward, virt_forward)
 STAGE(fastegnn_graph_post_forward, graph_post_forward)
-STAGE_B(fastegnn_graph_post_backward, graph_post_backward)
-STAGE_B(fastegnn_virt_backward, virt_backward)
-STAGE_B(fastegnn_graph_pre_backward, graph_pre_backward)
-STAGE_B(fastegnn_edge_backward, edge_backward)
+STAGE_B(fastegnn_graph_post_backward, graph_post_backward, G_GRAPH_POST)
+STAGE_B(fastegnn_virt_backward, virt_backward, G_VIRT)
+STAGE_B(fastegnn_graph_pre_backward, graph_pre_backward, G_GRAPH_PRE)
+STAGE_B(fastegnn_edge_backward, edge_backward, G_EDGE)
 STAGE(fastegnn_edge_col_reduce, edge_col_reduce)
-STAGE_B(fastegnn_node_pre_backward, node_pre_backward)
+STAGE_B(fastegnn_node_pre_backward, node_pre_backward, G_NODE_PRE)
+
+int fastegnn_wgrad_batch_open(const fastegnn_layer_t *L, void *stream, void **batch) {
+  FE_REQUIRE(L && batch && L->wg_slab, "fastegnn_wgrad_batch_open: null argument");
+  WgradBatch *wb = new WgradBatch(L->wg_slab, (hipStream_t)stream, has(L, FASTEGNN_F_BF16));
+  wb->max_split = 384;   // as fastegnn_layer_backward: node-level jobs and the edge stage's slabs share 4096 slabs
+  *batch = wb;
+  return FASTEGNN_OK;
+}
+int fastegnn_wgrad_batch_close(void *batch) {
+  if (!batch) return FASTEGNN_OK;
+  WgradBatch *wb = static_cast<WgradBatch *>(batch);
+  const int rc = wb->finish();
+  delete wb;
+  return rc;
+}
 
 int fastegnn_profile_enable(int32_t on) {
   g_prof_on = on != 0;
@@ -183,33 +237,9 @@ int fastegnn_layer_backward(const fastegnn_layer_t *L, void *stream) {
   // up to eight node-level jobs of N rows + the edge stage's 2 x 256 slabs share the lower half of the slab workspace
   // (4096 slabs): 384 partial slabs per job at most (at cfg4 sizes a job takes 256 anyway)
   wb.max_split = 384;
-  // The jobs queued by a stage are contracted at wb.finish(): no later stage may write what they still have to read.  The
-  // arrays each stage writes (its outputs in fastegnn_layer_t and its region of the wg_* workspaces, kernels.h) are checked
-  // against the operands queued so far -- host-side pointer arithmetic, no device work.
-  const size_t N = (size_t)L->N, BC = (size_t)L->B * L->C, rows = wg_node_rows(L), E = (size_t)L->graph.n_edges;
-  struct W { const float *p; size_t n; const char *what; };
-  auto guard = [&](std::initializer_list<W> ws) {
-    for (const W &w : ws) {
-      const int r = wb.guard_write(w.p, w.n, w.what);
-      if (r) return r;
-    }
-    return (int)FASTEGNN_OK;
-  };
-  const bool det = has(L, FASTEGNN_F_DETERMINISTIC);
-  auto guard_virt = [&]() {
-    return guard({{L->g_h, N * H, "g_h"}, {L->g_x, N * 3, "g_x"}, {L->g_A, N * H, "g_A"}, {L->g_aggm, N * H, "g_aggm"},
-                  {L->g_aggx, N * 3, "g_aggx"}, {L->g_svel, N, "g_svel"}, {L->g_sgrav, N, "g_sgrav"}, {L->g_Bc, BC * H, "g_Bc"},
-                  {L->g_Zp, BC * 3, "g_Zp"}, {L->wg_node, 2 * rows * H, "wg_node[0..2)"},
-                  {L->wg_virt, L->wg_virt ? fastegnn_wg_virt_floats_for(L->N, L->C, L->flags) : 0, "wg_virt"}});
-  };
-  auto guard_edge = [&]() {
-    return guard({{L->g_P, N * H, "g_P"}, {L->g_xrow, N * 3, "g_xrow"}, {det ? L->g_QXe : nullptr, E * QXLD, "g_QXe"},
-                  {L->g_QX_src, (size_t)L->graph.n_src * QXLD, "g_QX_src"}, {L->wg_edge, fastegnn_wg_edge_floats(L->graph.n_edges), "wg_edge"}});
-  };
-  auto guard_node_pre = [&]() {
-    return guard({{L->g_h, N * H, "g_h"}, {L->g_x, N * 3, "g_x"}, {L->g_vel, N * 3, "g_vel"},
-                  {L->wg_node ? L->wg_node + 2 * rows * H : nullptr, 2 * rows * H, "wg_node[2..4)"}});
-  };
+  auto guard_virt = [&]() { return guard_stage(L, wb, G_VIRT); };
+  auto guard_edge = [&]() { return guard_stage(L, wb, G_EDGE); };
+  auto guard_node_pre = [&]() { return guard_stage(L, wb, G_NODE_PRE); };
   if (has(L, FASTEGNN_F_EGNN)) {
     if ((rc = guard_virt())) return rc;
     if ((rc = virt_backward(L, st, &wb))) return rc;
@@ -223,8 +253,7 @@ int fastegnn_layer_backward(const fastegnn_layer_t *L, void *stream) {
   if ((rc = graph_post_backward(L, st, &wb))) return rc;
   if ((rc = guard_virt())) return rc;
   if ((rc = virt_backward(L, st, &wb))) return rc;
-  if ((rc = guard({{L->g_HvT, BC * H, "g_HvT"}, {L->g_Z, BC * 3, "g_Z"}, {L->g_xbar, (size_t)L->B * 4, "g_xbar"},
-                   {L->wg_node ? L->wg_node + 7 * rows * H : nullptr, rows * H, "wg_node[7..8)"}}))) return rc;
+  if ((rc = guard_stage(L, wb, G_GRAPH_PRE))) return rc;
   if ((rc = graph_pre_backward(L, st, &wb))) return rc;
   if ((rc = guard_edge())) return rc;
   if ((rc = edge_backward(L, st, &wb))) return rc;

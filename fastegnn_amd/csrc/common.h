@@ -725,16 +725,137 @@ __device__ __forceinline__ u32x4 round8(const float (&x)[8]) {
   return r;
 }
 
+// ---- 2-way fp16 split ("f16x2") of the FORWARD kernels' products (-DFE_FWD_F16=mask) -------------
+// x = h + l / 2^11 with h = fp16(x) (RNE) and l = fp16((x - h) * 2^11): the residual is exact in fp32, 11 + 11 significant
+// bits and a signed residual leave |x - h - l / 2^11| <= 2^-23 of x's binade (one bit short of fp32) down to |x| = 2^-14;
+// below that the absolute error is <= 2^-36.  One fp32 product becomes THREE fp16 products -- (l_w, h_x) and (h_w, l_x) into
+// an accumulator that carries the 2^11, folded into the result by one fma per output element, then (h_w, h_x); the dropped
+// (l, l) term is <= 2^-24 of |w||x| -- where bf16x3 needs six, and the operand split is 2.5 vector instructions per element
+// (v_cvt_pk_f16_f32, v_fma_mix_f32 for the residual straight from the packed half, v_fma_mixlo/hi_f16 for the scaled low
+// part) where the three-part bf16 split needs 5.5.  fp16 carries 5 exponent bits: operands must stay below 65 504 --
+// activations and weights do, gradients (1e-9 and below on the headline frame) do not, which is why only the forward
+// kernels have this form.  Images: the img3 layout with part 0 = h and part 1 = l (part 2 unused).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F2_UP = 2048.f, F2_DOWN = 1.0f / 2048.f;
+struct Split2 {
+  u32x4 p[2][2];   // [part h | l][k-step] : 8 fp16 per lane
+};
+// packed fp16 parts of the pair (a0 low half, a1 high half)
+__device__ __forceinline__ void part2_pack(float a0, float a1, unsigned &ph, unsigned &pl) {
+  const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, f16x2));
+  float r0, r1;
+  // r = a - float(h): src0 is read as the low / high half of the packed pair (op_sel_hi: f16 source, op_sel: which half)
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(a0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(a1));
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(l) : "v"(r0), "v"(r1), "s"(F2_UP));
+  ph = h;
+  pl = l;
+}
+// word (two fp16) of an f16x2 image: elements k0 (low half), k0 + 1 (high half) of part 0 (h) or 1 (l)
+__device__ __forceinline__ unsigned split2_word(float w0, float w1, int part) {
+  unsigned h, l;
+  part2_pack(w0, w1, h, l);
+  return part == 0 ? h : l;
+}
+__device__ __forceinline__ Split2 vsplit2(const Vec &v) {
+  Split2 S;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int e = 2 * w;
+      unsigned ph, pl;
+      part2_pack(v.t[2 * s + (e >> 2)][e & 3], v.t[2 * s + ((e + 1) >> 2)][(e + 1) & 3], ph, pl);
+      S.p[0][s][w] = ph;
+      S.p[1][s][w] = pl;
+    }
+  return S;
+}
+// acc += W x on an f16x2 image (img3 layout, parts h | l).  Output tile by output tile: the two cross products of both
+// k-steps into a 4-register accumulator, one fma per element folds it (scaled by 2^-11) into acc, then the (h, h) products.
+__device__ __forceinline__ void gemm64_f2(const unsigned *img3, const Split2 &in, Vec &acc) {
+  const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + lane_id();
+  const f16x8 xh0 = __builtin_bit_cast(f16x8, in.p[0][0]), xh1 = __builtin_bit_cast(f16x8, in.p[0][1]);
+  const f16x8 xl0 = __builtin_bit_cast(f16x8, in.p[1][0]), xl1 = __builtin_bit_cast(f16x8, in.p[1][1]);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f16x8 ah0 = __builtin_bit_cast(f16x8, ip[(t * 2 + 0) * 64]), ah1 = __builtin_bit_cast(f16x8, ip[(t * 2 + 1) * 64]);
+    const f16x8 al0 = __builtin_bit_cast(f16x8, ip[512 + (t * 2 + 0) * 64]), al1 = __builtin_bit_cast(f16x8, ip[512 + (t * 2 + 1) * 64]);
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, xh0, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xl0, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, xh1, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xl1, lo, 0, 0, 0);
+    f32x4 hi = acc.t[t];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hi[r] = __builtin_fmaf(lo[r], F2_DOWN, hi[r]);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh0, hi, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh1, hi, 0, 0, 0);
+    acc.t[t] = hi;
+  }
+}
+
+// -DFE_LOG2E_FOLD=mask (bit 0: edge_fwd): log2(e) folded into the packed weights.  silu(z) = z / (1 + exp2(-z log2 e)) spends one
+// of its five vector instructions on the argument scale; a pre-activation that comes out of an in-kernel product can arrive
+// in units of ln 2 instead (z2 = z log2 e: the image of that product and its bias are pre-scaled), silu2(z2) = z2 / (1 + exp2(-z2))
+// = silu(z) log2 e needs no scale, and the factor rides along: the NEXT product takes the scaled activation with unscaled
+// weights and a scaled bias, head vectors and the aggregation's 1/deg absorb 1 / log2 e.  The scaled image is split from the
+// double-precision product w * log2(e), so no weight is rounded twice.
+#ifndef FE_LOG2E_FOLD
+#define FE_LOG2E_FOLD 0
+#endif
+constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
+constexpr double LOG2E_D = 1.4426950408889634074;
+__device__ __forceinline__ float silu2_f(float z2) { return z2 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z2)); }
+__device__ __forceinline__ Vec vsilu2(const Vec &a) { return vmap(a, [](float z) { return silu2_f(z); }); }
+// word of a split image from two DOUBLE values (a scaled weight): parts as part_pack / part2_pack make them, the residuals
+// taken in double
+__device__ __forceinline__ unsigned split_word_d(double w0, double w1, int part, bool f16) {
+  unsigned out = 0;
+  double r[2] = {w0, w1};
+  if (f16) {
+    for (int e = 0; e < 2; ++e) {
+      const _Float16 h = (_Float16)(float)r[e];
+      const _Float16 l = (_Float16)(float)((r[e] - (double)(float)h) * (double)F2_UP);
+      const unsigned short bits = __builtin_bit_cast(unsigned short, part == 0 ? h : l);
+      out |= (unsigned)bits << (16 * e);
+    }
+    return part < 2 ? out : 0u;
+  }
+  for (int e = 0; e < 2; ++e) {
+    unsigned short bits = 0;
+    for (int k = 0; k <= part; ++k) {
+      const __bf16 b = (__bf16)(float)r[e];
+      bits = __builtin_bit_cast(unsigned short, b);
+      r[e] -= (double)(float)b;
+    }
+    out |= (unsigned)bits << (16 * e);
+  }
+  return out;
+}
+
+// Which forward kernels run on f16x2 images (bit 0 edge_fwd, bit 1 virt_fwd, bit 2 node_pre_fwd); pack_kernel writes the
+// split images those kernels read (and only they read) in the matching format.
+#ifndef FE_FWD_F16
+#define FE_FWD_F16 0
+#endif
 // Arithmetic form of the 64x64 layers of a kernel (template parameter of the stage kernels)
-enum GemmMode { GM_F32 = 0, GM_X3 = 1, GM_BF16 = 2 };
+enum GemmMode { GM_F32 = 0, GM_X3 = 1, GM_BF16 = 2, GM_F16 = 3 };
+constexpr int GM_EDGE_FWD = (FE_FWD_F16 & 1) ? GM_F16 : GM_X3;
+constexpr int GM_VIRT_FWD = (FE_FWD_F16 & 2) ? GM_F16 : GM_X3;
+constexpr int GM_NODE_PRE_FWD = (FE_FWD_F16 & 4) ? GM_F16 : GM_X3;
 // the B operand of one or several products in the chosen form: made once, used by every layer that reads it
 template <int MODE> struct OperandOf { typedef Vec type; };
 template <> struct OperandOf<GM_X3> { typedef Split type; };
 template <> struct OperandOf<GM_BF16> { typedef BfOp type; };
+template <> struct OperandOf<GM_F16> { typedef Split2 type; };
 template <int MODE>
 __device__ __forceinline__ typename OperandOf<MODE>::type make_operand(const Vec &v) {
   if constexpr (MODE == GM_X3) return vsplit(v);
   else if constexpr (MODE == GM_BF16) return vpack_bf(v);
+  else if constexpr (MODE == GM_F16) return vsplit2(v);
   else return v;
 }
 // image i of a resident image array (fp32 images for GM_F32, split images otherwise)
@@ -742,6 +863,7 @@ template <int MODE>
 __device__ __forceinline__ void gemm_op(const void *img, int i, const typename OperandOf<MODE>::type &in, Vec &acc) {
   if constexpr (MODE == GM_X3) gemm64_x3(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
   else if constexpr (MODE == GM_BF16) gemm64_b1(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
+  else if constexpr (MODE == GM_F16) gemm64_f2(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
   else gemm64(reinterpret_cast<const float *>(img) + i * IMG, in, acc);
 }
 // a product on an fp32 image (fp32-input MFMA) inside a kernel of form MODE: in bf16 mode the activation is rounded
@@ -792,6 +914,13 @@ enum ImgId {
   I_FIXED,                                               // then W3c[0..C) and W3cT[0..C)
 };
 __host__ __device__ inline int img_w3c(int c) { return I_FIXED + c; }
+// split image `id` is written as an f16x2 image (parts h | l, FE_FWD_F16) instead of the bf16 h | m | l parts
+__host__ __device__ inline bool img_is_f16(int id, int C) {
+  if (id == I_W2 || id == I_WX1) return (FE_FWD_F16 & 1) != 0;
+  if (id == I_V2 || id == I_WXV0 || id == I_WXX0 || (id >= I_FIXED && id < I_FIXED + C)) return (FE_FWD_F16 & 2) != 0;
+  if (id >= I_W1A && id <= I_WG0) return (FE_FWD_F16 & 4) != 0;
+  return false;
+}
 __host__ __device__ inline int img_w3ct(int C, int c) { return I_FIXED + C + c; }
 // wpack = [fp32 images n x 4096 floats][split images n x IMG3 words (h | m | l)][row-major split images (5 + C) x RM_WORDS]
 // row-major images: slot 0 V2, 1 WXV0, 2 WXX0 (virt_bwd), 3 W2, 4 WX1 (edge_bwd), 5 WVEL0, 6 WG0 (node_pre_bwd),

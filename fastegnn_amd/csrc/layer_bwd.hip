@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
     // virt_bwd.hip).  The running sum lives in a scratch tile of this wave in accumulator order (sixteen 16-byte
     // read-modify-writes per lane, L2 resident); the [o][k] slab is written once, at the end.
     f32x4 *sc = reinterpret_cast<f32x4 *>(A.cons_scratch + ((size_t)blockIdx.x * 2 + ckind) * IMG) + l;
-    float bs_tot[4] = {0.f, 0.f, 0.f, 0.f};
+    double bs_tot[4] = {0., 0., 0., 0.};   // bias column sums: fp32 between two flushes, double across them (virt_bwd.hip)
     bool flushed = false;
     int done = 0, since = 0;
     while (done < total) {
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
               *d = accA[ti][tk2];
               accA[ti][tk2] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            bs_tot[ti] += bsA[ti];
+            bs_tot[ti] += (double)bsA[ti];
             bsA[ti] = 0.f;
           }
           flushed = true;
@@ -1105,8 +1105,10 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       }
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
-      const float s0 = qsum(bs_tot[ti] + bsA[ti]);
-      if (q == 0) A.slab_b[sl * H + 16 * ti + j] = s0;
+      double s0 = bs_tot[ti] + (double)bsA[ti];
+      s0 += __shfl_xor(s0, 16);
+      s0 += __shfl_xor(s0, 32);
+      if (q == 0) A.slab_b[sl * H + 16 * ti + j] = (float)s0;
     }
   }
   if (!consumer && r0 < r1) {
@@ -1310,7 +1312,9 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
   const bool det = has(L, FASTEGNN_F_DETERMINISTIC);   // store + CSC reduce instead of the atomic scatter
   FE_REQUIRE(det ? L->g_QXe != nullptr : L->g_QX_src != nullptr, "edge_backward: g_QXe (deterministic) / g_QX_src null");
   const fastegnn_graph_t &gr = L->graph;
-  if (!det && gr.n_src > 0) (void)hipMemsetAsync(L->g_QX_src, 0, (size_t)gr.n_src * QXLD * sizeof(float), st);
+  FE_REQUIRE(!(det && has(L, FASTEGNN_F_GQX_ACCUM)), "edge_backward: FASTEGNN_F_GQX_ACCUM needs the atomic scatter");
+  if (!det && gr.n_src > 0 && !has(L, FASTEGNN_F_GQX_ACCUM))
+    (void)hipMemsetAsync(L->g_QX_src, 0, (size_t)gr.n_src * QXLD * sizeof(float), st);
   if (gr.n_edges == 0 || L->N == 0) {   // nothing to walk (with edges the kernel writes every row of g_P / g_xrow)
     (void)hipMemsetAsync(L->g_P, 0, (size_t)L->N * H * sizeof(float), st);
     (void)hipMemsetAsync(L->g_xrow, 0, (size_t)L->N * 3 * sizeof(float), st);

@@ -103,7 +103,7 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
   {
     ProfScope _ps_node_pre_fwd_kernel(K_NODE_PRE_FWD, st);
     if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL(node_pre_fwd_kernel<GM_BF16>, dim3(grid), dim3(64 * NODE_PRE_WAVES), lds, st, a);
-    else hipLaunchKernelGGL(node_pre_fwd_kernel<GM_X3>, dim3(grid), dim3(64 * NODE_PRE_WAVES), lds, st, a);
+    else hipLaunchKernelGGL(node_pre_fwd_kernel<GM_NODE_PRE_FWD>, dim3(grid), dim3(64 * NODE_PRE_WAVES), lds, st, a);
   }
   return check_launch("node_pre_fwd_kernel");
 }
@@ -240,7 +240,8 @@ __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs 
   float *vec = lds + EDGE_FWD_IMG_FLOATS;        // EV_COUNT vectors
   float *tiles = vec + EV_COUNT * H;             // per wave: [16][TS] + [16][4]
   load_images_x3(reinterpret_cast<unsigned *>(img), wpack_x3(a.wpack, C, I_W2), 2);
-  edge_load_vecs(vec, a);
+  constexpr bool FOLD = edge_fold<false, MODE, false>();   // S.m arrives as log2(e) x the message: 1/deg absorbs the factor
+  edge_load_vecs(vec, a, FOLD);
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
   float *mt = tiles + wv * (16 * TS + 64);
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs 
       int cnt = 0;   // edges of the current row seen so far == its in-degree at flush time (rows never straddle waves)
       auto flush = [&]() {
         const float inv = rcp_f((float)cnt);
-        a.aggm[(size_t)cur * H + l] = acc * inv;
+        a.aggm[(size_t)cur * H + l] = acc * (FOLD ? inv * LN2_F : inv);
         if (l < 3) a.aggx[(size_t)cur * 3 + l] = mean ? accx * inv : accx;
       };
       // rows without edges inside this wave's range get their zeros here (no memset of aggm / aggx ahead of the kernel):
@@ -349,7 +350,7 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
   {
     ProfScope _ps_edge_fwd_kernel(K_EDGE_FWD, st);
     if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL(edge_fwd_kernel<GM_BF16>, dim3(grid), dim3(64 * EDGE_FWD_WAVES), lds, st, a, L->C);
-    else hipLaunchKernelGGL(edge_fwd_kernel<GM_X3>, dim3(grid), dim3(64 * EDGE_FWD_WAVES), lds, st, a, L->C);
+    else hipLaunchKernelGGL(edge_fwd_kernel<GM_EDGE_FWD>, dim3(grid), dim3(64 * EDGE_FWD_WAVES), lds, st, a, L->C);
   }
   return check_launch("edge_fwd_kernel");
 }
@@ -660,7 +661,7 @@ int virt_forward(const fastegnn_layer_t *L, hipStream_t st) {
     ProfScope _ps_virt_fwd_kernel(K_VIRT_FWD, st);
     const size_t lds = virt_fwd_lds_bytes(L->C);
     if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL(virt_fwd_kernel<GM_BF16>, dim3(grid), dim3(64 * VIRT_WAVES), lds, st, a);
-    else hipLaunchKernelGGL(virt_fwd_kernel<GM_X3>, dim3(grid), dim3(64 * VIRT_WAVES), lds, st, a);
+    else hipLaunchKernelGGL(virt_fwd_kernel<GM_VIRT_FWD>, dim3(grid), dim3(64 * VIRT_WAVES), lds, st, a);
   }
   return check_launch("virt_fwd_kernel");
 }

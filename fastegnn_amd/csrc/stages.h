@@ -36,15 +36,18 @@ struct EdgeArgs {
 
 constexpr int EV_WR = 0, EV_WE = 1, EV_B2 = 9, EV_BX1 = 10, EV_WX2 = 11, EV_ATT = 12, EV_COUNT = 13;
 
-__device__ __forceinline__ void edge_load_vecs(float *vec, const EdgeArgs &a) {
+// fold: the forward kernel's log2(e) fold (common.h, FE_LOG2E_FOLD): biases of the two in-kernel products in units of ln 2,
+// the vectors that read their activations divided by log2(e)
+__device__ __forceinline__ void edge_load_vecs(float *vec, const EdgeArgs &a, bool fold = false) {
   const int ld = 2 * H + 1 + a.ea_dim;
+  const float up = fold ? LOG2E_F : 1.f, dn = fold ? LN2_F : 1.f;
   for (int i = threadIdx.x; i < H; i += blockDim.x) {
     vec[EV_WR * H + i] = a.E0W[(size_t)i * ld + ((a.flags & FASTEGNN_F_EGNN) ? 0 : 2 * H)];
     for (int k = 0; k < 8; ++k) vec[(EV_WE + k) * H + i] = k < a.ea_dim ? a.E0W[(size_t)i * ld + 2 * H + 1 + k] : 0.f;
-    vec[EV_B2 * H + i] = a.b2[i];
-    vec[EV_BX1 * H + i] = a.bx1[i];
-    vec[EV_WX2 * H + i] = a.wx2[i];
-    vec[EV_ATT * H + i] = a.attw ? a.attw[i] : 0.f;
+    vec[EV_B2 * H + i] = a.b2[i] * up;
+    vec[EV_BX1 * H + i] = a.bx1[i] * up;
+    vec[EV_WX2 * H + i] = a.wx2[i] * dn;
+    vec[EV_ATT * H + i] = a.attw ? a.attw[i] * dn : 0.f;
   }
 }
 
@@ -167,9 +170,19 @@ __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *ve
   FE_T(1)   // gathered rows arrived, pre-activation formed
 }
 // part 2: the two 64x64 layers and the coordinate head
+// does this instantiation run with the log2(e) fold?  (the forward kernel in an fp32-grade form of the SiLU build only)
+template <bool KEEP_D, int MODE, bool RM>
+constexpr bool edge_fold() {
+#ifdef FE_ACT_GENERIC
+  return false;
+#else
+  return !KEEP_D && !RM && (MODE == GM_X3 || MODE == GM_F16) && (FE_LOG2E_FOLD & 1) != 0;
+#endif
+}
 template <bool KEEP_D, int MODE = GM_F32, bool RM = false>
 __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img, const float *vec, int q, EdgeFwdState &S,
                                               Vec &pre FE_TP) {
+  constexpr bool FOLD = edge_fold<KEEP_D, MODE, RM>();   // S.mp, S.m0, S.m, S.up, S.u are then log2(e) x their values
   S.t = KEEP_D ? vsilu_keep_d(pre FE_ACT(a)) : vsilu(pre FE_ACT(a));
   FE_T(2)   // silu 1
   S.mp = vload_vec(vec + EV_B2 * H, q);
@@ -179,7 +192,8 @@ __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img
 #endif
   gemm_e<MODE, 0, RM>(img, S.t, S.mp);
   FE_T(3)   // gemm 1
-  S.m0 = KEEP_D ? vsilu_keep_d(S.mp FE_ACT(a)) : vsilu(S.mp FE_ACT(a));
+  if constexpr (FOLD) S.m0 = vsilu2(S.mp);
+  else S.m0 = KEEP_D ? vsilu_keep_d(S.mp FE_ACT(a)) : vsilu(S.mp FE_ACT(a));
   if (a.flags & FASTEGNN_F_ATTENTION) {
     S.att = sigmoid_f(vdot(S.m0, vload_vec(vec + EV_ATT * H, q)) + a.attb[0]);
     S.m = vscale(S.m0, S.att);
@@ -191,7 +205,8 @@ __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img
   S.up = vload_vec(vec + EV_BX1 * H, q);
   gemm_e<MODE, 1, RM>(img, S.m, S.up);
   FE_T(3)
-  S.u = KEEP_D ? vsilu_keep_d(S.up FE_ACT(a)) : vsilu(S.up FE_ACT(a));
+  if constexpr (FOLD) S.u = vsilu2(S.up);
+  else S.u = KEEP_D ? vsilu_keep_d(S.up FE_ACT(a)) : vsilu(S.up FE_ACT(a));
   const float sraw = vdot(S.u, vload_vec(vec + EV_WX2 * H, q)) + (a.bx2 ? a.bx2[0] : 0.f);
   S.s = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sraw) : sraw;
   FE_T(4)   // silu 3 + head dot

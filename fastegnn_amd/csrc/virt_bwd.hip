@@ -280,7 +280,10 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
     const int *filled = ctrl + VBC_FILLED + (role < 2 ? 0 : VB_MAXRING);
     int *drained = ctrl + VBC_DRAINED + role * VB_MAXRING;
     f32x4 acc[4][4];
-    float bs[4] = {0.f, 0.f, 0.f, 0.f}, bs_tot[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of G (bias gradient), two levels
+    // column sums of G (bias gradient), two levels: fp32 over the 768 rows between two flushes, DOUBLE across the flushes (the
+    // layer-0 bias sums of the coordinate heads cancel to ~1e-3 of their terms over a workgroup's 6 144 / 12 288 rows)
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    double bs_tot[4] = {0., 0., 0., 0.};
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
         }
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        bs_tot[ti] += bs[ti];
+        bs_tot[ti] += (double)bs[ti];
         bs[ti] = 0.f;
       }
       flushed = true;
@@ -411,8 +414,10 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
       }
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
-      const float s0 = qsum(bs_tot[ti] + bs[ti]);
-      if (q == 0) A.slab_b[sl * H + 16 * ti + j] = s0;
+      double s0 = bs_tot[ti] + (double)bs[ti];   // sum over the four q-lanes of the feature, in double
+      s0 += __shfl_xor(s0, 16);
+      s0 += __shfl_xor(s0, 32);
+      if (q == 0) A.slab_b[sl * H + 16 * ti + j] = (float)s0;
     }
 #ifdef VB_NO_PROD
   } else if (false) {

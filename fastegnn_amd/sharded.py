@@ -16,8 +16,20 @@ in it, so all segment means are complete locally.  Per layer the ranks exchange 
               or reduce-scatter g_QX_src [W*Npad,68] -> g_QX [Npad,68]
   once      all-reduce   parameter gradients (fastegnn_amd.dist.allreduce_gradients, by the caller)
 
+Schedule (round 4).  A rank's rows are ordered [interior | boundary]: a BOUNDARY row has at least one edge from a ghost
+column, an interior row reads own rows only (HaloPlan.build finds the split and renumbers the rank's rows; a rank whose
+rows lie in several graphs keeps its order and has no interior part).  The edge stage runs as two launches over the two
+row ranges: forward  node_pre -> [halo exchange] || graph_pre, edge(interior) -> edge(boundary); backward
+edge(boundary) -> [ghost gradients back] || edge(interior), graph_pre -> node_pre.  The centroid sums of layer l+1 travel
+in the same all-reduce as the pools of layer l (x_out of layer l is final after its virt stage), so a layer costs ONE
+small all-reduce per direction; the backward stages of a layer queue their weight-gradient contractions into one batch
+(fastegnn_wgrad_batch_*: one contraction launch + one reduction launch per layer, as the unsharded layer call has).
+With the C-ABI transport (FASTEGNN_COMM=abi) and FASTEGNN_SHARDED_SYNC=0 the collectives run on a second HIP stream,
+forked and joined with events -- a pattern a HIP graph capture records as parallel branches -- otherwise on the compute
+stream in program order (the default until RCCL with more than one rank has run on real hardware).
+
 The virtual state (Z, Hv) is replicated and updated identically everywhere; the per-graph stages
-(graph_pre / graph_post) run redundantly on every rank and only rank 0 keeps their weight gradients.
+(graph_pre / graph_post) run redundantly on every rank and only rank 0 contracts their weight gradients.
 The compute of every stage is one C-ABI call (include/fastegnn_hip.h); this file is only the
 orchestration, written against a small backend interface so that the world_size-2 gloo test can drive
 it on CPU with the oracle's stage functions (tests/test_sharded_cpu.py).
@@ -101,8 +113,22 @@ class HipBackend:
         K.check(self.lib.fastegnn_virtual_init_backward(K.ptr(g_HvT), B, Cn, K.ptr(g_vnf), _stream(self.dev)),
                 "fastegnn_virtual_init_backward")
 
-    def stage(self, name, spec, N, B, graph, t: Dict[str, torch.Tensor], params, grads=None):
+    def wgrad_open(self, spec, N, B, graph, t, params):
+        """One weight-gradient batch for the backward stages of a layer (fastegnn_wgrad_batch_open)."""
         L = _new_layer(spec, N, B, graph)
+        ptab = _PtrTable(params)
+        _fill(L, params=ptab.addr(), wg_slab=t["wg_slab"])
+        h = C.c_void_p()
+        K.check(self.lib.fastegnn_wgrad_batch_open(C.byref(L), _stream(self.dev), C.byref(h)), "fastegnn_wgrad_batch_open")
+        return h.value
+
+    def wgrad_close(self, handle):
+        if handle:
+            K.check(self.lib.fastegnn_wgrad_batch_close(C.c_void_p(handle)), "fastegnn_wgrad_batch_close")
+
+    def stage(self, name, spec, N, B, graph, t: Dict[str, torch.Tensor], params, grads=None, flags=0):
+        L = _new_layer(spec, N, B, graph)
+        L.flags |= flags
         ptab = _PtrTable(params)
         keep = [ptab]
         _fill(L, params=ptab.addr(), **{k: v for k, v in t.items() if v is not None})
@@ -134,6 +160,8 @@ class ShardPlan:
         # order[new] = caller's node id (None: identity): the plan's ranges are ranges of the REORDERED nodes
         self.order = order
         self.node_ids = order[self.n0:self.n1] if order is not None else None
+        # row ranges the edge stage is launched over: (first local row, rows, needs the exchanged table)
+        self.parts = [(0, self.nloc, True)]
 
     def rows(self, t: torch.Tensor) -> torch.Tensor:
         """This rank's rows of a per-node tensor given in the CALLER's node order."""
@@ -158,7 +186,7 @@ class ShardPlan:
     def alloc_grad_tables(self, be):
         return be.empty(self.world * self.Npad, K.QX_LD), be.empty(self.Npad, K.QX_LD)
 
-    def exchange_backward(self, comm, g_QX_src, g_QX):
+    def exchange_backward(self, comm, g_QX_src, g_QX, deterministic: bool = False):
         return comm.reduce_scatter("g_QX", g_QX, g_QX_src)
 
     def exchanged_bytes(self):
@@ -190,54 +218,96 @@ class HaloPlan(ShardPlan):
 
     mode = "halo"
 
-    def build(self, edge_index: torch.Tensor, comm) -> torch.Tensor:
+    def build(self, edge_index: torch.Tensor, comm, local_batch: Optional[torch.Tensor] = None, split: bool = True,
+              peers_want: Optional[torch.Tensor] = None) -> torch.Tensor:
         """edge_index: this rank's edges (rows in [n0,n1), cols = global ids in the plan's numbering).  Returns the edge
-        index with the columns remapped to the local source table."""
+        index with the rows renumbered [interior | boundary] (still offset by n0) and the columns remapped to the local
+        source table.  local_batch: graph id of the rank's rows (the split needs them to lie in ONE graph: data_batch must
+        stay ascending); split=False keeps the row order (one launch that waits for the halo).  peers_want: emulation of
+        one rank of a larger world in a single process (bench.py --emulate-world): the global ids of this rank's rows its
+        peers would ask for, grouped by peer, instead of the id exchange."""
         W, dev = self.world, edge_index.device
-        cols = edge_index[1]
+        rows, cols = edge_index[0], edge_index[1]
         remote = (cols < self.n0) | (cols >= self.n1)
         ghost = torch.unique(cols[remote])                                 # ascending => grouped by owner (contiguous ranges)
         owner = torch.div(ghost, self.Npad, rounding_mode="floor")
         recv_counts = torch.bincount(owner, minlength=W).to(torch.int64)   # rows this rank receives from each owner
-        send_counts = comm.exchange_counts(recv_counts)                    # rows each peer wants from this rank
-        self.recv_splits = [int(v) for v in recv_counts.tolist()]
-        self.send_splits = [int(v) for v in send_counts.tolist()]
-        want = comm.exchange_ids(ghost, self.send_splits, self.recv_splits)   # global ids of MY rows, grouped by asking peer
-        self.send_ids = (want - self.n0).contiguous()
-        if self.send_ids.numel() and (int(self.send_ids.min()) < 0 or int(self.send_ids.max()) >= self.nloc):
+        if peers_want is None:
+            send_counts = comm.exchange_counts(recv_counts)                # rows each peer wants from this rank
+            self.recv_splits = [int(v) for v in recv_counts.tolist()]
+            self.send_splits = [int(v) for v in send_counts.tolist()]
+            want = comm.exchange_ids(ghost, self.send_splits, self.recv_splits)   # global ids of MY rows, grouped by asking peer
+        else:
+            want = peers_want
+            self.recv_splits = [int(v) for v in recv_counts.tolist()]
+            self.send_splits = None
+        if want.numel() and (int(want.min()) < self.n0 or int(want.max()) >= self.n1):
             raise RuntimeError("HaloPlan: a peer asked for a row this rank does not own")
+        # [interior | boundary] order of the own rows (stable: the Morton locality inside each part survives)
+        is_b = torch.zeros(self.nloc, dtype=torch.bool, device=dev)
+        is_b[rows[remote] - self.n0] = True
+        one_graph = local_batch is None or local_batch.numel() == 0 or bool(local_batch[0] == local_batch[-1])
+        if split and one_graph and bool(is_b.any()):
+            lperm = torch.argsort(is_b.to(torch.int8), stable=True)        # lperm[new] = old local row
+            n_int = int((~is_b).sum())
+            self.parts = [p for p in ((0, n_int, False), (n_int, self.nloc - n_int, True)) if p[1] > 0]
+        else:
+            lperm = torch.arange(self.nloc, device=dev)
+            self.parts = [(0, self.nloc, bool(is_b.any()))]
+        self.n_int = sum(n for _, n, halo in self.parts if not halo)
+        lrank = torch.empty_like(lperm)
+        lrank[lperm] = torch.arange(self.nloc, device=dev)                 # lrank[old] = new
+        base = self.order[self.n0:self.n1].to(dev) if self.order is not None else torch.arange(self.n0, self.n1, device=dev)
+        self.node_ids = base[lperm]                                        # caller's node id of every local row
+        self.send_ids = lrank[want - self.n0].contiguous()
         self.n_ghost = int(ghost.numel())
         self.n_send = int(self.send_ids.numel())
         self.n_src = self.nloc + self.n_ghost
         self.n_table = self.nloc
         pos = torch.searchsorted(ghost, cols.clamp(min=0)) if self.n_ghost else torch.zeros_like(cols)
-        new_col = torch.where(remote, self.nloc + pos, cols - self.n0)
-        return torch.stack([edge_index[0], new_col]).contiguous()
+        own = lrank[(cols - self.n0).clamp(0, self.nloc - 1)]
+        new_col = torch.where(remote, self.nloc + pos, own)
+        return torch.stack([lrank[rows - self.n0] + self.n0, new_col]).contiguous()
 
     def alloc_tables(self, be):
         QX_src = be.zeros(max(self.n_src, 1), K.QX_LD)
         return QX_src[:self.nloc], QX_src          # node_pre writes the own rows in place: no copy
 
     def exchange_forward(self, comm, QX, QX_src):
-        if self.world == 1:
+        if self.world == 1:             # (never skipped on a rank-local condition: the all-to-all-v is a collective)
             return _Done()
-        send = QX.index_select(0, self.send_ids) if self.n_send else QX.new_zeros(0, K.QX_LD)
-        return _HaloWork(comm.all_to_all_v("QX_halo", QX_src[self.nloc:], send, self.recv_splits, self.send_splits))
+        if self.send_splits is None:     # emulated rank of a larger world: pack as a real rank would, fill the ghost rows locally
+            return comm.emulated_exchange("QX_halo", QX_src[self.nloc:], QX, self.send_ids)
+        return comm.halo_exchange("QX_halo", QX_src[self.nloc:], QX, self.send_ids, self.recv_splits, self.send_splits)
 
     def alloc_grad_tables(self, be):
         g_src = be.empty(max(self.n_src, 1), K.QX_LD)
         return g_src, g_src[:self.nloc]            # node_pre_bwd reads the own rows in place
 
-    def exchange_backward(self, comm, g_QX_src, g_QX):
+    def exchange_backward(self, comm, g_QX_src, g_QX, deterministic: bool = False):
         if self.world == 1:
             return _Done()
         back = g_QX_src.new_empty(self.n_send, K.QX_LD)
-        send = g_QX_src[self.nloc:self.nloc + self.n_ghost].contiguous()
-        work = comm.all_to_all_v("g_QX_halo", back, send, self.send_splits, self.recv_splits)
+        send = g_QX_src[self.nloc:self.nloc + self.n_ghost]
+        if self.send_splits is None:
+            work = comm.emulated_return("g_QX_halo", back, send)
+        else:
+            work = comm.all_to_all_v("g_QX_halo", back, send, self.send_splits, self.recv_splits)
 
         def add():
-            if self.n_send:
-                g_QX.index_add_(0, self.send_ids, back)
+            if not self.n_send:
+                return
+            if deterministic and self.send_splits is not None:
+                # FASTEGNN_F_DETERMINISTIC: a row may have been asked for by several peers; peer by peer in rank order, and
+                # inside a peer's block every id occurs once (no colliding atomics): the sum has a fixed order (ADVICE round 3)
+                off = 0
+                for n in self.send_splits:
+                    if n:
+                        ids = self.send_ids[off:off + n]
+                        g_QX[ids] = g_QX[ids] + back[off:off + n]
+                    off += n
+            else:
+                comm.scatter_add_rows(g_QX, self.send_ids, back)
         return _HaloWork(work, add)
 
     def exchanged_bytes(self):
@@ -300,38 +370,73 @@ class _Timed:
         return True
 
 
-_ABI_CACHE: Dict[tuple, object] = {}   # one RCCL communicator per (device, group) and process
+_ABI_CACHE: Dict[tuple, object] = {}   # one RCCL communicator per (device, group) and process; the key holds the group object
+_SIDE_STREAMS: Dict[torch.device, "torch.cuda.Stream"] = {}
+
+
+class _EventWork:
+    """Completion of work enqueued on the communication stream: the compute stream waits for the event recorded behind it
+    (stream-level dependency, no host wait; inside a HIP graph capture this becomes an edge between two branches)."""
+
+    def __init__(self, ev, keep=(), dev=None):
+        self.ev, self.keep, self.dev = ev, keep, dev      # keep: tensors the side stream reads / writes, alive until the join
+
+    def wait(self):
+        torch.cuda.current_stream(self.dev).wait_event(self.ev)
+        self.keep = ()
+        return True
 
 
 class _Comm:
-    """The three exchange steps of SURVEY 8e as asynchronous collectives (torch.distributed: RCCL on the GPU,
-    gloo in the CPU tests).  World size 1 short-circuits to local copies."""
+    """The exchange steps of SURVEY 8e (torch.distributed: RCCL on the GPU, gloo in the CPU tests; or the C-ABI transport).
+    World size 1 short-circuits to local copies."""
 
-    def __init__(self, group, stats: Optional[CommStats]):
+    def __init__(self, group, stats: Optional[CommStats], emulate: bool = False):
         self.group, self.stats = group, stats
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.emulate = emulate
         # a transport without device support (gloo): device tensors are staged through host memory, synchronously
         self.host_staged = self.world > 1 and dist.get_backend(group) == "gloo"
-        # Blocking collectives in program order (async_op=False: no overlap, nothing in flight behind a kernel) are the DEFAULT
-        # while RCCL with more than one rank has never run on the hardware this was built on (ADVICE round 2): the
-        # asynchronous schedule (each exchange waited for at its first consumer) is exercised only through gloo, where the
-        # staged transport is synchronous anyway.  FASTEGNN_SHARDED_SYNC=0 selects it.
+        # Blocking collectives in program order (async_op=False / the compute stream: no overlap, nothing in flight behind a
+        # kernel) are the DEFAULT while RCCL with more than one rank has never run on the hardware this was built on (ADVICE
+        # round 2); FASTEGNN_SHARDED_SYNC=0 selects the asynchronous schedule: torch transport -> async_op=True, C-ABI
+        # transport -> a second HIP stream forked / joined with events; each exchange is waited for at its first consumer.
         self.sync = os.environ.get("FASTEGNN_SHARDED_SYNC", "1") not in ("", "0")
-        # FASTEGNN_COMM=abi: the data-path collectives go through the C ABI (fastegnn_comm_*: RCCL on the CURRENT stream,
-        # capturable), created lazily on the first device tensor; plan-building exchanges stay on torch.distributed
+        # FASTEGNN_COMM=abi: the data-path collectives go through the C ABI (fastegnn_comm_*: RCCL on a stream this process
+        # chooses, capturable), created lazily on the first device tensor; plan-building exchanges stay on torch.distributed.
+        # NOTE (ADVICE round 3): that is a second RCCL communicator beside torch.distributed's; the two are never in flight
+        # together -- allreduce_gradients runs after the backward on the compute stream, behind every ABI collective -- but
+        # the combination is unverified on more than one rank: opt-in.
         self.use_abi = os.environ.get("FASTEGNN_COMM", "torch") == "abi" and not self.host_staged
         self._abi = None
 
     def abi(self, t):
         """The C-ABI communicator for tensor t's device, or None when this transport is not selected."""
-        if not (self.use_abi and t.is_cuda and self.world > 1):
+        if not (self.use_abi and t.is_cuda and (self.world > 1 or self.emulate)):
             return None
         if self._abi is None:
             from .comm import AbiComm
-            self._abi = _ABI_CACHE.get((t.device, id(self.group)))
+            key = (t.device, self.group)
+            self._abi = _ABI_CACHE.get(key)
             if self._abi is None:
-                self._abi = _ABI_CACHE[(t.device, id(self.group))] = AbiComm(t.device, self.group)
+                self._abi = _ABI_CACHE[key] = AbiComm(t.device, self.group)
         return self._abi
+
+    # -- C-ABI transport: on the compute stream (sync) or forked onto the communication stream
+    def _enqueue(self, t, fn, keep=()):
+        if self.sync:
+            fn()
+            return _Done()
+        cs = _SIDE_STREAMS.get(t.device)
+        if cs is None:
+            cs = _SIDE_STREAMS[t.device] = torch.cuda.Stream(t.device)
+        cur = torch.cuda.current_stream(t.device)
+        cs.wait_stream(cur)                      # everything enqueued so far precedes the collective
+        with torch.cuda.stream(cs):
+            fn()
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        return _EventWork(ev, keep, t.device)
 
     def _staged(self, fn, out, *inputs):
         h_in = [t.cpu() for t in inputs]
@@ -346,7 +451,7 @@ class _Comm:
             st = self.stats
             st.calls[name] = st.calls.get(name, 0) + 1
             st.bytes[name] = st.bytes.get(name, 0) + t.numel() * t.element_size()
-            if t.is_cuda:
+            if t.is_cuda and not torch.cuda.is_current_stream_capturing():
                 rec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 rec[0].record()
                 st.events.setdefault(name, []).append(rec)
@@ -354,10 +459,11 @@ class _Comm:
 
     def all_reduce(self, name, t):
         rec = self._note(name, t)
+        a = self.abi(t)
+        if a is not None:
+            return _Timed(self._enqueue(t, lambda: a.all_reduce(t), (t,)), rec)
         if self.world == 1:
             return _Timed(_Done(), rec)
-        if self.abi(t) is not None:
-            return _Timed(self._abi.all_reduce(t), rec)
         if self.host_staged and t.is_cuda:
             return _Timed(self._staged(lambda o: dist.all_reduce(o, group=self.group), t), rec)
         return _Timed(dist.all_reduce(t, group=self.group, async_op=not self.sync) or _Done(), rec)
@@ -367,8 +473,9 @@ class _Comm:
         if self.world == 1:
             out.copy_(inp)
             return _Timed(_Done(), rec)
-        if self.abi(out) is not None:
-            return _Timed(self._abi.all_gather(out, inp), rec)
+        a = self.abi(out)
+        if a is not None:
+            return _Timed(self._enqueue(out, lambda: a.all_gather(out, inp), (out, inp)), rec)
         if self.host_staged and out.is_cuda:
             return _Timed(self._staged(lambda o, i: dist.all_gather_into_tensor(o, i, group=self.group), out, inp), rec)
         return _Timed(dist.all_gather_into_tensor(out, inp, group=self.group, async_op=not self.sync) or _Done(), rec)
@@ -377,14 +484,63 @@ class _Comm:
         rec = self._note(name, out)
         if self.world == 1:
             return _Timed(_Done(), rec)
-        if self.abi(out) is not None:
-            return _Timed(self._abi.all_to_all_v(out, inp.contiguous(), out_splits, in_splits), rec)
+        a = self.abi(out)
+        if a is not None:
+            return _Timed(self._enqueue(out, lambda: a.all_to_all_v(out, inp.contiguous(), out_splits, in_splits), (out, inp)), rec)
         if self.host_staged and out.is_cuda:
             def fn(o, i):
                 dist.all_to_all_single(o, i, out_splits, in_splits, group=self.group)
             return _Timed(self._staged(fn, out, inp.contiguous()), rec)
         w = dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group, async_op=not self.sync)
         return _Timed(w if w is not None else _Done(), rec)
+
+    def halo_exchange(self, name, ghost_rows, table, send_ids, recv_splits, send_splits):
+        """Forward table exchange: pack the rows the peers asked for (send_ids into `table`) and all-to-all-v them into
+        `ghost_rows`.  C-ABI transport: pack kernel + grouped send / recv, both on the communication stream."""
+        a = self.abi(ghost_rows)
+        if a is not None and self.world > 1:
+            rec = self._note(name, ghost_rows)
+            box = []
+
+            def fn():
+                send = a.gather_rows(table, send_ids)
+                box.append(send)
+                a.all_to_all_v(ghost_rows, send, recv_splits, send_splits)
+            return _Timed(self._enqueue(ghost_rows, fn, (ghost_rows, table, box)), rec)
+        send = table.index_select(0, send_ids) if send_ids.numel() else table.new_zeros(0, table.size(1))
+        return self.all_to_all_v(name, ghost_rows, send, recv_splits, send_splits)
+
+    def scatter_add_rows(self, table, ids, rows):
+        """table[ids] += rows (ids may repeat: a row asked for by several peers)"""
+        a = self.abi(table)
+        if a is not None:
+            a.scatter_add_rows(table, ids, rows)
+        else:
+            table.index_add_(0, ids, rows)
+
+    # -- one rank of a larger world in a single process (bench.py --emulate-world): the same pack / unpack kernels and byte
+    #    counts, device copies in the place of the xGMI transfers; the ghost rows are filled with own rows (timing only)
+    def emulated_exchange(self, name, ghost_rows, table, send_ids):
+        rec = self._note(name, ghost_rows)
+        a = self.abi(ghost_rows)
+        n_g, n_own = ghost_rows.size(0), table.size(0)
+        fill = (torch.arange(n_g, device=table.device) * 7919) % max(n_own, 1)
+
+        def fn():
+            send = a.gather_rows(table, send_ids) if a is not None else table.index_select(0, send_ids)
+            ghost_rows.copy_(a.gather_rows(table, fill) if a is not None else table.index_select(0, fill))
+            return send
+        return _Timed(self._enqueue(ghost_rows, fn, (ghost_rows, table, fill)), rec)
+
+    def emulated_return(self, name, back, send):
+        rec = self._note(name, back)
+        n = min(back.size(0), send.size(0))
+
+        def fn():
+            back.zero_()
+            if n:
+                back[:n].copy_(send[:n])
+        return _Timed(self._enqueue(back, fn, (back, send)), rec)
 
     # plan-building exchanges (once per graph, blocking): int64 counts [W] and id lists
     def exchange_counts(self, counts):
@@ -415,8 +571,9 @@ class _Comm:
         if self.world == 1:
             out.copy_(inp)
             return _Timed(_Done(), rec)
-        if self.abi(out) is not None:
-            return _Timed(self._abi.reduce_scatter(out, inp), rec)
+        a = self.abi(out)
+        if a is not None:
+            return _Timed(self._enqueue(out, lambda: a.reduce_scatter(out, inp), (out, inp)), rec)
         if self.host_staged and out.is_cuda:
             return _Timed(self._staged(lambda o, i: dist.reduce_scatter_tensor(o, i, group=self.group), out, inp), rec)
         return _Timed(dist.reduce_scatter_tensor(out, inp, group=self.group, async_op=not self.sync) or _Done(), rec)
@@ -426,82 +583,123 @@ def _layer_lists(spec: _Spec, params, i):
     return [params[s] if s is not None else None for s in spec.layer_slots[i]]
 
 
+class _Part:
+    """One launch range of the edge stage: rows [row0, row0 + nrows) of the rank, their edges as a sorted graph."""
+
+    def __init__(self, graph, row0, nrows, halo, mask):
+        self.graph, self.row0, self.nrows, self.halo, self.mask = graph, row0, nrows, halo, mask
+        self.ea_sorted = None
+
+
+_EDGE_ROW_KEYS = ("P", "QX", "x", "aggm", "aggx", "g_aggm", "g_aggx", "g_P", "g_xrow")
+
+
+def _edge_view(t: Dict[str, torch.Tensor], part: _Part, **extra):
+    """The layer's buffers as the edge stage sees them for one part: every row-indexed array starts at the part's first row
+    (the part's graph numbers its rows from there), the source table and everything col-indexed stay whole."""
+    v = dict(t)
+    if part.row0 or part.nrows != t["P"].size(0):
+        for k in _EDGE_ROW_KEYS:
+            if k in v and v[k] is not None:
+                v[k] = v[k][part.row0:part.row0 + part.nrows]
+    v["ea_sorted"] = part.ea_sorted
+    v.update(extra)
+    return v
+
+
 class _ShardedFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, be, group, stats, spec: _Spec, plan: ShardPlan, graph, batch32, gptr, edge_attr, node_attr,
+    def forward(ctx, be, comm, spec: _Spec, plan: ShardPlan, parts, batch32, gptr, edge_attr, node_attr,
                 node_feat, node_loc, node_vel, loc_mean, *params):
         # edge_attr / node_attr: this rank's edges / rows; differentiable like in the single-GPU module (their gradients
         # are accumulated by the edge / virtual backward kernels when asked for)
-        ea_sorted = graph.permute(edge_attr.detach() if edge_attr is not None else None)
+        for pt in parts:
+            ea_p = edge_attr.detach()[pt.mask] if (edge_attr is not None and pt.mask is not None) else \
+                (edge_attr.detach() if edge_attr is not None else None)
+            pt.ea_sorted = pt.graph.permute(ea_p)
         node_attr = node_attr.detach().contiguous().float() if node_attr is not None else None
         W, rank = plan.world, plan.rank
-        N, Npad, B, Cn = plan.nloc, plan.Npad, loc_mean.size(0), spec.C
+        N, B, Cn = plan.nloc, loc_mean.size(0), spec.C
         params = [p.detach() for p in params]
         node_feat, node_loc, node_vel, loc_mean = (t.detach().contiguous().float()
                                                    for t in (node_feat, node_loc, node_vel, loc_mean))
+        g0 = parts[0].graph
         h = be.empty(N, H)
         be.embed_forward(node_feat, spec.nf, params[1], params[2], h)
         HvT = be.empty(B, Cn, H)
         be.virtual_init(params[0], B, Cn, HvT)
         x, Z = node_loc, loc_mean
         saved = []
-        comm = _Comm(group, stats)
-        # Collectives are issued asynchronously (RCCL runs them on its own stream) and waited for at their first
-        # consumer, so that every exchange has independent kernels in flight behind it:
-        #   all-reduce xsum_i      behind  node_pre_i
-        #   all-gather QX_i        behind  graph_post_{i-1} (deferred) and graph_pre_i
-        #   all-reduce pools_i     behind  pack_{i+1}, graph_xsum_{i+1}, node_pre_{i+1}
-        # (all ranks issue them in the same order: pools_{i-1}, xsum_i, QX_i)
+        # Order of the collectives (identical on all ranks): xsum_0 | per layer: QX_i, [pools_i + xsum_{i+1}].  Each is
+        # waited for at its first consumer; what runs in between does not depend on it:
+        #   halo QX_i              behind  graph_post_{i-1} (deferred), graph_pre_i, edge_i over the INTERIOR rows
+        #   all-reduce pools_i     behind  pack_{i+1}, node_pre_{i+1}
         pend = None     # (work, t, lp, b) of the previous layer: its graph_post is still to run
+        xsum = be.empty(B, 4)
+        be.stage("graph_xsum", spec, N, B, g0, dict(batch=batch32, x=x, xsum=xsum), _layer_lists(spec, params, 0))
+        w_xsum = comm.all_reduce("xsum", xsum)
         for i in range(spec.n_layers):
             lp = _layer_lists(spec, params, i)
-            b = dict(h=h, x=x)
-            b.update(be.carve(dict(wpack=(be.wpack_floats(Cn),), P=(N, H), A=(N, H), svel=(N,), sgrav=(N,), xsum=(B, 4),
+            b = dict(h=h, x=x, xsum=xsum)
+            b.update(be.carve(dict(wpack=(be.wpack_floats(Cn),), P=(N, H), A=(N, H), svel=(N,), sgrav=(N,),
                                    Bc=(B, Cn, H), aggm=(N, H), npre=(N, H), aggx=(N, 3))))
             b["QX"], b["QX_src"] = plan.alloc_tables(be)           # own rows | the table the edge kernels gather from
-            nV = B * Cn * H
-            pools = be.empty(nV + B * 3 * Cn)                      # poolV | poolX adjacent: one all-reduce
-            b["poolV"], b["poolX"] = pools[:nV].view(B, Cn, H), pools[nV:].view(B, 3, Cn)
+            nV, nX = B * Cn * H, B * 3 * Cn
+            last = i + 1 == spec.n_layers
+            pools = be.empty(nV + nX + (0 if last else B * 4))     # poolV | poolX | xsum of the next layer: one all-reduce
+            b["poolV"], b["poolX"] = pools[:nV].view(B, Cn, H), pools[nV:nV + nX].view(B, 3, Cn)
             b.update(h_out=be.empty(N, H), x_out=be.empty(N, 3), Z_out=be.empty(B, 3, Cn), HvT_out=be.empty(B, Cn, H))
-            t = dict(batch=batch32, gptr=gptr, vel=node_vel, ea_sorted=ea_sorted, node_attr=node_attr, **b)
-            be.stage("pack_weights", spec, N, B, graph, t, lp)
-            be.stage("graph_xsum", spec, N, B, graph, t, lp)
-            w_xsum = comm.all_reduce("xsum", b["xsum"])
-            be.stage("node_pre_forward", spec, N, B, graph, t, lp)
+            t = dict(batch=batch32, gptr=gptr, vel=node_vel, node_attr=node_attr, **b)
+            be.stage("pack_weights", spec, N, B, g0, t, lp)
+            be.stage("node_pre_forward", spec, N, B, g0, t, lp)
             w_qx = plan.exchange_forward(comm, b["QX"], b["QX_src"])
             if pend is not None:                                   # virtual state of this layer <- previous layer's pools
                 pend[0].wait()
-                be.stage("graph_post_forward", spec, N, B, graph, pend[1], pend[2])
+                be.stage("graph_post_forward", spec, N, B, g0, pend[1], pend[2])
                 Z, HvT = pend[3]["Z_out"], pend[3]["HvT_out"]
                 for k in ("aggx", "poolX", "h_out", "x_out", "Z_out", "HvT_out"):
                     del pend[3][k]
+            else:
+                w_xsum.wait()
             b["Z"], b["HvT"] = Z, HvT
             t["Z"], t["HvT"] = Z, HvT
-            w_xsum.wait()
-            be.stage("graph_pre_forward", spec, N, B, graph, t, lp)
-            w_qx.wait()
-            be.stage("edge_forward", spec, N, B, graph, t, lp)
-            be.stage("virt_forward", spec, N, B, graph, t, lp)
+            be.stage("graph_pre_forward", spec, N, B, g0, t, lp)
+            waited = False
+            for pt in parts:                                       # interior rows first: they read own rows only
+                if pt.halo and not waited:
+                    w_qx.wait()
+                    waited = True
+                be.stage("edge_forward", spec, pt.nrows, B, pt.graph, _edge_view(t, pt), lp)
+            if not waited:
+                w_qx.wait()
+            be.stage("virt_forward", spec, N, B, g0, t, lp)
+            if not last:                                           # x_out is final: the next layer's centroid sums ride along
+                xsum = pools[nV + nX:].view(B, 4)
+                be.stage("graph_xsum", spec, N, B, g0, dict(batch=batch32, x=b["x_out"], xsum=xsum), lp)
             pend = (comm.all_reduce("pools", pools), t, lp, b)
             saved.append(b)
             h, x = b["h_out"], b["x_out"]
         pend[0].wait()
-        be.stage("graph_post_forward", spec, N, B, graph, pend[1], pend[2])
+        be.stage("graph_post_forward", spec, N, B, g0, pend[1], pend[2])
         Z = pend[3]["Z_out"]
         for k in ("aggx", "poolX", "h_out", "x_out", "Z_out", "HvT_out"):
             del pend[3][k]
-        ctx.be, ctx.group, ctx.spec, ctx.plan, ctx.graph, ctx.saved = be, group, spec, plan, graph, saved
+        ctx.be, ctx.spec, ctx.plan, ctx.parts, ctx.saved = be, spec, plan, parts, saved
         ctx.comm = comm
-        ctx.misc = (batch32, gptr, ea_sorted, node_attr, node_feat, node_vel, params)
+        ctx.misc = (batch32, gptr, node_attr, node_feat, node_vel, params)
+        ctx.ea_shape = edge_attr.shape if edge_attr is not None else None
         return x, Z
 
     @staticmethod
     def backward(ctx, g_loc, g_vloc):
-        be, group, spec, plan, graph, saved = ctx.be, ctx.group, ctx.spec, ctx.plan, ctx.graph, ctx.saved
+        be, spec, plan, parts, saved = ctx.be, ctx.spec, ctx.plan, ctx.parts, ctx.saved
         comm = ctx.comm
-        batch32, gptr, ea_sorted, node_attr, node_feat, node_vel, params = ctx.misc
+        batch32, gptr, node_attr, node_feat, node_vel, params = ctx.misc
         W, rank = plan.world, plan.rank
-        N, Npad, B, Cn, E = plan.nloc, plan.Npad, saved[0]["Z"].size(0), spec.C, graph.E
+        N, B, Cn = plan.nloc, saved[0]["Z"].size(0), spec.C
+        g0 = parts[0].graph
+        E_max = max(pt.graph.E for pt in parts)
+        det = bool(spec.flags & K.F_DETERMINISTIC)
         # gradient buffers: ONE zero-filled allocation carved into 16-byte aligned views (one fill launch instead of one
         # per parameter; the slices become the .grad tensors, so fastegnn_amd.dist.allreduce_gradients reduces the flat
         # buffer in place)
@@ -514,49 +712,64 @@ class _ShardedFunction(torch.autograd.Function):
                 off += n
             return out
         grads = flat_like(params)
-        # the per-graph stages run on every rank; only rank 0 keeps their weight gradients
-        dummy = grads if rank == 0 else flat_like(params)
         g_h = be.zeros(N, H)
         g_x = (g_loc if g_loc is not None else be.zeros(N, 3)).contiguous().float()
         g_Z = (g_vloc if g_vloc is not None else be.zeros(B, 3, Cn)).contiguous().float()
         g_HvT = be.zeros(B, Cn, H)
         g_vel = be.zeros(N, 3)
         sc = be.carve(dict(g_poolV=(B, Cn, H), g_poolX=(B, 3, Cn), g_xbar=(B, 4), g_A=(N, H), g_P=(N, H),
-                           g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,), g_QXe=(max(E, 1) if spec.flags & K.F_DETERMINISTIC else 1, K.QX_LD),
-                           g_xrow=(N, 3), wg_edge=(be.wg_edge_floats(E),), wg_virt=(be.wg_virt_floats(N, Cn, spec.flags),),
+                           g_aggm=(N, H), g_aggx=(N, 3), g_svel=(N,), g_sgrav=(N,), g_QXe=(max(E_max, 1) if det else 1, K.QX_LD),
+                           g_xrow=(N, 3), wg_edge=(be.wg_edge_floats(E_max),), wg_virt=(be.wg_virt_floats(N, Cn, spec.flags),),
                            wg_node=(be.wg_node_floats(N, B, Cn),), wg_slab=(be.wg_slab_floats(),)))
         nV = B * Cn * H
         gpools = be.empty(nV + B * 3 * Cn)                                 # g_Bc | g_Zp adjacent: one all-reduce
         sc["g_Bc"], sc["g_Zp"] = gpools[:nV].view(B, Cn, H), gpools[nV:].view(B, 3, Cn)
         sc["g_QX_src"], sc["g_QX"] = plan.alloc_grad_tables(be)
-        want_ea = ctx.needs_input_grad[8] and ea_sorted is not None and E > 0
-        want_na = ctx.needs_input_grad[9] and node_attr is not None
-        if want_ea:
-            sc["g_ea_sorted"] = be.zeros(E, spec.ea)
+        has_ea = ctx.ea_shape is not None and ctx.ea_shape[1] > 0
+        want_ea = ctx.needs_input_grad[7] and has_ea
+        want_na = ctx.needs_input_grad[8] and node_attr is not None
+        g_ea_parts = [be.zeros(max(pt.graph.E, 1), spec.ea) if want_ea else None for pt in parts]
         if want_na:
             sc["g_node_attr"] = be.zeros(N, spec.na)
+        # backward order of the parts: the rows that feed ghost columns first, so that their share of g_QX_src travels while
+        # the interior rows are computed
+        bparts = sorted(range(len(parts)), key=lambda k: not parts[k].halo)
         for i in reversed(range(spec.n_layers)):
             b = saved[i]
             lp = _layer_lists(spec, params, i)
             lg = _layer_lists(spec, grads, i)
-            ld = _layer_lists(spec, dummy, i)
+            # the per-graph stages run on every rank (their outputs are needed everywhere); only rank 0 contracts their
+            # weight gradients -- the other ranks pass an empty gradient table and queue no job for them
+            lr = lg if rank == 0 else [None] * len(lg)
             out = dict(g_h=be.empty(N, H), g_x=be.empty(N, 3), g_Z=be.empty(B, 3, Cn), g_HvT=be.empty(B, Cn, H))
-            t = dict(batch=batch32, gptr=gptr, vel=node_vel, ea_sorted=ea_sorted, node_attr=node_attr,
+            t = dict(batch=batch32, gptr=gptr, vel=node_vel, node_attr=node_attr,
                      g_h_out=g_h, g_x_out=g_x, g_Z_out=g_Z, g_HvT_out=g_HvT, g_vel=g_vel, **b, **out, **sc)
-            be.stage("graph_post_backward", spec, N, B, graph, t, lp, ld)
-            be.stage("virt_backward", spec, N, B, graph, t, lp, lg)
-            w_pools = comm.all_reduce("g_pools", gpools)           # behind the edge backward
-            be.stage("edge_backward", spec, N, B, graph, t, lp, lg)
-            be.stage("edge_col_reduce", spec, N, B, graph, t, lp, lg)
-            w_qx = plan.exchange_backward(comm, sc["g_QX_src"], sc["g_QX"])   # behind graph_pre_backward
-            w_pools.wait()
-            be.stage("graph_pre_backward", spec, N, B, graph, t, lp, ld)
-            w_qx.wait()
-            be.stage("node_pre_backward", spec, N, B, graph, t, lp, lg)
+            wb = be.wgrad_open(spec, N, B, g0, t, lp)              # one contraction + one reduction launch for the layer
+            t["wgrad_batch"] = wb
+            try:
+                be.stage("graph_post_backward", spec, N, B, g0, t, lp, lr)
+                be.stage("virt_backward", spec, N, B, g0, t, lp, lg)
+                w_pools = comm.all_reduce("g_pools", gpools)       # behind the edge backward
+                w_qx = _Done()
+                n_halo = max(sum(1 for pt in parts if pt.halo), 1)
+                for n_done, k in enumerate(bparts):
+                    pt = parts[k]
+                    extra = dict(g_ea_sorted=g_ea_parts[k]) if want_ea else {}
+                    acc = K.F_GQX_ACCUM if n_done > 0 else 0      # (a second part exists in the atomic mode only)
+                    be.stage("edge_backward", spec, pt.nrows, B, pt.graph, _edge_view(t, pt, **extra), lp, lg, flags=acc)
+                    be.stage("edge_col_reduce", spec, pt.nrows, B, pt.graph, _edge_view(t, pt), lp, lg)
+                    if n_done + 1 == n_halo:   # everything that scatters into ghost rows has run: send them home now
+                        w_qx = plan.exchange_backward(comm, sc["g_QX_src"], sc["g_QX"], det)
+                w_pools.wait()
+                be.stage("graph_pre_backward", spec, N, B, g0, t, lp, lr)
+                w_qx.wait()
+                be.stage("node_pre_backward", spec, N, B, g0, t, lp, lg)
+            finally:
+                be.wgrad_close(wb)
             g_h, g_x, g_Z, g_HvT = out["g_h"], out["g_x"], out["g_Z"], out["g_HvT"]
             saved[i] = None
-        be.virtual_init_backward(g_HvT, B, Cn, dummy[0])
-        g_nf = torch.empty_like(node_feat) if ctx.needs_input_grad[10] else None
+        be.virtual_init_backward(g_HvT, B, Cn, grads[0] if rank == 0 else be.zeros(*params[0].shape))
+        g_nf = torch.empty_like(node_feat) if ctx.needs_input_grad[9] else None
         be.embed_backward(node_feat, g_h, spec.nf, params[1], grads[1], grads[2], g_nf)
         # The last layer's node_mlp / node_mlp_virtual feed nothing: the reference's autograd (and the single-GPU module)
         # leave their .grad None and torch.optim.Adam / FusedAdam then skip them; the kernels wrote zeros.
@@ -565,10 +778,19 @@ class _ShardedFunction(torch.autograd.Function):
             if s_ is not None and suffix.startswith(("node_mlp.", "node_mlp_virtual.")) and not (spec.flags & K.F_RF):
                 grads[s_] = None
         g_ea = None
-        if want_ea:   # back to this rank's edge order: sorted edge k is local edge perm[k]
-            g_ea = torch.empty_like(sc["g_ea_sorted"])
-            g_ea.index_copy_(0, graph.perm[:E].long(), sc["g_ea_sorted"])
-        return (None,) * 8 + (g_ea, sc["g_node_attr"] if want_na else None, g_nf, g_x, g_vel, g_Z, *grads)
+        if want_ea:   # back to this rank's edge order: sorted edge k of a part is the part's input edge perm[k]
+            g_ea = be.zeros(*ctx.ea_shape)
+            for pt, gp in zip(parts, g_ea_parts):
+                E = pt.graph.E
+                if E == 0:
+                    continue
+                un = torch.empty_like(gp[:E])
+                un.index_copy_(0, pt.graph.perm[:E].long(), gp[:E])
+                if pt.mask is None:
+                    g_ea = un
+                else:
+                    g_ea[pt.mask] = un
+        return (None,) * 7 + (g_ea, sc["g_node_attr"] if want_na else None, g_nf, g_x, g_vel, g_Z, *grads)
 
 
 class ShardedFastEGNN(torch.nn.Module):
@@ -587,30 +809,46 @@ class ShardedFastEGNN(torch.nn.Module):
     """
 
     def __init__(self, model: FastEGNN, group=None, backend=None, stats: Optional[CommStats] = None,
-                 exchange: Optional[str] = None):
+                 exchange: Optional[str] = None, emulate: Optional[tuple] = None):
         """exchange: "halo" (ghost rows only, all-to-all-v; default) or "allgather" (the whole table); the environment
-        variable FASTEGNN_SHARDED_EXCHANGE overrides the default."""
+        variable FASTEGNN_SHARDED_EXCHANGE overrides the default.  emulate=(world, rank): this single process plays ONE
+        rank of a larger world (bench.py --emulate-world): its share of the rows and edges, the pack / unpack kernels and
+        byte counts of its halo, device copies in the place of the transfers -- timing of a shard's compute and fixed
+        costs on one GPU; the ghost rows hold stand-in data, so the outputs mean nothing."""
         super().__init__()
         self.exchange = exchange or os.environ.get("FASTEGNN_SHARDED_EXCHANGE", "halo")
         if self.exchange not in ("halo", "allgather"):
             raise ValueError("ShardedFastEGNN: exchange must be 'halo' or 'allgather'")
+        if emulate is not None and (self.exchange != "halo" or dist.is_initialized() and dist.get_world_size(group) > 1):
+            raise ValueError("ShardedFastEGNN: emulate=(world, rank) needs the halo exchange and a single process")
         self.model = model
         self.group = group
         self.backend = backend
         self.stats = stats
+        self.emulate = emulate
         self.plan: Optional[ShardPlan] = None
+        self._comm: Optional[_Comm] = None
 
     def _world_rank(self):
+        if self.emulate is not None:
+            return self.emulate
         if not dist.is_initialized():
             return 1, 0
         return dist.get_world_size(self.group), dist.get_rank(self.group)
 
+    def comm(self) -> _Comm:
+        if self._comm is None or self._comm.stats is not self.stats:
+            self._comm = _Comm(self.group, self.stats, emulate=self.emulate is not None)
+        return self._comm
+
     def shard_inputs(self, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None,
-                     node_attr=None, reorder: bool = False) -> Dict[str, torch.Tensor]:
+                     node_attr=None, reorder: bool = False, split: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         """This rank's share of a batch: its node rows, the edges aggregating into them, the replicated per-graph
         tensors.  Collective when the exchange is "halo" (the ranks tell each other which rows they need).
         reorder=True first sorts the nodes of every graph along a Morton curve (`morton_order`), so that a rank owns a
-        compact region of space; `plan.node_ids` / `plan.rows()` map the caller's node order to this rank's rows."""
+        compact region of space; `plan.node_ids` / `plan.rows()` map the caller's node order to this rank's rows.
+        split (default: on unless the model's backward is the deterministic store + reduce form, whose col-keyed sum
+        runs over ONE graph): order the rank's rows [interior | boundary] and run the edge stage as two launches."""
         world, rank = self._world_rank()
         N = node_loc.size(0)
         order = None
@@ -623,11 +861,21 @@ class ShardedFastEGNN(torch.nn.Module):
         # (edge_attr / node_attr keep their autograd link: the selection below is differentiable, so a gradient computed
         # for this rank's edges / rows flows back into the caller's full tensors -- zero where another rank owns the edge)
         ei, ea = plan.edges(edge_index, edge_attr)
-        if plan.mode == "halo":
-            ei = plan.build(ei, _Comm(self.group, None))
         db = data_batch if order is None else data_batch[order]
+        if plan.mode == "halo":
+            if split is None:
+                split = not bool(getattr(self.model, "deterministic", False)) and \
+                    os.environ.get("FASTEGNN_SHARDED_SPLIT", "1") not in ("", "0")
+            want = None
+            if self.emulate is not None:
+                # the rows of this rank its peers' edges read, grouped by peer (a real world learns them in plan.build)
+                rows, cols = edge_index[0], edge_index[1]
+                m = ((rows < plan.n0) | (rows >= plan.n1)) & (cols >= plan.n0) & (cols < plan.n1)
+                peer = torch.div(rows[m], plan.Npad, rounding_mode="floor")
+                want = torch.unique(peer * N + cols[m]) % N          # (peer, col) pairs, ascending by peer then col
+            ei = plan.build(ei, self.comm(), db[plan.n0:plan.n1], split, peers_want=want)
         return dict(plan=plan, node_feat=plan.rows(node_feat), node_loc=plan.rows(node_loc), node_vel=plan.rows(node_vel),
-                    edge_index=ei, edge_attr=ea, data_batch=db[plan.n0:plan.n1].contiguous(), loc_mean=loc_mean,
+                    edge_index=ei, edge_attr=ea, data_batch=plan.rows(data_batch), loc_mean=loc_mean,
                     node_attr=plan.rows(node_attr).float() if node_attr is not None else None)
 
     def forward_local(self, local: Dict[str, torch.Tensor]):
@@ -639,7 +887,18 @@ class ShardedFastEGNN(torch.nn.Module):
             m._plist = [pidx[n] for n in m._spec.names]
         be = self.backend or HipBackend(local["node_loc"].device, act=m._spec.act_kind != K.ACT_SILU)
         spec = m._spec
-        graph = be.build_graph(local["edge_index"], plan.nloc, plan.n_src, plan.n0, csc=bool(m._spec.flags & K.F_DETERMINISTIC))
+        csc = bool(m._spec.flags & K.F_DETERMINISTIC)
+        if csc and len(plan.parts) > 1:
+            raise RuntimeError("ShardedFastEGNN: the deterministic backward needs an unsplit plan (shard_inputs(split=False))")
+        ei = local["edge_index"]
+        parts = []
+        for row0, nrows, halo in plan.parts:
+            if len(plan.parts) == 1:
+                mask, ei_p = None, ei
+            else:
+                mask = (ei[0] >= plan.n0 + row0) & (ei[0] < plan.n0 + row0 + nrows)
+                ei_p = ei[:, mask].contiguous()
+            parts.append(_Part(be.build_graph(ei_p, nrows, plan.n_src, plan.n0 + row0, csc=csc), row0, nrows, halo, mask))
         B = local["loc_mean"].size(0)
         batch32, gptr = be.build_batch(local["data_batch"], plan.nloc, B)
         self.plan = plan
@@ -649,7 +908,7 @@ class ShardedFastEGNN(torch.nn.Module):
         plist = m._plist
         if m.hidden_nf < K.H:
             plist = be.pad_params(spec.names, m.hidden_nf, spec.C, bool(spec.flags & K.F_RF), plist)
-        return _ShardedFunction.apply(be, self.group, self.stats, spec, plan, graph, batch32, gptr, ea,
+        return _ShardedFunction.apply(be, self.comm(), spec, plan, parts, batch32, gptr, ea,
                                       local["node_attr"], local["node_feat"], local["node_loc"], local["node_vel"],
                                       local["loc_mean"], *plist)
 

@@ -77,7 +77,12 @@ enum {
    * order by fastegnn_edge_col_reduce: that sum is then order-independent (the rest of the backward keeps its
    * rounding-level run-to-run differences: pools and ticket-ordered in-workgroup sums); 0.26 ms per step slower at cfg4 in
    * fp32, faster than the atomics with bf16 operands; 272 bytes of scratch per edge. */
-  FASTEGNN_F_DETERMINISTIC = 1024
+  FASTEGNN_F_DETERMINISTIC = 1024,
+  /* Backward, atomic mode only: fastegnn_edge_backward does NOT zero g_QX_src before it scatters into it -- an earlier
+   * launch of the same layer over OTHER rows has already done so.  The sharded caller runs a rank's boundary rows (rows
+   * with an edge from a ghost column) and its interior rows as two launches, so that the ghost rows' gradients travel
+   * while the interior rows are still being computed (bits 11..14 hold the activation kind, below). */
+  FASTEGNN_F_GQX_ACCUM = 32768
 };
 /* Activation of every MLP (the reference's act_fn, models/FastEGNN.py:227): bits 11..14 of the flags hold one of the
  * FASTEGNN_ACT_* kinds, fastegnn_layer_t.act_param its parameter.  libfastegnn_hip.so is compiled for SiLU and rejects
@@ -222,15 +227,21 @@ typedef struct {
   float *wg_virt;             /* [fastegnn_wg_virt_floats_for(N,C,flags)] weight-gradient operands of the virtual stage */
   float *wg_node;             /* [fastegnn_wg_node_floats(N,B,C)] node-level weight-gradient operands */
   float *wg_slab;             /* [fastegnn_wg_slab_floats()] partial 64x64 slabs of the weight-gradient GEMMs */
+  /* Backward STAGE entry points only (fastegnn_layer_backward keeps its own): an open weight-gradient batch
+   * (fastegnn_wgrad_batch_open) into which the stage queues its contraction jobs instead of contracting and reducing them
+   * itself -- ONE contraction launch and ONE reduction launch per layer for a caller that drives the stages one by one
+   * (the sharded path, which has collectives between them).  The operands a stage queues (its g_* outputs and its region
+   * of wg_node) must stay untouched until fastegnn_wgrad_batch_close.  NULL: the stage finishes its own jobs. */
+  void *wgrad_batch;
 } fastegnn_layer_t;
 
 /* ---- library ---- */
 const char *fastegnn_last_error(void);
 /* ABI revision: FASTEGNN_ABI_VERSION of the header the library was built from.  It changes whenever the layout of
- * fastegnn_layer_t / fastegnn_graph_t or the meaning of an argument changes (round 3 inserted act_param: 100 -> 101).
+ * fastegnn_layer_t / fastegnn_graph_t or the meaning of an argument changes (round 3 inserted act_param: 100 -> 101; round 4 appended wgrad_batch: 102).
  * A binding MUST compare it with the FASTEGNN_ABI_VERSION it was written against AND check fastegnn_sizeof_layer() /
  * fastegnn_sizeof_graph() against its own mirror of the descriptors before the first call (fastegnn_amd/_lib.py does). */
-#define FASTEGNN_ABI_VERSION 101
+#define FASTEGNN_ABI_VERSION 102
 int fastegnn_version(void);
 /* floats of the packed weight-image buffer for C virtual channels */
 size_t fastegnn_wpack_floats(int32_t C);
@@ -248,6 +259,12 @@ size_t fastegnn_wg_virt_floats_for(int32_t N, int32_t C, int32_t flags);
  * a multiple of 4 floats so that one allocation can be carved into 16-byte aligned pieces */
 size_t fastegnn_backward_scratch_floats(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C);
 size_t fastegnn_backward_scratch_floats_for(int32_t N, int32_t E, int32_t n_src, int32_t B, int32_t C, int32_t flags);
+/* A weight-gradient batch shared by the backward stage calls of ONE layer (fastegnn_layer_t.wgrad_batch).  open: L gives
+ * wg_slab (the batch takes the lower half of the slab workspace, as fastegnn_layer_backward's does) and the operand mode;
+ * the stages must run on `stream`.  close: contracts and reduces everything queued (two launches), then frees the handle --
+ * also call it after a failed stage.  Host-side objects only: capturable. */
+int fastegnn_wgrad_batch_open(const fastegnn_layer_t *L, void *stream, void **batch);
+int fastegnn_wgrad_batch_close(void *batch);
 /* struct sizes, so that a foreign-language binding can verify its mirror of the descriptors */
 size_t fastegnn_sizeof_layer(void);
 size_t fastegnn_sizeof_graph(void);

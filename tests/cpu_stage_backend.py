@@ -47,8 +47,14 @@ class CpuOracleBackend:
     def wg_edge_floats(self, E):
         return 4
 
-    def wg_virt_floats(self, N, Cn):
+    def wg_virt_floats(self, N, Cn, flags=0):
         return 4
+
+    def wgrad_open(self, spec, N, B, graph, t, params):   # the oracle's stages contract their own weight gradients
+        return None
+
+    def wgrad_close(self, handle):
+        pass
 
     def wg_node_floats(self, N, B, Cn):
         return 4
@@ -86,14 +92,18 @@ class CpuOracleBackend:
         p = {f"L.{s}": t for s, t in zip(PARAM_SLOTS, params) if t is not None}
         return F.LayerW(p, "L", self.cfg), p
 
-    def _G(self, grads):
+    def _G(self, grads, params):
+        """gradient accumulators by layer-local name; a slot the caller left empty (the per-graph stages on ranks other
+        than 0) gets a scratch tensor that is dropped afterwards"""
         from fastegnn_amd._lib import PARAM_SLOTS
-        return {f"L.{s}": t for s, t in zip(PARAM_SLOTS, grads) if t is not None}
+        return {f"L.{s}": (g if g is not None else torch.zeros_like(p))
+                for s, g, p in zip(PARAM_SLOTS, grads, params) if p is not None}
 
-    def stage(self, name, spec, N, B, graph, t, params, grads=None):
+    def stage(self, name, spec, N, B, graph, t, params, grads=None, flags=0):
+        from fastegnn_amd._lib import F_GQX_ACCUM
         cfg = self.cfg
         w, _ = self._w(params)
-        G = self._G(grads) if grads is not None else None
+        G = self._G(grads, params) if grads is not None else None
         grav = torch.tensor(list(cfg.gravity)) if cfg.gravity is not None else None
         cnt = t["xsum"][:, 3].clamp(min=1) if "xsum" in t else None
         batch = t["batch"]
@@ -170,12 +180,12 @@ class CpuOracleBackend:
             g_P, g_Q, (g_xr, g_xs) = F.edge_bwd(w, cfg, G, "L", graph.csr, t["P"], src[:, :H], t["x"], t["ea_sorted"],
                                                 t["g_aggm"], t["g_aggx"], x_src=src[:, H:H + 3])
             t["g_P"].copy_(g_P); t["g_xrow"].copy_(g_xr)
-            self._gq = (g_Q, g_xs)
+            if not flags & F_GQX_ACCUM:      # the first launch of a layer zeroes the col-keyed sums, a later one adds to them
+                t["g_QX_src"].zero_()
+            t["g_QX_src"][:, :H] += g_Q
+            t["g_QX_src"][:, H:H + 3] += g_xs
         elif name == "edge_col_reduce":
-            g_Q, g_xs = self._gq
-            t["g_QX_src"].zero_()
-            t["g_QX_src"][:, :H] = g_Q
-            t["g_QX_src"][:, H:H + 3] = g_xs
+            pass                             # (the atomic form of the product path: edge_backward has already summed)
         elif name == "node_pre_backward":
             gq = t["g_QX"]
             g_h = F.node_pre_bwd(w, cfg, G, "L", t["h"], t["g_P"], gq[:N, :H], t["g_A"], t["g_svel"],

@@ -22,6 +22,20 @@ pytestmark = pytest.mark.gpu
 
 SIZES = [1500, 900, 1301]     # 3 701 nodes: Npad = 1 851, graph 1 straddles the rank boundary
 C, L = 8, 3
+# other shapes travel to the spawned ranks through the environment: "n0,n1,...;C"
+#   one graph over both ranks: every rank's rows lie in ONE graph, so both run the [interior | boundary] split (round 4)
+ONE_GRAPH = "3701;8"
+#   a few hundred nodes per rank with C = 16: the producer / consumer form of the virtual backward has ~36 MB of constant-size
+#   scratch that the five-array size formula does not cover on small shards (wg_virt was under-allocated)
+SMALL = "300,180,201;16"
+
+
+def _shape():
+    v = os.environ.get("FASTEGNN_TEST_SHARDED_SHAPE")
+    if not v:
+        return SIZES, C
+    sizes, c = v.split(";")
+    return [int(x) for x in sizes.split(",")], int(c)
 
 
 def _free_port():
@@ -34,7 +48,8 @@ def _free_port():
 
 def _inputs():
     from tests.test_gpu_properties import _batch
-    inp = _batch(SIZES, 9, C, seed=31)
+    sizes, c = _shape()
+    inp = _batch(sizes, 9, c, seed=31)
     g = torch.Generator().manual_seed(32)
     target = inp["node_loc"] + torch.randn(inp["node_loc"].shape, generator=g) * 0.2
     return inp, target
@@ -43,7 +58,7 @@ def _inputs():
 def _model(hidden=64):
     torch.manual_seed(9)
     cls = fastegnn_amd.FastRF if os.environ.get("FASTEGNN_TEST_SHARDED_MODEL") == "FastRF" else fastegnn_amd.FastEGNN
-    m = cls(2, 0, 2, abs(hidden), C, device="cuda", n_layers=L, gravity=[0, -1, 0], attention=True)
+    m = cls(2, 0, 2, abs(hidden), _shape()[1], device="cuda", n_layers=L, gravity=[0, -1, 0], attention=True)
     with torch.no_grad():
         for k, v in m.named_parameters():
             if k.endswith((".coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
@@ -78,8 +93,10 @@ def _worker(rank, world, port, exchange, reorder, q, backend="gloo", comm="torch
     grads = {k: (p.grad.cpu().numpy().copy() if p.grad is not None else None) for k, p in m.named_parameters()}
     ids = plan.node_ids.cpu() if plan.node_ids is not None else torch.arange(plan.n0, plan.n1)
     grads["__edge_attr__"] = inp["edge_attr"].grad.cpu().numpy().copy()
+    summary = stats.summary()
+    summary["__parts__"] = [(r0, n, bool(h)) for r0, n, h in plan.parts]
     q.put((rank, ids.numpy().copy(), plan.exchanged_bytes(), loc.detach().cpu().numpy().copy(),
-           vloc.detach().cpu().numpy().copy(), grads, stats.summary()))
+           vloc.detach().cpu().numpy().copy(), grads, summary))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -107,9 +124,14 @@ def _run_and_check(exchange, reorder, backend, comm, hidden=64):
     loc, vloc = loc.detach().cpu(), vloc.detach().cpu()
     N = target.size(0)
     assert sorted(i for r in res for i in r[1].tolist()) == list(range(N))
+    npad = (N + 1) // 2
     for rank, ids, xbytes, loc_r, vloc_r, grads, summary in res:
         ids = torch.from_numpy(ids)
-        assert len(ids) == (1851 if rank == 0 else N - 1851)
+        assert len(ids) == (npad if rank == 0 else N - npad)
+        parts = summary.pop("__parts__")
+        assert sum(n for _, n, _ in parts) == len(ids)
+        if len(_shape()[0]) == 1 and exchange == "halo":      # one graph: interior rows first, then the rows with ghost columns
+            assert [h for _, _, h in parts] == [False, True], parts
         assert rel_err(loc_r, loc[ids]) < 2e-6, rel_err(loc_r, loc[ids])
         assert rel_err(vloc_r, vloc) < 2e-6
         for k, p in m.named_parameters():
@@ -123,15 +145,24 @@ def _run_and_check(exchange, reorder, backend, comm, hidden=64):
         # exchange volume per layer and direction
         if exchange == "allgather":      # the padded source table both ways
             assert summary["QX"]["calls_per_step"] == L and summary["g_QX"]["calls_per_step"] == L
-            assert summary["QX"]["bytes_per_step"] == L * 2 * 1851 * 68 * 4
+            assert summary["QX"]["bytes_per_step"] == L * 2 * npad * 68 * 4
         else:                            # only the ghost rows, the same number back
             assert summary["QX_halo"]["calls_per_step"] == L and summary["g_QX_halo"]["calls_per_step"] == L
-            assert summary["QX_halo"]["bytes_per_step"] == L * xbytes <= L * 1851 * 68 * 4
+            assert summary["QX_halo"]["bytes_per_step"] == L * xbytes <= L * npad * 68 * 4
 
 
 @pytest.mark.parametrize("exchange,reorder", [("allgather", False), ("halo", False), ("halo", True)])
 def test_two_ranks_on_one_gpu_match_the_unsharded_model(exchange, reorder):
     _run_and_check(exchange, reorder, "gloo", "torch")
+
+
+@pytest.mark.parametrize("shape", [ONE_GRAPH, SMALL])
+def test_two_ranks_split_and_small_shards_match_the_unsharded_model(shape, monkeypatch):
+    """ONE_GRAPH: both ranks order their rows [interior | boundary] and run the edge stage as two launches per direction
+    (the second backward launch adds to the col-keyed sums of the first: FASTEGNN_F_GQX_ACCUM); SMALL: 341 nodes per rank
+    with C = 16 (the scratch sizes of the virtual backward on a small shard)."""
+    monkeypatch.setenv("FASTEGNN_TEST_SHARDED_SHAPE", shape)
+    _run_and_check("halo", True, "gloo", "torch")
 
 
 def test_two_ranks_narrow_hidden_nf_match_the_unsharded_model():
@@ -154,3 +185,52 @@ def test_two_ranks_over_rccl_match_the_unsharded_model(exchange, reorder, comm):
     """The same check over RCCL / xGMI, with torch.distributed's collectives and with the C-ABI transport
     (FASTEGNN_COMM=abi).  Skipped on the pool's one-GPU boxes: RCCL with two ranks has never run there."""
     _run_and_check(exchange, reorder, "nccl", comm)
+
+
+def test_emulated_rank_async_abi_transport_and_graph_capture(monkeypatch):
+    """One process plays rank 1 of 4 (ShardedFastEGNN(emulate=...)): its share of the rows and edges, the [interior | boundary]
+    split, the pack / unpack kernels of its halo, the single-rank RCCL communicator of the C-ABI transport on a SECOND stream
+    forked and joined with events (FASTEGNN_SHARDED_SYNC=0) -- and the whole step captured into ONE HIP graph whose replay
+    must reproduce the eager pass (the ghost rows hold stand-in data: only self-consistency is checked here)."""
+    from fastegnn_amd.sharded import ShardedFastEGNN
+    from tests.test_gpu_properties import _batch
+    monkeypatch.setenv("FASTEGNN_COMM", "abi")
+    monkeypatch.setenv("FASTEGNN_SHARDED_SYNC", "0")
+    inp = {k: v.cuda() for k, v in _batch([6000], 9, 8, seed=5).items()}
+    torch.manual_seed(3)
+    m = fastegnn_amd.FastEGNN(2, 0, 2, 64, 8, device="cuda", n_layers=2, gravity=[0, -1, 0])
+    sm = ShardedFastEGNN(m, emulate=(4, 1))
+    local = sm.shard_inputs(**inp, reorder=True)
+    plan = local["plan"]
+    assert [h for _, _, h in plan.parts] == [False, True] and plan.n_int > 0
+    assert plan.nloc == 1500 and 0 < plan.n_ghost < 4500 and 0 < plan.n_send
+    assert int(plan.send_ids.min()) >= 0 and int(plan.send_ids.max()) < plan.nloc
+    params = list(m.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        loc, vloc = sm.forward_local(local)
+        (loc.pow(2).mean() + vloc.pow(2).mean()).backward()
+        return loc, vloc
+    loc0, vloc0 = step()
+    g0 = [p.grad.clone() for p in params if p.grad is not None]
+    assert torch.isfinite(loc0).all() and all(torch.isfinite(g).all() for g in g0)
+    torch.cuda.synchronize()
+    gs = torch.cuda.Stream()
+    gs.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(gs):
+        step()
+    torch.cuda.current_stream().wait_stream(gs)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=gs):
+        loc1, vloc1 = step()
+    for p in params:
+        if p.grad is not None:
+            p.grad.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert rel_err(loc1, loc0) < 1e-6 and rel_err(vloc1, vloc0) < 1e-6
+    g1 = [p.grad for p in params if p.grad is not None]
+    for a, b in zip(g1, g0):
+        assert rel_err(a, b) < 1e-3

@@ -88,6 +88,7 @@ def _worker(rank, world, port, gravity, exchange, reorder, q, hidden=64):
     allreduce_gradients(m.parameters())
     grads = {k: (p.grad.numpy().copy() if p.grad is not None else None) for k, p in m.named_parameters()}
     ids = plan.node_ids.numpy().copy() if plan.node_ids is not None else np.arange(plan.n0, plan.n1)
+    grads["__parts__"] = [(r0, n, bool(h)) for r0, n, h in plan.parts]
     q.put((rank, ids, plan.exchanged_bytes(), loc.detach().numpy().copy(), vloc.detach().numpy().copy(), grads))
     dist.barrier()
     dist.destroy_process_group()
@@ -120,7 +121,11 @@ def test_sharded_graph_matches_single_process_oracle(world, gravity, exchange, r
     seen = np.concatenate([r[1] for r in res])
     assert sorted(seen.tolist()) == list(range(target.size(0)))        # every node owned by exactly one rank
     last = CFG["n_layers"] - 1
+    split_seen = False
     for rank, ids, xbytes, loc_r, vloc_r, grads in res:
+        parts = grads.pop("__parts__")
+        assert sum(n for _, n, _ in parts) == len(ids)
+        split_seen |= [h for _, _, h in parts] == [False, True]
         assert rel_err(loc_r, loc.detach()[torch.from_numpy(ids)]) < 1e-5
         assert rel_err(vloc_r, vloc.detach()) < 1e-5
         if exchange == "halo":                                             # ghosts are at most the remote nodes
@@ -131,6 +136,10 @@ def test_sharded_graph_matches_single_process_oracle(world, gravity, exchange, r
                 continue
             assert grads[k] is not None, k
             assert rel_err(grads[k], v.grad) < 2e-4, (rank, k, rel_err(grads[k], v.grad))
+    if exchange == "halo" and world == 2:
+        # rank 0's rows (12 of graph 0's 14 nodes) lie in one graph: it orders them [interior | boundary] and launches the edge
+        # stage twice (with four ranks every row of a 6-node shard has a ghost column: one launch)
+        assert split_seen
 
 
 def test_morton_order_keeps_graphs_contiguous_and_localises_neighbours():
