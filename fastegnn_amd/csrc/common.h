@@ -836,6 +836,88 @@ __device__ __forceinline__ unsigned split_word_d(double w0, double w1, int part,
   return out;
 }
 
+// ---- f16x2 for GRADIENT operands: per-item power-of-two scale ---------------------------------------------------------------
+// Gradients sit far below fp16's range (1e-9 on the headline frame): the 64 values of an item are multiplied by s = 2^k, k chosen
+// from the item's largest magnitude so that it lands in [2^14, 2^15), split as above, and the product is multiplied by 1/s (both
+// exact).  Errors are then 2^-23 of the item's LARGEST component, which is what an fp32 dot product over the item gives too.
+struct Split2s {
+  Split2 s;
+  float inv;   // 1 / scale of this lane's item
+};
+__device__ __forceinline__ float qmax(float p) {   // max over the four q-lanes of an item (as qsum)
+  float a = p, b = p;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  p = fmaxf(a, b);
+  a = p; b = p;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ Split2s vsplit2_scaled(const Vec &v) {
+  float m = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(v.t[t][r]));
+  m = qmax(m);
+  // m in [2^(e-127), 2^(e-126)): scale 2^(141-e) puts it into [2^14, 2^15).  Exponent fields clamped to the normal range: items
+  // whose largest component is below 2^-113 (or zero) get inv = 0 -- their product is dropped, it is below fp32's range anyway.
+  int se = 268 - (int)(f2u(m) >> 23);
+  se = se > 254 ? 254 : (se < 1 ? 1 : se);
+  const float sc = __builtin_bit_cast(float, (unsigned)se << 23);
+  Split2s S;
+  S.inv = __builtin_bit_cast(float, (unsigned)(254 - se) << 23);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int e = 2 * w;
+      const float a0 = v.t[2 * s + (e >> 2)][e & 3], a1 = v.t[2 * s + ((e + 1) >> 2)][(e + 1) & 3];
+      unsigned h, l;
+      float r0, r1;
+      asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(h) : "v"(a0), "v"(a1), "v"(sc));
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(sc), "v"(h));
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(sc), "v"(h));
+      asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(l) : "v"(r0), "v"(r1), "s"(F2_UP));
+      S.s.p[0][s][w] = h;
+      S.s.p[1][s][w] = l;
+    }
+  return S;
+}
+// f16x2 products on a ROW-MAJOR image whose parts 0 | 1 hold the fp16 h | l of the weight (pack.hip, slots RM_F16 + k): plain and
+// transposed reads as for the bf16 parts (16-bit elements either way).  SCALED: the operand is a Split2s, the result is
+// multiplied by the item's 1 / scale before it is added to acc.
+template <bool TR, bool SCALED>
+__device__ __forceinline__ void gemm64_f2_rm_(const char *img, const Split2 &in, float inv, Vec &acc) {
+  const f16x8 xh0 = __builtin_bit_cast(f16x8, in.p[0][0]), xh1 = __builtin_bit_cast(f16x8, in.p[0][1]);
+  const f16x8 xl0 = __builtin_bit_cast(f16x8, in.p[1][0]), xl1 = __builtin_bit_cast(f16x8, in.p[1][1]);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f16x8 ah0 = __builtin_bit_cast(f16x8, rm_frag<TR>(img, 0, t, 0)), ah1 = __builtin_bit_cast(f16x8, rm_frag<TR>(img, 0, t, 1));
+    const f16x8 al0 = __builtin_bit_cast(f16x8, rm_frag<TR>(img, 1, t, 0)), al1 = __builtin_bit_cast(f16x8, rm_frag<TR>(img, 1, t, 1));
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, xh0, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xl0, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, xh1, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xl1, lo, 0, 0, 0);
+    if constexpr (SCALED) {
+      f32x4 hi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hi[r] = lo[r] * F2_DOWN;
+      hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh0, hi, 0, 0, 0);
+      hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh1, hi, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc.t[t][r] = __builtin_fmaf(hi[r], inv, acc.t[t][r]);
+    } else {
+      f32x4 hi = acc.t[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hi[r] = __builtin_fmaf(lo[r], F2_DOWN, hi[r]);
+      hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh0, hi, 0, 0, 0);
+      hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh1, hi, 0, 0, 0);
+      acc.t[t] = hi;
+    }
+  }
+}
+
 // Which forward kernels run on f16x2 images (bit 0 edge_fwd, bit 1 virt_fwd, bit 2 node_pre_fwd); pack_kernel writes the
 // split images those kernels read (and only they read) in the matching format.
 #ifndef FE_FWD_F16
@@ -846,11 +928,28 @@ enum GemmMode { GM_F32 = 0, GM_X3 = 1, GM_BF16 = 2, GM_F16 = 3 };
 constexpr int GM_EDGE_FWD = (FE_FWD_F16 & 1) ? GM_F16 : GM_X3;
 constexpr int GM_VIRT_FWD = (FE_FWD_F16 & 2) ? GM_F16 : GM_X3;
 constexpr int GM_NODE_PRE_FWD = (FE_FWD_F16 & 4) ? GM_F16 : GM_X3;
+// -DFE_BWD_F16=mask: the producers of edge_bwd_pc (bit 0) / virt_bwd_pc (bit 1) on f16x2 products (their in-workgroup weight-
+// gradient consumers keep the bf16x3 form: a contraction over ROWS has no per-item scale)
+#ifndef FE_BWD_F16
+#define FE_BWD_F16 0
+#endif
+constexpr int GM_EDGE_BWD = (FE_BWD_F16 & 1) ? GM_F16 : GM_X3;
+constexpr int GM_VIRT_BWD = (FE_BWD_F16 & 2) ? GM_F16 : GM_X3;
 // the B operand of one or several products in the chosen form: made once, used by every layer that reads it
 template <int MODE> struct OperandOf { typedef Vec type; };
 template <> struct OperandOf<GM_X3> { typedef Split type; };
 template <> struct OperandOf<GM_BF16> { typedef BfOp type; };
 template <> struct OperandOf<GM_F16> { typedef Split2 type; };
+// the B operand made from a GRADIENT (transposed products): the f16x2 form scales per item, the other forms do not care
+template <int MODE> struct GradOperandOf { typedef typename OperandOf<MODE>::type type; };
+template <> struct GradOperandOf<GM_F16> { typedef Split2s type; };
+template <int MODE>
+__device__ __forceinline__ typename OperandOf<MODE>::type make_operand(const Vec &v);
+template <int MODE>
+__device__ __forceinline__ typename GradOperandOf<MODE>::type make_grad_operand(const Vec &v) {
+  if constexpr (MODE == GM_F16) return vsplit2_scaled(v);
+  else return make_operand<MODE>(v);
+}
 template <int MODE>
 __device__ __forceinline__ typename OperandOf<MODE>::type make_operand(const Vec &v) {
   if constexpr (MODE == GM_X3) return vsplit(v);
@@ -871,9 +970,16 @@ __device__ __forceinline__ void gemm_op(const void *img, int i, const typename O
 // product (TR = false) or transposed product (TR = true) on a row-major split image, forms GM_X3 / GM_BF16
 template <int MODE, bool TR, bool PIPE = true>
 __device__ __forceinline__ void gemm_rm(const char *img, const typename OperandOf<MODE>::type &in, Vec &acc) {
-  static_assert(MODE == GM_X3 || MODE == GM_BF16, "row-major images hold bf16 parts");
+  static_assert(MODE == GM_X3 || MODE == GM_BF16 || MODE == GM_F16, "row-major images hold 16-bit parts");
   if constexpr (MODE == GM_X3) gemm64_x3_rm<TR, PIPE>(img, in, acc);
+  else if constexpr (MODE == GM_F16) gemm64_f2_rm_<TR, false>(img, in, 1.f, acc);
   else gemm64_b1_rm<TR>(img, in, acc);
+}
+// the same with a gradient operand (make_grad_operand)
+template <int MODE, bool TR, bool PIPE = true>
+__device__ __forceinline__ void gemm_rm_g(const char *img, const typename GradOperandOf<MODE>::type &in, Vec &acc) {
+  if constexpr (MODE == GM_F16) gemm64_f2_rm_<TR, true>(img, in.s, in.inv, acc);
+  else gemm_rm<MODE, TR, PIPE>(img, in, acc);
 }
 template <int MODE>
 __device__ __forceinline__ void gemm64_m(const float *img, const Vec &in, Vec &acc) {
@@ -923,9 +1029,11 @@ __host__ __device__ inline bool img_is_f16(int id, int C) {
 }
 __host__ __device__ inline int img_w3ct(int C, int c) { return I_FIXED + C + c; }
 // wpack = [fp32 images n x 4096 floats][split images n x IMG3 words (h | m | l)][row-major split images (5 + C) x RM_WORDS]
-// row-major images: slot 0 V2, 1 WXV0, 2 WXX0 (virt_bwd), 3 W2, 4 WX1 (edge_bwd), 5 WVEL0, 6 WG0 (node_pre_bwd),
+// row-major images: slot 0 V2, 1 WXV0, 2 WXX0 (virt_bwd), 3 W2, 4 WX1 (edge_bwd), 5 WVEL0, 6 WG0 (node_pre_bwd), 7..11 f16x2 forms of 0..4,
 // RM_FIXED + c: W3c[c] (virtual backward)
-constexpr int RM_FIXED = 7;
+// 7..11: the f16x2 forms (parts h | l, part 2 unused) of slots 0..4, for the backward producers built with FE_BWD_F16
+constexpr int RM_F16 = 7;
+constexpr int RM_FIXED = 12;
 __host__ __device__ inline size_t wpack_images(int C) { return (size_t)(I_FIXED + 2 * C); }
 __host__ __device__ inline size_t wpack_rm_images(int C) { return (size_t)(RM_FIXED + (C > 0 ? C : 0)); }
 __host__ __device__ inline size_t wpack_floats(int C) { return wpack_images(C) * (IMG + IMG3) + wpack_rm_images(C) * RM_WORDS; }

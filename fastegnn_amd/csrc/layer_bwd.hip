@@ -918,7 +918,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   float *ring = tiles + PC_PROD * 16 * TS;
   int *ctrl = reinterpret_cast<int *>(ring + 2 * PC_RING * PC_SLOT);
   {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, A.C, 3));   // slots 3, 4 are consecutive
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, A.C, (MODE == GM_F16 ? RM_F16 : 0) + 3));   // slots 3, 4 (f16x2: 10, 11) are consecutive
     u32x4 *dst = reinterpret_cast<u32x4 *>(img);
     for (int i = threadIdx.x; i < 2 * RM_BYTES / 16; i += blockDim.x) dst[i] = src[i];
   }
@@ -1353,10 +1353,10 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
       const dim3 g3(grid), b3(64 * PC_WAVES);
       if (L->ea <= 2) {
         if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_BF16, 2>), g3, b3, lds, st, A);
-        else hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_X3, 2>), g3, b3, lds, st, A);
+        else hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_EDGE_BWD, 2>), g3, b3, lds, st, A);
       } else {
         if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_BF16, 7>), g3, b3, lds, st, A);
-        else hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_X3, 7>), g3, b3, lds, st, A);
+        else hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_EDGE_BWD, 7>), g3, b3, lds, st, A);
       }
     }
     if ((rc = check_launch("edge_bwd_pc_kernel"))) return rc;

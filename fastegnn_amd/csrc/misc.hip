@@ -585,14 +585,13 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
     double t = 0.;
 #pragma unroll
     for (int u = 0; u < 8; ++u) t += part[u][e];
+    // (atomic: two jobs of one batch may add into the same gradient -- the sharded caller runs a layer's edge backward as two
+    // launches, each with its own partial slabs; a plain read-modify-write lost one of the two sums)
     if (bias_block) {
-      a.db[e] = (float)((double)a.db[e] + t);
+      atomicAdd(&a.db[e], (float)t);
     } else {
       const int o = blockIdx.z, k = e;
-      if (k < a.kmax) {
-        float *d = dW + (size_t)o * a.lddw + a.c0 + (size_t)k * a.ks;
-        *d = (float)((double)*d + t);
-      }
+      if (k < a.kmax) atomicAdd(dW + (size_t)o * a.lddw + a.c0 + (size_t)k * a.ks, (float)t);
     }
   }
 }

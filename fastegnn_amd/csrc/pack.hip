@@ -115,6 +115,16 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) rm[p * (RM_PART / 4) + idx] = split_word(w0, w1, p);
     }
+    if (slot < 5 && !a.bf16) {   // the f16x2 form of the same image (slots RM_F16 + slot; backward producers with FE_BWD_F16)
+      unsigned *rf = reinterpret_cast<unsigned *>(const_cast<char *>(wpack_rm(a.wpack, a.C, RM_F16 + slot)));
+      for (int idx = threadIdx.x; idx < 64 * (RM_RS / 4); idx += 256) {
+        const int o = idx / (RM_RS / 4), w = idx % (RM_RS / 4);
+        const float w0 = w < 32 ? at(o, 2 * w) : 0.f, w1 = w < 32 ? at(o, 2 * w + 1) : 0.f;
+        rf[idx] = split2_word(w0, w1, 0);
+        rf[(RM_PART / 4) + idx] = split2_word(w0, w1, 1);
+        rf[2 * (RM_PART / 4) + idx] = 0u;
+      }
+    }
   }
 }
 

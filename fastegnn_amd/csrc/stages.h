@@ -133,11 +133,18 @@ __device__ __forceinline__ void gemm_i(const void *img, int i, const Vec &in, Ve
 // two row-major images W2 | WX1 read plain or transposed (RM = true, edge_bwd: half the LDS, which its rings take)
 template <int MODE, int I, bool RM>
 __device__ __forceinline__ void gemm_e(const void *img, const Vec &in, Vec &acc) {
-  const auto op = make_operand<MODE>(in);
-  EF_PRIO_ON();
-  if constexpr (RM) gemm_rm<MODE, (I >= 2), false>(static_cast<const char *>(img) + (I & 1) * RM_BYTES, op, acc);
-  else gemm_op<MODE>(img, I, op, acc);
-  EF_PRIO_OFF();
+  if constexpr (RM && I >= 2) {   // the transposed products take gradients: the f16x2 form scales them per item
+    const auto op = make_grad_operand<MODE>(in);
+    EF_PRIO_ON();
+    gemm_rm_g<MODE, true, false>(static_cast<const char *>(img) + (I & 1) * RM_BYTES, op, acc);
+    EF_PRIO_OFF();
+  } else {
+    const auto op = make_operand<MODE>(in);
+    EF_PRIO_ON();
+    if constexpr (RM) gemm_rm<MODE, false, false>(static_cast<const char *>(img) + (I & 1) * RM_BYTES, op, acc);
+    else gemm_op<MODE>(img, I, op, acc);
+    EF_PRIO_OFF();
+  }
 }
 
 // part 1: consumes the gathered operands (geometry + first-layer pre-activation)

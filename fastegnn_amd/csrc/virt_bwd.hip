@@ -224,7 +224,7 @@ __device__ __forceinline__ void vb_accum_items(float *row, const Vec &u, int j, 
 
 template <bool BF, bool ATT>
 __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args A) {
-  constexpr int SM = BF ? GM_BF16 : GM_X3;
+  constexpr int SM = BF ? GM_BF16 : GM_VIRT_BWD;
   typedef typename OperandOf<SM>::type SOp;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VirtArgs &a = A.f;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
   float *ringB = ringA + A.ringA * VB_SLOT_A;
   int *ctrl = reinterpret_cast<int *>(ringB + A.ringB * VB_SLOT_B);
   {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, C, 0));   // slots 0..2 are consecutive
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, C, SM == GM_F16 ? RM_F16 : 0));   // slots 0..2 (f16x2: 7..9) are consecutive
     u32x4 *dst = reinterpret_cast<u32x4 *>(rmimg);
     for (int i = threadIdx.x; i < 3 * RM_BYTES / 16; i += blockDim.x) dst[i] = src[i];
   }
@@ -442,9 +442,9 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
 #endif
     auto mm = [&](int which, const SOp &op, Vec &acc) { VB_PRIO_ON(); gemm_rm<SM, false>(rmimg + which * RM_BYTES, op, acc); VB_PRIO_OFF(); };
     auto mmT = [&](int which, const Vec &g, Vec &acc) {
-      const auto op = make_operand<SM>(g);
+      const auto op = make_grad_operand<SM>(g);   // (the f16x2 form scales a gradient per item)
       VB_PRIO_ON();
-      gemm_rm<SM, true>(rmimg + which * RM_BYTES, op, acc);
+      gemm_rm_g<SM, true>(rmimg + which * RM_BYTES, op, acc);
       VB_PRIO_OFF();
     };
     VB2_T0()

@@ -162,6 +162,8 @@ class ShardPlan:
         self.node_ids = order[self.n0:self.n1] if order is not None else None
         # row ranges the edge stage is launched over: (first local row, rows, needs the exchanged table)
         self.parts = [(0, self.nloc, True)]
+        self.edge_perm = None      # HaloPlan.build: order of the rank's edges by part (None: as given)
+        self.edge_counts = None    # edges per part, in that order
 
     def rows(self, t: torch.Tensor) -> torch.Tensor:
         """This rank's rows of a per-node tensor given in the CALLER's node order."""
@@ -267,7 +269,20 @@ class HaloPlan(ShardPlan):
         pos = torch.searchsorted(ghost, cols.clamp(min=0)) if self.n_ghost else torch.zeros_like(cols)
         own = lrank[(cols - self.n0).clamp(0, self.nloc - 1)]
         new_col = torch.where(remote, self.nloc + pos, own)
-        return torch.stack([lrank[rows - self.n0] + self.n0, new_col]).contiguous()
+        new_row = lrank[rows - self.n0]
+        ei = torch.stack([new_row + self.n0, new_col])
+        if len(self.parts) > 1:
+            # the rank's edges grouped by part (stable), so that a part's edges -- and its rows of edge_attr -- are a contiguous
+            # slice: no data-dependent selection inside the step (a boolean mask is a host synchronisation, which a HIP graph
+            # capture of the step does not allow)
+            in_b = new_row >= self.n_int
+            self.edge_perm = torch.argsort(in_b.to(torch.int8), stable=True)
+            n_b = int(in_b.sum())
+            self.edge_counts = [ei.size(1) - n_b, n_b]
+            ei = ei[:, self.edge_perm]
+        else:
+            self.edge_perm, self.edge_counts = None, [ei.size(1)]
+        return ei.contiguous()
 
     def alloc_tables(self, be):
         QX_src = be.zeros(max(self.n_src, 1), K.QX_LD)
@@ -587,6 +602,7 @@ class _Part:
     """One launch range of the edge stage: rows [row0, row0 + nrows) of the rank, their edges as a sorted graph."""
 
     def __init__(self, graph, row0, nrows, halo, mask):
+        # mask: (first, last) positions of the part's edges in the rank's edge list, or None (the whole list)
         self.graph, self.row0, self.nrows, self.halo, self.mask = graph, row0, nrows, halo, mask
         self.ea_sorted = None
 
@@ -614,8 +630,9 @@ class _ShardedFunction(torch.autograd.Function):
         # edge_attr / node_attr: this rank's edges / rows; differentiable like in the single-GPU module (their gradients
         # are accumulated by the edge / virtual backward kernels when asked for)
         for pt in parts:
-            ea_p = edge_attr.detach()[pt.mask] if (edge_attr is not None and pt.mask is not None) else \
-                (edge_attr.detach() if edge_attr is not None else None)
+            ea_p = edge_attr.detach() if edge_attr is not None else None
+            if ea_p is not None and pt.mask is not None:
+                ea_p = ea_p[pt.mask[0]:pt.mask[1]]
             pt.ea_sorted = pt.graph.permute(ea_p)
         node_attr = node_attr.detach().contiguous().float() if node_attr is not None else None
         W, rank = plan.world, plan.rank
@@ -789,7 +806,7 @@ class _ShardedFunction(torch.autograd.Function):
                 if pt.mask is None:
                     g_ea = un
                 else:
-                    g_ea[pt.mask] = un
+                    g_ea[pt.mask[0]:pt.mask[1]] = un
         return (None,) * 7 + (g_ea, sc["g_node_attr"] if want_na else None, g_nf, g_x, g_vel, g_Z, *grads)
 
 
@@ -874,6 +891,8 @@ class ShardedFastEGNN(torch.nn.Module):
                 peer = torch.div(rows[m], plan.Npad, rounding_mode="floor")
                 want = torch.unique(peer * N + cols[m]) % N          # (peer, col) pairs, ascending by peer then col
             ei = plan.build(ei, self.comm(), db[plan.n0:plan.n1], split, peers_want=want)
+            if plan.edge_perm is not None and ea is not None:
+                ea = ea[plan.edge_perm]
         return dict(plan=plan, node_feat=plan.rows(node_feat), node_loc=plan.rows(node_loc), node_vel=plan.rows(node_vel),
                     edge_index=ei, edge_attr=ea, data_batch=plan.rows(data_batch), loc_mean=loc_mean,
                     node_attr=plan.rows(node_attr).float() if node_attr is not None else None)
@@ -891,14 +910,13 @@ class ShardedFastEGNN(torch.nn.Module):
         if csc and len(plan.parts) > 1:
             raise RuntimeError("ShardedFastEGNN: the deterministic backward needs an unsplit plan (shard_inputs(split=False))")
         ei = local["edge_index"]
-        parts = []
-        for row0, nrows, halo in plan.parts:
-            if len(plan.parts) == 1:
-                mask, ei_p = None, ei
-            else:
-                mask = (ei[0] >= plan.n0 + row0) & (ei[0] < plan.n0 + row0 + nrows)
-                ei_p = ei[:, mask].contiguous()
-            parts.append(_Part(be.build_graph(ei_p, nrows, plan.n_src, plan.n0 + row0, csc=csc), row0, nrows, halo, mask))
+        parts, e0 = [], 0
+        counts = plan.edge_counts if plan.edge_counts is not None else [ei.size(1)]
+        for (row0, nrows, halo), ne in zip(plan.parts, counts):
+            sl = None if len(plan.parts) == 1 else (e0, e0 + ne)      # the part's edges: a slice of the rank's edge list
+            ei_p = ei if sl is None else ei[:, sl[0]:sl[1]].contiguous()
+            parts.append(_Part(be.build_graph(ei_p, nrows, plan.n_src, plan.n0 + row0, csc=csc), row0, nrows, halo, sl))
+            e0 += ne
         B = local["loc_mean"].size(0)
         batch32, gptr = be.build_batch(local["data_batch"], plan.nloc, B)
         self.plan = plan

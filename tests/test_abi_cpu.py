@@ -79,7 +79,8 @@ def test_struct_mirrors_and_sizes():
     assert L.fastegnn_sizeof_graph() == C.sizeof(K.GraphT)
     assert L.fastegnn_version() >= 100
     # fp32 + split images of the 34 + 2C matrices, row-major split images (64 rows x 144 B x 3 parts) of V2, WXV0, WXX0, W3c[c]
-    assert L.fastegnn_wpack_floats(16) == (34 + 32) * (4096 + 4096 + 2048) + (7 + 16) * (3 * 64 * 144 // 4)
+    # 34 fixed + 2 C images (fp32 + split) and 12 fixed (7 bf16-part + 5 f16x2 forms) + C row-major images
+    assert L.fastegnn_wpack_floats(16) == (34 + 32) * (4096 + 4096 + 2048) + (12 + 16) * (3 * 64 * 144 // 4)
     assert L.fastegnn_profile_kernels() >= 15
 
 
