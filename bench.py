@@ -269,6 +269,14 @@ def kernel_model(N, E, B, C, L, gravity=True):
     return f
 
 
+def recompute_free_units(N, E, B, C):
+    """FLOPs per launch WITHOUT the forward products a backward kernel recomputes (SURVEY 8d's convention: backward = 2 x
+    forward -- the transposed products and the weight-gradient contractions): what `roofline.frac_algorithmic` is computed
+    from, so that recomputation shows up as lost efficiency instead of as achieved FLOPs."""
+    NC = N * C
+    return {"edge_bwd_kernel": E * 4 * UNIT, "virt_bwd_kernel": NC * 6 * UNIT}
+
+
 def operand_bytes(N, E, B, C, gravity=True):
     """Bytes the streaming helper kernels must read per launch (distinct operand arrays, each counted once)."""
     heads = 2 if gravity else 1
@@ -656,10 +664,15 @@ def main():
         if t_mfma >= t_hbm:
             roof = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak_mfma,
                     "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / peak_mfma, 4), "traffic": traffic}
+            # the same fraction without the forward products a backward kernel recomputes (3 of virt_bwd's 9 units per (node,
+            # channel), 2 of edge_bwd's 6 per edge): `frac` counts executed algorithmic work, this one useful work
+            rf = recompute_free_units(kN, kE, B, C).get(dom)
+            roof["frac_algorithmic"] = round((rf / fl) * roof["frac"], 4) if rf else roof["frac"]
             if dtype != "bf16":
                 # the fp32-grade products of this kernel are bf16x3 on the matrix pipe; a bare chain of them reaches
                 # 224 TFLOP/s fp32-equivalent on this part (tools/gpu_bf3.py): the kernel's real ceiling
                 roof["frac_of_bf16x3_ceiling"] = round(kernels[dom]["tflops"] / BF16X3_CEILING_TFLOPS, 4)
+                roof["frac_algorithmic_of_bf16x3_ceiling"] = round(roof["frac_algorithmic"] * peak_mfma / BF16X3_CEILING_TFLOPS, 4)
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["gbs"], "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic}

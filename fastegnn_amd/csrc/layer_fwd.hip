@@ -434,17 +434,14 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
 #pragma unroll
     for (int i = 0; i < STG; ++i) dst[threadIdx.x + i * 64 * VIRT_WAVES] = pre_w[i];
   };
-  // few tiles per workgroup (a small shard / a small batch: every workgroup has less than one step of VIRT_WAVES tiles): every
-  // tile is dealt to the waves by channel instead of leaving most waves idle while one of them walks all C channels of its
-  // tile -- a 12 500-node shard (1/8 of the headline frame) has 3 tiles per workgroup: 3 x C / VIRT_WAVES channel steps per wave
-  // instead of C (round 4, from the emulated-rank bench: virt_fwd took 0.48 ms per step where an eighth of the full frame's is 0.19)
-  const bool all_split = C >= VIRT_WAVES && 2 * (t_hi - t_lo) <= VIRT_WAVES;   // (at most half a step: the host sizes the grid for it)
-  for (int tb = t_lo; tb < t_hi; tb += (all_split ? 1 : VIRT_WAVES)) {
+  for (int tb = t_lo; tb < t_hi; tb += VIRT_WAVES) {
     // a single left-over tile is dealt to the waves by channel (wave w takes c = w, w + VIRT_WAVES, ...); the
-    // channel sums of the node-MLP accumulator and of the coordinate update are combined through LDS
-    const bool split = all_split || (t_hi - tb == 1 && C >= VIRT_WAVES);
+    // channel sums of the node-MLP accumulator and of the coordinate update are combined through LDS.
+    // (Round 4 measured the same deal for EVERY tile of a small shard -- 3 tiles per workgroup at 12 500 nodes, an emulated rank of
+    // eight: 0.517 against 0.479 ms per step; the per-tile epilogue through the image stage costs what the idle waves cost.)
+    const bool split = t_hi - tb == 1 && C >= VIRT_WAVES;
     const bool own = !split || wv == 0;
-    const int n0 = tb * 16, nend = min(a.N, min(t_hi, tb + (all_split ? 1 : VIRT_WAVES)) * 16);
+    const int n0 = tb * 16, nend = min(a.N, min(t_hi, tb + VIRT_WAVES) * 16);
     const int bfirst = a.batch[n0], blast = a.batch[nend - 1];
     const bool fast = bfirst == blast;   // every node of this step in ONE graph: its pools, Bc rows and Z sit in LDS
     const bool staged = C > 0 && !rf && !split;
@@ -660,10 +657,7 @@ int virt_forward(const fastegnn_layer_t *L, hipStream_t st) {
   }
   if (L->N == 0) return check_launch("virt_forward(memset)");
   VirtArgs a = make_virt_args(L);
-  int ntg = cdiv(L->N, 16 * VIRT_WAVES);
-  // fewer than one step of tiles per CU: one workgroup per tile up to one per CU, the kernel then deals every tile's channels to
-  // its waves (all_split)
-  if (ntg < 128 && L->C >= VIRT_WAVES) ntg = cdiv(L->N, 16);
+  const int ntg = cdiv(L->N, 16 * VIRT_WAVES);
   int grid = ntg < 256 ? ntg : 256;   // one workgroup per CU (LDS), each with an equal share of the tiles
   {
     ProfScope _ps_virt_fwd_kernel(K_VIRT_FWD, st);

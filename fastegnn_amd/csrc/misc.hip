@@ -775,9 +775,9 @@ struct WgsArgs {
   int ldg, ldf, kf, lddw, c0, rows_per_wg;
 };
 // (round 4: double accumulators -- per thread, in the workgroup's LDS sums and therefore in the partial that leaves the
-// workgroup -- and at most 64 workgroups: the gradient of embedding_in is the end of the whole backward chain, a column sum
+// workgroup -- and at most 256 workgroups (64 measured 0.27 instead of 0.05 ms per step at cfg4: too few rows in flight): the gradient of embedding_in is the end of the whole backward chain, a column sum
 // over N rows that cancels; with fp32 chains and up to 512 float atomics in arrival order it measured 2.4 x the reference's
-// own error on the goldens.  The final += into dW / db is still a float atomic per workgroup: <= 64 well-rounded partials.)
+// own error on the goldens.  The final += into dW / db is still a float atomic per workgroup: <= 256 well-rounded partials.)
 __global__ __launch_bounds__(256) void wgrad_small_kernel(WgsArgs a) {
   const int o = threadIdx.x & 63, w = wave_id();
   const long m0 = (long)blockIdx.x * a.rows_per_wg;
@@ -785,7 +785,20 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgsArgs a) {
   if (m1 > a.M) m1 = a.M;
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double bs = 0.;
-  for (long m = m0 + w; m < m1; m += 4) {
+  long m = m0 + w;
+  for (; m + 12 < m1; m += 16) {   // four rows in flight per wave
+    float g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g[u] = a.G[(size_t)(m + 4 * u) * a.ldg + o];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bs += (double)g[u];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < a.kf) acc[k] += (double)g[u] * (double)a.F[(size_t)(m + 4 * u) * a.ldf + k];
+    }
+  }
+  for (; m < m1; m += 4) {
     const float g = a.G[(size_t)m * a.ldg + o];
     bs += (double)g;
 #pragma unroll
@@ -809,7 +822,7 @@ static int launch_wgrad_small_b(const float *G, int ldg, const float *F, int ldf
   FE_REQUIRE(kf >= 0 && kf <= 8, "wgrad_small: kf > 8 unsupported");
   WgsArgs a{G, F, dW, db, M, ldg, ldf, kf, lddw, c0, 0};
   long nsplit = (M + 255) / 256;
-  if (nsplit > 64) nsplit = 64;
+  if (nsplit > 256) nsplit = 256;
   long rows = (M + nsplit - 1) / nsplit;
   a.rows_per_wg = (int)rows;
   nsplit = (M + rows - 1) / rows;

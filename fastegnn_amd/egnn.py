@@ -75,8 +75,11 @@ def _egnn_pad_layout(name: str, shape, h: int):
 
 class _EGNNFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, spec, graph, ea_sorted, x, h_in, v, *params):
+    def forward(ctx, spec, graph, edge_fea, x, h_in, v, *params):
         lib = K.lib()
+        # edge_fea is a differentiable input (basic.py:313 concatenates it into the message MLP's input): its gradient is
+        # accumulated by the edge backward kernel in sorted-edge order when asked for
+        ea_sorted = graph.permute(edge_fea.detach() if edge_fea is not None else None)
         dev = x.device
         st = _stream(dev)
         N = x.size(0)
@@ -130,6 +133,8 @@ class _EGNNFunction(torch.autograd.Function):
                               g_QXe=(max(E, 1) if spec.flags & K.F_DETERMINISTIC else 1, K.QX_LD), g_QX_src=(N, K.QX_LD), g_xrow=(N, 3),
                               wg_edge=(lib.fastegnn_wg_edge_floats(E),), wg_node=(lib.fastegnn_wg_node_floats(N, 1, 0),), wg_slab=(lib.fastegnn_wg_slab_floats(),)))
         sc["g_xbar"] = torch.zeros(1, 4, **f32)
+        want_ea = ctx.needs_input_grad[2] and ea_sorted is not None and E > 0
+        g_ea_sorted = torch.zeros(E, spec.ea, **f32) if want_ea else None
         for i in reversed(range(spec.n_layers)):
             b = saved[i]
             ptab = _PtrTable([params[s] if s is not None else None for s in spec.layer_slots[i]])
@@ -142,13 +147,19 @@ class _EGNNFunction(torch.autograd.Function):
             L.g_QX = sc["g_QX_src"].data_ptr()
             if ea_sorted is not None:
                 L.ea_sorted = ea_sorted.data_ptr()
+            if g_ea_sorted is not None:
+                L.g_ea_sorted = g_ea_sorted.data_ptr()
             K.check(lib.fastegnn_layer_backward(C.byref(L), st), f"fastegnn_layer_backward[egnn {i}]")
             g_h, g_x = out["g_h"], out["g_x"]
             saved[i] = None
         g_hin = torch.empty_like(h_in) if ctx.needs_input_grad[4] else None
         K.check(lib.fastegnn_embed_backward(K.ptr(h_in), K.ptr(g_h), N, spec.nf, K.ptr(params[0]), K.ptr(grads[0]),
                                             K.ptr(grads[1]), K.ptr(g_hin), st), "fastegnn_embed_backward")
-        return (None, None, None, g_x, g_hin, g_vel, *grads)
+        g_ea = None
+        if g_ea_sorted is not None:   # back to the caller's edge order: sorted edge k is input edge perm[k]
+            g_ea = torch.empty_like(g_ea_sorted)
+            g_ea.index_copy_(0, graph.perm[:E].long(), g_ea_sorted)
+        return (None, None, g_ea, g_x, g_hin, g_vel, *grads)
 
 
 class EGNN(nn.Module):
@@ -198,8 +209,6 @@ class EGNN(nn.Module):
     def forward(self, x, h, edge_index, edge_fea, v=None):
         if not x.is_cuda:
             raise RuntimeError("fastegnn_amd.EGNN runs on a gfx950 GPU only (no CPU fallback)")
-        if edge_fea is not None and edge_fea.requires_grad:
-            raise NotImplementedError("fastegnn_amd: gradient w.r.t. edge_fea is not implemented")
         if self._spec is None:
             self._build_spec()
         N = x.size(0)
@@ -211,12 +220,13 @@ class EGNN(nn.Module):
             if len(self._graph_cache) >= 8:
                 self._graph_cache.pop(next(iter(self._graph_cache)))
             self._graph_cache[key] = graph
-        ea_sorted = graph.permute(edge_fea.detach() if edge_fea is not None else None)
+        if edge_fea is not None and edge_fea.size(1) == 0:
+            edge_fea = None
         vv = v if v is not None else torch.zeros_like(x)
         plist = self._plist
         if self.hidden_nf < H:   # 64-wide images of the parameters (fastegnn_pad_params; the reverse mode slices the gradients back)
             plist = list(_PadParams.apply(tuple(self._spec.names), self.hidden_nf, 0, _egnn_pad_layout, *plist))
-        x_out, h_out = _EGNNFunction.apply(self._spec, graph, ea_sorted, x, h, vv, *plist)
+        x_out, h_out = _EGNNFunction.apply(self._spec, graph, edge_fea, x, h, vv, *plist)
         if self.hidden_nf < H:
             h_out = h_out[:, :self.hidden_nf]     # the padded features are identically zero
         return (x_out, v, h_out) if v is not None else (x_out, h_out)

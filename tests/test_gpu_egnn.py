@@ -52,18 +52,24 @@ def test_egnn_mid_size_vs_oracle():
     p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.named_parameters()}
     x = torch.randn(N, 3, generator=g); h = torch.rand(N, 2, generator=g); v = torch.randn(N, 3, generator=g) * 0.2
     ei = torch.randint(0, N, (2, Ed), generator=g); ea = torch.rand(Ed, 2, generator=g)
-    xo, vo, ho = m(x=x.cuda(), h=h.cuda(), edge_index=ei.cuda(), edge_fea=ea.cuda(), v=v.cuda())
+    # edge_fea is a differentiable input of the reference layer (basic.py:313): its gradient comes back in the caller's edge order
+    ea_gpu = ea.cuda().requires_grad_(True)
+    xo, vo, ho = m(x=x.cuda(), h=h.cuda(), edge_index=ei.cuda(), edge_fea=ea_gpu, v=v.cuda())
     (xo.pow(2).mean() + ho.pow(2).mean()).backward()
-    xr, hr = E.forward(p, 3, x, h, ei, ea, v)
+    ea32 = ea.clone().requires_grad_(True)
+    xr, hr = E.forward(p, 3, x, h, ei, ea32, v)
     (xr.pow(2).mean() + hr.pow(2).mean()).backward()
     assert rel_err(xo, xr) < 1e-5 and rel_err(ho, hr) < 2e-5
     dt = torch.float64
     p64 = {k: t.detach().to(dt).clone().requires_grad_(True) for k, t in p.items()}
-    x64, h64 = E.forward(p64, 3, x.to(dt), h.to(dt), ei, ea.to(dt), v.to(dt))
+    ea64 = ea.to(dt).requires_grad_(True)
+    x64, h64 = E.forward(p64, 3, x.to(dt), h.to(dt), ei, ea64, v.to(dt))
     (x64.pow(2).mean() + h64.pow(2).mean()).backward()
     bad = []
     for k, prm in m.named_parameters():
         grad_check("egnn_mid_size", k, prm.grad, p[k].grad, p64[k].grad, bad)
+    assert ea_gpu.grad is not None and ea_gpu.grad.shape == ea.shape
+    grad_check("egnn_mid_size", "gin/edge_fea", ea_gpu.grad.cpu(), ea32.grad, ea64.grad, bad)
     assert not bad, bad
 
 

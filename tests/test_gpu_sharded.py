@@ -193,10 +193,10 @@ def test_emulated_rank_async_abi_transport_and_graph_capture(monkeypatch):
     forked and joined with events (FASTEGNN_SHARDED_SYNC=0) -- and the whole step captured into ONE HIP graph whose replay
     must reproduce the eager pass (the ghost rows hold stand-in data: only self-consistency is checked here)."""
     from fastegnn_amd.sharded import ShardedFastEGNN
-    from tests.test_gpu_properties import _batch
     monkeypatch.setenv("FASTEGNN_COMM", "abi")
     monkeypatch.setenv("FASTEGNN_SHARDED_SYNC", "0")
-    inp = {k: v.cuda() for k, v in _batch([6000], 9, 8, seed=5).items()}
+    import bench
+    inp, _ = bench.make_frame(6000, 8, 5, "cuda", radius=0.035)        # a radius graph: neighbours are near in space
     torch.manual_seed(3)
     m = fastegnn_amd.FastEGNN(2, 0, 2, 64, 8, device="cuda", n_layers=2, gravity=[0, -1, 0])
     sm = ShardedFastEGNN(m, emulate=(4, 1))

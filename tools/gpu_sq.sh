@@ -1,26 +1,53 @@
 #!/bin/bash
-# SQ counters (separate passes, kernel trace only) on ONE layer of the cfg4 frame; per-kernel averages
+# SQ counters (separate passes, kernel trace only: gpurun refuses --pmc together with other trace domains) on ONE layer of the cfg4
+# frame; per-kernel per-launch averages and the derived ratios the DESIGN.md claims rest on.  Output: gpurun_out/$tag/sq_counters.txt
+# (copy it to profiles/).  The program goes directly after `--` (no shell / env hop under the profiler).
 tag=${1:-sq}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp
 run() { n=$1; shift
-  timeout 500 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/$tag/$n -- python3 $R/bench.py --layers 1 --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/$tag/$n.log 2>&1
+  timeout 500 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/$tag/$n -- python3 $R/bench.py --layers 1 --steps 1 --warmup 1 --no-cpu-baseline --hipgraph off > $R/gpurun_out/$tag/$n.log 2>&1
 }
 run p1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU
 run p2 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM
+run p3 SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT
 cd $R
-python - <<PY
-import csv, glob, collections
-for n in ("p1","p2"):
-    fs=glob.glob("gpurun_out/$tag/%s/*/*counter_collection.csv"%n)
-    if not fs: print(n,"no file"); continue
-    agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(set)
+python - <<PY | tee gpurun_out/$tag/sq_counters.txt
+import csv, glob, collections, subprocess
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
+for n in ("p1", "p2", "p3"):
+    fs = glob.glob("gpurun_out/$tag/%s/*/*counter_collection.csv" % n)
+    if not fs:
+        print("#", n, "no counter file (see gpurun_out/$tag/%s.log)" % n); continue
     for r in csv.DictReader(open(fs[0])):
-        k=r["Kernel_Name"].split("(")[0].replace("void ","").split("<")[0].replace("_pc_kernel","_kernel")
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if not k.startswith("fe::"): continue
-        agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
-    print("==",n)
-    for k in ("fe::edge_fwd_kernel","fe::virt_fwd_kernel","fe::edge_bwd_kernel","fe::virt_bwd_kernel","fe::wgrad_tn_kernel"):
-        if k in agg: print(k, len(cnt[k]), {a:("%.4g"%(b/len(cnt[k]))) for a,b in agg[k].items()})
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, n)].add(r["Dispatch_Id"])
+print("# rocprofv3 --pmc (three passes, kernel trace only) of: python3 bench.py --layers 1 --steps 1 --warmup 1 --hipgraph off")
+print("# cfg4 frame (100 000 nodes, 1.92 M edges, C = 16), ONE layer, fp32 mode; values are per-LAUNCH averages summed over the chip.")
+print("# commit:", subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "(snapshot without .git)")
+names = ["fe::edge_fwd_kernel", "fe::virt_fwd_kernel", "fe::edge_bwd_pc_kernel", "fe::virt_bwd_pc_kernel", "fe::virt_bwd_gv_kernel",
+         "fe::virt_bwd_node_kernel", "fe::node_pre_fwd_kernel", "fe::node_pre_bwd_kernel", "fe::wgrad_tn_kernel", "fe::wgrad_reduce_kernel"]
+for k in names:
+    if k not in agg: continue
+    a = agg[k]
+    def per(c, n):
+        l = len(cnt[(k, n)]) or 1
+        return a.get(c, 0.0) / l
+    v = {c: per(c, n) for n, cs in (("p1", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_SALU"]),
+                                    ("p2", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_VMEM"]),
+                                    ("p3", ["SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_IDX_ACTIVE"])) for c in cs}
+    print(f"\n{k}  ({len(cnt[(k, 'p1')])} launches sampled)")
+    for c, x in v.items():
+        print(f"  {c:30s} {x:16.4g}")
+    wc, bc = v["SQ_WAVE_CYCLES"] or 1, v["SQ_BUSY_CYCLES"] or 1
+    print("  -- derived")
+    print(f"  VALU instructions per MFMA instruction            {v['SQ_INSTS_VALU'] / max(v['SQ_INSTS_MFMA'], 1):10.2f}")
+    print(f"  issue model 4 N_valu + 8 N_mfma / ACTIVE_INST_VALU  {(4 * v['SQ_INSTS_VALU'] + 8 * v['SQ_INSTS_MFMA']) / max(v['SQ_ACTIVE_INST_VALU'], 1):10.3f}   (1.0: the vector issue port is what ACTIVE_INST_VALU counts)")
+    print(f"  vector-issue share  ACTIVE_INST_VALU / WAVE_CYCLES  {v['SQ_ACTIVE_INST_VALU'] / wc:10.3f}   (of a wave's resident time)")
+    print(f"  MFMA-pipe busy      VALU_MFMA_BUSY / BUSY_CYCLES    {v['SQ_VALU_MFMA_BUSY_CYCLES'] / bc:10.3f}   (per-SE counters: compare kernels, not absolutes)")
+    print(f"  waiting             WAIT_INST_ANY / WAVE_CYCLES     {v['SQ_WAIT_INST_ANY'] / wc:10.3f}")
+    print(f"  waiting on LDS      WAIT_INST_LDS / WAVE_CYCLES     {v['SQ_WAIT_INST_LDS'] / wc:10.3f}")
+    print(f"  LDS bank conflicts  LDS_BANK_CONFLICT / ACTIVE_INST_LDS {v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_ACTIVE_INST_LDS'], 1):8.3f}")
 PY
