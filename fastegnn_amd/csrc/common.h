@@ -804,7 +804,7 @@ __device__ __forceinline__ void gemm64_f2(const unsigned *img3, const Split2 &in
 // weights and a scaled bias, head vectors and the aggregation's 1/deg absorb 1 / log2 e.  The scaled image is split from the
 // double-precision product w * log2(e), so no weight is rounded twice.
 #ifndef FE_LOG2E_FOLD
-#define FE_LOG2E_FOLD 0
+#define FE_LOG2E_FOLD 1   // adopted in round 4 (edge_fwd 0.870 -> 0.854 ms per step, parity green; profiles/r04_lever_f16x2_fwd_bwd_fold.txt)
 #endif
 constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
 constexpr double LOG2E_D = 1.4426950408889634074;
@@ -921,7 +921,7 @@ __device__ __forceinline__ void gemm64_f2_rm_(const char *img, const Split2 &in,
 // Which forward kernels run on f16x2 images (bit 0 edge_fwd, bit 1 virt_fwd, bit 2 node_pre_fwd); pack_kernel writes the
 // split images those kernels read (and only they read) in the matching format.
 #ifndef FE_FWD_F16
-#define FE_FWD_F16 0
+#define FE_FWD_F16 7   // adopted in round 4: cfg4 step 12.20 -> 11.90 ms on one box, parity suite green, FEWER comparisons beyond 2 x ref
 #endif
 // Arithmetic form of the 64x64 layers of a kernel (template parameter of the stage kernels)
 enum GemmMode { GM_F32 = 0, GM_X3 = 1, GM_BF16 = 2, GM_F16 = 3 };
@@ -931,7 +931,7 @@ constexpr int GM_NODE_PRE_FWD = (FE_FWD_F16 & 4) ? GM_F16 : GM_X3;
 // -DFE_BWD_F16=mask: the producers of edge_bwd_pc (bit 0) / virt_bwd_pc (bit 1) on f16x2 products (their in-workgroup weight-
 // gradient consumers keep the bf16x3 form: a contraction over ROWS has no per-item scale)
 #ifndef FE_BWD_F16
-#define FE_BWD_F16 0
+#define FE_BWD_F16 3   // adopted in round 4: 11.90 -> 11.45 ms (virt_bwd 3.51 -> 3.30, edge_bwd 3.39 -> 3.16); -DFE_BWD_F16=0 restores bf16x3
 #endif
 constexpr int GM_EDGE_BWD = (FE_BWD_F16 & 1) ? GM_F16 : GM_X3;
 constexpr int GM_VIRT_BWD = (FE_BWD_F16 & 2) ? GM_F16 : GM_X3;
