@@ -806,6 +806,12 @@ __device__ __forceinline__ void gemm64_f2(const unsigned *img3, const Split2 &in
 #ifndef FE_LOG2E_FOLD
 #define FE_LOG2E_FOLD 1   // adopted in round 4 (edge_fwd 0.870 -> 0.854 ms per step, parity green; profiles/r04_lever_f16x2_fwd_bwd_fold.txt)
 #endif
+// (the generic-activation build keeps the plain form: the fold is a property of SiLU)
+#ifdef FE_ACT_GENERIC
+constexpr bool LOG2E_FOLD_EDGE = false;
+#else
+constexpr bool LOG2E_FOLD_EDGE = (FE_LOG2E_FOLD & 1) != 0;
+#endif
 constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
 constexpr double LOG2E_D = 1.4426950408889634074;
 __device__ __forceinline__ float silu2_f(float z2) { return z2 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z2)); }

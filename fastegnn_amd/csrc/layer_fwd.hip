@@ -421,8 +421,9 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
   // the K = H*C contraction of node_mlp.0 reads W3c[c] from an LDS stage of two slots that the whole workgroup refills (all
   // waves walk the channels in step): channel c + 1 is written into the other slot while channel c is in use, channel
   // c + 2 is on its way into registers -- ONE workgroup barrier per channel.
-  constexpr int STG = IMG3 / 4 / (64 * VIRT_WAVES);   // 16-byte pieces per thread
-  static_assert(STG * 4 * 64 * VIRT_WAVES == IMG3, "stage copy must tile the image");
+  // 16-byte pieces per thread: one per part of the image (h | m | l; an f16x2 image has two parts, the third is not copied)
+  static_assert(2048 == 4 * 64 * VIRT_WAVES, "one part of a split image per pass of the stage copy");
+  constexpr int STG = MODE == GM_F16 ? 2 : 3;
   u32x4 pre_w[STG];
   auto fetch_w3c = [&](int c) {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_x3(a.wpack, C, img_w3c(c)));

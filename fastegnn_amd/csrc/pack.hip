@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
   for (int idx = threadIdx.x; idx < IMG / 2; idx += 256) {
     int o = idx >> 5, k = (idx & 31) * 2;
     const float w0 = at(o, k), w1 = at(o, k + 1);
-    if (!a.bf16 && (FE_LOG2E_FOLD & 1) && id == I_W2) {   // edge_fwd's first in-kernel product delivers z * log2(e) (common.h)
+    if (!a.bf16 && LOG2E_FOLD_EDGE && id == I_W2) {   // edge_fwd's first in-kernel product delivers z * log2(e) (common.h)
       const bool f16 = img_is_f16(id, a.C);
       for (int p = 0; p < 3; ++p) d3[img3_index(p, o, k)] = split_word_d((double)w0 * LOG2E_D, (double)w1 * LOG2E_D, p, f16);
       continue;

@@ -180,11 +180,7 @@ __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *ve
 // does this instantiation run with the log2(e) fold?  (the forward kernel in an fp32-grade form of the SiLU build only)
 template <bool KEEP_D, int MODE, bool RM>
 constexpr bool edge_fold() {
-#ifdef FE_ACT_GENERIC
-  return false;
-#else
-  return !KEEP_D && !RM && (MODE == GM_X3 || MODE == GM_F16) && (FE_LOG2E_FOLD & 1) != 0;
-#endif
+  return !KEEP_D && !RM && (MODE == GM_X3 || MODE == GM_F16) && LOG2E_FOLD_EDGE;
 }
 template <bool KEEP_D, int MODE = GM_F32, bool RM = false>
 __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img, const float *vec, int q, EdgeFwdState &S,

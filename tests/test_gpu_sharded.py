@@ -213,7 +213,10 @@ def test_emulated_rank_async_abi_transport_and_graph_capture(monkeypatch):
         loc, vloc = sm.forward_local(local)
         (loc.pow(2).mean() + vloc.pow(2).mean()).backward()
         return loc, vloc
-    loc0, vloc0 = step()
+    # (only detached copies of the eager pass are kept: holding an output WITH its autograd graph across a later capture makes
+    # hipStreamEndCapture segfault on this stack -- with the unsharded module and torch's own transport just the same,
+    # tools/scratch/capture_keep_repro.py)
+    loc0, vloc0 = (t.detach().clone() for t in step())
     g0 = [p.grad.clone() for p in params if p.grad is not None]
     assert torch.isfinite(loc0).all() and all(torch.isfinite(g).all() for g in g0)
     torch.cuda.synchronize()
@@ -224,7 +227,7 @@ def test_emulated_rank_async_abi_transport_and_graph_capture(monkeypatch):
     torch.cuda.current_stream().wait_stream(gs)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=gs):
-        loc1, vloc1 = step()
+        loc1, vloc1 = (t.detach() for t in step())
     for p in params:
         if p.grad is not None:
             p.grad.zero_()
