@@ -981,6 +981,8 @@ __device__ __forceinline__ void gemm_rm(const char *img, const typename OperandO
   else if constexpr (MODE == GM_F16) gemm64_f2_rm_<TR, false>(img, in, 1.f, acc);
   else gemm64_b1_rm<TR>(img, in, acc);
 }
+// bytes of one row-major image as a kernel of form MODE keeps it in LDS: an f16x2 image has two parts
+template <int MODE> constexpr int rm_lds_bytes() { return MODE == GM_F16 ? 2 * RM_PART : RM_BYTES; }
 // the same with a gradient operand (make_grad_operand)
 template <int MODE, bool TR, bool PIPE = true>
 __device__ __forceinline__ void gemm_rm_g(const char *img, const typename GradOperandOf<MODE>::type &in, Vec &acc) {

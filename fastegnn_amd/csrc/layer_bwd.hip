@@ -892,7 +892,8 @@ constexpr int PC_RING = FE_PC_RING;                  // slots per ring; one ring
 constexpr int PC_FLUSH = FE_PC_FLUSH;       // tickets (16-edge operand sets) a consumer accumulates in registers between two scratch updates
 constexpr int PC_RS = 68;                   // row stride of a slot tile
 constexpr int PC_SLOT = 2 * 16 * PC_RS;     // floats per slot: G tile | T tile
-constexpr int PC_IMG_FLOATS = 2 * RM_WORDS;   // W2 | WX1 as row-major split images: each serves the product and its transpose
+// W2 | WX1 as row-major split images, each serving the product and its transpose (an f16x2 image keeps two parts in LDS)
+template <int MODE> constexpr int pc_img_floats() { return 2 * (rm_lds_bytes<MODE>() / 4); }
 enum { PC_HEAD = 0, PC_TOTAL = 2, PC_FILLED = 4, PC_DRAINED = 4 + 2 * PC_RING, PC_CTRL = 4 + 4 * PC_RING };
 #ifdef FE_SAFE_WAITS   // ring flags as workgroup-scope acquire loads / release stores instead of relaxed accesses between fences
 __device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -913,14 +914,18 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const EdgeArgs &a = A.f;
   float *img = lds;                    // W2, WX1 (row-major split images, common.h)
-  float *vec = lds + PC_IMG_FLOATS;
+  float *vec = lds + pc_img_floats<MODE>();
   float *tiles = vec + EV_COUNT * H;   // per producer [16][TS]; the 4 pad columns of a row hold its g_d scalars
   float *ring = tiles + PC_PROD * 16 * TS;
   int *ctrl = reinterpret_cast<int *>(ring + 2 * PC_RING * PC_SLOT);
   {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, A.C, (MODE == GM_F16 ? RM_F16 : 0) + 3));   // slots 3, 4 (f16x2: 10, 11) are consecutive
-    u32x4 *dst = reinterpret_cast<u32x4 *>(img);
-    for (int i = threadIdx.x; i < 2 * RM_BYTES / 16; i += blockDim.x) dst[i] = src[i];
+    // slots 3, 4 (f16x2: 10, 11) are consecutive in wpack, RM_BYTES apart; only the parts this form reads are copied
+    constexpr int RMS = rm_lds_bytes<MODE>();
+    const char *src = wpack_rm(a.wpack, A.C, (MODE == GM_F16 ? RM_F16 : 0) + 3);
+    for (int i = threadIdx.x; i < 2 * (RMS / 16); i += blockDim.x) {
+      const int im = i / (RMS / 16), k = i % (RMS / 16);
+      reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(img) + im * RMS)[k] = reinterpret_cast<const u32x4 *>(src + (size_t)im * RM_BYTES)[k];
+    }
   }
   edge_load_vecs(vec, a);
   if (threadIdx.x < PC_CTRL) ctrl[threadIdx.x] = 0;
@@ -1347,7 +1352,8 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
     A.slab_b = wb.tab.slab_b;
     FE_REQUIRE(L->wg_edge, "edge_backward: wg_edge null");
     A.cons_scratch = L->wg_edge;
-    const size_t lds = (PC_IMG_FLOATS + EV_COUNT * H + PC_PROD * 16 * TS + 2 * PC_RING * PC_SLOT + PC_CTRL) * sizeof(float);
+    const int imgf = has(L, FASTEGNN_F_BF16) ? pc_img_floats<GM_BF16>() : pc_img_floats<GM_EDGE_BWD>();
+    const size_t lds = (imgf + EV_COUNT * H + PC_PROD * 16 * TS + 2 * PC_RING * PC_SLOT + PC_CTRL) * sizeof(float);
     {
       ProfScope _ps_edge_bwd_kernel(K_EDGE_BWD, st);
       const dim3 g3(grid), b3(64 * PC_WAVES);

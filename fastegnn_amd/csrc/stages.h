@@ -136,12 +136,12 @@ __device__ __forceinline__ void gemm_e(const void *img, const Vec &in, Vec &acc)
   if constexpr (RM && I >= 2) {   // the transposed products take gradients: the f16x2 form scales them per item
     const auto op = make_grad_operand<MODE>(in);
     EF_PRIO_ON();
-    gemm_rm_g<MODE, true, false>(static_cast<const char *>(img) + (I & 1) * RM_BYTES, op, acc);
+    gemm_rm_g<MODE, true, false>(static_cast<const char *>(img) + (I & 1) * rm_lds_bytes<MODE>(), op, acc);
     EF_PRIO_OFF();
   } else {
     const auto op = make_operand<MODE>(in);
     EF_PRIO_ON();
-    if constexpr (RM) gemm_rm<MODE, false, false>(static_cast<const char *>(img) + (I & 1) * RM_BYTES, op, acc);
+    if constexpr (RM) gemm_rm<MODE, false, false>(static_cast<const char *>(img) + (I & 1) * rm_lds_bytes<MODE>(), op, acc);
     else gemm_op<MODE>(img, I, op, acc);
     EF_PRIO_OFF();
   }

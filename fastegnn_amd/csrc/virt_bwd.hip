@@ -181,7 +181,7 @@ constexpr int VB_RS = 68;                     // row stride of a ring tile
 constexpr int VB_TILE = 16 * VB_RS;           // floats per 16 x 64 tile
 constexpr int VB_SLOT_A = 3 * VB_TILE;        // g_ux | g_uX | v   (read by consumers X and XX)
 constexpr int VB_SLOT_B = 2 * VB_TILE;        // g_vp | t          (read by consumer V2)
-constexpr int VB_MAXRING = 4;
+constexpr int VB_MAXRING = 6;
 // control words (LDS ints): unit ticket, ring heads A / B, per ring slot: filled, drained (ring A: one per consumer)
 enum { VBC_UNIT = 0, VBC_HEAD = 1, VBC_FILLED = 4, VBC_DRAINED = 4 + 2 * VB_MAXRING, VBC_CTRL = 4 + 5 * VB_MAXRING };
 // rank-1 gradient accumulators of the workgroup in LDS: [w_xv2 | w_xx2 | w_vr | att_w | att_b], in up to VB_MAXBANK banks
@@ -204,8 +204,8 @@ struct VirtBwd2Args {
   int NGF, ringA, ringB, nbank;   // NGF: channel groups of a fine tile
 };
 
-inline size_t vb_lds_floats(int C, int ringA, int ringB, int nbank) {
-  return (size_t)3 * RM_WORDS + VV_COUNT * H + (size_t)nbank * VB_RACC + (size_t)C * H + ((3 * C + 3) & ~3) + (size_t)ringA * VB_SLOT_A +
+inline size_t vb_lds_floats(int C, int ringA, int ringB, int nbank, int img_bytes = RM_BYTES) {
+  return (size_t)3 * (img_bytes / 4) + VV_COUNT * H + (size_t)nbank * VB_RACC + (size_t)C * H + ((3 * C + 3) & ~3) + (size_t)ringA * VB_SLOT_A +
          (size_t)ringB * VB_SLOT_B + VBC_CTRL;
 }
 
@@ -229,8 +229,9 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VirtArgs &a = A.f;
   const int C = a.C;
+  constexpr int RMS = rm_lds_bytes<SM>();               // LDS bytes per image: an f16x2 image has two parts (36.9 instead of 55.3 KB)
   char *rmimg = reinterpret_cast<char *>(lds);          // V2 | WXV0 | WXX0, row-major split images (product and transpose)
-  float *vec = lds + 3 * RM_WORDS;
+  float *vec = lds + 3 * (RMS / 4);
   float *racc0 = vec + VV_COUNT * H;                    // [nbank][5][64]
   float *gBc_l = racc0 + A.nbank * VB_RACC;             // [C][64]
   float *gZ_l = gBc_l + C * H;                          // [3][C]
@@ -238,9 +239,12 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
   float *ringB = ringA + A.ringA * VB_SLOT_A;
   int *ctrl = reinterpret_cast<int *>(ringB + A.ringB * VB_SLOT_B);
   {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, C, SM == GM_F16 ? RM_F16 : 0));   // slots 0..2 (f16x2: 7..9) are consecutive
-    u32x4 *dst = reinterpret_cast<u32x4 *>(rmimg);
-    for (int i = threadIdx.x; i < 3 * RM_BYTES / 16; i += blockDim.x) dst[i] = src[i];
+    // slots 0..2 (f16x2: 7..9) are consecutive in wpack, RM_BYTES apart; only the parts this form reads are copied
+    const char *src = wpack_rm(a.wpack, C, SM == GM_F16 ? RM_F16 : 0);
+    for (int i = threadIdx.x; i < 3 * (RMS / 16); i += blockDim.x) {
+      const int im = i / (RMS / 16), k = i % (RMS / 16);
+      reinterpret_cast<u32x4 *>(rmimg + im * RMS)[k] = reinterpret_cast<const u32x4 *>(src + (size_t)im * RM_BYTES)[k];
+    }
   }
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < A.nbank * VB_RACC + C * H + 3 * C; i += blockDim.x) racc0[i] = 0.f;
@@ -440,11 +444,11 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
 #define VB_PRIO_ON()
 #define VB_PRIO_OFF()
 #endif
-    auto mm = [&](int which, const SOp &op, Vec &acc) { VB_PRIO_ON(); gemm_rm<SM, false>(rmimg + which * RM_BYTES, op, acc); VB_PRIO_OFF(); };
+    auto mm = [&](int which, const SOp &op, Vec &acc) { VB_PRIO_ON(); gemm_rm<SM, false>(rmimg + which * RMS, op, acc); VB_PRIO_OFF(); };
     auto mmT = [&](int which, const Vec &g, Vec &acc) {
       const auto op = make_grad_operand<SM>(g);   // (the f16x2 form scales a gradient per item)
       VB_PRIO_ON();
-      gemm_rm_g<SM, true>(rmimg + which * RM_BYTES, op, acc);
+      gemm_rm_g<SM, true>(rmimg + which * RMS, op, acc);
       VB_PRIO_OFF();
     };
     VB2_T0()
@@ -785,11 +789,16 @@ int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shar
   if ((rc = bb.add_slabs(g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], grid, &A.slab_v2))) return rc;
   A.slab = bb.tab.slab; A.slab_b = bb.tab.slab_b;
   // rings: as many slots as the 160 KB of LDS leave (three per ring at C <= 32)
-  A.ringA = 3; A.ringB = 3; A.nbank = 1;
-  while (vb_lds_floats(C, A.ringA, A.ringB, 1) * sizeof(float) > 160 * 1024 && A.ringB > 2) --A.ringB;
-  while (vb_lds_floats(C, A.ringA, A.ringB, 1) * sizeof(float) > 160 * 1024 && A.ringA > 2) --A.ringA;
-  while (A.nbank < VB_MAXBANK && vb_lds_floats(C, A.ringA, A.ringB, A.nbank + 1) * sizeof(float) <= 160 * 1024) ++A.nbank;
-  const size_t lds = vb_lds_floats(C, A.ringA, A.ringB, A.nbank) * sizeof(float);
+  // ring slots: as many as FE_VB_RING asks for (default 3 + 3) and the LDS holds; the f16x2 images leave 18 KB more than the bf16 ones
+  static const int ring_want = getenv("FE_VB_RING") ? atoi(getenv("FE_VB_RING")) : 33;   // two digits: ring A, ring B
+  const int imgb = bf ? RM_BYTES : (GM_VIRT_BWD == GM_F16 ? rm_lds_bytes<GM_F16>() : RM_BYTES);
+  A.ringA = ring_want / 10; A.ringB = ring_want % 10; A.nbank = 1;
+  if (A.ringA < 2 || A.ringA > VB_MAXRING) A.ringA = 3;
+  if (A.ringB < 2 || A.ringB > VB_MAXRING) A.ringB = 3;
+  while (vb_lds_floats(C, A.ringA, A.ringB, 1, imgb) * sizeof(float) > 160 * 1024 && A.ringB > 2) --A.ringB;
+  while (vb_lds_floats(C, A.ringA, A.ringB, 1, imgb) * sizeof(float) > 160 * 1024 && A.ringA > 2) --A.ringA;
+  while (A.nbank < VB_MAXBANK && vb_lds_floats(C, A.ringA, A.ringB, A.nbank + 1, imgb) * sizeof(float) <= 160 * 1024) ++A.nbank;
+  const size_t lds = vb_lds_floats(C, A.ringA, A.ringB, A.nbank, imgb) * sizeof(float);
   FE_REQUIRE(lds <= 160 * 1024, "virt_backward: LDS budget exceeded");
   {
     ProfScope ps(K_VIRT_BWD, st);

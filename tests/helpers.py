@@ -102,6 +102,11 @@ GRAD_FLOOR = 1e-6
 # kernels) each sit at a random point of the same rounding-noise band, so "2 x the reference's own draw" is not a
 # bound; the floor granted is the measured band, never more than 1.5e-5.
 GRAD_EXCEPTIONS = [
+    # Round 4 (f16x2 products, double-precision slab reduce / bias totals / embedding sums; profiles/r04_gradient_tolerance_report.txt:
+    # 4 245 comparisons over the whole -m gpu suite, 29 beyond 2 x ref + 1e-6, none beyond what is granted here): the entries for
+    # the layer-0 bias sums of the virtual coordinate heads on the cfg4 / cfg5 shapes (factor 4 until round 3: now 0.35-0.69 of
+    # the PLAIN tolerance over four runs on four boxes) and for the no-edges case are gone; floors of the edge stage, the
+    # embedding bias, the scalar head biases and the virtual coordinate head tightened to ~2 x what was measured.
     # (case regex, tensor regex, factor, floor, why) -- re-measured at the end of round 3 on an MI355X with FASTEGNN_TOL_DUMP
     # over the whole -m gpu suite (4 054 comparisons over 45 cases, 29 beyond 2 x ref + 1e-6; the operand split of the
     # bf16x3 products rounds to nearest since then, which took the attention goldens' excesses down 2-4 x): every entry
@@ -127,20 +132,23 @@ GRAD_EXCEPTIONS = [
      "g_a = <g_m, m0> is itself a cancelling 64-term dot product; the CPU re-association above measures 10.8x the "
      "reference's draw on att_mlp.0.bias (9.1e-6 vs 8.4e-7); HIP: 8.0x (6.77e-6, ragged3_attention gcl_1), 5.65e-6 "
      "against a reference draw of 1.4e-8 on the 4 000-node GELU case (23.5-33x and factor 40 with the truncating split)"),
-    (r".", r"(edge_mlp|coord_mlp_r|edge_message_net\.scalar_net\.mlp|coord_net\.mlp)\.", 2.0, 1.5e-5,
+    (r".", r"(edge_mlp|coord_mlp_r|edge_message_net\.scalar_net\.mlp|coord_net\.mlp)\.", 2.0, 1e-5,
      "parameter gradients of the edge stage: sums over up to 370 k edges with cancellation (max|g| ~1e-8 on the last "
      "layers of the radius-graph cases): measured <= 1.02e-5 over 2 x ref (cfg5 shape at 20 k nodes, "
      "gcl_3.edge_mlp.0.bias 1.39e-5 vs ref 1.87e-6) where the reference sits at 1e-6..6e-6.  NOT the transcendentals: one "
      "Newton step on the sigmoid's reciprocal and an exp2 argument corrected to < 1 ulp, in the backward recompute, were "
      "both measured (profiles/r03_lever_*.txt) and move this figure by < 5 %; the bf16x3 split's rounding mode moves it "
-     "by 10 % -- what remains is the order of the fp32 sums (floor 2e-5 until round 3)"),
+     "by 10 % -- what remains is the order of the fp32 sums (floor 2e-5 until round 3, 1.5e-5 in round 3; round 4 with f16x2 "
+     "products and double-precision slab sums: <= 5.1e-6 over 2 x ref in four runs, gcl_3.edge_mlp.0.bias 8.83e-6 vs 1.87e-6)"),
     (r".", r"embedding_in\.bias", 2.0, 3e-6,
      "the column sum of the gradient that leaves the first layer -- every rounding of the whole backward chain ends in "
-     "it: 3.4e-6 / 2.7e-6 against the reference's 1.1e-6 / 7.9e-7 (nbody5_cfg1_trained, train_ragged_simulation)"),
-    (r".", r"(gravity_mlp|coord_mlp_vel)\.2\.bias", 2.0, 3e-6,
+     "it: 3.4e-6 / 2.7e-6 against the reference's 1.1e-6 / 7.9e-7 (nbody5_cfg1_trained, train_ragged_simulation); round 4, with "
+     "double accumulators in the embedding's weight-gradient kernel: 1.51e-6 over 2 x ref (nbody5_cfg1: 6.36e-6 vs 2.42e-6) -- the "
+     "error sits in g_h, not in its column sum"),
+    (r".", r"(gravity_mlp|coord_mlp_vel)\.2\.bias", 2.0, 2.5e-6,
      "scalar head biases: one number, the sum of N per-node terms: 2.44e-6 against the reference's 3.7e-7 "
      "(nbody5_cfg1_trained, gcl_1.coord_mlp_vel.2.bias), 3.28e-6 against 1.10e-6 (act_softplus, gcl_0.gravity_mlp.2.bias)"),
-    (r".", r"coord_mlp_v_virtual\.|att_mlp_virtual\.", 2.0, 8e-6,
+    (r".", r"coord_mlp_v_virtual\.|att_mlp_virtual\.", 2.0, 5e-6,
      "the virtual coordinate head and gate: [1,64] / scalar gradients summed per (tile, channel) over the tile first (DPP) and "
      "then across tiles in LDS -- a different association of a cancelling sum: 5.81e-6 over 2 x ref "
      "(ragged3_attention, gcl_0.att_mlp_virtual.0.bias 9.60e-6 vs 1.89e-6; 1.26e-5 / 1.36e-5 and floor 1e-5 with the "
@@ -149,14 +157,6 @@ GRAD_EXCEPTIONS = [
      "activations other than SiLU at 4 000 nodes: bias gradients are column sums over 32 k - 48 k rows behind erf / exp / "
      "log1p evaluations of 2-4 ulp; measured 4.64e-6 against 2 x ref + 1e-6 = 2.96e-6 (act_mid_gelu, "
      "gcl_1.edge_mlp_virtual.0.bias)"),
-    (r"no_edges", r"edge_mlp_virtual\.2\.bias", 2.0, 2e-6,
-     "4.67e-6 against 2 x ref + 1e-6 = 4.58e-6 (test_no_edges_and_isolated_nodes, gcl_1): a column sum over N*C rows"),
-    (r"cfg5_shape|cfg4_headline", r"gcl_0\.coord_mlp_[rv]_virtual\.0\.bias", 4.0, 1e-6,
-     "column sums over N*C = 320 k - 640 k rows that cancel to ~1e-3 of their terms; BOTH sides of the rule move: the "
-     "reference's own fp32 result is 9.6e-5 .. 1.4e-4 from fp64 depending on the host's thread count (cfg4 headline shape, "
-     "gcl_0.coord_mlp_v_virtual.0.bias) and 1.18e-4 (cfg5 shape, r_virtual), the HIP result 2.29e-4 .. 2.63e-4 over "
-     "twelve runs on different boxes and summation orders (ticket order; DPP or shuffle tile sums): 1.65 .. 2.64 x the "
-     "reference's draw of the same run (tools/gpu_tolrepeat.sh)"),
 ]
 
 

@@ -41,13 +41,20 @@ for k in names:
     print(f"\n{k}  ({len(cnt[(k, 'p1')])} launches sampled)")
     for c, x in v.items():
         print(f"  {c:30s} {x:16.4g}")
-    wc, bc = v["SQ_WAVE_CYCLES"] or 1, v["SQ_BUSY_CYCLES"] or 1
+    # Units (checked on edge_fwd: 5.85 M MFMAs x 16 cycles = VALU_MFMA_BUSY_CYCLES exactly): *_BUSY_CYCLES in cycles; WAVE_CYCLES,
+    # ACTIVE_INST_* and WAIT_INST_* in units of 4 cycles, summed over waves.  ACTIVE_INST_VALU / WAVE_CYCLES is the share of a wave's
+    # resident time in which it issues vector / MFMA instructions; times the waves per SIMD it is the SIMD's vector-issue utilisation.
+    wps = {"fe::edge_fwd_kernel": 4, "fe::virt_fwd_kernel": 2, "fe::edge_bwd_pc_kernel": 2, "fe::virt_bwd_pc_kernel": 2,
+           "fe::node_pre_fwd_kernel": 2, "fe::node_pre_bwd_kernel": 2}.get(k)
+    wc = v["SQ_WAVE_CYCLES"] or 1
+    share = v["SQ_ACTIVE_INST_VALU"] / wc
     print("  -- derived")
-    print(f"  VALU instructions per MFMA instruction            {v['SQ_INSTS_VALU'] / max(v['SQ_INSTS_MFMA'], 1):10.2f}")
-    print(f"  issue model 4 N_valu + 8 N_mfma / ACTIVE_INST_VALU  {(4 * v['SQ_INSTS_VALU'] + 8 * v['SQ_INSTS_MFMA']) / max(v['SQ_ACTIVE_INST_VALU'], 1):10.3f}   (1.0: the vector issue port is what ACTIVE_INST_VALU counts)")
-    print(f"  vector-issue share  ACTIVE_INST_VALU / WAVE_CYCLES  {v['SQ_ACTIVE_INST_VALU'] / wc:10.3f}   (of a wave's resident time)")
-    print(f"  MFMA-pipe busy      VALU_MFMA_BUSY / BUSY_CYCLES    {v['SQ_VALU_MFMA_BUSY_CYCLES'] / bc:10.3f}   (per-SE counters: compare kernels, not absolutes)")
-    print(f"  waiting             WAIT_INST_ANY / WAVE_CYCLES     {v['SQ_WAIT_INST_ANY'] / wc:10.3f}")
-    print(f"  waiting on LDS      WAIT_INST_LDS / WAVE_CYCLES     {v['SQ_WAIT_INST_LDS'] / wc:10.3f}")
-    print(f"  LDS bank conflicts  LDS_BANK_CONFLICT / ACTIVE_INST_LDS {v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_ACTIVE_INST_LDS'], 1):8.3f}")
+    print(f"  VALU instructions per MFMA instruction                   {v['SQ_INSTS_VALU'] / max(v['SQ_INSTS_MFMA'], 1):8.2f}")
+    print(f"  issue model (4 N_valu + 8 N_mfma) / (4 ACTIVE_INST_VALU)    {(4 * v['SQ_INSTS_VALU'] + 8 * v['SQ_INSTS_MFMA']) / max(4 * v['SQ_ACTIVE_INST_VALU'], 1):8.3f}   (1.0: the issue port is what ACTIVE_INST_VALU counts)")
+    print(f"  vector-issue share of a wave  ACTIVE_INST_VALU / WAVE_CYCLES {share:8.3f}" + (f"   x {wps} waves per SIMD = {share * wps:.2f} of the SIMD's issue slots" if wps else ""))
+    if wps:
+        print(f"  MFMA pipe busy  VALU_MFMA_BUSY_CYCLES / (4 WAVE_CYCLES / {wps})   {v['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * wc / wps):8.3f}   (of the SIMD's time)")
+    print(f"  waiting (any)   WAIT_INST_ANY / WAVE_CYCLES                {v['SQ_WAIT_INST_ANY'] / wc:8.3f}")
+    print(f"  waiting on LDS  WAIT_INST_LDS / WAVE_CYCLES                {v['SQ_WAIT_INST_LDS'] / wc:8.3f}")
+    print(f"  LDS bank conflicts  LDS_BANK_CONFLICT / ACTIVE_INST_LDS    {v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_ACTIVE_INST_LDS'], 1):8.3f}")
 PY
