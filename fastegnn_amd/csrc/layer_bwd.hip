@@ -882,8 +882,10 @@ struct EdgeBwdArgs {
 constexpr int PC_WAVES = 8;
 constexpr int PC_CONS = 3, PC_CONS2 = 7;
 constexpr int PC_PROD = 6;                  // producer waves
+// (round 4, with the f16x2 producers, two repeats on one box, tools/gpu_ab_rings2.sh: 2 slots 3.23-3.26, 3 slots 3.16-3.20,
+//  4 slots 3.25-3.27, 5 slots 3.24 ms per step; round 2 had gone from 2 to 4 with the bf16x3 producers)
 #ifndef FE_PC_RING
-#define FE_PC_RING 4
+#define FE_PC_RING 3
 #endif
 constexpr int PC_RING = FE_PC_RING;                  // slots per ring; one ring per weight (kind 0: edge_mlp.2, kind 1: coord_mlp_r.0)
 #ifndef FE_PC_FLUSH

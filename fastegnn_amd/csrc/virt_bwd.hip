@@ -789,8 +789,9 @@ int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shar
   if ((rc = bb.add_slabs(g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], grid, &A.slab_v2))) return rc;
   A.slab = bb.tab.slab; A.slab_b = bb.tab.slab_b;
   // rings: as many slots as the 160 KB of LDS leave (three per ring at C <= 32)
-  // ring slots: as many as FE_VB_RING asks for (default 3 + 3) and the LDS holds; the f16x2 images leave 18 KB more than the bf16 ones
-  static const int ring_want = getenv("FE_VB_RING") ? atoi(getenv("FE_VB_RING")) : 33;   // two digits: ring A, ring B
+  // ring slots: as many as FE_VB_RING asks for and the LDS holds; the f16x2 images leave 28 KB more than the bf16 ones.  Default
+  // 5 + 4 (round 4, two repeats on one box, tools/gpu_ab_rings2.sh: 3+3 3.47, 4+4 3.42, 5+4 3.40, 5+5 3.42, 6+4 3.47 ms per step)
+  static const int ring_want = getenv("FE_VB_RING") ? atoi(getenv("FE_VB_RING")) : 54;   // two digits: ring A, ring B
   const int imgb = bf ? RM_BYTES : (GM_VIRT_BWD == GM_F16 ? rm_lds_bytes<GM_F16>() : RM_BYTES);
   A.ringA = ring_want / 10; A.ringB = ring_want % 10; A.nbank = 1;
   if (A.ringA < 2 || A.ringA > VB_MAXRING) A.ringA = 3;
