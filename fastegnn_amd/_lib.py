@@ -12,7 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FASTEGNN_SAFE_WAITS=1 loads the -DFE_SAFE_WAITS build of the same sources (csrc/Makefile): every hand-counted wait,
 # LDS-DMA copy and relaxed LDS flag in its conservative form.  Same ABI, same results; a diagnostic, not a fallback.
 SAFE_WAITS = os.environ.get("FASTEGNN_SAFE_WAITS", "0") not in ("", "0")
-LIB_PATH = os.path.join(_HERE, "libfastegnn_hip_safe.so" if SAFE_WAITS else "libfastegnn_hip.so")
+# FASTEGNN_WIDE_RANGE=1 loads the build without the f16x2 products (csrc/Makefile: libfastegnn_hip_x3.so, the bf16x3 arithmetic of
+# rounds 1-3): fp32's exponent range for every operand, ~6 % slower.  The default build's f16x2 operands overflow beyond 65 504.
+WIDE_RANGE = os.environ.get("FASTEGNN_WIDE_RANGE", "0") not in ("", "0")
+LIB_PATH = os.path.join(_HERE, "libfastegnn_hip_safe.so" if SAFE_WAITS else
+                        ("libfastegnn_hip_x3.so" if WIDE_RANGE else "libfastegnn_hip.so"))
 
 ABI_VERSION = 102   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
 H = 64

@@ -602,5 +602,11 @@ class FastEGNN(nn.Module):
         if self.hidden_nf < H:
             rf = bool(spec.flags & K.F_RF)
             plist = list(_PadParams.apply(tuple(spec.names), self.hidden_nf, spec.C, rf, *plist))
-        return _FastEGNNFunction.apply(spec, graph, batch32, gptr, edge_attr, node_attr, node_feat, node_loc, node_vel,
-                                       loc_mean, *plist)
+        out = _FastEGNNFunction.apply(spec, graph, batch32, gptr, edge_attr, node_attr, node_feat, node_loc, node_vel,
+                                      loc_mean, *plist)
+        if _DEBUG_CHECKS and not (bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[1]).all())):
+            raise FloatingPointError(
+                "fastegnn_amd: non-finite outputs.  The default library multiplies on 2-part fp16 splits: hidden activations "
+                "and [64,64] weights beyond 65 504 overflow there (the reference's fp32 does not).  FASTEGNN_WIDE_RANGE=1 loads "
+                "libfastegnn_hip_x3.so, the same kernels on 3-part bf16 splits with fp32's exponent range.")
+        return out

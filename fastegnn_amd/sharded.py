@@ -864,8 +864,9 @@ class ShardedFastEGNN(torch.nn.Module):
         tensors.  Collective when the exchange is "halo" (the ranks tell each other which rows they need).
         reorder=True first sorts the nodes of every graph along a Morton curve (`morton_order`), so that a rank owns a
         compact region of space; `plan.node_ids` / `plan.rows()` map the caller's node order to this rank's rows.
-        split (default: on unless the model's backward is the deterministic store + reduce form, whose col-keyed sum
-        runs over ONE graph): order the rank's rows [interior | boundary] and run the edge stage as two launches."""
+        split: order the rank's rows [interior | boundary] and run the edge stage as two launches (default: with the
+        asynchronous schedule, FASTEGNN_SHARDED_SYNC=0, where the halo then travels behind the interior rows; never with the
+        deterministic backward, whose col-keyed sum runs over ONE graph; FASTEGNN_SHARDED_SPLIT=0/1 overrides)."""
         world, rank = self._world_rank()
         N = node_loc.size(0)
         order = None
@@ -881,8 +882,13 @@ class ShardedFastEGNN(torch.nn.Module):
         db = data_batch if order is None else data_batch[order]
         if plan.mode == "halo":
             if split is None:
-                split = not bool(getattr(self.model, "deterministic", False)) and \
-                    os.environ.get("FASTEGNN_SHARDED_SPLIT", "1") not in ("", "0")
+                # Two launch ranges pay when the halo travels BEHIND the interior rows (the asynchronous schedule); with the
+                # collectives in program order they only cost a second CSR build and eight more launches per step (measured on
+                # an emulated rank of eight: 3.46 against 3.1x ms) -- so: on with FASTEGNN_SHARDED_SYNC=0, off otherwise, and
+                # FASTEGNN_SHARDED_SPLIT=0/1 overrides.  Never with the deterministic backward (one col-keyed sum per graph).
+                env = os.environ.get("FASTEGNN_SHARDED_SPLIT", "")
+                want = (env not in ("", "0")) if env != "" else not self.comm().sync
+                split = want and not bool(getattr(self.model, "deterministic", False))
             want = None
             if self.emulate is not None:
                 # the rows of this rank its peers' edges read, grouped by peer (a real world learns them in plan.build)

@@ -162,6 +162,7 @@ def test_two_ranks_split_and_small_shards_match_the_unsharded_model(shape, monke
     (the second backward launch adds to the col-keyed sums of the first: FASTEGNN_F_GQX_ACCUM); SMALL: 341 nodes per rank
     with C = 16 (the scratch sizes of the virtual backward on a small shard)."""
     monkeypatch.setenv("FASTEGNN_TEST_SHARDED_SHAPE", shape)
+    monkeypatch.setenv("FASTEGNN_SHARDED_SPLIT", "1")      # (on by default only with the asynchronous schedule)
     _run_and_check("halo", True, "gloo", "torch")
 
 

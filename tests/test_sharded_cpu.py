@@ -72,8 +72,10 @@ def _loss(loc_rows, vloc, target_rows, n_total):
 
 
 def _worker(rank, world, port, gravity, exchange, reorder, q, hidden=64):
+    # (FASTEGNN_SHARDED_SPLIT=1: the [interior | boundary] launch ranges, which are on by default only with the asynchronous
+    # schedule, are what this test is to cover)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), FASTEGNN_SHARDED_SPLIT="1")
     init_from_env("gloo")
     inp, target = _inputs()
     m = _model(gravity, hidden)
