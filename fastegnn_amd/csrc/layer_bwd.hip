@@ -978,7 +978,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
 #endif
     const int total = lds_ld(&ctrl[PC_TOTAL]);   // tiles of this workgroup = tickets per ring
     f32x4 accA[4][4];
-    float bsA[4] = {0.f, 0.f, 0.f, 0.f};
+    double bsA[4] = {0., 0., 0., 0.};   // bias column sums: eight rows at a time in fp32, everything across tickets in double
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
     // K = 32 edges per step: tickets tk, tk+1 of one ring; lane (q,i) takes feature i of the rows 4q+e of the first
     // (e < 4) and of the second slot (e >= 4), the same map for both operands.  With the 68-float row stride the
     // rows of the two quarter-waves read together sit 16 banks apart: conflict-free b32 reads
-    auto contract = [&](int kind, int tk, f32x4 (&acc)[4][4], float (&bs)[4]) {
+    auto contract = [&](int kind, int tk, f32x4 (&acc)[4][4], double (&bs)[4]) {
       const int s0 = tk % PC_RING, r0w = tk / PC_RING;
       const bool two = tk + 1 < total;
       const int s1 = (tk + 1) % PC_RING, r1w = (tk + 1) / PC_RING;
@@ -1032,8 +1032,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
         const float (&x)[8] = xa[ti];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bs[ti] += x[e];
+        bs[ti] += (double)(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7])));
         if constexpr (MODE == GM_BF16) {
           const bf16x8 ah = __builtin_bit_cast(bf16x8, round8(x));
 #pragma unroll
@@ -1088,8 +1087,8 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
               *d = accA[ti][tk2];
               accA[ti][tk2] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            bs_tot[ti] += (double)bsA[ti];
-            bsA[ti] = 0.f;
+            bs_tot[ti] += bsA[ti];
+            bsA[ti] = 0.;
           }
           flushed = true;
           since = 0;
@@ -1112,7 +1111,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       }
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
-      double s0 = bs_tot[ti] + (double)bsA[ti];
+      double s0 = bs_tot[ti] + bsA[ti];
       s0 += __shfl_xor(s0, 16);
       s0 += __shfl_xor(s0, 32);
       if (q == 0) A.slab_b[sl * H + 16 * ti + j] = (float)s0;
@@ -1378,13 +1377,13 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
 extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { (void)E; return (size_t)256 * 2 * fe::IMG; }
 // weight-gradient operand workspaces of the virtual / node-level stages (layouts: virt_backward, graph_post_backward,
 // graph_pre_backward, node_pre_backward above; virt_backward_pc in virt_bwd.hip).  The flag-less queries return the
-// largest size any wiring needs (the FastRF / C > 32 form of B4 materialises five operand arrays); the _for variants
-// take the layer's flags: the FastEGNN wiring with C <= 32 keeps v and Gv only (+ the per-group parts of g_A / g_x).
+// largest size any wiring needs (the FastRF / EGNN form of B4 materialises five operand arrays); the _for variants
+// take the layer's flags: the FastEGNN wiring keeps v and Gv only (+ the per-group parts of g_A / g_x).
 extern "C" size_t fastegnn_wg_virt_floats(int32_t N, int32_t C) {
   size_t n = (size_t)5 * ((size_t)(N > 0 ? N : 0) + fe::WGV_PAD) * (size_t)(C > 0 ? C : 0) * fe::H;
   // the producer / consumer form carries constant terms (part tiles, consumer scratch: ~36 MB at C = 16) that exceed the
   // five-array size on small shards: the flag-less query is the maximum over both forms
-  if (C >= 1 && C <= 32) {
+  if (C >= 1 && C <= 64) {
     const size_t pc = fe::virt_pc_wg_floats((size_t)(N > 0 ? N : 0), (size_t)C);
     if (pc > n) n = pc;
   }

@@ -1,4 +1,4 @@
-// B4 (virtual stage backward) for 1 <= C <= 32 without the FastRF / EGNN wirings: the adjoint of
+// B4 (virtual stage backward) for 1 <= C <= 64 (32 until round 4) without the FastRF / EGNN wirings: the adjoint of
 // edge_mode_virtual / coord_model_vel (virtual part) / coord_model_virtual / node_model
 // (models/FastEGNN.py:111-119,136-166) as three kernels.  Math: oracle/factored.py (virt_bwd).
 //
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
     f32x4 acc[4][4];
     // column sums of G (bias gradient), two levels: fp32 over the 768 rows between two flushes, DOUBLE across the flushes (the
     // layer-0 bias sums of the coordinate heads cancel to ~1e-3 of their terms over a workgroup's 6 144 / 12 288 rows)
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    double bs_tot[4] = {0., 0., 0., 0.};
+    double bs[4] = {0., 0., 0., 0.};      // (eight rows at a time in fp32, then double: 1.46e-5 against a tolerance of 1.21e-5 on
+    double bs_tot[4] = {0., 0., 0., 0.};   //  edge_mlp_virtual.2.bias at C = 48 with fp32 chains of 768 rows)
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
         }
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        bs_tot[ti] += (double)bs[ti];
-        bs[ti] = 0.f;
+        bs_tot[ti] += bs[ti];
+        bs[ti] = 0.;
       }
       flushed = true;
     };
@@ -365,8 +365,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
         const float (&x)[8] = xa[ti];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bs[ti] += x[e];
+        bs[ti] += (double)(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7])));
         if constexpr (BF) {
           const bf16x8 ah = __builtin_bit_cast(bf16x8, round8(x));
 #pragma unroll
@@ -418,7 +417,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
       }
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
-      double s0 = bs_tot[ti] + (double)bs[ti];   // sum over the four q-lanes of the feature, in double
+      double s0 = bs_tot[ti] + bs[ti];   // sum over the four q-lanes of the feature, in double
       s0 += __shfl_xor(s0, 16);
       s0 += __shfl_xor(s0, 32);
       if (q == 0) A.slab_b[sl * H + 16 * ti + j] = (float)s0;
@@ -718,7 +717,7 @@ __global__ __launch_bounds__(256) void virt_bwd_combine_kernel(float *g_A, float
 
 bool virt_backward_uses_pc(const fastegnn_layer_t *L) {
   static const bool off = getenv("FASTEGNN_VIRT_BWD_OLD") && atoi(getenv("FASTEGNN_VIRT_BWD_OLD")) != 0;
-  return !off && L->C >= 1 && L->C <= 32 && !has(L, FASTEGNN_F_RF) && !has(L, FASTEGNN_F_EGNN);
+  return !off && L->C >= 1 && L->C <= 64 && !has(L, FASTEGNN_F_RF) && !has(L, FASTEGNN_F_EGNN);
 }
 // floats of wg_virt: Gv, overwritten row by row with v ([C][N + pad][64]) | parts of g_A and g_x | consumer scratch
 size_t virt_pc_wg_floats(size_t N, size_t C) {
@@ -788,7 +787,7 @@ int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shar
   if ((rc = bb.add_slabs(g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], grid, &A.slab_X))) return rc;
   if ((rc = bb.add_slabs(g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], grid, &A.slab_v2))) return rc;
   A.slab = bb.tab.slab; A.slab_b = bb.tab.slab_b;
-  // rings: as many slots as the 160 KB of LDS leave (three per ring at C <= 32)
+  // rings: as many slots as the 160 KB of LDS leave
   // ring slots: as many as FE_VB_RING asks for and the LDS holds; the f16x2 images leave 28 KB more than the bf16 ones.  Default
   // 5 + 4 (round 4, two repeats on one box, tools/gpu_ab_rings2.sh: 3+3 3.47, 4+4 3.42, 5+4 3.40, 5+5 3.42, 6+4 3.47 ms per step)
   static const int ring_want = getenv("FE_VB_RING") ? atoi(getenv("FE_VB_RING")) : 54;   // two digits: ring A, ring B

@@ -250,7 +250,7 @@ size_t fastegnn_wg_slab_floats(void);
 size_t fastegnn_wg_edge_floats(int32_t E);
 size_t fastegnn_wg_virt_floats(int32_t N, int32_t C);
 size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C);
-/* wg_virt for a layer with these FASTEGNN_F_* flags: the FastEGNN wiring with C <= 32 contracts three of the virtual
+/* wg_virt for a layer with these FASTEGNN_F_* flags: the FastEGNN wiring contracts three of the virtual
  * stage's weight gradients inside the workgroup and keeps ONE [C][N+16][64] array plus constant-size part tiles and
  * consumer scratch (~36 MB at C = 16) instead of five arrays; the flag-less query above returns the maximum over both
  * forms, i.e. an upper bound for every wiring and every N (on small shards the constant terms dominate) */

@@ -153,6 +153,11 @@ GRAD_EXCEPTIONS = [
      "then across tiles in LDS -- a different association of a cancelling sum: 5.81e-6 over 2 x ref "
      "(ragged3_attention, gcl_0.att_mlp_virtual.0.bias 9.60e-6 vs 1.89e-6; 1.26e-5 / 1.36e-5 and floor 1e-5 with the "
      "truncating split)"),
+    (r"^act_", r"^gin/", 2.0, 2.5e-6,
+     "input gradients of the 17-node activation goldens (generic-activation library): the end of the whole backward chain on "
+     "a graph whose sums have a dozen terms -- max error over 34-51 numbers, 6.1e-7 .. 1.69e-6 over six builds / runs of round "
+     "4 (the col-side scatter's atomic order moves it between runs) where the reference sits at 2.7e-7: at the 1e-6 floor of the "
+     "plain rule, not above its factor"),
     (r"act_mid", r"\.bias$", 2.0, 5e-6,
      "activations other than SiLU at 4 000 nodes: bias gradients are column sums over 32 k - 48 k rows behind erf / exp / "
      "log1p evaluations of 2-4 ulp; measured 4.64e-6 against 2 x ref + 1e-6 = 2.96e-6 (act_mid_gelu, "

@@ -197,6 +197,14 @@ def test_c32_vs_oracle():
     _check_vs_oracle(cfg, _batch([257], 15, 32, seed=6), seed=6)
 
 
+@pytest.mark.parametrize("C", [48, 64])
+def test_more_than_32_channels_vs_oracle(C):
+    """virtual_channels above 32 (the constructor allows up to 64): since round 4 on the producer / consumer form of the virtual
+    backward as well (its three f16x2 images leave the LDS the larger per-graph accumulators need; the ring slots give way)."""
+    cfg = R.Config(2, 0, 2, 64, C, n_layers=2, gravity=[0, -1, 0])
+    _check_vs_oracle(cfg, _batch([700, 333], 9, C, seed=60 + C), seed=60 + C, case=f"test_c{C}")
+
+
 def test_wide_edge_attr_and_node_feat_vs_oracle():
     """edge_attr_nf = 5 (the generic edge-attribute path of the edge kernels: every BASELINE configuration has 2), node_feat_nf = 4,
     one attribute-less variant (edge_attr_nf = 0 is what EGNN-style callers without edge features pass)."""
