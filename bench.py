@@ -34,6 +34,7 @@ PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak (= fp
 PEAK_MFMA_BF16_TFLOPS = 2500.0 # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak
 BF16X3_CEILING_TFLOPS = 224.0  # measured chain of bf16x3 64x64 products (fp32-equivalent FLOPs), DESIGN.md section 4
+F16X2_CEILING_TFLOPS = 314.0   # the same chain (split + product + SiLU, 4 waves / SIMD) on f16x2 products: tools/gpu_bf3.py, round 4
 H = 64
 UNIT = 2 * H * H               # FLOPs of one 64x64 mat-vec
 
@@ -673,6 +674,10 @@ def main():
                 # 224 TFLOP/s fp32-equivalent on this part (tools/gpu_bf3.py): the kernel's real ceiling
                 roof["frac_of_bf16x3_ceiling"] = round(kernels[dom]["tflops"] / BF16X3_CEILING_TFLOPS, 4)
                 roof["frac_algorithmic_of_bf16x3_ceiling"] = round(roof["frac_algorithmic"] * peak_mfma / BF16X3_CEILING_TFLOPS, 4)
+                # since round 4 the producers of the fused kernels multiply on f16x2 products (3 MFMAs instead of 6), whose bare
+                # chain reaches 314 TFLOP/s fp32-equivalent: the fractions against THAT ceiling are the honest ones
+                roof["frac_of_f16x2_ceiling"] = round(kernels[dom]["tflops"] / F16X2_CEILING_TFLOPS, 4)
+                roof["frac_algorithmic_of_f16x2_ceiling"] = round(roof["frac_algorithmic"] * peak_mfma / F16X2_CEILING_TFLOPS, 4)
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["gbs"], "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic}

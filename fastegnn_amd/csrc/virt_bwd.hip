@@ -488,6 +488,9 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
       const size_t part = ((size_t)blockIdx.x * VB_FINE_TILES + fslot) * (A.NGF - 1) + (grp - 1);
       float *dA = grp == 0 ? A.g_A : A.gA_part + part * 16 * H;
       const unsigned offA = grp == 0 ? offN : (unsigned)j * H + 4u * q;
+#ifdef VB_GA_REGS   // measured variant: the tile's g_A in 16 registers across the channels of the unit instead of through memory
+      Vec ga_acc = vzero();
+#endif
 #pragma unroll 1
       for (int c = c_lo; c < c_hi; ++c) {
         asm volatile("" ::: "memory");
@@ -612,13 +615,20 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
 #endif
           VB2_T(8)   // g_vp + publish to ring B
           // requested here, consumed after the product: the tile's running g_A
+#ifndef VB_GA_REGS
           if (c > c_lo) ga = vload_u(dA, offA);
+#endif
           mmT(0, g_vp, g_t);
         }
         VB2_T(9)   // V2^T product
         const Vec g_pre = vmul(g_t, d_pre);
+#ifdef VB_GA_REGS
+        vadd(ga_acc, g_pre);
+        if (c + 1 == c_hi && valid) vstore_u(dA, offA, ga_acc);
+#else
         vadd(ga, g_pre);   // g_A of the tile accumulates through memory (the same lane re-reads its own row)
         if (valid) vstore_u(dA, offA, ga);
+#endif
         vb_accum_items(racc + 2 * H, vscale(g_pre, vr), j, q);
         const float g_vr = vdot(g_pre, vload_vec(vec + VV_WVR * H, q));
         const float ivr = vr > 0.f ? g_vr * rcp_f(vr) : 0.f;

@@ -58,6 +58,13 @@ class E_GCL_vel(nn.Module):
         raise RuntimeError("E_GCL_vel is evaluated inside FastEGNN.forward by the HIP library")
 
 
+# FASTEGNN_DEBUG_CHECKS=1: validate the index inputs on every forward (host sync).  The kernels trust them: an
+# out-of-range col is an out-of-bounds gather, an unsorted data_batch breaks the graph pointer search; the
+# reference raises an index error in these cases.
+_DEBUG_CHECKS = os.environ.get("FASTEGNN_DEBUG_CHECKS", "0") not in ("", "0")
+
+
+
 # ------------------------------------------------------------------------------------------
 # sorted graph handle
 # ------------------------------------------------------------------------------------------
@@ -76,6 +83,14 @@ class SortedGraph:
         dev = edge_index.device
         E = edge_index.size(1)
         n_src = n_rows if n_src is None else n_src
+        if _DEBUG_CHECKS and E:
+            # the radix sorts cover only the bits an id of the given range can have: an id outside its range would be mis-sorted
+            # silently -- halo-remapped columns of the sharded path make that more plausible than it used to be
+            r_lo, r_hi = int(edge_index[0].min()) - row_begin, int(edge_index[0].max()) - row_begin
+            c_lo, c_hi = int(edge_index[1].min()), int(edge_index[1].max())
+            if r_lo < 0 or r_hi >= n_rows or c_lo < 0 or c_hi >= n_src:
+                raise IndexError(f"fastegnn_amd: edge_index rows span [{r_lo}, {r_hi}] of {n_rows} rows, columns [{c_lo}, {c_hi}] "
+                                 f"of a {n_src}-row source table")
         i32 = dict(dtype=torch.int32, device=dev)
         self.n_rows, self.n_src, self.E = n_rows, n_src, E
         self.rowptr = torch.empty(n_rows + 1, **i32)
@@ -124,12 +139,6 @@ class SortedGraph:
 # ------------------------------------------------------------------------------------------
 # helpers
 # ------------------------------------------------------------------------------------------
-# FASTEGNN_DEBUG_CHECKS=1: validate the index inputs on every forward (host sync).  The kernels trust them: an
-# out-of-range col is an out-of-bounds gather, an unsorted data_batch breaks the graph pointer search; the
-# reference raises an index error in these cases.
-_DEBUG_CHECKS = os.environ.get("FASTEGNN_DEBUG_CHECKS", "0") not in ("", "0")
-
-
 def _check_indices(edge_index, data_batch, N, B):
     if isinstance(edge_index, torch.Tensor) and edge_index.numel():
         lo, hi = int(edge_index.min()), int(edge_index.max())
