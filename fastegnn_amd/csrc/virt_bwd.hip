@@ -488,7 +488,10 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
       const size_t part = ((size_t)blockIdx.x * VB_FINE_TILES + fslot) * (A.NGF - 1) + (grp - 1);
       float *dA = grp == 0 ? A.g_A : A.gA_part + part * 16 * H;
       const unsigned offA = grp == 0 ? offN : (unsigned)j * H + 4u * q;
-#ifdef VB_GA_REGS   // measured variant: the tile's g_A in 16 registers across the channels of the unit instead of through memory
+      // the tile's g_A stays in 16 registers across the channels of the unit and is stored once (round 4; round 3 accumulated it
+      // through memory per channel: with the bf16x3 operands there was no room -- now 9 spilled registers, virt_bwd 3.21 -> 3.10 ms
+      // per step, 1.30 -> 1.11 GB of HBM traffic per launch; -DVB_GA_MEM restores the old form)
+#ifndef VB_GA_MEM
       Vec ga_acc = vzero();
 #endif
 #pragma unroll 1
@@ -615,14 +618,14 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
 #endif
           VB2_T(8)   // g_vp + publish to ring B
           // requested here, consumed after the product: the tile's running g_A
-#ifndef VB_GA_REGS
+#ifdef VB_GA_MEM
           if (c > c_lo) ga = vload_u(dA, offA);
 #endif
           mmT(0, g_vp, g_t);
         }
         VB2_T(9)   // V2^T product
         const Vec g_pre = vmul(g_t, d_pre);
-#ifdef VB_GA_REGS
+#ifndef VB_GA_MEM
         vadd(ga_acc, g_pre);
         if (c + 1 == c_hi && valid) vstore_u(dA, offA, ga_acc);
 #else
