@@ -179,13 +179,30 @@ __device__ __forceinline__ Vec vmul(const Vec &a, const Vec &b) {
   return vmap2(a, b, [](float x, float y) { return x * y; });
 }
 __device__ __forceinline__ Vec vscale(const Vec &a, float s) { return vmap(a, [s](float z) { return z * s; }); }
+// Element-wise forms: the f32x4 forms (-DFE_PACKED_VEC) lower to v_pk_fma_f32 / v_pk_add_f32, which the constants table of
+// MI355X_MICROARCH.md prices above the two plain instructions they replace when MFMAs are in flight.  Measured in round 4, two
+// repeats on one box: cfg4 step 10.988 -> 10.950 ms with the plain instructions (72 v_pk_fma_f32 -> 144 v_fmac_f32 in edge_fwd).
 __device__ __forceinline__ void vaxpy(Vec &acc, float s, const Vec &a) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc.t[t] += s * a.t[t];
+  for (int t = 0; t < 4; ++t) {
+#ifndef FE_PACKED_VEC
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc.t[t][r] = __builtin_fmaf(s, a.t[t][r], acc.t[t][r]);
+#else
+    acc.t[t] += s * a.t[t];
+#endif
+  }
 }
 __device__ __forceinline__ void vadd(Vec &acc, const Vec &a) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc.t[t] += a.t[t];
+  for (int t = 0; t < 4; ++t) {
+#ifndef FE_PACKED_VEC
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc.t[t][r] += a.t[t][r];
+#else
+    acc.t[t] += a.t[t];
+#endif
+  }
 }
 
 // natural-order 64-vector (bias, head weight, ...) -> this lane's 16 elements

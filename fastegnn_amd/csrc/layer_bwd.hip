@@ -1252,11 +1252,21 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         const float gx = pt[ex * TS + H + (kx & 3)];
         if (l < 3 * nvalid) atomicAdd(reinterpret_cast<float *>(gb + (cx * (QXLD * 4u) + 4u * (unsigned)(H + kx))), -gx);
       }
+      // row changes inside the tile from one DPP compare + ballot (as in edge_fwd_kernel); the row id is read only at a change
+#ifndef FE_WALK_READLANE
+      const int prevrow = __builtin_amdgcn_update_dpp(rowv, rowv, 0x111, 0xf, 0xf, false);   // row_shr:1
+      const unsigned starts = (unsigned)__builtin_amdgcn_ballot_w64(j == 0 ? rowv != cur : rowv != prevrow) & 0xffffu;
+#endif
 #pragma unroll
       for (int ee = 0; ee < 16; ++ee) {
         if (ee < nvalid) {
+#ifndef FE_WALK_READLANE
+          if ((starts >> ee) & 1u) {
+            const int rw = __builtin_amdgcn_readlane(rowv, ee);
+#else
           const int rw = __builtin_amdgcn_readlane(rowv, ee);
           if (rw != cur) {
+#endif
             if (cur >= 0) flush();
             zero_rows(cur >= 0 ? cur + 1 : r0, rw);
             cur = rw;

@@ -300,11 +300,23 @@ __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs 
           xv[ee] = xt[ee * 4 + (l & 3)];
         }
         const int rowv = S.row;
+        // where the row changes inside the tile: ONE lane compare with the lane below (DPP) and a ballot instead of sixteen
+        // v_readlane + scalar compares; the row id itself is read only at a change (~2 per tile at degree 19)
+#ifndef FE_WALK_READLANE
+        const int prevrow = __builtin_amdgcn_update_dpp(rowv, rowv, 0x111, 0xf, 0xf, false);   // row_shr:1 (lane 0 of a row keeps its own)
+        const unsigned long long chg = __builtin_amdgcn_ballot_w64(j == 0 ? rowv != cur : rowv != prevrow);
+        const unsigned starts = (unsigned)chg & 0xffffu;      // lanes 0..15 (q = 0): one bit per edge of the tile
+#endif
 #pragma unroll
         for (int ee = 0; ee < 16; ++ee) {
           if (ee < nvalid) {
+#ifndef FE_WALK_READLANE
+            if ((starts >> ee) & 1u) {
+              const int rw = __builtin_amdgcn_readlane(rowv, ee);
+#else
             const int rw = __builtin_amdgcn_readlane(rowv, ee);
             if (rw != cur) {
+#endif
               if (cur >= 0) flush();
               zero_rows(cur >= 0 ? cur + 1 : r0, rw);
               cur = rw;
