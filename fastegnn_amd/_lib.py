@@ -18,13 +18,14 @@ WIDE_RANGE = os.environ.get("FASTEGNN_WIDE_RANGE", "0") not in ("", "0")
 LIB_PATH = os.path.join(_HERE, "libfastegnn_hip_safe.so" if SAFE_WAITS else
                         ("libfastegnn_hip_x3.so" if WIDE_RANGE else "libfastegnn_hip.so"))
 
-ABI_VERSION = 102   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
+ABI_VERSION = 103   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
 H = 64
 QX_LD = 68
 FEATW = 8
 
 # flags (fastegnn_hip.h)
 F_ATTENTION, F_NORMALIZE, F_TANH, F_RESIDUAL, F_GRAVITY, F_COORDS_SUM, F_EGNN, F_RF, F_BF16, F_EGNN_NORM = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+F_WPACK_READY = 65536   # the layer's weight images were packed by fastegnn_pack_weights_all
 F_GQX_ACCUM = 32768   # edge_backward scatters into g_QX_src without zeroing it (second launch of a layer; include/fastegnn_hip.h)
 F_DETERMINISTIC = 1024   # backward: per-edge rows + CSC reduce instead of the atomic scatter (include/fastegnn_hip.h)
 
@@ -173,6 +174,7 @@ def lib(act: bool = False):
     L.fastegnn_gather_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_scatter_add_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_wg_slab_floats.restype = C.c_size_t
+    L.fastegnn_pack_weights_all.argtypes = [C.POINTER(C.POINTER(LayerT)), _i32, _vp]
     L.fastegnn_wgrad_batch_open.argtypes = [C.POINTER(LayerT), _vp, C.POINTER(_vp)]
     L.fastegnn_wgrad_batch_close.argtypes = [_vp]
     L.fastegnn_sizeof_layer.restype = C.c_size_t
@@ -212,7 +214,7 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_comm_unique_id_bytes", "fastegnn_comm_unique_id", "fastegnn_comm_init", "fastegnn_comm_destroy", "fastegnn_comm_rank",
     "fastegnn_comm_world", "fastegnn_comm_all_reduce", "fastegnn_comm_all_gather", "fastegnn_comm_reduce_scatter",
     "fastegnn_comm_all_to_all_v", "fastegnn_gather_rows", "fastegnn_scatter_add_rows",
-    "fastegnn_wgrad_batch_open", "fastegnn_wgrad_batch_close",
+    "fastegnn_wgrad_batch_open", "fastegnn_wgrad_batch_close", "fastegnn_pack_weights_all",
 ]
 
 

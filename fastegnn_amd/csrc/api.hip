@@ -170,6 +170,15 @@ STAGE_B(fastegnn_edge_backward, edge_backward, G_EDGE)
 STAGE(fastegnn_edge_col_reduce, edge_col_reduce)
 STAGE_B(fastegnn_node_pre_backward, node_pre_backward, G_NODE_PRE)
 
+int fastegnn_pack_weights_all(const fastegnn_layer_t *const *layers, int32_t n, void *stream) {
+  FE_REQUIRE(layers && n >= 1, "fastegnn_pack_weights_all: no layers");
+  for (int k = 0; k < n; ++k) {
+    int rc = check_layer(layers[k], "fastegnn_pack_weights_all");
+    if (rc) return rc;
+  }
+  return pack_weights_all(layers, n, (hipStream_t)stream);
+}
+
 int fastegnn_wgrad_batch_open(const fastegnn_layer_t *L, void *stream, void **batch) {
   FE_REQUIRE(L && batch && L->wg_slab, "fastegnn_wgrad_batch_open: null argument");
   WgradBatch *wb = new WgradBatch(L->wg_slab, (hipStream_t)stream, has(L, FASTEGNN_F_BF16));

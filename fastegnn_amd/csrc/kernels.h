@@ -88,6 +88,7 @@ int launch_wgrad_small(const float *G, int ldg, const float *F, int ldf, int kf,
 
 // stage launchers
 int pack_weights(const fastegnn_layer_t *L, hipStream_t st);
+int pack_weights_all(const fastegnn_layer_t *const *layers, int n, hipStream_t st);
 int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st);
 int graph_xsum(const fastegnn_layer_t *L, hipStream_t st);
 int graph_pre_forward(const fastegnn_layer_t *L, hipStream_t st);

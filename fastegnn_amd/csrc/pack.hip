@@ -14,6 +14,10 @@ struct PackArgs {
   float *wpack;
   int C, ea, na, egnn, rf, bf16;
 };
+constexpr int PACK_MAX_LAYERS = 8;   // layers per launch of the multi-layer form (8 x 336 bytes of kernel arguments)
+struct PackArgsN {
+  PackArgs l[PACK_MAX_LAYERS];
+};
 
 __device__ __forceinline__ PackDesc pack_desc(const PackArgs &a, int id) {
   const int C = a.C;
@@ -71,8 +75,11 @@ __device__ __forceinline__ PackDesc pack_desc(const PackArgs &a, int id) {
   return d;
 }
 
-__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
-  const int id = blockIdx.x;
+__device__ __forceinline__ void pack_image(const PackArgs &a, int id);
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) { pack_image(a, blockIdx.x); }
+// blockIdx.y = layer
+__global__ __launch_bounds__(256) void pack_all_kernel(PackArgsN an) { pack_image(an.l[blockIdx.y], blockIdx.x); }
+__device__ __forceinline__ void pack_image(const PackArgs &a, int id) {
   const PackDesc d = pack_desc(a, id);
   float *dst = a.wpack + (size_t)id * IMG;
   unsigned *d3 = const_cast<unsigned *>(wpack_x3(a.wpack, a.C, id));
@@ -128,8 +135,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
   }
 }
 
-int pack_weights(const fastegnn_layer_t *L, hipStream_t st) {
-  FE_REQUIRE(L->params && L->wpack, "pack_weights: params/wpack null");
+static PackArgs pack_args(const fastegnn_layer_t *L) {
   PackArgs a;
   for (int i = 0; i < FASTEGNN_P_COUNT; ++i) a.p[i] = L->params[i];
   a.wpack = L->wpack;
@@ -139,8 +145,30 @@ int pack_weights(const fastegnn_layer_t *L, hipStream_t st) {
   a.egnn = has(L, FASTEGNN_F_EGNN) ? 1 : 0;
   a.rf = has(L, FASTEGNN_F_RF) ? 1 : 0;
   a.bf16 = has(L, FASTEGNN_F_BF16) ? 1 : 0;
+  return a;
+}
+int pack_weights(const fastegnn_layer_t *L, hipStream_t st) {
+  FE_REQUIRE(L->params && L->wpack, "pack_weights: params/wpack null");
+  if (has(L, FASTEGNN_F_WPACK_READY)) return FASTEGNN_OK;   // fastegnn_pack_weights_all has packed this layer
+  const PackArgs a = pack_args(L);
   { ProfScope _ps_pack_kernel(K_PACK, st); hipLaunchKernelGGL(pack_kernel, dim3(I_FIXED + 2 * L->C), dim3(256), 0, st, a); }
   return check_launch("pack_kernel");
+}
+int pack_weights_all(const fastegnn_layer_t *const *layers, int n, hipStream_t st) {
+  FE_REQUIRE(layers && n >= 1, "pack_weights_all: no layers");
+  for (int k = 0; k < n; ++k) {
+    FE_REQUIRE(layers[k] && layers[k]->params && layers[k]->wpack, "pack_weights_all: params/wpack null");
+    FE_REQUIRE(layers[k]->C == layers[0]->C, "pack_weights_all: the layers of one launch share virtual_channels");
+  }
+  for (int k0 = 0; k0 < n; k0 += PACK_MAX_LAYERS) {
+    const int m = n - k0 < PACK_MAX_LAYERS ? n - k0 : PACK_MAX_LAYERS;
+    PackArgsN an;
+    for (int k = 0; k < m; ++k) an.l[k] = pack_args(layers[k0 + k]);
+    for (int k = m; k < PACK_MAX_LAYERS; ++k) an.l[k] = an.l[0];
+    ProfScope _ps(K_PACK, st);
+    hipLaunchKernelGGL(pack_all_kernel, dim3(I_FIXED + 2 * layers[0]->C, m), dim3(256), 0, st, an);
+  }
+  return check_launch("pack_all_kernel");
 }
 
 }  // namespace fe

@@ -385,18 +385,31 @@ class _FastEGNNFunction(torch.autograd.Function):
         K.check(lib.fastegnn_virtual_init(K.ptr(params[0]), B, Cn, K.ptr(HvT), st), "fastegnn_virtual_init")
         x, Z = node_loc, loc_mean
         saved = []
-        nwp = lib.fastegnn_wpack_floats(Cn)
+        nwp = (lib.fastegnn_wpack_floats(Cn) + 3) // 4 * 4
+        # the weight images of ALL layers in one launch (fastegnn_pack_weights_all): four launches of 34 + 2C small workgroups
+        # were four launch latencies in front of the step
+        wpack_all = torch.empty(spec.n_layers, nwp, **f32)
+        tabs = [_PtrTable([params[s] if s is not None else None for s in spec.layer_slots[i]]) for i in range(spec.n_layers)]
+        packs = (C.POINTER(K.LayerT) * spec.n_layers)()
+        keep = []
         for i in range(spec.n_layers):
-            tab = _PtrTable([params[s] if s is not None else None for s in spec.layer_slots[i]])
-            b = dict(h=h, x=x, Z=Z, HvT=HvT)
+            Lp = _new_layer(spec, N, B, graph)
+            _fill(Lp, params=tabs[i].addr(), wpack=wpack_all[i])
+            keep.append(Lp)
+            packs[i] = C.pointer(Lp)
+        K.check(lib.fastegnn_pack_weights_all(packs, spec.n_layers, st), "fastegnn_pack_weights_all")
+        for i in range(spec.n_layers):
+            tab = tabs[i]
+            b = dict(h=h, x=x, Z=Z, HvT=HvT, wpack=wpack_all[i])
             b.update(_carve(dev, dict(
-                wpack=(nwp,), P=(N, H), QX=(N, K.QX_LD), A=(N, H), svel=(N,), sgrav=(N,), xsum=(B, 4),
+                P=(N, H), QX=(N, K.QX_LD), A=(N, H), svel=(N,), sgrav=(N,), xsum=(B, 4),
                 Bc=(B, Cn, H), aggm=(N, H), npre=(N, H), poolV=(B, Cn, H))))
             # outputs / forward-only scratch: separate allocations so that they can be freed individually
             b.update(_carve(dev, dict(aggx=(N, 3), poolX=(B, 3, Cn))))
             b.update(h_out=torch.empty(N, H, **f32), x_out=torch.empty(N, 3, **f32),
                      Z_out=torch.empty(B, 3, Cn, **f32), HvT_out=torch.empty(B, Cn, H, **f32))
             L = _new_layer(spec, N, B, graph)
+            L.flags |= K.F_WPACK_READY
             _fill(L, batch=batch32, gptr=gptr, vel=node_vel, params=tab.addr(), **b)
             L.QX_src = b["QX"].data_ptr()
             if ea_sorted is not None:

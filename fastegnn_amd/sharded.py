@@ -113,6 +113,19 @@ class HipBackend:
         K.check(self.lib.fastegnn_virtual_init_backward(K.ptr(g_HvT), B, Cn, K.ptr(g_vnf), _stream(self.dev)),
                 "fastegnn_virtual_init_backward")
 
+    def pack_all(self, spec, N, B, graph, layer_params, wpacks):
+        """the weight images of every layer in one launch (fastegnn_pack_weights_all)"""
+        n = len(layer_params)
+        arr = (C.POINTER(K.LayerT) * n)()
+        keep = []
+        for i in range(n):
+            L = _new_layer(spec, N, B, graph)
+            ptab = _PtrTable(layer_params[i])
+            _fill(L, params=ptab.addr(), wpack=wpacks[i])
+            keep.append((L, ptab))
+            arr[i] = C.pointer(L)
+        K.check(self.lib.fastegnn_pack_weights_all(arr, n, _stream(self.dev)), "fastegnn_pack_weights_all")
+
     def wgrad_open(self, spec, N, B, graph, t, params):
         """One weight-gradient batch for the backward stages of a layer (fastegnn_wgrad_batch_open)."""
         L = _new_layer(spec, N, B, graph)
@@ -655,10 +668,13 @@ class _ShardedFunction(torch.autograd.Function):
         xsum = be.empty(B, 4)
         be.stage("graph_xsum", spec, N, B, g0, dict(batch=batch32, x=x, xsum=xsum), _layer_lists(spec, params, 0))
         w_xsum = comm.all_reduce("xsum", xsum)
+        nwp = (be.wpack_floats(Cn) + 3) // 4 * 4
+        wpacks = be.empty(spec.n_layers, nwp)
+        be.pack_all(spec, N, B, g0, [_layer_lists(spec, params, i) for i in range(spec.n_layers)], wpacks)
         for i in range(spec.n_layers):
             lp = _layer_lists(spec, params, i)
-            b = dict(h=h, x=x, xsum=xsum)
-            b.update(be.carve(dict(wpack=(be.wpack_floats(Cn),), P=(N, H), A=(N, H), svel=(N,), sgrav=(N,),
+            b = dict(h=h, x=x, xsum=xsum, wpack=wpacks[i])
+            b.update(be.carve(dict(P=(N, H), A=(N, H), svel=(N,), sgrav=(N,),
                                    Bc=(B, Cn, H), aggm=(N, H), npre=(N, H), aggx=(N, 3))))
             b["QX"], b["QX_src"] = plan.alloc_tables(be)           # own rows | the table the edge kernels gather from
             nV, nX = B * Cn * H, B * 3 * Cn
@@ -667,7 +683,6 @@ class _ShardedFunction(torch.autograd.Function):
             b["poolV"], b["poolX"] = pools[:nV].view(B, Cn, H), pools[nV:nV + nX].view(B, 3, Cn)
             b.update(h_out=be.empty(N, H), x_out=be.empty(N, 3), Z_out=be.empty(B, 3, Cn), HvT_out=be.empty(B, Cn, H))
             t = dict(batch=batch32, gptr=gptr, vel=node_vel, node_attr=node_attr, **b)
-            be.stage("pack_weights", spec, N, B, g0, t, lp)
             be.stage("node_pre_forward", spec, N, B, g0, t, lp)
             w_qx = plan.exchange_forward(comm, b["QX"], b["QX_src"])
             if pend is not None:                                   # virtual state of this layer <- previous layer's pools

@@ -82,7 +82,10 @@ enum {
    * launch of the same layer over OTHER rows has already done so.  The sharded caller runs a rank's boundary rows (rows
    * with an edge from a ghost column) and its interior rows as two launches, so that the ghost rows' gradients travel
    * while the interior rows are still being computed (bits 11..14 hold the activation kind, below). */
-  FASTEGNN_F_GQX_ACCUM = 32768
+  FASTEGNN_F_GQX_ACCUM = 32768,
+  /* Forward: wpack already holds this layer's weight images (fastegnn_pack_weights_all packed every layer of the model in
+   * one launch): fastegnn_layer_forward / fastegnn_pack_weights skip the per-layer pack launch. */
+  FASTEGNN_F_WPACK_READY = 65536
 };
 /* Activation of every MLP (the reference's act_fn, models/FastEGNN.py:227): bits 11..14 of the flags hold one of the
  * FASTEGNN_ACT_* kinds, fastegnn_layer_t.act_param its parameter.  libfastegnn_hip.so is compiled for SiLU and rejects
@@ -238,10 +241,10 @@ typedef struct {
 /* ---- library ---- */
 const char *fastegnn_last_error(void);
 /* ABI revision: FASTEGNN_ABI_VERSION of the header the library was built from.  It changes whenever the layout of
- * fastegnn_layer_t / fastegnn_graph_t or the meaning of an argument changes (round 3 inserted act_param: 100 -> 101; round 4 appended wgrad_batch: 102).
+ * fastegnn_layer_t / fastegnn_graph_t or the meaning of an argument changes (round 3 inserted act_param: 100 -> 101; round 4 appended wgrad_batch and added fastegnn_pack_weights_all / FASTEGNN_F_WPACK_READY: 103).
  * A binding MUST compare it with the FASTEGNN_ABI_VERSION it was written against AND check fastegnn_sizeof_layer() /
  * fastegnn_sizeof_graph() against its own mirror of the descriptors before the first call (fastegnn_amd/_lib.py does). */
-#define FASTEGNN_ABI_VERSION 102
+#define FASTEGNN_ABI_VERSION 103
 int fastegnn_version(void);
 /* floats of the packed weight-image buffer for C virtual channels */
 size_t fastegnn_wpack_floats(int32_t C);
@@ -330,6 +333,10 @@ int fastegnn_virtual_init_backward(const float *g_HvT, int32_t B, int32_t C, flo
 
 /* ---- one layer, staged ---- */
 int fastegnn_pack_weights(const fastegnn_layer_t *L, void *stream);
+/* The weight images of n layers of ONE model (same C, ea, na, flags; each descriptor needs params, wpack and the sizes) in one
+ * launch: a layer's images are 34 + 2C small workgroups, and four launches of them cost four launch latencies in front of a step
+ * that is otherwise 74 launches.  Set FASTEGNN_F_WPACK_READY in the flags of the layer calls that follow. */
+int fastegnn_pack_weights_all(const fastegnn_layer_t *const *layers, int32_t n, void *stream);
 int fastegnn_node_pre_forward(const fastegnn_layer_t *L, void *stream);   /* S1 */
 int fastegnn_graph_xsum(const fastegnn_layer_t *L, void *stream);         /* S2a: local xsum */
 int fastegnn_graph_pre_forward(const fastegnn_layer_t *L, void *stream);  /* S2b: xsum -> Bc */

@@ -50,6 +50,9 @@ class CpuOracleBackend:
     def wg_virt_floats(self, N, Cn, flags=0):
         return 4
 
+    def pack_all(self, spec, N, B, graph, layer_params, wpacks):   # the oracle's stages read the parameters directly
+        pass
+
     def wgrad_open(self, spec, N, B, graph, t, params):   # the oracle's stages contract their own weight gradients
         return None
 
