@@ -111,12 +111,17 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // =====================================================================================
 // S2a graph_xsum: per-graph sum of coordinates and node count (global_mean_pool(coord), :212)
 // =====================================================================================
-// A wave owns 1024 consecutive nodes and walks them 64 at a time (lane = node).  data_batch is ascending, so a
+// A wave owns XSUM_PER_WAVE consecutive nodes and walks them 64 at a time (lane = node; 1024 nodes until round 4: sixteen
+// dependent iterations made the 100 000-node launch 19 us long for 1.6 MB of input -- now four).  data_batch is ascending, so a
 // 64-node group normally lies inside one graph: the lanes keep partial sums and the wave leaves ONE atomic set per
 // (wave, graph) run; groups that straddle graphs (mini-batches of small graphs) are reduced by a segmented scan over the
 // lanes (data_batch is sorted, so a graph is a run of lanes) and add once per (group, graph).
+#ifndef FE_XSUM_PER_WAVE
+#define FE_XSUM_PER_WAVE 256
+#endif
+constexpr int XSUM_PER_WAVE = FE_XSUM_PER_WAVE;
 __global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const int32_t *batch, int N, float *xsum) {
-  constexpr int PER_WAVE = 1024;
+  constexpr int PER_WAVE = XSUM_PER_WAVE;
   const int l = lane_id();
   const int n0 = global_wave_id() * PER_WAVE, n1 = min(N, n0 + PER_WAVE);
   if (n0 >= n1) return;
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const i
 int graph_xsum(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(L->xsum && L->batch && L->x, "graph_xsum: null buffer");
   (void)hipMemsetAsync(L->xsum, 0, (size_t)L->B * 4 * sizeof(float), st);
-  if (L->N > 0) { ProfScope _ps_graph_xsum_kernel(K_XSUM, st); hipLaunchKernelGGL(graph_xsum_kernel, dim3(cdiv(L->N, 4096)), dim3(256), 0, st, L->x, L->batch, L->N, L->xsum); }   // 4 waves x 1024 nodes
+  if (L->N > 0) { ProfScope _ps_graph_xsum_kernel(K_XSUM, st); hipLaunchKernelGGL(graph_xsum_kernel, dim3(cdiv(L->N, 4 * XSUM_PER_WAVE)), dim3(256), 0, st, L->x, L->batch, L->N, L->xsum); }   // 4 waves x XSUM_PER_WAVE nodes
   return check_launch("graph_xsum_kernel");
 }
 
