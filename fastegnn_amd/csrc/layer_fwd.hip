@@ -111,13 +111,14 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
 // =====================================================================================
 // S2a graph_xsum: per-graph sum of coordinates and node count (global_mean_pool(coord), :212)
 // =====================================================================================
-// A wave owns XSUM_PER_WAVE consecutive nodes and walks them 64 at a time (lane = node; 1024 nodes until round 4: sixteen
-// dependent iterations made the 100 000-node launch 19 us long for 1.6 MB of input -- now four).  data_batch is ascending, so a
+// A wave owns XSUM_PER_WAVE consecutive nodes and walks them 64 at a time (lane = node).  (Round 4 measured 256 nodes per wave --
+// four iterations instead of sixteen, four times the waves: 26 us per launch at 100 000 nodes either way; with one big graph the
+// launch is bound by the same-address atomics of its 98 - 391 waves, not by the loop.)  data_batch is ascending, so a
 // 64-node group normally lies inside one graph: the lanes keep partial sums and the wave leaves ONE atomic set per
 // (wave, graph) run; groups that straddle graphs (mini-batches of small graphs) are reduced by a segmented scan over the
 // lanes (data_batch is sorted, so a graph is a run of lanes) and add once per (group, graph).
 #ifndef FE_XSUM_PER_WAVE
-#define FE_XSUM_PER_WAVE 256
+#define FE_XSUM_PER_WAVE 1024
 #endif
 constexpr int XSUM_PER_WAVE = FE_XSUM_PER_WAVE;
 __global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const int32_t *batch, int N, float *xsum) {
