@@ -33,7 +33,7 @@ const char *kKernelNames[K_COUNT] = {
   "pack_kernel", "node_pre_fwd_kernel", "graph_xsum_kernel", "graph_pre_fwd_kernel", "edge_fwd_kernel",
   "virt_fwd_kernel", "graph_post_fwd_kernel", "graph_post_bwd_kernel", "virt_bwd_kernel", "graph_pre_bwd_kernel",
   "edge_bwd_kernel", "edge_col_reduce_kernel", "node_pre_bwd_kernel", "wgrad_tn_kernel", "wgrad_small_kernel",
-  "build_csr", "misc", "wgrad_reduce_kernel", "virt_bwd_node_kernel", "virt_bwd_gv_kernel", "wgrad_bundle_kernel"};
+  "build_csr", "misc", "wgrad_reduce_kernel", "virt_bwd_node_kernel", "virt_bwd_gv_kernel"};
 }  // namespace
 void prof_begin(int id, hipStream_t st) {
   hipEvent_t e = get_event();

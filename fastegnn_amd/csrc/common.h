@@ -750,8 +750,9 @@ __device__ __forceinline__ u32x4 round8(const float (&x)[8]) {
 // (l, l) term is <= 2^-24 of |w||x| -- where bf16x3 needs six, and the operand split is 2.5 vector instructions per element
 // (v_cvt_pk_f16_f32, v_fma_mix_f32 for the residual straight from the packed half, v_fma_mixlo/hi_f16 for the scaled low
 // part) where the three-part bf16 split needs 5.5.  fp16 carries 5 exponent bits: operands must stay below 65 504 --
-// activations and weights do, gradients (1e-9 and below on the headline frame) do not, which is why only the forward
-// kernels have this form.  Images: the img3 layout with part 0 = h and part 1 = l (part 2 unused).
+// activations and weights do, gradients (1e-9 and below on the headline frame) do not: the backward kernels split them
+// relative to a per-item power of two (Split2s / vsplit2_scaled below).  Images: the img3 layout with part 0 = h and
+// part 1 = l (part 2 unused).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr float F2_UP = 2048.f, F2_DOWN = 1.0f / 2048.f;

@@ -25,7 +25,7 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 enum KernelId {
   K_PACK = 0, K_NODE_PRE_FWD, K_XSUM, K_GRAPH_PRE_FWD, K_EDGE_FWD, K_VIRT_FWD, K_GRAPH_POST_FWD,
   K_GRAPH_POST_BWD, K_VIRT_BWD, K_GRAPH_PRE_BWD, K_EDGE_BWD, K_COL_REDUCE, K_NODE_PRE_BWD,
-  K_WGRAD_TN, K_WGRAD_SMALL, K_CSR, K_MISC, K_WGRAD_REDUCE, K_VIRT_BWD_NODE, K_VIRT_BWD_GV, K_WGRAD_BUNDLE, K_COUNT
+  K_WGRAD_TN, K_WGRAD_SMALL, K_CSR, K_MISC, K_WGRAD_REDUCE, K_VIRT_BWD_NODE, K_VIRT_BWD_GV, K_COUNT
 };
 extern bool g_prof_on;
 void prof_begin(int id, hipStream_t st);
@@ -41,7 +41,8 @@ struct ProfScope {
 //   batched over `nb` with strides (sG, sT, sW) in floats.  Jobs are queued and run by finish().
 constexpr int WGV_PAD = 16;        // padding rows (x C) behind each [N*C,64] operand array of the virtual backward
 constexpr int WG_MAX_JOBS = 24;
-constexpr int WG_SLABS = 8192;   // the upper half is the virtual-stage bundle's (WgradBatch slab_base)   // 64x64 partial slabs in the wg_slab workspace (+ 64-float bias slabs)
+constexpr int WG_SLABS = 8192;   // 64x64 partial slabs in the wg_slab workspace (+ 64-float bias slabs); the upper half is the
+                                 // virtual stage's own batch (WgradBatch slab_base)
 struct WgJob {
   const float *G, *T;
   float *dW, *db;
@@ -53,12 +54,11 @@ struct WgTable {
   WgJob job[WG_MAX_JOBS];
   float *slab, *slab_b;
   int n_jobs;
-  int n_bundle;   // jobs [0, n_bundle) form the wave-parallel bundle (wgrad_bundle_kernel), the rest run in wgrad_tn_kernel
 };
 struct WgradBatch {
   WgTable tab;
   hipStream_t st;
-  int n_wg, n_slab, max_nb, n_bundle_wg;
+  int n_wg, n_slab, max_nb;
   bool round;   // applied to the jobs added from now on
   int min_rows; // smallest row range given to one workgroup (short operands are split that far to fill the chip)
   int max_split; // most workgroups (= partial slabs) one job may take, times its batch count
@@ -71,7 +71,6 @@ struct WgradBatch {
   // a job whose partial slabs (nsplit of them, [64][64] + [64] bias each) are written by the caller's own kernel:
   // only the fixed-order reduction into dW / db runs here.  *slab_begin receives the first slab index.
   int plan();
-  int close_bundle();
   int add_slabs(float *dW, int lddw, int c0, int ks, float *db, int nsplit, int *slab_begin);
   int finish();
   // The contractions are deferred to finish(): a job's operand rows must stay untouched until then.  A stage that is about
@@ -101,9 +100,7 @@ int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *s
 int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
 int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
 int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
-// virt_bwd.hip: the producer/consumer form of B4 (1 <= C <= 32, FastEGNN wiring); virt_backward dispatches to it
-bool virt_backward_uses_pc(const fastegnn_layer_t *L);
-int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared);
+// virt_bwd.hip: floats of wg_virt for B4 (1 <= C <= 64)
 size_t virt_pc_wg_floats(size_t N, size_t C);
 int edge_col_reduce(const fastegnn_layer_t *L, hipStream_t st);
 int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);

@@ -12,19 +12,6 @@
 
 namespace fe {
 
-// in-kernel phase stamps of virt_bwd (diagnostic builds only: -DFE_STAMP; tools/gpu_stamp_vb.py)
-#ifdef FE_STAMP
-__device__ unsigned long long g_vb_stamps[16];
-#define VB_T0() unsigned _vb_prev = (unsigned)__builtin_amdgcn_s_memtime(); unsigned _vb_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define VB_T(i) { __builtin_amdgcn_sched_barrier(0); const unsigned _t = (unsigned)__builtin_amdgcn_s_memtime(); \
-                  _vb_acc[i] += _t - _vb_prev; _vb_prev = _t; __builtin_amdgcn_sched_barrier(0); }
-#define VB_TEND() if (lane_id() == 0) { for (int _k = 0; _k < 9; ++_k) atomicAdd(&g_vb_stamps[_k], (unsigned long long)_vb_acc[_k]); }
-#else
-#define VB_T0()
-#define VB_T(i)
-#define VB_TEND()
-#endif
-
 __device__ __forceinline__ Vec vdsilu_mul(const Vec &g, const Vec &z FE_ACT_P) {
   return vmap2(g, z, [=](float a, float b) { return a * dsilu_f(b FE_ACT_A); });
 }
@@ -128,641 +115,7 @@ int graph_post_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *s
   return shared ? FASTEGNN_OK : wb.finish();
 }
 
-// =====================================================================================
-// B4 virt_bwd
-// =====================================================================================
-struct VirtBwdArgs {
-  VirtArgs f;
-  const float *g_h_out, *g_x_out, *g_poolV, *g_poolX, *npre_in;
-  float *g_h, *g_x, *g_A, *g_aggm, *g_aggx, *g_svel, *g_sgrav, *g_Bc, *g_Zp;
-  float *wg_t3, *wg_gnp;                     // [N,64] node-level operands
-  float *wg_v, *wg_t, *wg_gux, *wg_guX, *wg_gvp;  // [C][N + WGV_PAD][64] (channel, node) operands
-  size_t wg_cstride;                              // floats per channel block = (N + WGV_PAD) * 64
-  float *d_wxv2, *d_wxx2, *d_wvr, *d_attw, *d_attb;  // rank-1 gradients (d_wvr strided by ld)
-  int ld_v0;
-};
-
-constexpr int virt_bwd_img_floats(bool x3h) { return x3h ? 5 * RM_WORDS : 6 * IMG; }   // X3H: 3 images + 2 stage buffers
-// RF (FastRF reduced layer) is a compile-time switch: as a run-time flag it cost the FastEGNN path 10 %
-// (register allocation of the channel loop)
-// BF: bf16 operand mode (FASTEGNN_F_BF16): split-image sites run one bf16 product of the rounded activation, fp32-image
-// sites round their activation (every image holds bf16-rounded weights then).
-template <bool RF, bool X3H, bool BF>
-__global__ __launch_bounds__(64 * VIRT_BWD_WAVES) void virt_bwd_kernel(VirtBwdArgs A) {
-  constexpr int SM = X3H ? (BF ? GM_BF16 : GM_X3) : GM_F32;    // arithmetic form of the split-image sites
-  constexpr int FM = BF ? GM_BF16 : GM_F32;                    // fp32-image sites: gemm64_m<FM> rounds in bf16 mode
-  typedef typename OperandOf<SM>::type SOp;
-  auto sop = [](const Vec &v) -> SOp { return make_operand<SM>((BF && !X3H) ? vround(v) : v); };
-  (void)FM;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const VirtArgs &a = A.f;
-  const int C = a.C;
-  // X3H (C <= 32): three ROW-MAJOR split images V2, WXV0, WXX0 (common.h) serve the three recomputed products by row
-  // reads and their three transposes by ds_read_b64_tr_b16 -- no V2T / WXV0T / WXX0T copies, every product on the matrix
-  // pipe -- followed by two stage buffers for the row-major image of W3c[c] (read transposed), filled by LDS-DMA one
-  // channel ahead.  Otherwise (C > 32): six fp32 images V2 WXV0 WXX0 V2T WXV0T WXX0T and an fp32 W3cT stage behind the pools.
-  float *img = lds;
-  char *rmimg = reinterpret_cast<char *>(lds);
-  char *stage0 = rmimg + 3 * RM_BYTES, *stage1 = stage0 + RM_BYTES;
-  constexpr int S_V2T = 3;
-  const void *simg = static_cast<const void *>(img);   // (C > 32) images of the recomputed products
-  float *vec = lds + virt_bwd_img_floats(X3H);
-  float *gBc_l = vec + 16 * H;                   // [C][64]
-  float *gZ_l = gBc_l + C * H;                   // [3][C]
-  // fp32 stage: W3cT[c] of the channel in flight (C > 32), the node-level images of a tile's prologue, the combine tile
-  float *w3ct_l = X3H ? reinterpret_cast<float *>(stage1) : gZ_l + ((3 * C + 3) & ~3);
-  if constexpr (X3H) {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, C, 0));   // slots 0..2 are consecutive
-    u32x4 *dst = reinterpret_cast<u32x4 *>(rmimg);
-    for (int i = threadIdx.x; i < 3 * RM_BYTES / 16; i += blockDim.x) dst[i] = src[i];
-  } else {
-    load_images(img, a.wpack + (size_t)I_V2 * IMG, 6);
-  }
-  // the product with resident weight `which` (0 V2, 1 WXV0, 2 WXX0) and with its transpose
-  auto mm = [&](int which, const SOp &op, Vec &acc) {
-    if constexpr (X3H) gemm_rm<SM, false>(rmimg + which * RM_BYTES, op, acc);
-    else gemm_op<SM>(simg, which, op, acc);
-  };
-  auto mmT = [&](int which, const Vec &g, Vec &acc) {
-    if constexpr (X3H) gemm_rm<SM, true>(rmimg + which * RM_BYTES, make_operand<SM>(g), acc);
-    else gemm64_m<FM>(img + (S_V2T + which) * IMG, g, acc);
-  };
-  // LDS-DMA of the row-major image of W3c[c] (27 wave-instructions of 1 KiB, dealt to the four waves)
-  auto dma_w3c = [&](int c, char *dst) {
-    const char *src = wpack_rm(a.wpack, C, RM_FIXED + c);
-    const int ln = lane_id();
-    // a FIXED number of copy instructions per wave (the odd last one repeats chunk 26): the compiler can then count the
-    // outstanding vector-memory operations across the channel loop instead of falling back to vmcnt(0) behind the copy
-    constexpr int NCH = RM_BYTES / 1024, PER = (NCH + VIRT_BWD_WAVES - 1) / VIRT_BWD_WAVES;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      int ch = wave_id() + k * VIRT_BWD_WAVES;
-      ch = ch < NCH ? ch : NCH - 1;
-      // Issued as inline assembly on purpose: for the builtin the compiler tracks "LDS written by an outstanding vector
-      // memory operation" and, the carved LDS array being one object to its alias analysis, puts s_waitcnt vmcnt(0) in
-      // front of the next LDS read of ANY image -- i.e. it waited for the copy it had just issued (and for the operand
-      // stores in flight) at the first product of every channel.  The waits that order this copy are explicit: vmcnt
-      // before the workgroup barrier at the top of the channel that reads the image.  (Operations the compiler does
-      // not count only make its own vmcnt(N) waits stricter, never wrong: vmcnt retires in issue order.)
-      const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)(dst + ch * 1024);
-      const char *ga = src + ch * 1024 + ln * 16;
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(ga) : "memory");   // (m0 is a reserved register: the compiler keeps nothing in it across the statement)
-    }
-  };
-#ifdef FE_SAFE_WAITS
-  // -DFE_SAFE_WAITS (libfastegnn_hip_safe.so): no LDS-DMA and no counted waits -- the image of channel c is copied through
-  // registers by the whole workgroup between two full barriers at the top of channel c
-  auto copy_w3c_sync = [&](int c, char *dst) {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_rm(a.wpack, C, RM_FIXED + c));
-    __syncthreads();
-    for (int i = threadIdx.x; i < RM_BYTES / 16; i += blockDim.x) reinterpret_cast<u32x4 *>(dst)[i] = src[i];
-    __syncthreads();
-  };
-#endif
-  virt_load_vecs(vec, a);
-  for (int i = threadIdx.x; i < C * H + 3 * C; i += blockDim.x) gBc_l[i] = 0.f;
-  __syncthreads();
-  const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
-  // a workgroup owns a contiguous run of 16-node tiles and walks it VIRT_BWD_WAVES tiles at a time.  When exactly
-  // one tile is left for the last step, its channels are dealt to the four waves (wave w takes c = w, w+4, ...)
-  // instead of leaving three SIMDs idle for a whole tile; the channel sums are combined through LDS.
-  const int ntiles = (a.N + 15) >> 4;
-  const int t_lo = (int)((long)blockIdx.x * ntiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
-  const float invC = C > 0 ? 1.0f / (float)C : 0.f;
-  const bool tanh_on = a.flags & FASTEGNN_F_TANH, att_on = a.flags & FASTEGNN_F_ATTENTION;
-  const float attb0 = att_on ? a.attb[0] : 0.f;   // (read once: a load in the channel body would wait behind that channel's stores)
-  const bool clamp_aggx = a.flags & FASTEGNN_F_EGNN;
-  constexpr bool rf = RF;
-  const float *gpv_base = rf ? a.Bc : A.g_poolV;   // FastRF: no pooled-message gradient (the rows are ignored)
-  Vec acc_wxv2 = vzero(), acc_wxx2 = vzero(), acc_wvr = vzero(), acc_att = vzero();
-  float acc_attb = 0.f;
-  int cur = -1;
-  VB_T0()
-  auto flush_pools = [&]() {
-    for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
-      atomicAdd(&A.g_Bc[(size_t)cur * C * H + i], gBc_l[i]);
-      gBc_l[i] = 0.f;
-    }
-    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
-      atomicAdd(&A.g_Zp[(size_t)cur * 3 * C + i], gZ_l[i]);
-      gZ_l[i] = 0.f;
-    }
-  };
-  for (int tb = t_lo; tb < t_hi; tb += VIRT_BWD_WAVES) {
-    const bool split = t_hi - tb == 1 && C >= VIRT_BWD_WAVES;
-    const bool own = !split || wv == 0;   // split: every wave recomputes the tile prologue, wave 0 stores it
-    const int n0 = tb * 16, nend = min(a.N, min(t_hi, tb + VIRT_BWD_WAVES) * 16);
-    const int bfirst = a.batch[n0], blast = a.batch[nend - 1];
-    const bool fast = bfirst == blast;
-    if (fast && bfirst != cur) {
-      __syncthreads();
-      if (cur >= 0) flush_pools();
-      __syncthreads();
-      cur = bfirst;
-    }
-    const int nb = split ? n0 : n0 + wv * 16;
-    {   // a wave without valid nodes runs the body on masked lanes (every contribution is zero): the
-        // workgroup walks the channels in step for the W3cT stage below
-      const int n = nb + j;
-      const bool valid = n < nend;
-      const int nc = valid ? n : nend - 1;
-      const int b = a.batch[nc];
-      // wave-uniform bases of this 128-node group + one 32-bit lane offset per array family
-      const size_t g0 = (size_t)n0;
-      const unsigned offN = (unsigned)(nc - n0) * H + 4u * q;            // [N,64] arrays
-      const unsigned offB = (unsigned)b * C * H + 4u * q;                // [B,C,64] arrays (+ c*H)
-      const float *b_gho = A.g_h_out + g0 * H, *b_npre = A.npre_in + g0 * H, *b_A = a.A + g0 * H;
-      float *b_t3 = A.wg_t3 + g0 * H, *b_gnp = A.wg_gnp + g0 * H, *b_gh = A.g_h + g0 * H, *b_gam = A.g_aggm + g0 * H;
-      float *b_gA = A.g_A + g0 * H;
-      // operand stores are unconditional (no exec-mask branch in the channel body, a fixed number of stores per channel):
-      // lanes past the last node fall into the padding rows behind each array (row n >= N), a wave whose tile belongs to
-      // the next workgroup stores to those rows too
-      const bool live = split || tb + wv < t_hi;
-      // (channel-major arrays: the 16 rows a wave stores for one channel are 4 KB of consecutive bytes, and the
-      // weight-gradient kernels stream a channel's rows instead of striding over them)
-      const size_t gs = live ? g0 : (size_t)a.N;
-      const unsigned offST = (live ? (unsigned)(n - n0) : (unsigned)j) * H + 4u * q;
-      float *b_v = A.wg_v + gs * H, *b_t = A.wg_t + gs * H, *b_gux = A.wg_gux + gs * H;
-      float *b_guX = A.wg_guX + gs * H, *b_gvp = A.wg_gvp + gs * H;
-      VB_T(7)   // tile bookkeeping (previous tile's tail, pool flush, batch lookups)
-      // ---- node MLP adjoint (node_model, :153-166); FastRF: h passes through, no segment-mean message
-      const Vec g_out = vmask(vload_u(b_gho, offN), valid);
-      Vec g_np = vzero();
-      if constexpr (rf) {
-        if (valid && own) {
-          vstore_u(b_gh, offN, g_out);
-          vstore_u(b_gam, offN, vzero());
-        }
-      } else {
-        // The three node-level images (W4T, W3AT, W3BT) pass through the W3cT stage, one after the other: read straight
-        // from global memory by a single wave per SIMD they cost 49 k cycles per tile (phase stamps), 11 % of the kernel.
-        // The workgroup's waves reach this point together (the channel loop below runs in lock step).
-        constexpr int NSTG = IMG / 4 / (64 * VIRT_BWD_WAVES);
-        auto stage_image = [&](int id) {
-          const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (size_t)id * IMG);
-          f32x4 tmp[NSTG];
-#pragma unroll
-          for (int i = 0; i < NSTG; ++i) tmp[i] = src[threadIdx.x + i * 64 * VIRT_BWD_WAVES];
-          __syncthreads();          // every wave is done with the previous content of the stage
-#ifndef FE_SAFE_WAITS
-          if constexpr (X3H) {      // both stage buffers are free now: channel 0's image lands under the prologue
-            if (id == I_W4T && C > 0 && !split) dma_w3c(0, stage0);
-          }
-#endif
-          f32x4 *dst = reinterpret_cast<f32x4 *>(w3ct_l);
-#pragma unroll
-          for (int i = 0; i < NSTG; ++i) dst[threadIdx.x + i * 64 * VIRT_BWD_WAVES] = tmp[i];
-          __syncthreads();
-        };
-        {
-          const Vec npre = vload_u(b_npre, offN);
-          Vec g_t3 = vzero();
-          stage_image(I_W4T);
-          gemm64_m<FM>(w3ct_l, g_out, g_t3);
-          g_np = vdsilu_mul(g_t3, npre FE_ACT(a));
-          if (valid && own) vstore_u(b_t3, offN, vsilu(npre FE_ACT(a)));
-        }
-        if (valid && own) vstore_u(b_gnp, offN, g_np);
-        {
-          Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
-          stage_image(I_W3AT);
-          gemm64_m<FM>(w3ct_l, g_np, g_h);
-          if (valid && own) vstore_u(b_gh, offN, g_h);
-        }
-        {
-          Vec g_am = vzero();
-          stage_image(I_W3BT);
-          gemm64_m<FM>(w3ct_l, g_np, g_am);
-          if (valid && own) vstore_u(b_gam, offN, g_am);
-        }
-      }
-      float gxn[3], xi[3], gx[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        gxn[k] = valid ? A.g_x_out[(size_t)nc * 3 + k] : 0.f;
-        xi[k] = a.x[(size_t)nc * 3 + k];
-        gx[k] = own ? gxn[k] : 0.f;
-      }
-      if (valid && q == 0 && own) {
-        float sv = 0.f, sg = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          // clamp(tot_f, -100, 100) of the EGNN baseline passes the gradient only inside the interval
-          const bool pass = !clamp_aggx || fabsf(a.aggx[(size_t)n * 3 + k]) <= 100.f;
-          A.g_aggx[(size_t)n * 3 + k] = pass ? gxn[k] : 0.f;
-          sv += gxn[k] * a.vel[(size_t)n * 3 + k];
-          sg += gxn[k] * a.g[k];
-        }
-        A.g_svel[n] = sv;
-        if (a.flags & FASTEGNN_F_GRAVITY) A.g_sgrav[n] = sg;
-      }
-      VB_T(0)   // node-MLP adjoint of the tile
-      Vec g_A = vzero();
-      const float *Zb = a.Z + (size_t)b * 3 * C;
-      // Channel-invariant rows stay in registers, and the per-channel rows of channel c+1 are requested
-      // at the top of channel c, ahead of that channel's operand stores: a load issued after the
-      // stores could only be waited for together with them (vmcnt counts stores too).
-      const Vec Arow = vload_u(b_A, offN);
-      const Vec g_np_m = BF ? vround(vmask(g_np, valid)) : vmask(g_np, valid);   // B operand of every W3cT product
-      Vec nBc = vzero(), nGpv = vzero();
-      float nZ[3] = {0.f, 0.f, 0.f}, nGpx[3] = {0.f, 0.f, 0.f};
-      const int c_first = split ? wv : 0, c_step = split ? VIRT_BWD_WAVES : 1;
-      if (c_first < C) {   // the virtual-node buffers are null for the EGNN baseline (C = 0)
-        nBc = vload_u(a.Bc, offB + (unsigned)c_first * H);
-        nGpv = vload_u(gpv_base, offB + (unsigned)c_first * H);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          nZ[k] = Zb[k * C + c_first];
-          nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C + c_first];
-        }
-      }
-      // The first channel's rows are waited for HERE, ahead of the loop: the loop body re-requests them one channel
-      // ahead and waits for them at its END with an exact count (vmcnt(20): the channel's 20 operand stores stay in
-      // flight).  Entering the loop with the requests still pending made the compiler merge "just issued" into the loop
-      // header's state, and the first use of a row at the top of EVERY channel -- behind the freshly issued LDS-DMA
-      // copy of the next image -- became s_waitcnt vmcnt(0): one copy round trip per channel, the "channel top" phase
-      // of the stamps (2.6-3.1 k of 25.6 k cycles).
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        asm volatile("" : "+v"(nBc.t[t]));
-        asm volatile("" : "+v"(nGpv.t[t]));
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        asm volatile("" : "+v"(nZ[k]));
-        asm volatile("" : "+v"(nGpx[k]));
-      }
-      // W3cT[c] goes through an LDS stage refilled once per workgroup and channel.  C > 32: the fp32 image of channel
-      // c+1 is fetched into registers at the top of channel c (ahead of that channel's stores) and committed at the top
-      // of c+1 between two barriers.  X3H: the row-major image of W3c[c+1] is sent to the other stage buffer by LDS-DMA
-      // right after the single barrier of channel c (that barrier's vmcnt(0) retires the copy of channel c).
-      constexpr int STG = IMG / 4 / (64 * VIRT_BWD_WAVES);
-      f32x4 pre_w[X3H ? 1 : STG];
-      auto fetch_w3ct = [&](int c) {
-        if constexpr (!X3H) {
-          const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (size_t)img_w3ct(C, c) * IMG);
-#pragma unroll
-          for (int i = 0; i < STG; ++i) pre_w[i] = src[threadIdx.x + i * 64 * VIRT_BWD_WAVES];
-        }
-      };
-      if constexpr (!rf && !X3H) { if (C > 0 && !split) fetch_w3ct(0); }
-      for (int c = c_first; c < C; c += c_step) {
-        VB_T(7)
-        // Recompute the forward of (tile, c) interleaved with its adjoint so that each activation is
-        // dead as soon as its gradient is formed.
-        asm volatile("" ::: "memory");
-        if constexpr (!rf) if (!split) {
-          if constexpr (X3H) {
-            // channel c's image has landed (every wave waits for its share of the copy) and every wave is done with
-            // channel c-1, whose buffer the next copy overwrites.  Behind the first channel of a tile the wait is NOT
-            // vmcnt(0): the copy of channel c was issued at the top of channel c-1, ahead of that channel's row
-            // requests and of its 20 operand stores (unconditional, see offST) -- vmcnt counts in issue order, so
-            // "at most 16 outstanding" retires the copy and the rows without waiting for the stores to reach L2
-            // (with vmcnt(0) the channel top cost 2.6-3.1 k of the 25.6 k cycles of a (tile, channel), stamps).
-#ifdef FE_SAFE_WAITS
-            copy_w3c_sync(c, (c & 1) ? stage1 : stage0);
-            (void)dma_w3c;
-#else
-            if (c == c_first) {
-              __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): channel 0's copy was issued in the tile prologue
-              __syncthreads();
-            } else {
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-              __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16) expcnt(7) lgkmcnt(0)
-              __builtin_amdgcn_s_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            }
-            if (c + 1 < C) dma_w3c(c + 1, ((c + 1) & 1) ? stage1 : stage0);
-#endif
-          } else {
-            __syncthreads();          // every wave is done with the previous channel's stage
-            f32x4 *dst = reinterpret_cast<f32x4 *>(w3ct_l);
-#pragma unroll
-            for (int i = 0; i < STG; ++i) dst[threadIdx.x + i * 64 * VIRT_BWD_WAVES] = pre_w[i];
-            __syncthreads();
-            fetch_w3ct(c + 1 < C ? c + 1 : c);
-          }
-        }
-        const unsigned oc = offST;
-        const size_t cb = (size_t)c * A.wg_cstride;   // this channel's block (wave-uniform)
-        const Vec Bc_c = nBc, gpv_c = nGpv;
-        float vd[3], gpX[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          vd[k] = nZ[k] - xi[k];
-          gpX[k] = valid ? nGpx[k] : 0.f;
-        }
-        {
-          const int cn = c + c_step < C ? c + c_step : c;
-          const unsigned obn = offB + (unsigned)cn * H;
-          nBc = vload_u(a.Bc, obn);
-          nGpv = vload_u(gpv_base, obn);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            nZ[k] = Zb[k * C + cn];
-            nGpx[k] = A.g_poolX[((size_t)b * 3 + k) * C + cn];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        VB_T(1)   // channel top: workgroup sync, W3cT stage, next-channel rows requested
-        const float vr = sqrt_f(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
-        auto make_pre = [&]() {
-          Vec p = Arow;
-          vadd(p, Bc_c);
-          vaxpy(p, vr, vload_vec(vec + VV_WVR * H, q));
-          return p;
-        };
-        Vec vp = vload_vec(vec + VV_C2 * H, q);
-        Vec d_pre = make_pre();
-        {
-          const Vec t = vsilu_keep_d(d_pre FE_ACT(a));      // d_pre <- silu'(pre)
-          WG_STORE(vstore_u(b_t + cb, oc, t);)
-          mm(0, sop(t), vp);
-        }
-        const Vec v0 = vsilu_keep_d(vp FE_ACT(a));          // vp <- silu'(vp)
-        float att = 1.f;
-        Vec v = v0;
-        if (att_on) {
-          att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + attb0);
-          v = vscale(v0, att);
-        }
-        WG_STORE(vstore_u(b_v + cb, oc, v);)
-        const SOp vs = sop(v);   // feeds both coordinate heads
-        // d/dv: node_mlp.0 column block of channel c  +  pool of node_model_virtual
-        VB_T(2)   // pre, silu, V2 product, silu, operand of the heads
-        Vec g_v = rf ? vzero() : vmask(gpv_c, valid);
-        if constexpr (!rf) {
-          if (split) gemm64(a.wpack + (size_t)img_w3ct(C, c) * IMG, g_np_m, g_v);   // the stage serves one channel at a time
-          else if constexpr (X3H) gemm_rm<SM, true>((c & 1) ? stage1 : stage0, make_operand<SM>(g_np_m), g_v);
-          else gemm64(w3ct_l, g_np_m, g_v);                                          // (g_np_m is rounded already in bf16 mode)
-        }
-        float g_vd[3];
-        float sx, sX;
-        VB_T(3)   // W3cT product
-        {  // coord_mlp_r_virtual head: forward, then its adjoint
-          Vec uxp = vload_vec(vec + VV_BXV0 * H, q);
-          mm(1, vs, uxp);
-          const Vec ux = vsilu_keep_d(uxp FE_ACT(a));       // uxp <- silu'(uxp)
-          const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
-          sx = tanh_on ? tanh_f(sr) : sr;
-          float g_sx = 0.f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) g_sx -= vd[k] * invC * gxn[k];
-          const float g_sr = tanh_on ? g_sx * (1.f - sx * sx) : g_sx;
-          vaxpy(acc_wxv2, g_sr, ux);
-          const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
-          WG_STORE(vstore_u(b_gux + cb, oc, g_up);)
-          mmT(1, g_up, g_v);
-        }
-        VB_T(4)   // head x: forward product, silu, dot, transposed product
-        {  // coord_mlp_v_virtual head
-          Vec uXp = vload_vec(vec + VV_BXX0 * H, q);
-          mm(2, vs, uXp);
-          const Vec uX = vsilu_keep_d(uXp FE_ACT(a));
-          const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
-          sX = tanh_on ? tanh_f(sr) : sr;
-          float g_sX = 0.f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) g_sX += vd[k] * gpX[k];
-          const float g_sr = tanh_on ? g_sX * (1.f - sX * sX) : g_sX;
-          vaxpy(acc_wxx2, g_sr, uX);
-          const Vec g_up = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
-          WG_STORE(vstore_u(b_guX + cb, oc, g_up);)
-          mmT(2, g_up, g_v);
-        }
-        VB_T(5)   // head X
-#pragma unroll
-        for (int k = 0; k < 3; ++k) g_vd[k] = -sx * invC * gxn[k] + sX * gpX[k];
-        Vec g_v0 = g_v;
-        if (att_on) {
-          const float g_a = vdot(g_v, v0);
-          const float g_z = g_a * att * (1.f - att);
-          vaxpy(acc_att, g_z, v0);
-          if (q == 0) acc_attb += g_z;
-          g_v0 = vscale(g_v, att);
-          vaxpy(g_v0, g_z, vload_vec(vec + VV_ATT * H, q));
-        }
-        Vec g_t = vzero();
-        {
-          const Vec g_vp = vmul(g_v0, vp);
-          WG_STORE(vstore_u(b_gvp + cb, oc, g_vp);)
-          mmT(0, g_vp, g_t);
-        }
-        VB_T(6)   // attention adjoint, g_vp, V2T product
-        const Vec g_pre = vmul(g_t, d_pre);
-        vadd(g_A, g_pre);
-        vaxpy(acc_wvr, vr, g_pre);
-        const float g_vr = vdot(g_pre, vload_vec(vec + VV_WVR * H, q));
-        const float ivr = vr > 0.f ? g_vr * rcp_f(vr) : 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          g_vd[k] += ivr * vd[k];
-          gx[k] -= g_vd[k];
-        }
-        // pools over the nodes of the tile: g_Bc[b,c,:] += g_pre, g_Zp[b,:,c] += g_vd.  The sum over the 16 items
-        // of the tile runs on DPP row rotations in the D layout (no transpose tile in LDS: that space holds
-        // split images instead); g_pre of a masked lane is zero.
-        if (fast) {
-          // (all sums first, then ONE masked block of LDS atomics: sixteen separate `if (j == 0)` blocks cut the
-          // channel body into as many scheduling regions)
-          float pz[3], sr[4][4];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) pz[k] = jsum((valid && q == 0) ? g_vd[k] : 0.f);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sr[t][r] = jsum_dpp(g_pre.t[t][r]);
-          if (j == 0) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) atomicAdd(&gBc_l[c * H + 16 * t + 4 * q + r], sr[t][r]);
-            if (q == 0) {
-#pragma unroll
-              for (int k = 0; k < 3; ++k) atomicAdd(&gZ_l[k * C + c], pz[k]);
-            }
-          }
-        } else {
-          if (valid && q == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) atomicAdd(&A.g_Zp[((size_t)b * 3 + k) * C + c], g_vd[k]);
-          }
-          if (valid) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                atomicAdd(&A.g_Bc[((size_t)b * C + c) * H + 16 * t + 4 * q + r], g_pre.t[t][r]);
-          }
-        }
-        VB_T(8)   // g_pre consumers: g_A, w_vr, vr adjoint, pools
-      }
-      if (split) {   // sum the four waves' channel shares of g_A and g_x ([16][68] floats in the idle W3cT stage)
-        float *comb = w3ct_l;
-        __syncthreads();
-        for (int i = threadIdx.x; i < 16 * TS; i += blockDim.x) comb[i] = 0.f;
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(&comb[j * TS + 16 * t + 4 * q + r], g_A.t[t][r]);
-        if (q == 0) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) atomicAdd(&comb[j * TS + H + k], gx[k]);
-        }
-        __syncthreads();
-        if (own) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) g_A.t[t] = *reinterpret_cast<const f32x4 *>(comb + j * TS + 16 * t + 4 * q);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) gx[k] = comb[j * TS + H + k];
-        }
-        __syncthreads();   // comb is the W3cT stage of the next workgroup step
-      }
-      if (valid && own) {
-        vstore_u(b_gA, offN, g_A);
-        if (q == 0) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) A.g_x[(size_t)n * 3 + k] = gx[k];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (cur >= 0) flush_pools();
-  VB_TEND()
-  // rank-1 weight gradients held per lane -> LDS (reuse the vector area) -> one atomic set per workgroup
-  float *red = vec;   // [5][64]; the weight vectors are dead now
-  __syncthreads();
-  for (int i = threadIdx.x; i < 5 * H; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
-  vec_reduce_lds(red + 0 * H, acc_wxv2, j, q);
-  vec_reduce_lds(red + 1 * H, acc_wxx2, j, q);
-  vec_reduce_lds(red + 2 * H, acc_wvr, j, q);
-  if (att_on) {
-    vec_reduce_lds(red + 3 * H, acc_att, j, q);
-    float s = jsum(acc_attb);
-    if (l == 0) atomicAdd(&red[4 * H], s);
-  }
-  __syncthreads();
-  if (threadIdx.x < H && C > 0) {
-    const int o = threadIdx.x;
-    atomicAdd(&A.d_wxv2[o], red[o]);
-    atomicAdd(&A.d_wxx2[o], red[H + o]);
-    // w_vr is column 2H of edge_mlp_virtual.0.weight (row stride ld_v0)
-    atomicAdd(&A.d_wvr[(size_t)o * A.ld_v0], red[2 * H + o]);
-    if (att_on) {
-      atomicAdd(&A.d_attw[o], red[3 * H + o]);
-      if (o == 0) atomicAdd(A.d_attb, red[4 * H]);
-    }
-  }
-}
-
-int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
-  if (virt_backward_uses_pc(L)) return virt_backward_pc(L, st, shared);   // virt_bwd.hip
-  const bool egnn = has(L, FASTEGNN_F_EGNN);
-  FE_REQUIRE(L->h && L->A && L->x && L->vel && L->aggm && L->npre && L->batch && L->wpack && (!egnn || L->aggx),
-             "virt_backward: null saved buffer");
-  FE_REQUIRE(L->g_h_out && L->g_x_out && L->g_h && L->g_x && L->g_A && L->g_aggm && L->g_aggx && L->g_svel &&
-                 L->wg_node && L->grads,
-             "virt_backward: null gradient buffer");
-  FE_REQUIRE(egnn ? L->C == 0 : (L->Bc && L->Z && L->g_poolV && L->g_poolX && L->g_Bc && L->g_Zp && L->wg_virt && L->C >= 1),
-             "virt_backward: virtual buffers null or bad C");
-  const int N = L->N, C = L->C;
-  if (C > 0) {
-    (void)hipMemsetAsync(L->g_Bc, 0, (size_t)L->B * C * H * sizeof(float), st);
-    (void)hipMemsetAsync(L->g_Zp, 0, (size_t)L->B * 3 * C * sizeof(float), st);
-  }
-  if (N == 0) return check_launch("virt_backward(memset)");
-  float *const *g = L->grads;
-  VirtBwdArgs A;
-  A.f = make_virt_args(L);
-  A.g_h_out = L->g_h_out; A.g_x_out = L->g_x_out; A.g_poolV = L->g_poolV; A.g_poolX = L->g_poolX; A.npre_in = L->npre;
-  A.g_h = L->g_h; A.g_x = L->g_x; A.g_A = L->g_A; A.g_aggm = L->g_aggm; A.g_aggx = L->g_aggx;
-  A.g_svel = L->g_svel; A.g_sgrav = L->g_sgrav; A.g_Bc = L->g_Bc; A.g_Zp = L->g_Zp;
-  A.wg_t3 = L->wg_node; A.wg_gnp = L->wg_node + (size_t)N * H;
-  // (arrays are [C][N + WGV_PAD][64]: every channel block ends in WGV_PAD rows that masked lanes store to -- the operand
-  // stores carry no exec mask)
-  const size_t np_rows = (size_t)N + WGV_PAD;           // rows per channel block
-  const size_t vstride = np_rows * (size_t)C * H;
-  A.wg_cstride = np_rows * H;
-  A.wg_v = L->wg_virt; A.wg_t = L->wg_virt + vstride; A.wg_gux = L->wg_virt + 2 * vstride;
-  A.wg_guX = L->wg_virt + 3 * vstride; A.wg_gvp = L->wg_virt + 4 * vstride;
-  A.ld_v0 = 2 * H + 1 + C;
-  A.d_wxv2 = g[FASTEGNN_P_CRV2_W]; A.d_wxx2 = g[FASTEGNN_P_CVV2_W];
-  A.d_wvr = g[FASTEGNN_P_VIRT0_W] ? g[FASTEGNN_P_VIRT0_W] + 2 * H : nullptr;
-  A.d_attw = g[FASTEGNN_P_ATTV_W]; A.d_attb = g[FASTEGNN_P_ATTV_B];
-  FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || (A.d_attw && A.d_attb), "virt_backward: attention grads null");
-  FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
-  const int ntg = cdiv(N, 16 * VIRT_BWD_WAVES);
-  int grid = ntg < 256 ? ntg : 256;   // one workgroup per CU, each with an equal share of the tiles
-  {
-    ProfScope _ps_virt_bwd_kernel(K_VIRT_BWD, st);
-    const bool x3h = C <= 32, bf = has(L, FASTEGNN_F_BF16);
-    const size_t lds = virt_lds_bytes(C, 0, 0) + (virt_bwd_img_floats(x3h) + (x3h ? 0 : IMG) + 4) * sizeof(float);
-    const dim3 g3(grid), b3(64 * VIRT_BWD_WAVES);
-#define FE_VB(RF_, X3H_, BF_) hipLaunchKernelGGL((virt_bwd_kernel<RF_, X3H_, BF_>), g3, b3, lds, st, A)
-    if (has(L, FASTEGNN_F_RF)) {
-      if (x3h) { if (bf) FE_VB(true, true, true); else FE_VB(true, true, false); }
-      else { if (bf) FE_VB(true, false, true); else FE_VB(true, false, false); }
-    } else {
-      if (x3h) { if (bf) FE_VB(false, true, true); else FE_VB(false, true, false); }
-      else { if (bf) FE_VB(false, false, true); else FE_VB(false, false, false); }
-    }
-#undef FE_VB
-  }
-  int rc = check_launch("virt_bwd_kernel");
-  if (rc) return rc;
-  const int ld_n0 = 2 * H + H * C + L->na;
-  WgradBatch local(L->wg_slab, st);
-  WgradBatch &wb = shared ? *shared : local;
-  wb.round = has(L, FASTEGNN_F_BF16);
-#ifndef FE_BUNDLE_MAXC
-#define FE_BUNDLE_MAXC 16
-#endif
-  if (C > 0 && C <= FE_BUNDLE_MAXC) {
-    // (a batch of its own, in the upper half of the slab workspace: a bundle is the first jobs of a batch)
-    WgradBatch bb(L->wg_slab, st, has(L, FASTEGNN_F_BF16), WG_SLABS / 2, WG_SLABS / 2);
-    bb.min_rows = 128;
-    // the four contractions over the (node, channel) rows as ONE wave-parallel bundle, all in the batched geometry
-    // "N rows x C channel slices" so that the waves of a workgroup walk the same rows: the node_mlp.0 block of channel c
-    // (g_np, v[:,c]), the two coordinate heads (g_ux, v), (g_uX, v) and edge_mlp_virtual.2 (g_vp, t); `v` is read by
-    // three of them and reaches HBM once.  Measured (ms per step, weight-gradient kernels): cfg4 (C = 16) plain jobs 3.85,
-    // this bundle 3.52-3.64, a three-job bundle over the contiguous N*C rows 4.31; cfg5 (C = 32, consecutive rows of a
-    // channel 8 KB apart) plain 47.7, this bundle 52.9, three-job bundle 57.1 -- hence the switch on C.
-    const long cb = (long)A.wg_cstride;   // channel block stride: batch slice c of a job = channel c
-    // (order: wave w of a bundle workgroup runs job w)
-    if ((rc = bb.add(A.wg_gnp, H, A.wg_v, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, cb, 1))) return rc;
-    if ((rc = bb.add(A.wg_gux, H, A.wg_v, H, N, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], C, cb, cb, 0))) return rc;
-    if ((rc = bb.add(A.wg_guX, H, A.wg_v, H, N, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], C, cb, cb, 0))) return rc;
-    if ((rc = bb.add(A.wg_gvp, H, A.wg_t, H, N, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], C, cb, cb, 0))) return rc;
-    if ((rc = bb.close_bundle())) return rc;
-    if ((rc = bb.finish())) return rc;
-  } else if (C > 0) {
-    // plain jobs, one batch slice per channel, in a batch of their own (upper half of the slab workspace)
-    WgradBatch bb(L->wg_slab, st, has(L, FASTEGNN_F_BF16), WG_SLABS / 2, WG_SLABS / 2);
-    const long cb = (long)A.wg_cstride;
-    if ((rc = bb.add(A.wg_gnp, H, A.wg_v, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, cb, 1))) return rc;
-    // coordinate heads and edge_mlp_virtual.2 over the (channel, node) rows
-    if ((rc = bb.add(A.wg_gux, H, A.wg_v, H, N, g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], C, cb, cb, 0))) return rc;
-    if ((rc = bb.add(A.wg_guX, H, A.wg_v, H, N, g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], C, cb, cb, 0))) return rc;
-    if ((rc = bb.add(A.wg_gvp, H, A.wg_t, H, N, g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], C, cb, cb, 0))) return rc;
-    if ((rc = bb.finish())) return rc;
-  }
-  // node_mlp.2
-  if ((rc = wb.add(L->g_h_out, H, A.wg_t3, H, N, g[FASTEGNN_P_NODE2_W], H, 0, 1, g[FASTEGNN_P_NODE2_B]))) return rc;
-  // node_mlp.0: [h | agg | flat(v) | node_attr]
-  if ((rc = wb.add(A.wg_gnp, H, L->h, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 0, 1, g[FASTEGNN_P_NODE0_B]))) return rc;
-  if ((rc = wb.add(A.wg_gnp, H, L->aggm, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, H, 1, nullptr))) return rc;
-  if (!shared && (rc = wb.finish())) return rc;
-  if (L->na > 0) {
-    if ((rc = launch_wgrad_small(A.wg_gnp, H, L->node_attr, L->na, L->na, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H + H * C, st))) return rc;
-    // d loss / d node_attr (+=, only when the caller asks): g_np x the node_attr columns of node_mlp.0.weight
-    if (L->g_node_attr && !has(L, FASTEGNN_F_RF))
-      if ((rc = launch_dgrad_small(A.wg_gnp, N, L->na, L->params[FASTEGNN_P_NODE0_W], ld_n0, 2 * H + H * C, L->g_node_attr, 1, st))) return rc;
-  }
-  return FASTEGNN_OK;
-}
+// B4 (virt_backward: the adjoint of the virtual stage and of node_model) lives in virt_bwd.hip
 
 // =====================================================================================
 // B3 graph_pre_bwd: adjoint of Bc / Gram / centroid
@@ -1385,26 +738,16 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
 // the edge stage contracts its weight gradients inside the workgroup: no operand workspace, only the running sums of its
 // two consumer waves per workgroup (256 x 2 tiles of 64x64)
 extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { (void)E; return (size_t)256 * 2 * fe::IMG; }
-// weight-gradient operand workspaces of the virtual / node-level stages (layouts: virt_backward, graph_post_backward,
-// graph_pre_backward, node_pre_backward above; virt_backward_pc in virt_bwd.hip).  The flag-less queries return the
-// largest size any wiring needs (the FastRF / EGNN form of B4 materialises five operand arrays); the _for variants
-// take the layer's flags: the FastEGNN wiring keeps v and Gv only (+ the per-group parts of g_A / g_x).
+// weight-gradient operand workspaces of the virtual / node-level stages (layouts: virt_backward in virt_bwd.hip,
+// graph_post_backward, graph_pre_backward, node_pre_backward above).  One form of B4 serves every wiring since round 4
+// (v / Gv + the per-group parts of g_A / g_x + consumer scratch); the _for variant is kept for ABI stability.
 extern "C" size_t fastegnn_wg_virt_floats(int32_t N, int32_t C) {
-  size_t n = (size_t)5 * ((size_t)(N > 0 ? N : 0) + fe::WGV_PAD) * (size_t)(C > 0 ? C : 0) * fe::H;
-  // the producer / consumer form carries constant terms (part tiles, consumer scratch: ~36 MB at C = 16) that exceed the
-  // five-array size on small shards: the flag-less query is the maximum over both forms
-  if (C >= 1 && C <= 64) {
-    const size_t pc = fe::virt_pc_wg_floats((size_t)(N > 0 ? N : 0), (size_t)C);
-    if (pc > n) n = pc;
-  }
+  const size_t n = C >= 1 ? fe::virt_pc_wg_floats((size_t)(N > 0 ? N : 0), (size_t)C) : 0;
   return n > 4 ? n : 4;
 }
 extern "C" size_t fastegnn_wg_virt_floats_for(int32_t N, int32_t C, int32_t flags) {
-  fastegnn_layer_t L{};
-  L.N = N; L.C = C; L.flags = flags;
-  if (!fe::virt_backward_uses_pc(&L)) return fastegnn_wg_virt_floats(N, C);
-  const size_t n = fe::virt_pc_wg_floats((size_t)(N > 0 ? N : 0), (size_t)C);
-  return n > 4 ? n : 4;
+  (void)flags;
+  return fastegnn_wg_virt_floats(N, C);
 }
 extern "C" size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C) {
   const size_t m = (size_t)(N > 0 ? N : 0), g = (size_t)(B > 0 ? B : 0) * (size_t)(C > 0 ? C : 0);
@@ -1659,16 +1002,6 @@ int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *sha
 
 }  // namespace fe
 
-#ifdef FE_STAMP
-extern "C" int fastegnn_debug_read_vb_stamps(unsigned long long *out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::g_vb_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-  if (reset) {
-    unsigned long long z[16] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(fe::g_vb_stamps), z, sizeof(z));
-  }
-  return 0;
-}
-#endif
 
 #ifdef FE_STAMP
 extern "C" int fastegnn_debug_read_eb_stamps(unsigned long long *out, int reset) {

@@ -401,8 +401,8 @@ __global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_tn_kernel(WgTable tab) {
 #endif
   __shared__ float redb[H];
   float *red = smem;
-  // locate the job of this workgroup (the wave-parallel bundle, if any, is served by wgrad_bundle_kernel)
-  int jb = tab.n_bundle;
+  // locate the job of this workgroup
+  int jb = 0;
 #pragma unroll 1
   while (jb + 1 < tab.n_jobs && (int)blockIdx.x >= tab.job[jb + 1].wg_begin) ++jb;
   const WgJob &a = tab.job[jb];
@@ -498,55 +498,6 @@ __global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_tn_kernel(WgTable tab) {
 #endif
 }
 
-// Wave-parallel bundle: up to four jobs of the SAME geometry (M, nb, strides, row split) that share operand rows --
-// the virtual stage's (g_np, v), (g_ux, v), (g_uX, v), (g_vp, t) -- are contracted by the four waves of one workgroup
-// over the same row range: wave w runs job w over every 16-row tile of the range, so the shared `v` rows are fetched
-// from HBM once and hit in L1/L2 for the other two waves (5 operand streams instead of 8).  Each wave keeps its own
-// 64x64 accumulator and writes its own partial slab; nothing is reduced across waves.
-// Round-2 counters say the sharing is only partial: FETCH_SIZE x 2 = 3.44 GB per cfg4 launch against 2.05 GB of distinct
-// operand bytes (the three readers of `v` drift apart), moved at ~6 TB/s, so the kernel sits on both its byte and its
-// fp32-MFMA budget (0.33 ms of matrix-pipe time in a 0.56 ms launch).  Variants measured against 2.93 ms per step for
-// all weight-gradient kernels, none kept: `v` staged once per workgroup behind one barrier per tile 4.05 (every step
-// waits for the slowest of four load streams); two tiles of prefetch per wave 3.07 (not latency-bound); a wave
-// contracting a pair of jobs that share `v` (two accumulators, 6 streams instead of 8) 3.70 (256 registers, serialised
-// LDS reads in front of 128 MFMAs per tile).
-__global__ __launch_bounds__(256, FE_WG_OCC) void wgrad_bundle_kernel(WgTable tab) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 16 * WTS];
-  const int w = wave_id();
-  if (w >= tab.n_bundle) return;
-  const WgJob &a = tab.job[w];
-  const int bidx = blockIdx.x % a.nb, split = blockIdx.x / a.nb;
-  const int l = lane_id(), i = l & 15, q = l >> 4;
-  const float *G = a.G + (size_t)bidx * a.sG;
-  const float *T = a.T + (size_t)bidx * a.sT;
-  const long m0 = (long)split * a.rows_per_wg;
-  long m1 = m0 + a.rows_per_wg;
-  if (m1 > a.M) m1 = a.M;
-  float *gt = smem + (w * 2 + 0) * 16 * WTS, *tt = smem + (w * 2 + 1) * 16 * WTS;
-  f32x4 acc[4][4];
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-    for (int tk = 0; tk < 4; ++tk) acc[ti][tk] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool want_bias = a.db != nullptr;
-  wg_accumulate(G, T, a.ldg, a.ldt, m0, m1, 16, want_bias, a.round != 0, gt, tt, acc, bsum);
-  const size_t sidx = (size_t)a.slab_begin + (size_t)bidx * a.nsplit + split;
-  float *dst = tab.slab + sidx * IMG;
-#pragma unroll
-  for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-    for (int tk = 0; tk < 4; ++tk)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(16 * ti + 4 * q + r) * H + 16 * tk + i] = acc[ti][tk][r];
-#pragma unroll
-  for (int ti = 0; ti < 4; ++ti) {
-    const float sb = qsum(bsum[ti]);
-    if (q == 0) tab.slab_b[sidx * H + 16 * ti + i] = sb;
-  }
-}
-
-
 // Sum the partial slabs of every (job, batch) and accumulate into the gradients.  A workgroup owns
 // 64 consecutive elements of one 64x64 tile; its 8 waves sum interleaved subsets of the splits
 // (8 independent loads in flight per thread) and the 8 partials are added in a fixed order.
@@ -599,8 +550,6 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
 WgradBatch::WgradBatch(float *slab, hipStream_t st_, bool round_bf16, int slab_base_, int slab_cap_)
     : st(st_), round(round_bf16), slab_base(slab_base_), slab_cap(slab_cap_) {
   tab.n_jobs = 0;
-  tab.n_bundle = 0;
-  n_bundle_wg = 0;
   min_rows = 256;
   // most workgroups (= partial slabs) per job: sweep at cfg4 (contraction + reduction, ms per step) 256: 3.22, 512: 3.17,
   // 768: 3.23, 1024: 3.28 (FE_WG_CAP overrides it for such sweeps; re-swept in round 3: 256 / 512 within 2 %, 128 and 1024 worse)
@@ -617,7 +566,7 @@ WgradBatch::WgradBatch(float *slab, hipStream_t st_, bool round_bf16, int slab_b
 
 // Slab bookkeeping: jobs whose slabs the caller's own kernel writes (add_slabs) need their slab range at once and take
 // it from the TOP of the batch's share; contraction jobs (add) only record the split they would like -- their ranges are
-// assigned by plan() (from close_bundle() / finish()), scaled down together if the share cannot hold them all (many long
+// assigned by plan() (from finish()), scaled down together if the share cannot hold them all (many long
 // jobs in one layer-wide batch: N >= 393 k with B*C >= 30 k overflowed the round-2 budget and failed the backward).
 int WgradBatch::add(const float *G, int ldg, const float *T, int ldt, long M, float *dW, int lddw, int c0, int ks,
                     float *db, int nb, long sG, long sT, long sW, int kmax) {
@@ -702,23 +651,6 @@ int WgradBatch::guard_write(const float *p, size_t n, const char *what) const {
   return FASTEGNN_OK;
 }
 
-// The FIRST jobs added to a batch may form the wave-parallel bundle (wgrad_bundle_kernel): <= 4 jobs with identical
-// M / nb / row split whose operands overlap.  Call after adding them, before any other add().
-int WgradBatch::close_bundle() {
-  FE_REQUIRE(tab.n_bundle == 0 && tab.n_jobs <= 4, "wgrad: a bundle is the first <= 4 jobs of a batch");
-  if (tab.n_jobs == 0) return FASTEGNN_OK;
-  int rc = plan();
-  if (rc) return rc;
-  planned = false;                            // jobs may still be added behind the bundle
-  for (int k = 1; k < tab.n_jobs; ++k)
-    FE_REQUIRE(tab.job[k].M == tab.job[0].M && tab.job[k].nb == tab.job[0].nb && tab.job[k].rows_per_wg == tab.job[0].rows_per_wg &&
-                   tab.job[k].nsplit == tab.job[0].nsplit,
-               "wgrad: bundle jobs must share their geometry");
-  tab.n_bundle = tab.n_jobs;
-  n_bundle_wg = tab.job[0].nsplit * tab.job[0].nb;
-  return FASTEGNN_OK;
-}
-
 int WgradBatch::add_slabs(float *dW, int lddw, int c0, int ks, float *db, int nsplit, int *slab_begin) {
   FE_REQUIRE(dW && slab_begin && nsplit > 0, "wgrad: add_slabs arguments");
   FE_REQUIRE(tab.slab, "wgrad: wg_slab workspace is null");
@@ -740,16 +672,6 @@ int WgradBatch::finish() {
   if (tab.n_jobs == 0) return FASTEGNN_OK;
   int rc = plan();
   if (rc) return rc;
-  if (tab.n_bundle > 0) {
-    // (the bundle's jobs are contracted by wgrad_bundle_kernel: take their workgroups out of wgrad_tn_kernel's grid)
-    int shift = 0;
-    for (int k = 0; k < tab.n_bundle; ++k) shift += tab.job[k].nsplit * tab.job[k].nb;
-    for (int k = 0; k < tab.n_jobs; ++k) tab.job[k].wg_begin = k < tab.n_bundle ? -1 : tab.job[k].wg_begin - shift;
-    n_wg -= shift;
-    { ProfScope _ps(K_WGRAD_BUNDLE, st); hipLaunchKernelGGL(wgrad_bundle_kernel, dim3((unsigned)n_bundle_wg), dim3(256), 0, st, tab); }
-    rc = check_launch("wgrad_bundle_kernel");
-    if (rc) return rc;
-  }
   if (n_wg > 0) {
     { ProfScope _ps(K_WGRAD_TN, st); hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, tab); }
     rc = check_launch("wgrad_tn_kernel");
@@ -757,8 +679,6 @@ int WgradBatch::finish() {
   }
   { ProfScope _ps(K_WGRAD_REDUCE, st); hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tab.n_jobs, (unsigned)max_nb, IMG / H + 1), dim3(512), 0, st, tab); }
   tab.n_jobs = 0;   // the batch may be refilled: slabs and workgroup ranges start over
-  tab.n_bundle = 0;
-  n_bundle_wg = 0;
   n_wg = 0;
   n_slab = slab_base;
   slab_top = slab_base + slab_cap;

@@ -1,6 +1,6 @@
-// B4 (virtual stage backward) for 1 <= C <= 64 (32 until round 4) without the FastRF / EGNN wirings: the adjoint of
-// edge_mode_virtual / coord_model_vel (virtual part) / coord_model_virtual / node_model
-// (models/FastEGNN.py:111-119,136-166) as three kernels.  Math: oracle/factored.py (virt_bwd).
+// B4 (virtual stage backward) for 1 <= C <= 64, and since round 4 the FastRF / EGNN wirings too (the round-2 single-kernel
+// form and its wgrad bundle are gone): the adjoint of edge_mode_virtual / coord_model_vel (virtual part) /
+// coord_model_virtual / node_model (models/FastEGNN.py:111-119,136-166) as three kernels.  Math: oracle/factored.py (virt_bwd).
 //
 //   virt_bwd_node_kernel  node_mlp adjoint of every node: g_np, g_h (partial), g_aggm, the node-level weight-gradient
 //                         operands, the per-node scalars of the coordinate update.
@@ -14,7 +14,7 @@
 //                         coord_mlp_v_virtual.0, edge_mlp_virtual.2 -- are contracted INSIDE the workgroup by two consumer
 //                         waves fed through LDS rings (as in edge_bwd_pc_kernel); only `v` still goes to HBM, for the
 //                         per-channel node_mlp.0 blocks.  Round 2 stored five [C][N][64] operand arrays here (2.05 GB
-//                         per cfg4 launch) and read them back in wgrad_bundle_kernel.
+//                         per cfg4 launch) and read them back in a bundled weight-gradient kernel.
 #include <cstdlib>
 #include "stages.h"
 
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(64 * VB_NODE_WAVES) void virt_bwd_node_kernel(VirtN
   constexpr int SM = BF ? GM_BF16 : GM_X3;   // split images: bf16x3 products (or one bf16 product of the rounded operand)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned *img = reinterpret_cast<unsigned *>(lds);
-  load_images_x3(img, wpack_x3(a.wpack, a.C, I_W3AT), 3);   // W3AT, W3BT, W4T (consecutive ids)
+  const bool rf = a.flags & FASTEGNN_F_RF;   // FastRF.py:186: no node_model, the node features pass through
+  if (!rf) load_images_x3(img, wpack_x3(a.wpack, a.C, I_W3AT), 3);   // W3AT, W3BT, W4T (consecutive ids)
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4;
   const int wave = global_wave_id(), nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -73,21 +74,28 @@ __global__ __launch_bounds__(64 * VB_NODE_WAVES) void virt_bwd_node_kernel(VirtN
     const bool valid = n < a.N;
     const int nc = valid ? n : a.N - 1;
     const Vec g_out = vb_mask(vload_row(a.g_h_out + (size_t)nc * H, q), valid);
-    const Vec npre = vload_row(a.npre + (size_t)nc * H, q);
-    Vec g_t3 = vzero();
-    gemm_op<SM>(img, 2, make_operand<SM>(g_out), g_t3);
-    const Vec g_np = vb_dsilu_mul(g_t3, npre FE_ACT(a));
-    if (valid) {
-      vstore_row(a.wg_t3 + (size_t)n * H, q, vsilu(npre FE_ACT(a)));
-      vstore_row(a.wg_gnp + (size_t)n * H, q, g_np);
+    if (rf) {
+      if (valid) {
+        vstore_row(a.g_h + (size_t)n * H, q, g_out);
+        vstore_row(a.g_aggm + (size_t)n * H, q, vzero());   // the segment-mean message feeds nothing
+      }
+    } else {
+      const Vec npre = vload_row(a.npre + (size_t)nc * H, q);
+      Vec g_t3 = vzero();
+      gemm_op<SM>(img, 2, make_operand<SM>(g_out), g_t3);
+      const Vec g_np = vb_dsilu_mul(g_t3, npre FE_ACT(a));
+      if (valid) {
+        vstore_row(a.wg_t3 + (size_t)n * H, q, vsilu(npre FE_ACT(a)));
+        vstore_row(a.wg_gnp + (size_t)n * H, q, g_np);
+      }
+      const typename OperandOf<SM>::type gop = make_operand<SM>(g_np);   // shared by the two products
+      Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
+      gemm_op<SM>(img, 0, gop, g_h);
+      if (valid) vstore_row(a.g_h + (size_t)n * H, q, g_h);
+      Vec g_am = vzero();
+      gemm_op<SM>(img, 1, gop, g_am);
+      if (valid) vstore_row(a.g_aggm + (size_t)n * H, q, g_am);
     }
-    const typename OperandOf<SM>::type gop = make_operand<SM>(g_np);   // shared by the two products
-    Vec g_h = (a.flags & FASTEGNN_F_RESIDUAL) ? g_out : vzero();
-    gemm_op<SM>(img, 0, gop, g_h);
-    if (valid) vstore_row(a.g_h + (size_t)n * H, q, g_h);
-    Vec g_am = vzero();
-    gemm_op<SM>(img, 1, gop, g_am);
-    if (valid) vstore_row(a.g_aggm + (size_t)n * H, q, g_am);
     if (valid && q == 0) {
       float sv = 0.f, sg = 0.f;
 #pragma unroll
@@ -598,7 +606,10 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
           g_v0 = vscale(g_v, att);
           vaxpy(g_v0, g_z, vload_vec(vec + VV_ATT * H, q));
         }
-        Vec g_t = vzero(), ga = vzero();
+        Vec g_t = vzero();
+#ifdef VB_GA_MEM
+        Vec ga = vzero();
+#endif
         {
           const Vec g_vp = vmul(g_v0, vp);
 #ifndef VB_DIAG_NOPUB
@@ -728,48 +739,25 @@ __global__ __launch_bounds__(256) void virt_bwd_combine_kernel(float *g_A, float
   }
 }
 
-bool virt_backward_uses_pc(const fastegnn_layer_t *L) {
-  static const bool off = getenv("FASTEGNN_VIRT_BWD_OLD") && atoi(getenv("FASTEGNN_VIRT_BWD_OLD")) != 0;
-  return !off && L->C >= 1 && L->C <= 64 && !has(L, FASTEGNN_F_RF) && !has(L, FASTEGNN_F_EGNN);
-}
 // floats of wg_virt: Gv, overwritten row by row with v ([C][N + pad][64]) | parts of g_A and g_x | consumer scratch
 size_t virt_pc_wg_floats(size_t N, size_t C) {
   const size_t NGF = (C + VB_GF - 1) / VB_GF;
   return (N + WGV_PAD) * C * H + (size_t)256 * VB_FINE_TILES * (NGF - 1) * 16 * (H + 4) + (size_t)256 * 3 * IMG;
 }
 
-int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
-  FE_REQUIRE(L->h && L->A && L->x && L->vel && L->aggm && L->npre && L->batch && L->wpack, "virt_backward: null saved buffer");
-  FE_REQUIRE(L->g_h_out && L->g_x_out && L->g_h && L->g_x && L->g_A && L->g_aggm && L->g_aggx && L->g_svel && L->wg_node &&
-                 L->grads && L->wg_slab,
-             "virt_backward: null gradient buffer");
-  FE_REQUIRE(L->Bc && L->Z && L->g_poolV && L->g_poolX && L->g_Bc && L->g_Zp && L->wg_virt, "virt_backward: virtual buffers null");
-  const int N = L->N, C = L->C;
-  (void)hipMemsetAsync(L->g_Bc, 0, (size_t)L->B * C * H * sizeof(float), st);
-  (void)hipMemsetAsync(L->g_Zp, 0, (size_t)L->B * 3 * C * sizeof(float), st);
-  if (N == 0) return check_launch("virt_backward(memset)");
-  const bool bf = has(L, FASTEGNN_F_BF16), att = has(L, FASTEGNN_F_ATTENTION);
+// B4b + B4c: the (node, channel) part -- Gv, then the producer / consumer kernel and its weight gradients
+static int virt_backward_channels(const fastegnn_layer_t *L, hipStream_t st, float *wg_gnp) {
+  const int N = L->N, C = L->C, ntiles = cdiv(N, 16);
+  const bool bf = has(L, FASTEGNN_F_BF16), att = has(L, FASTEGNN_F_ATTENTION), rf = has(L, FASTEGNN_F_RF);
   float *const *g = L->grads;
-  FE_REQUIRE(!att || (g[FASTEGNN_P_ATTV_W] && g[FASTEGNN_P_ATTV_B]), "virt_backward: attention grads null");
-  FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
   const size_t cstride = ((size_t)N + WGV_PAD) * H;
   float *wg_v = L->wg_virt, *Gv = L->wg_virt;   // one array: virt_bwd_gv writes Gv, virt_bwd_pc replaces each row by v
   const int NGF = (C + VB_GF - 1) / VB_GF;
   float *gA_part = Gv + cstride * C, *gx_part = gA_part + (size_t)256 * VB_FINE_TILES * (NGF - 1) * 16 * H;
-  float *wg_t3 = L->wg_node, *wg_gnp = L->wg_node + (size_t)N * H;
-  const int ntiles = cdiv(N, 16);
   int rc;
-  {   // B4a
-    VirtNodeArgs a{L->g_h_out, L->npre, L->g_x_out, L->vel, L->aggx, L->wpack, wg_t3, wg_gnp, L->g_h, L->g_aggm, L->g_aggx,
-                   L->g_svel, L->g_sgrav, N, L->flags, C, {L->gravity[0], L->gravity[1], L->gravity[2]}, L->act_param};
-    int grid = cdiv(ntiles, VB_NODE_WAVES);
-    if (grid > 256) grid = 256;
-    ProfScope ps(K_VIRT_BWD_NODE, st);
-    if (bf) hipLaunchKernelGGL((virt_bwd_node_kernel<true>), dim3(grid), dim3(64 * VB_NODE_WAVES), 3 * IMG3 * sizeof(float), st, a);
-    else hipLaunchKernelGGL((virt_bwd_node_kernel<false>), dim3(grid), dim3(64 * VB_NODE_WAVES), 3 * IMG3 * sizeof(float), st, a);
-  }
-  if ((rc = check_launch("virt_bwd_node_kernel"))) return rc;
-  {   // B4b
+  if (rf) {   // FastRF: no node_model and no pooled messages -- d/dv is the recomputed heads' part alone
+    (void)hipMemsetAsync(Gv, 0, cstride * C * sizeof(float), st);
+  } else {
     const int ngroups = cdiv(C, VB_GV_CH);
     int nranges = 256 / ngroups;
     const int max_ranges = cdiv(ntiles, VB_GV_WAVES);   // at least one tile per wave where possible
@@ -824,13 +812,61 @@ int virt_backward_pc(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shar
     hipLaunchKernelGGL(virt_bwd_combine_kernel, dim3(grid * VB_FINE_TILES), dim3(256), 0, st, L->g_A, L->g_x, gA_part, gx_part, N, NGF - 1, grid);
     if ((rc = check_launch("virt_bwd_combine_kernel"))) return rc;
   }
-  const int ld_n0 = 2 * H + H * C + L->na;
   // node_mlp.0 block of channel c: (g_np, v[:, c]) -- one batch slice per channel
-  if ((rc = bb.add(wg_gnp, H, wg_v, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, (long)cstride, 1))) return rc;
-  if ((rc = bb.finish())) return rc;
+  if (!rf) {
+    const int ld_n0 = 2 * H + H * C + L->na;
+    if ((rc = bb.add(wg_gnp, H, wg_v, H, N, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, nullptr, C, 0, (long)cstride, 1))) return rc;
+  }
+  return bb.finish();
+}
+
+// One form for the three wirings: FastEGNN; FastRF (FASTEGNN_F_RF: no node_model -- B4a passes g_h through, Gv = 0, no
+// node_mlp jobs); the EGNN baseline (FASTEGNN_F_EGNN, C = 0: B4a and the node_mlp jobs only).
+int virt_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared) {
+  const bool egnn = has(L, FASTEGNN_F_EGNN), rf = has(L, FASTEGNN_F_RF);
+  FE_REQUIRE(L->h && L->A && L->x && L->vel && L->aggm && L->npre && L->batch && L->wpack && (!egnn || L->aggx),
+             "virt_backward: null saved buffer");
+  FE_REQUIRE(L->g_h_out && L->g_x_out && L->g_h && L->g_x && L->g_A && L->g_aggm && L->g_aggx && L->g_svel && L->wg_node &&
+                 L->grads && L->wg_slab,
+             "virt_backward: null gradient buffer");
+  FE_REQUIRE(egnn ? L->C == 0
+                  : (L->Bc && L->Z && (rf || L->g_poolV) && L->g_poolX && L->g_Bc && L->g_Zp && L->wg_virt && L->C >= 1 && L->C <= 64),
+             "virt_backward: virtual buffers null or virtual_channels outside [1,64] (0 with FASTEGNN_F_EGNN)");
+  const int N = L->N, C = L->C;
+  if (C > 0) {
+    (void)hipMemsetAsync(L->g_Bc, 0, (size_t)L->B * C * H * sizeof(float), st);
+    (void)hipMemsetAsync(L->g_Zp, 0, (size_t)L->B * 3 * C * sizeof(float), st);
+  }
+  if (N == 0) return check_launch("virt_backward(memset)");
+  const bool bf = has(L, FASTEGNN_F_BF16);
+  float *const *g = L->grads;
+  FE_REQUIRE(!has(L, FASTEGNN_F_ATTENTION) || C == 0 || (g[FASTEGNN_P_ATTV_W] && g[FASTEGNN_P_ATTV_B]), "virt_backward: attention grads null");
+  FE_REQUIRE(!has(L, FASTEGNN_F_GRAVITY) || L->g_sgrav, "virt_backward: g_sgrav null");
+  float *wg_t3 = L->wg_node, *wg_gnp = L->wg_node + (size_t)N * H;
+  const int ntiles = cdiv(N, 16);
+  int rc;
+  {   // B4a
+    VirtNodeArgs a{L->g_h_out, L->npre, L->g_x_out, L->vel, L->aggx, L->wpack, wg_t3, wg_gnp, L->g_h, L->g_aggm, L->g_aggx,
+                   L->g_svel, L->g_sgrav, N, L->flags, C, {L->gravity[0], L->gravity[1], L->gravity[2]}, L->act_param};
+    int grid = cdiv(ntiles, VB_NODE_WAVES);
+    if (grid > 256) grid = 256;
+    ProfScope ps(K_VIRT_BWD_NODE, st);
+    if (bf) hipLaunchKernelGGL((virt_bwd_node_kernel<true>), dim3(grid), dim3(64 * VB_NODE_WAVES), 3 * IMG3 * sizeof(float), st, a);
+    else hipLaunchKernelGGL((virt_bwd_node_kernel<false>), dim3(grid), dim3(64 * VB_NODE_WAVES), 3 * IMG3 * sizeof(float), st, a);
+  }
+  if ((rc = check_launch("virt_bwd_node_kernel"))) return rc;
+  if (C == 0) {   // no virtual nodes: the coordinate gradient passes through, nothing reaches A
+    (void)hipMemcpyAsync(L->g_x, L->g_x_out, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemsetAsync(L->g_A, 0, (size_t)N * H * sizeof(float), st);
+    if ((rc = check_launch("virt_backward(C = 0)"))) return rc;
+  } else if ((rc = virt_backward_channels(L, st, wg_gnp))) {
+    return rc;
+  }
+  if (rf) return FASTEGNN_OK;   // no node_mlp
   WgradBatch local(L->wg_slab, st);
   WgradBatch &wb = shared ? *shared : local;
   wb.round = bf;
+  const int ld_n0 = 2 * H + H * C + L->na;
   // node_mlp.2
   if ((rc = wb.add(L->g_h_out, H, wg_t3, H, N, g[FASTEGNN_P_NODE2_W], H, 0, 1, g[FASTEGNN_P_NODE2_B]))) return rc;
   // node_mlp.0: [h | agg | flat(v) | node_attr]
