@@ -253,10 +253,10 @@ size_t fastegnn_wg_slab_floats(void);
 size_t fastegnn_wg_edge_floats(int32_t E);
 size_t fastegnn_wg_virt_floats(int32_t N, int32_t C);
 size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C);
-/* wg_virt for a layer with these FASTEGNN_F_* flags: the FastEGNN wiring contracts three of the virtual
- * stage's weight gradients inside the workgroup and keeps ONE [C][N+16][64] array plus constant-size part tiles and
- * consumer scratch (~36 MB at C = 16) instead of five arrays; the flag-less query above returns the maximum over both
- * forms, i.e. an upper bound for every wiring and every N (on small shards the constant terms dominate) */
+/* wg_virt: three of the virtual stage's weight gradients are contracted inside the workgroup, so the workspace is ONE
+ * [C][N+16][64] array plus constant-size part tiles and consumer scratch (~36 MB at C = 16; 4 floats at C = 0).  Until
+ * round 4 the FastRF / EGNN wirings kept five arrays and the size depended on the flags; every wiring has the one form
+ * now and the _for variant (kept for ABI stability) ignores `flags`. */
 size_t fastegnn_wg_virt_floats_for(int32_t N, int32_t C, int32_t flags);
 /* floats of all backward scratch arrays of fastegnn_layer_t together (g_poolV ... wg_slab), each array rounded up to
  * a multiple of 4 floats so that one allocation can be carved into 16-byte aligned pieces */
