@@ -168,12 +168,44 @@ __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *ve
   vadd(pre, G.qv);
   // EGNN(norm=True): F.normalize of the 1x1 Gram (basic.py:271-272, eps 1e-12)
   S.rf = (a.flags & FASTEGNN_F_EGNN_NORM) ? (S.r >= 1e-12f ? 1.0f : S.r * 1e12f) : S.r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) S.eav[k] = I.eav[k];
+#ifdef FE_EDGE_PRE_VALU   // rounds 1-3: one vector fma per element and scalar feature
   vaxpy(pre, S.rf, vload_vec(vec + EV_WR * H, q));
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    S.eav[k] = I.eav[k];
+  for (int k = 0; k < 8; ++k)
     if (k < a.ea_dim) vaxpy(pre, S.eav[k], vload_vec(vec + (EV_WE + k) * H, q));
+#else
+  // The rank-(1 + ea_dim) update pre[o][e] += sum_k Wf[o][k] * feat[k][e], feat = (radial | edge_attr), on the matrix pipe:
+  // K = 4 features per v_mfma_f32_16x16x4_f32 (fp32 products, as the vector form).  Lane (q, j) supplies Wf[16t + j][4s + q]
+  // as the A operand of block t (rows 4s + q of `vec`: EV_WR = 0, EV_WE + k = 1 + k; rows past the last feature are zero)
+  // and feature 4s + q of its own edge as B; `pre` is the accumulator.  48 vector fmas and 12 LDS reads of a 16-edge tile
+  // at edge_attr_nf = 2 become 3 selects, 4 LDS words and 4 MFMAs on a pipe that is a quarter busy.
+  static_assert(EV_WR == 0 && EV_WE == 1, "feature rows of vec");
+  {
+    const int j = lane_id() & 15;
+    // (selects of VALUES: a conditional expression over the struct's members is an lvalue, and the select of addresses it
+    // becomes keeps the whole EdgeFwdState in scratch memory)
+    const float r_ = S.rf, e0 = I.eav[0], e1 = I.eav[1], e2 = I.eav[2];
+    float f0 = e2;
+    f0 = q == 2 ? e1 : f0;
+    f0 = q == 1 ? e0 : f0;
+    f0 = q == 0 ? r_ : f0;
+    const float *w0 = vec + q * H + j;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) pre.t[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[16 * t], f0, pre.t[t], 0, 0, 0);
+    if (a.ea_dim > 3) {   // wave-uniform
+      const float e3 = I.eav[3], e4 = I.eav[4], e5 = I.eav[5], e6 = I.eav[6];
+      float f1 = e6;
+      f1 = q == 2 ? e5 : f1;
+      f1 = q == 1 ? e4 : f1;
+      f1 = q == 0 ? e3 : f1;
+      const float *w1 = w0 + 4 * H;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pre.t[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[16 * t], f1, pre.t[t], 0, 0, 0);
+    }
   }
+#endif
   FE_T(1)   // gathered rows arrived, pre-activation formed
 }
 // part 2: the two 64x64 layers and the coordinate head
@@ -288,10 +320,25 @@ __device__ __forceinline__ void virt_tile_forward(const VirtArgs &a, const void 
     S.vd[2] = Zb[2 * C + c] - xi[2];
   }
   S.vr = sqrt_f(S.vd[0] * S.vd[0] + S.vd[1] * S.vd[1] + S.vd[2] * S.vd[2]);
-  S.pre = Ai;
-  if (BcL) vadd(S.pre, vload_vec(BcL + c * H, q));
-  else vadd(S.pre, vload_row(a.Bc + ((size_t)b * C + c) * H, q));
-  vaxpy(S.pre, S.vr, vload_vec(vec + VV_WVR * H, q));
+#ifdef FE_VIRT_PRE_MFMA   // measured lever, rejected (round 4: virt_fwd 1.336 -> 1.341 ms per step, tools/gpu_lever_virt_pre_mfma.sh)
+  if (BcL) {
+    // pre = A[n] + Bc[c] + vr * w_vr as ONE rank-2 update on the matrix pipe (as edge_tile_pre): features (vr, 1) of the
+    // node against the columns (w_vr | Bc[c]); lanes q = 0 supply w_vr and vr, lanes q = 1 Bc[c] and 1, the others a zero
+    // feature.  16 adds + 16 fmas + 8 LDS reads per (tile, channel) become 4 MFMAs + 4 LDS words -- and nothing is gained:
+    // this kernel runs two waves per SIMD with its matrix pipe twice as busy as edge_fwd's.
+    const int j = lane_id() & 15;
+    const float *wsrc = (q == 0 ? vec + VV_WVR * H : BcL + c * H) + j;
+    const float f = q == 0 ? S.vr : (q == 1 ? 1.f : 0.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) S.pre.t[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wsrc[16 * t], f, Ai.t[t], 0, 0, 0);
+  } else
+#endif
+  {
+    S.pre = Ai;
+    if (BcL) vadd(S.pre, vload_vec(BcL + c * H, q));
+    else vadd(S.pre, vload_row(a.Bc + ((size_t)b * C + c) * H, q));
+    vaxpy(S.pre, S.vr, vload_vec(vec + VV_WVR * H, q));
+  }
   S.t = vsilu(S.pre FE_ACT(a));
   VF_T(1)   // geometry, pre-activation, silu 1
   S.vp = vload_vec(vec + VV_C2 * H, q);
