@@ -9,7 +9,7 @@ backend; a single-process world needs no process group at all)."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional
+from typing import List
 
 import torch
 import torch.distributed as dist

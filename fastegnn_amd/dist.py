@@ -10,7 +10,7 @@ C entry points (include/fastegnn_hip.h).
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional, Tuple
+from typing import Iterable, Optional, Tuple
 
 import torch
 import torch.distributed as dist

@@ -4,7 +4,7 @@ the host (``datasets/simulation/dataset.py:80,96-101``) -- ``radius_graph(r)`` w
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 

@@ -307,7 +307,7 @@ class _PadParams(torch.autograd.Function):
     def _table(layouts, narrow, wide):
         tab = (K.PadDesc * len(layouts))()
         for d, lay, a, b in zip(tab, layouts, narrow, wide):
-            rows, cols, rows_dst, blocks, out_shape = lay[:5]
+            rows, cols, rows_dst, blocks = lay[:4]
             d.lead = lay[5] if len(lay) > 5 else 0
             d.src, d.dst = a.data_ptr(), b.data_ptr()
             d.rows, d.cols, d.rows_dst = rows, cols, rows_dst

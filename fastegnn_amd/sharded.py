@@ -38,7 +38,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.distributed as dist
@@ -648,7 +648,6 @@ class _ShardedFunction(torch.autograd.Function):
                 ea_p = ea_p[pt.mask[0]:pt.mask[1]]
             pt.ea_sorted = pt.graph.permute(ea_p)
         node_attr = node_attr.detach().contiguous().float() if node_attr is not None else None
-        W, rank = plan.world, plan.rank
         N, B, Cn = plan.nloc, loc_mean.size(0), spec.C
         params = [p.detach() for p in params]
         node_feat, node_loc, node_vel, loc_mean = (t.detach().contiguous().float()
@@ -727,7 +726,7 @@ class _ShardedFunction(torch.autograd.Function):
         be, spec, plan, parts, saved = ctx.be, ctx.spec, ctx.plan, ctx.parts, ctx.saved
         comm = ctx.comm
         batch32, gptr, node_attr, node_feat, node_vel, params = ctx.misc
-        W, rank = plan.world, plan.rank
+        rank = plan.rank
         N, B, Cn = plan.nloc, saved[0]["Z"].size(0), spec.C
         g0 = parts[0].graph
         E_max = max(pt.graph.E for pt in parts)
