@@ -230,8 +230,10 @@ def profile_collect():
 
 def check(rc: int, what: str):
     if rc != 0:
-        msg = lib().fastegnn_last_error()
-        raise RuntimeError(f"fastegnn_amd: {what} failed (code {rc}): {msg.decode() if msg else '?'}")
+        # every loaded build keeps its own last-error string (the generic-activation library is a second shared object)
+        msgs = [f"[{os.path.basename(path)}] {m.decode()}" for path, m in
+                ((path, L.fastegnn_last_error()) for path, L in _libs.items()) if m]
+        raise RuntimeError(f"fastegnn_amd: {what} failed (code {rc}): {' | '.join(msgs) if msgs else '?'}")
 
 
 def ptr(t):

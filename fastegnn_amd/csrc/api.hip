@@ -66,8 +66,8 @@ static int check_layer(const fastegnn_layer_t *L, const char *who) {
       set_error(std::string(who) + ": unknown activation kind in the flags");
       return FASTEGNN_E_INVALID;
     }
-    if ((L->flags & (FASTEGNN_F_BF16 | FASTEGNN_F_EGNN)) && act != FASTEGNN_ACT_SILU) {
-      set_error(std::string(who) + ": activations other than SiLU are not combined with the bf16 operand mode / the EGNN wiring");
+    if ((L->flags & FASTEGNN_F_BF16) && act != FASTEGNN_ACT_SILU) {
+      set_error(std::string(who) + ": activations other than SiLU are not combined with the bf16 operand mode");
       return FASTEGNN_E_INVALID;
     }
 #else

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import _lib as K
-from .model import SortedGraph, _PadParams, _PtrTable, _carve, _fill, _new_layer, _stream
+from .model import SortedGraph, _PadParams, _PtrTable, _activation_kind, _carve, _fill, _new_layer, _stream
 
 H = K.H
 
@@ -76,7 +76,7 @@ def _egnn_pad_layout(name: str, shape, h: int):
 class _EGNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, graph, edge_fea, x, h_in, v, *params):
-        lib = K.lib()
+        lib = K.lib(act=spec.act_kind != K.ACT_SILU)
         # edge_fea is a differentiable input (basic.py:313 concatenates it into the message MLP's input): its gradient is
         # accumulated by the edge backward kernel in sorted-edge order when asked for
         ea_sorted = graph.permute(edge_fea.detach() if edge_fea is not None else None)
@@ -113,8 +113,8 @@ class _EGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_x, g_h):
-        lib = K.lib()
         spec, graph, saved = ctx.spec, ctx.graph, ctx.saved
+        lib = K.lib(act=spec.act_kind != K.ACT_SILU)
         batch, ea_sorted, h_in, v, params = ctx.misc
         dev = v.device
         st = _stream(dev)
@@ -168,9 +168,14 @@ class EGNN(nn.Module):
     def __init__(self, n_layers, in_node_nf, in_edge_nf, hidden_nf, activation=nn.SiLU(), device='cpu', with_v=False,
                  flat=False, norm=False):
         super().__init__()
-        if not 1 <= hidden_nf <= H or flat or not isinstance(activation, nn.SiLU):
-            raise NotImplementedError("fastegnn_amd.EGNN: hidden_nf<=64 (narrower runs zero-padded), SiLU, flat=False only "
+        if not 1 <= hidden_nf <= H or flat:
+            raise NotImplementedError("fastegnn_amd.EGNN: hidden_nf<=64 (narrower runs zero-padded), flat=False only "
                                       "(flat=True means 256-wide Tanh MLPs)")
+        # `activation` (basic.py:324; BaseMLP puts it behind every first layer and behind the message MLP, :181-192): the same
+        # kinds as FastEGNN's act_fn, on the generic-activation build of the library when it is not SiLU
+        self._act = _activation_kind(activation)
+        if self._act[0] in (K.ACT_SIGMOID, K.ACT_SOFTPLUS) and hidden_nf < H:
+            raise NotImplementedError("fastegnn_amd.EGNN: hidden_nf < 64 runs zero-padded, which needs activation(0) = 0")
         self.hidden_nf = hidden_nf
         self.norm = bool(norm)
         if in_edge_nf > 7 or in_node_nf > 8:
@@ -202,8 +207,9 @@ class EGNN(nn.Module):
             layer_slots.append(slots)
         self._plist = [pidx[n] for n in names]
         self._spec = SimpleNamespace(C=0, ea=self.in_edge_nf, na=0, nf=self.in_node_nf, n_layers=self.n_layers,
-                                     flags=K.F_EGNN | (K.F_EGNN_NORM if self.norm else 0) | (K.F_DETERMINISTIC if self.deterministic else 0),
-                                     gravity=[0.0, 0.0, 0.0],
+                                     flags=K.F_EGNN | (K.F_EGNN_NORM if self.norm else 0) | (K.F_DETERMINISTIC if self.deterministic else 0)
+                                     | (self._act[0] << K.F_ACT_SHIFT),
+                                     act_kind=self._act[0], act_param=self._act[1], gravity=[0.0, 0.0, 0.0],
                                      layer_slots=layer_slots, names=names)
 
     def forward(self, x, h, edge_index, edge_fea, v=None):

@@ -100,3 +100,33 @@ def test_egnn_narrow_hidden_nf_vs_oracle(hidden):
         assert prm.grad is not None and prm.grad.shape == prm.shape, k
         grad_check("egnn_narrow", k, prm.grad, p[k].grad, p64[k].grad, bad)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("act,q", [("relu", 0.0), ("leaky_relu", 0.2), ("gelu", 0.0), ("tanh", 0.0)])
+def test_egnn_other_activation_vs_oracle(act, q):
+    """`activation` other than SiLU on the EGNN sibling (basic.py:324; BaseMLP :181-192 puts it behind every first layer and
+    behind the message MLP): the generic-activation library on the FASTEGNN_F_EGNN wiring, forward and every gradient."""
+    from oracle import fastegnn_ref as R
+    from tests.gpu_util import act_module
+    cfg = R.Config(2, 0, 2, 64, 0, act=act, act_param=q)
+    fn = R.act_of(cfg)
+    g = torch.Generator().manual_seed(17)
+    N, Ed = 1500, 18000
+    torch.manual_seed(8)
+    m = fastegnn_amd.EGNN(n_layers=2, in_node_nf=2, in_edge_nf=2, hidden_nf=64, activation=act_module(cfg), device="cuda", with_v=True)
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.named_parameters()}
+    x = torch.randn(N, 3, generator=g); h = torch.rand(N, 2, generator=g); v = torch.randn(N, 3, generator=g) * 0.2
+    ei = torch.randint(0, N, (2, Ed), generator=g); ea = torch.rand(Ed, 2, generator=g)
+    xo, _, ho = m(x=x.cuda(), h=h.cuda(), edge_index=ei.cuda(), edge_fea=ea.cuda(), v=v.cuda())
+    (xo.pow(2).mean() + ho.pow(2).mean()).backward()
+    xr, hr = E.forward(p, 2, x, h, ei, ea, v, act=fn)
+    (xr.pow(2).mean() + hr.pow(2).mean()).backward()
+    assert rel_err(xo, xr) < 1e-5 and rel_err(ho, hr) < 2e-5
+    dt = torch.float64
+    p64 = {k: t.detach().to(dt).clone().requires_grad_(True) for k, t in p.items()}
+    x64, h64 = E.forward(p64, 2, x.to(dt), h.to(dt), ei, ea.to(dt), v.to(dt), act=fn)
+    (x64.pow(2).mean() + h64.pow(2).mean()).backward()
+    bad = []
+    for k, prm in m.named_parameters():
+        grad_check(f"egnn_act_{act}", k, prm.grad, p[k].grad, p64[k].grad, bad)
+    assert not bad, bad
