@@ -15,7 +15,7 @@ FASTEGNN_COMM=abi FASTEGNN_SHARDED_SYNC=0 $B --emulate-world 8 --hipgraph on > $
 FASTEGNN_COMM=abi $B --emulate-world 8 --emulate-rank 3 --hipgraph on > $S/emu8_r3_sync.json 2>> $S/err.txt
 FASTEGNN_COMM=abi $B --emulate-world 8 --hipgraph off > $S/emu8_r0_sync_eager.json 2>> $S/err.txt
 FASTEGNN_COMM=abi python bench.py --config cfg5 --emulate-world 8 --steps 10 --warmup 2 --no-cpu-baseline > $S/cfg5_emu8_r0.json 2>> $S/err.txt
-python -m pytest tests -m gpu -q > gpurun_out/$tag/pytest_full.txt 2>&1; echo "exit $?" >> gpurun_out/$tag/pytest_full.txt
+if [ -z "$SKIP_SUITE" ]; then python -m pytest tests -m gpu -q > gpurun_out/$tag/pytest_full.txt 2>&1; echo "exit $?" >> gpurun_out/$tag/pytest_full.txt; fi
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("$S/*.json")):
@@ -24,4 +24,4 @@ for f in sorted(glob.glob("$S/*.json")):
         print(f"{f.split('/')[-1]:28s} ms/step {d['ms_per_step']:8.3f} eager {d.get('eager_ms_per_step')} launches {sum(v['launches_per_step'] for v in k.values()):.0f} kernel-sum {sum(v['ms_per_step'] for v in k.values()):.3f}")
     except Exception as e: print(f, "FAILED", e)
 PY
-grep -v "amdgpu.ids" gpurun_out/$tag/pytest_full.txt | tail -4 | cut -c1-300
+[ -z "$SKIP_SUITE" ] && grep -v "amdgpu.ids" gpurun_out/$tag/pytest_full.txt | tail -4 | cut -c1-300
