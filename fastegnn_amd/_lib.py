@@ -18,7 +18,7 @@ WIDE_RANGE = os.environ.get("FASTEGNN_WIDE_RANGE", "0") not in ("", "0")
 LIB_PATH = os.path.join(_HERE, "libfastegnn_hip_safe.so" if SAFE_WAITS else
                         ("libfastegnn_hip_x3.so" if WIDE_RANGE else "libfastegnn_hip.so"))
 
-ABI_VERSION = 103   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
+ABI_VERSION = 104   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
 H = 64
 QX_LD = 68
 FEATW = 8
@@ -177,6 +177,16 @@ def lib(act: bool = False):
     L.fastegnn_pack_weights_all.argtypes = [C.POINTER(C.POINTER(LayerT)), _i32, _vp]
     L.fastegnn_wgrad_batch_open.argtypes = [C.POINTER(LayerT), _vp, C.POINTER(_vp)]
     L.fastegnn_wgrad_batch_close.argtypes = [_vp]
+    _i64, _f = C.c_int64, C.c_float   # the wide path (include/fastegnn_hip.h "the WIDE path")
+    L.fastegnn_wide_linear.argtypes = [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]
+    L.fastegnn_wide_linear_dx.argtypes = [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]
+    L.fastegnn_wide_linear_dw.argtypes = [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp]
+    L.fastegnn_wide_act.argtypes = [_vp, _i64, _i32, _f, _vp, _vp]
+    L.fastegnn_wide_act_backward.argtypes = [_vp, _vp, _i64, _i32, _f, _vp, _vp]
+    L.fastegnn_wide_gather_add.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp, _vp]
+    L.fastegnn_wide_scatter_add.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp]
+    L.fastegnn_wide_rowscale.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp]
+    L.fastegnn_wide_rowdot.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp]
     L.fastegnn_sizeof_layer.restype = C.c_size_t
     L.fastegnn_sizeof_graph.restype = C.c_size_t
     if L.fastegnn_sizeof_layer() != C.sizeof(LayerT) or L.fastegnn_sizeof_graph() != C.sizeof(GraphT):
@@ -215,6 +225,8 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_comm_world", "fastegnn_comm_all_reduce", "fastegnn_comm_all_gather", "fastegnn_comm_reduce_scatter",
     "fastegnn_comm_all_to_all_v", "fastegnn_gather_rows", "fastegnn_scatter_add_rows",
     "fastegnn_wgrad_batch_open", "fastegnn_wgrad_batch_close", "fastegnn_pack_weights_all",
+    "fastegnn_wide_linear", "fastegnn_wide_linear_dx", "fastegnn_wide_linear_dw", "fastegnn_wide_act", "fastegnn_wide_act_backward",
+    "fastegnn_wide_gather_add", "fastegnn_wide_scatter_add", "fastegnn_wide_rowscale", "fastegnn_wide_rowdot",
 ]
 
 

@@ -524,14 +524,20 @@ class FastEGNN(nn.Module):
             raise ValueError("fastegnn_amd: mlp_dtype must be torch.float32 or torch.bfloat16")
         self.mlp_dtype = mlp_dtype
         assert virtual_channels > 0, f'Channels of virtual node must greater than 0 (got {virtual_channels})'
-        if not 1 <= hidden_nf <= H:   # (< 64 runs zero-padded on the 64-wide tiles, see _pad_param)
-            raise NotImplementedError(f"fastegnn_amd: hidden_nf must be at most {H} in this build (got {hidden_nf})")
+        # hidden_nf < 64 runs zero-padded on the 64-wide tiles (_pad_param); 64 < hidden_nf <= 256 takes the unfused WIDE path
+        # (fastegnn_amd/wide.py: the reference's op sequence on generic-width HIP operators; FastEGNN, fp32 only)
+        self._wide = hidden_nf > H
+        if not 1 <= hidden_nf <= 256:
+            raise NotImplementedError(f"fastegnn_amd: hidden_nf must be at most 256 in this build (got {hidden_nf})")
+        if self._wide and (mlp_dtype != torch.float32 or (self._extra_flags & (K.F_RF | K.F_EGNN))):
+            raise NotImplementedError("fastegnn_amd: hidden_nf > 64 (the unfused wide path) is built for FastEGNN with fp32 "
+                                      "operands only")
         self._act = _activation_kind(act_fn)
         if self._act[0] in (K.ACT_SIGMOID, K.ACT_SOFTPLUS) and hidden_nf < H:
             raise NotImplementedError("fastegnn_amd: hidden_nf < 64 runs zero-padded, which needs act_fn(0) = 0")
         if self._act[0] != K.ACT_SILU and mlp_dtype != torch.float32:
             raise NotImplementedError("fastegnn_amd: the bf16 operand mode is built for SiLU only")
-        if virtual_channels > 64 or edge_attr_nf > 7 or node_feat_nf > 8:
+        if not self._wide and (virtual_channels > 64 or edge_attr_nf > 7 or node_feat_nf > 8):   # (the wide path has no such limits)
             raise NotImplementedError("fastegnn_amd: supports virtual_channels<=64, edge_attr_nf<=7, node_feat_nf<=8")
         self.hidden_nf = hidden_nf
         self.device = device
@@ -601,6 +607,13 @@ class FastEGNN(nn.Module):
             raise ValueError("edge_attr width does not match edge_attr_nf")
         if (node_attr.size(1) if node_attr is not None else 0) != self.node_attr_nf:
             raise ValueError("node_attr width does not match node_attr_nf")
+        if self._wide:
+            from . import wide
+            if _DEBUG_CHECKS:
+                _check_indices(edge_index, data_batch, node_loc.size(0), loc_mean.size(0))
+            if edge_attr is not None and edge_attr.size(1) == 0:
+                edge_attr = None
+            return wide.forward(self, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr, node_attr)
         dev = node_loc.device
         N, B = node_loc.size(0), loc_mean.size(0)   # B from loc_mean: no .item() sync (cf. :267)
         if self._spec is None:

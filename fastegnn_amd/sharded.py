@@ -847,6 +847,8 @@ class ShardedFastEGNN(torch.nn.Module):
         byte counts of its halo, device copies in the place of the transfers -- timing of a shard's compute and fixed
         costs on one GPU; the ghost rows hold stand-in data, so the outputs mean nothing."""
         super().__init__()
+        if getattr(model, "_wide", False):
+            raise NotImplementedError("ShardedFastEGNN: hidden_nf > 64 (the unfused wide path) runs on one GPU only")
         self.exchange = exchange or os.environ.get("FASTEGNN_SHARDED_EXCHANGE", "halo")
         if self.exchange not in ("halo", "allgather"):
             raise ValueError("ShardedFastEGNN: exchange must be 'halo' or 'allgather'")

@@ -1,0 +1,258 @@
+"""The WIDE path: ``FastEGNN`` with ``64 < hidden_nf <= 256`` (the reference takes any ``--dim_hidden``:
+``main_nbody.py:27``, ``models/FastEGNN.py:28-99``).
+
+The fused stage kernels are built on 64-wide register tiles; a wider model runs UNFUSED: the op sequence of
+``models/FastEGNN.py:102-223`` (edge_model, edge_mode_virtual, coord_model_vel, coord_model_virtual, node_model,
+node_model_virtual), every hidden-sized tensor op of it one launch of ``csrc/wide.hip`` behind the C ABI
+(``fastegnn_wide_*`` in ``include/fastegnn_hip.h``): nn.Linear as ``fastegnn_wide_linear`` over the weight's column blocks (a
+Linear over a ``torch.cat`` is the sum of Linears over the pieces, so nothing is concatenated), the activations, the row
+gathers ``node_feat[row]`` / ``virtual_node_feat[data_batch]``, the segment sums, the gates.  The backward is composed by
+autograd from the matching ``_dx`` / ``_dw`` / ``_backward`` entry points.  What stays in torch is the 3-vector geometry
+(``[E,3]``, ``[N,3,C]``, ``[B,C,C]`` tensors) and views.  Correctness first (fp32 FMA GEMMs, fp32 atomics): this path is
+several times slower per FLOP than the fused one -- DESIGN.md section 9 -- and exists so that the constructor takes the
+reference's whole ``hidden_nf`` range.  No CPU fallback: the library is loaded on first use and its absence raises."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as K
+from .model import _stream
+
+MAX_WIDE = 256
+
+
+def _f32(t):
+    return t.contiguous().float()
+
+
+class _Linear(torch.autograd.Function):
+    """out = (base) + X . W[:, c0:c0+K]^T (+ bias)"""
+
+    @staticmethod
+    def forward(ctx, X, W, c0, Kc, bias, base):
+        X, W = _f32(X), W.contiguous()
+        M, O = X.size(0), W.size(0)
+        out = torch.empty(M, O, dtype=torch.float32, device=X.device)
+        b = _f32(bias) if bias is not None else None
+        bs = _f32(base) if base is not None else None
+        K.check(K.lib().fastegnn_wide_linear(K.ptr(X), M, Kc, K.ptr(W), W.size(1), c0, K.ptr(b), K.ptr(bs), K.ptr(out), O,
+                                             _stream(X.device)), "fastegnn_wide_linear")
+        ctx.save_for_backward(X, W)
+        ctx.meta = (c0, Kc, bias is not None, base is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, W = ctx.saved_tensors
+        c0, Kc, has_bias, has_base = ctx.meta
+        g = _f32(g)
+        M, O = g.shape
+        lib, st = K.lib(), _stream(g.device)
+        gX = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gX = torch.empty(M, Kc, dtype=torch.float32, device=g.device)
+            K.check(lib.fastegnn_wide_linear_dx(K.ptr(g), M, O, K.ptr(W), W.size(1), c0, Kc, K.ptr(gX), 0, st), "fastegnn_wide_linear_dx")
+        want_w, want_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[4]
+        if want_w or want_b:
+            gW = torch.zeros_like(W) if want_w else None
+            gb = torch.zeros(O, dtype=torch.float32, device=g.device) if want_b else None
+            K.check(lib.fastegnn_wide_linear_dw(K.ptr(g), K.ptr(X), M, O, Kc, K.ptr(gW), W.size(1), c0, K.ptr(gb), st),
+                    "fastegnn_wide_linear_dw")
+        return gX, gW, None, None, gb, (g if has_base else None)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, kind, p):
+        z = _f32(z)
+        y = torch.empty_like(z)
+        K.check(K.lib().fastegnn_wide_act(K.ptr(z), z.numel(), kind, p, K.ptr(y), _stream(z.device)), "fastegnn_wide_act")
+        ctx.save_for_backward(z)
+        ctx.meta = (kind, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        g = _f32(g)
+        dz = torch.empty_like(z)
+        K.check(K.lib().fastegnn_wide_act_backward(K.ptr(z), K.ptr(g), z.numel(), ctx.meta[0], ctx.meta[1], K.ptr(dz),
+                                                   _stream(z.device)), "fastegnn_wide_act_backward")
+        return dz, None, None
+
+
+class _GatherAdd(torch.autograd.Function):
+    """out[m] = (base[m]) + X[idx[m]]"""
+
+    @staticmethod
+    def forward(ctx, X, idx, base):
+        X = _f32(X)
+        M, W = idx.numel(), X.size(1)
+        out = torch.empty(M, W, dtype=torch.float32, device=X.device)
+        bs = _f32(base) if base is not None else None
+        K.check(K.lib().fastegnn_wide_gather_add(K.ptr(X), K.ptr(idx), M, W, K.ptr(bs), K.ptr(out), _stream(X.device)),
+                "fastegnn_wide_gather_add")
+        ctx.save_for_backward(idx)
+        ctx.meta = (X.size(0), base is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = _f32(g)
+        gX = None
+        if ctx.needs_input_grad[0]:
+            gX = torch.zeros(ctx.meta[0], g.size(1), dtype=torch.float32, device=g.device)
+            K.check(K.lib().fastegnn_wide_scatter_add(K.ptr(gX), K.ptr(idx), idx.numel(), g.size(1), K.ptr(g), _stream(g.device)),
+                    "fastegnn_wide_scatter_add")
+        return gX, None, (g if ctx.meta[1] else None)
+
+
+class _ScatterAdd(torch.autograd.Function):
+    """table[idx[m]] += rows[m] into a zeroed [R, W] table"""
+
+    @staticmethod
+    def forward(ctx, rows, idx, R):
+        rows = _f32(rows)
+        table = torch.zeros(R, rows.size(1), dtype=torch.float32, device=rows.device)
+        K.check(K.lib().fastegnn_wide_scatter_add(K.ptr(table), K.ptr(idx), idx.numel(), rows.size(1), K.ptr(rows),
+                                                  _stream(rows.device)), "fastegnn_wide_scatter_add")
+        ctx.save_for_backward(idx)
+        return table
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = _f32(g)
+        out = torch.empty(idx.numel(), g.size(1), dtype=torch.float32, device=g.device)
+        K.check(K.lib().fastegnn_wide_gather_add(K.ptr(g), K.ptr(idx), idx.numel(), g.size(1), None, K.ptr(out), _stream(g.device)),
+                "fastegnn_wide_gather_add")
+        return out, None, None
+
+
+class _RowScale(torch.autograd.Function):
+    """Y[m, :] = X[m, :] * s[m]"""
+
+    @staticmethod
+    def forward(ctx, X, s):
+        X, s = _f32(X), _f32(s)
+        Y = torch.empty_like(X)
+        K.check(K.lib().fastegnn_wide_rowscale(K.ptr(X), K.ptr(s), X.size(0), X.size(1), K.ptr(Y), _stream(X.device)),
+                "fastegnn_wide_rowscale")
+        ctx.save_for_backward(X, s)
+        return Y
+
+    @staticmethod
+    def backward(ctx, g):
+        X, s = ctx.saved_tensors
+        g = _f32(g)
+        lib, st = K.lib(), _stream(g.device)
+        gX = gs = None
+        if ctx.needs_input_grad[0]:
+            gX = torch.empty_like(X)
+            K.check(lib.fastegnn_wide_rowscale(K.ptr(g), K.ptr(s), X.size(0), X.size(1), K.ptr(gX), st), "fastegnn_wide_rowscale")
+        if ctx.needs_input_grad[1]:
+            gs = torch.empty(X.size(0), dtype=torch.float32, device=g.device)
+            K.check(lib.fastegnn_wide_rowdot(K.ptr(g), K.ptr(X), X.size(0), X.size(1), K.ptr(gs), st), "fastegnn_wide_rowdot")
+        return gX, gs
+
+
+def _rowscale(X, s):
+    return _RowScale.apply(X, s.reshape(-1))
+
+
+def _lin(X, W, c0=0, Kc=None, bias=None, base=None):
+    return _Linear.apply(X, W, c0, W.size(1) - c0 if Kc is None else Kc, bias, base)
+
+
+def _small_segment_sum(t, idx, R):
+    """[M, small] rows summed by idx (3-vector geometry: torch)"""
+    return torch.zeros(R, t.size(1), dtype=t.dtype, device=t.device).index_add_(0, idx, t)
+
+
+def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None, node_attr=None):
+    """FastEGNN.forward (models/FastEGNN.py:255-276) for hidden_nf > 64 -> (node_loc, virtual_node_loc)."""
+    dev = node_loc.device
+    Hn, C = model.hidden_nf, model.virtual_channels
+    kind, p = model._act
+    N, B = node_loc.size(0), loc_mean.size(0)
+    act = lambda z: _Act.apply(z, kind, p)                       # noqa: E731
+    row, col = edge_index[0].contiguous().long(), edge_index[1].contiguous().long()
+    batch = data_batch.contiguous().long()
+    ones = dict(dtype=torch.float32, device=dev)
+    inv_cnt_row = 1.0 / torch.zeros(N, **ones).index_add_(0, row, torch.ones(row.numel(), **ones)).clamp(min=1)
+    inv_cnt_b = 1.0 / torch.zeros(B, **ones).index_add_(0, batch, torch.ones(N, **ones)).clamp(min=1)
+    ar_c = torch.arange(C, device=dev)
+    idx_n = torch.arange(N, device=dev).repeat_interleave(C)                       # row n*C + c -> n
+    idx_bc = (batch.unsqueeze(1) * C + ar_c.unsqueeze(0)).reshape(-1)              # row n*C + c -> b(n)*C + c
+    gravity = torch.tensor(model.gravity, **ones) if model.gravity is not None else None
+    coords_sum = bool(getattr(model, "_extra_flags", 0) & K.F_COORDS_SUM)         # E_GCL_vel(coords_agg='sum'), :126
+
+    x, vel = node_loc.float(), node_vel.float()
+    Z = loc_mean.float()                                                            # virtual_node_loc [B, 3, C]
+    # virtual_node_feat [B, H, C] is kept as rows (b, c) of width H
+    HvT = model.virtual_node_feat.repeat(B, 1, 1).permute(0, 2, 1).reshape(B * C, Hn)
+    h = _lin(node_feat.float(), model.embedding_in.weight, 0, model.node_feat_nf, model.embedding_in.bias)
+
+    def head(seq, X):   # coord_mlp: Linear(H, H), act, Linear(H, 1, bias=False) [, Tanh]   (:55-67)
+        s = _lin(act(_lin(X, seq[0].weight, 0, Hn, seq[0].bias)), seq[2].weight, 0, Hn, None)
+        return torch.tanh(s) if model.tanh else s
+
+    def scalar_head(seq, X):   # Linear(H, H), act, Linear(H, 1)   (:75-88)
+        return _lin(act(_lin(X, seq[0].weight, 0, Hn, seq[0].bias)), seq[2].weight, 0, Hn, seq[2].bias)
+
+    for i in range(model.n_layers):
+        g = getattr(model, "gcl_%d" % i)
+        # ---- coord2radial (:176-185) and the virtual geometry (:200-201): 3-vectors, torch
+        cd = x[row] - x[col]
+        radial = (cd * cd).sum(1, keepdim=True)
+        if model.normalize:
+            cd = cd / (torch.sqrt(radial).detach() + 1e-8)
+        vcd = Z[batch] - x.unsqueeze(-1)                                            # [N, 3, C]
+        vr = torch.norm(vcd, p=2, dim=1, keepdim=True)                              # [N, 1, C]
+        # ---- edge_model (:102-108): Linear over cat[h[row], h[col], radial, edge_attr] = P[row] + Q[col] + feat . W[:, 2H:]
+        W1 = g.edge_mlp[0].weight
+        feat = radial if edge_attr is None else torch.cat([radial, edge_attr.float()], 1)
+        pre = _GatherAdd.apply(_lin(h, W1, Hn, Hn), col,
+                               _GatherAdd.apply(_lin(h, W1, 0, Hn, g.edge_mlp[0].bias), row, _lin(feat, W1, 2 * Hn, feat.size(1))))
+        m = act(_lin(act(pre), g.edge_mlp[2].weight, 0, Hn, g.edge_mlp[2].bias))   # [E, H]
+        if model.attention:
+            m = _rowscale(m, torch.sigmoid(_lin(m, g.att_mlp[0].weight, 0, Hn, g.att_mlp[0].bias)))
+        # ---- edge_mode_virtual (:111-119): rows (n, c); input cat[h, Hv[b], vr, m_X[b][:, c]]
+        cm = _small_segment_sum(x, batch, B) * inv_cnt_b.unsqueeze(1)               # global_mean_pool(coord)
+        mX = Z - cm.unsqueeze(-1)
+        mX = torch.einsum('bij,bjk->bik', mX.permute(0, 2, 1), mX)                  # [B, C, C]
+        Wv = g.edge_mlp_virtual[0].weight
+        Bc = _lin(mX.permute(0, 2, 1).reshape(B * C, C), Wv, 2 * Hn + 1, C, None, _lin(HvT, Wv, Hn, Hn))
+        pv = _GatherAdd.apply(Bc, idx_bc, _GatherAdd.apply(_lin(h, Wv, 0, Hn, g.edge_mlp_virtual[0].bias), idx_n,
+                                                           _lin(vr.reshape(N * C, 1), Wv, 2 * Hn, 1)))
+        v = act(_lin(act(pv), g.edge_mlp_virtual[2].weight, 0, Hn, g.edge_mlp_virtual[2].bias))   # [N*C, H]
+        if model.attention:
+            v = _rowscale(v, torch.sigmoid(_lin(v, g.att_mlp_virtual[0].weight, 0, Hn, g.att_mlp_virtual[0].bias)))
+        # ---- coord_model_vel (:122-145)
+        trans = cd * head(g.coord_mlp_r, m)
+        agg = _small_segment_sum(trans, row, N)
+        x_new = x + (agg if coords_sum else agg * inv_cnt_row.unsqueeze(1))
+        x_new = x_new + torch.mean(-vcd * head(g.coord_mlp_r_virtual, v).reshape(N, 1, C), dim=-1)
+        x_new = x_new + scalar_head(g.coord_mlp_vel, h) * vel
+        if gravity is not None:
+            x_new = x_new + scalar_head(g.gravity_mlp, h) * gravity
+        # ---- coord_model_virtual (:147-151)
+        transX = vcd * head(g.coord_mlp_v_virtual, v).reshape(N, 1, C)
+        Z_new = Z + (_small_segment_sum(transX.reshape(N, 3 * C), batch, B) * inv_cnt_b.unsqueeze(1)).reshape(B, 3, C)
+        # ---- node_model (:154-166): Linear over cat[h, agg, flat(v), node_attr]; flat(v) of the reference is (h, c)-ordered
+        aggm = _rowscale(_ScatterAdd.apply(m, row, N), inv_cnt_row)
+        W3 = g.node_mlp[0].weight
+        W3v = W3[:, 2 * Hn:2 * Hn + Hn * C].reshape(W3.size(0), Hn, C).permute(0, 2, 1).reshape(W3.size(0), C * Hn)
+        npre = _lin(aggm, W3, Hn, Hn, None, _lin(h, W3, 0, Hn, g.node_mlp[0].bias))
+        npre = _lin(v.view(N, C * Hn), W3v, 0, C * Hn, None, npre)
+        if node_attr is not None:
+            npre = _lin(node_attr.float(), W3, 2 * Hn + Hn * C, node_attr.size(1), None, npre)
+        h_new = _lin(act(npre), g.node_mlp[2].weight, 0, Hn, g.node_mlp[2].bias, h if model.residual else None)
+        # ---- node_model_virtual (:168-178)
+        poolV = _rowscale(_ScatterAdd.apply(v.view(N, C * Hn), batch, B), inv_cnt_b).view(B * C, Hn)
+        Wn = g.node_mlp_virtual[0].weight
+        zv = _lin(poolV, Wn, Hn, Hn, None, _lin(HvT, Wn, 0, Hn, g.node_mlp_virtual[0].bias))
+        HvT = _lin(act(zv), g.node_mlp_virtual[2].weight, 0, Hn, g.node_mlp_virtual[2].bias, HvT if model.residual else None)
+        h, x, Z = h_new, x_new, Z_new
+    return x, Z

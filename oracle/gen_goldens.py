@@ -502,6 +502,10 @@ def main():
                   loc_mean=_loc_mean(loc, batch, 3), edge_attr=torch.rand(ei.size(1), 2, generator=gen))
         train_case(FastEGNN, "train_ragged_simulation", rg, sigma=1.0, ragged_sizes=sizes)
         return
+    if "--wide" in sys.argv:   # hidden_nf above 64 (main_nbody.py:27 --dim_hidden): the unfused wide path's golden
+        run_case(FastEGNN, "wide_h128_two_graphs", sizes=[40, 23], edges=[300, 150], nf=2, na=0, ea=2, C=4, H=128, L=2, seed=31,
+                 attention=True, gravity=[0, -1, 0], coord_scale=100.0, loc_scale=1.0)
+        return
     if "--act" in sys.argv:   # act_fn other than the default SiLU: only these files are (re)written
         common = dict(sizes=[7, 4, 9], edges=[25, 10, 25], nf=2, na=0, ea=2, C=4, isolate=(2, 3), L=2, coord_scale=300.0,
                       gravity=[0, -1, 0])

@@ -16,7 +16,7 @@ def golden_names(include_fp64=False, silu_only=False):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
     if silu_only:
         names = [n for n in names if not n.startswith("act_")]
-    names = [n for n in names if not n.startswith(("train_", "egnn_", "dataset_", "fastrf_"))]   # other fixture families have their own tests
+    names = [n for n in names if not n.startswith(("train_", "egnn_", "dataset_", "fastrf_", "wide_"))]   # other fixture families have their own tests
     if not include_fp64:
         names = [n for n in names if not n.endswith("_fp64")]
     return names

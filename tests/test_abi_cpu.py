@@ -121,8 +121,13 @@ def test_seeded_init_equals_reference_init():
 def test_error_behaviour():
     with pytest.raises(AssertionError):
         fastegnn_amd.FastEGNN(2, 0, 2, 64, 0)                 # models/FastEGNN.py:255
+    assert fastegnn_amd.FastEGNN(2, 0, 2, 128, 3)._wide          # 64 < hidden_nf <= 256: the unfused wide path (fastegnn_amd/wide.py)
     with pytest.raises(NotImplementedError):
-        fastegnn_amd.FastEGNN(2, 0, 2, 128, 3)                # wider than the 64-wide tiles (narrower runs zero-padded)
+        fastegnn_amd.FastEGNN(2, 0, 2, 257, 3)                # beyond the wide path's range
+    with pytest.raises(NotImplementedError):
+        fastegnn_amd.FastEGNN(2, 0, 2, 128, 3, mlp_dtype=torch.bfloat16)   # the wide path is fp32 only
+    with pytest.raises(NotImplementedError):
+        fastegnn_amd.FastRF(2, 0, 2, 128, 3)                  # ... and FastEGNN only
     with pytest.raises(NotImplementedError):
         fastegnn_amd.FastEGNN(2, 0, 2, 64, 3, act_fn=torch.nn.Hardswish())      # not one of the eight kinds of the C ABI
     with pytest.raises(NotImplementedError):
@@ -133,6 +138,8 @@ def test_error_behaviour():
     kw, _, _ = g.model_kwargs()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(**kw)                                               # CPU tensors: never a silent fallback
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fastegnn_amd.FastEGNN(1, 0, 1, 128, 3)(**kw)          # the wide path likewise
 
 
 def test_product_does_not_import_oracle():

@@ -11,7 +11,8 @@ TOL_OUT = 2e-6
 TOL_GRAD = 2e-5
 
 
-@pytest.mark.parametrize("name", golden_names(include_fp64=True))
+# (wide_h128_two_graphs: hidden_nf = 128, the golden of the unfused wide path -- tests/test_gpu_wide.py)
+@pytest.mark.parametrize("name", golden_names(include_fp64=True) + ["wide_h128_two_graphs"])
 def test_oracle_matches_reference_golden(name):
     g = Golden(name)
     dt = torch.float64 if name.endswith("_fp64") else torch.float32
