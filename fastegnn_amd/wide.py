@@ -7,7 +7,7 @@ node_model_virtual), every hidden-sized tensor op of it one launch of ``csrc/wid
 (``fastegnn_wide_*`` in ``include/fastegnn_hip.h``): nn.Linear as ``fastegnn_wide_linear`` over the weight's column blocks (a
 Linear over a ``torch.cat`` is the sum of Linears over the pieces, so nothing is concatenated), the activations, the row
 gathers ``node_feat[row]`` / ``virtual_node_feat[data_batch]``, the segment sums, the gates.  The backward is composed by
-autograd from the matching ``_dx`` / ``_dw`` / ``_backward`` entry points.  What stays in torch is the 3-vector geometry
+autograd from the matching ``_dx`` / ``_dw`` / ``_backward`` entry points.  What stays in torch is the elementwise 3-vector geometry
 (``[E,3]``, ``[N,3,C]``, ``[B,C,C]`` tensors) and views.  Correctness first (fp32 FMA GEMMs, fp32 atomics): this path is
 several times slower per FLOP than the fused one -- DESIGN.md section 9 -- and exists so that the constructor takes the
 reference's whole ``hidden_nf`` range.  No CPU fallback: the library is loaded on first use and its absence raises."""
@@ -165,9 +165,13 @@ def _lin(X, W, c0=0, Kc=None, bias=None, base=None):
     return _Linear.apply(X, W, c0, W.size(1) - c0 if Kc is None else Kc, bias, base)
 
 
-def _small_segment_sum(t, idx, R):
-    """[M, small] rows summed by idx (3-vector geometry: torch)"""
-    return torch.zeros(R, t.size(1), dtype=t.dtype, device=t.device).index_add_(0, idx, t)
+def _rows(X, idx):
+    """X[idx] for a [R, w] table (also the 3-vector geometry: torch's own index backward sorts the indices per call)"""
+    return _GatherAdd.apply(X, idx, None)
+
+
+def _segment_sum(t, idx, R):
+    return _ScatterAdd.apply(t, idx, R)
 
 
 def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None, node_attr=None):
@@ -204,11 +208,11 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
     for i in range(model.n_layers):
         g = getattr(model, "gcl_%d" % i)
         # ---- coord2radial (:176-185) and the virtual geometry (:200-201): 3-vectors, torch
-        cd = x[row] - x[col]
+        cd = _rows(x, row) - _rows(x, col)
         radial = (cd * cd).sum(1, keepdim=True)
         if model.normalize:
             cd = cd / (torch.sqrt(radial).detach() + 1e-8)
-        vcd = Z[batch] - x.unsqueeze(-1)                                            # [N, 3, C]
+        vcd = _rows(Z.reshape(B, 3 * C), batch).view(N, 3, C) - x.unsqueeze(-1)      # [N, 3, C]
         vr = torch.norm(vcd, p=2, dim=1, keepdim=True)                              # [N, 1, C]
         # ---- edge_model (:102-108): Linear over cat[h[row], h[col], radial, edge_attr] = P[row] + Q[col] + feat . W[:, 2H:]
         W1 = g.edge_mlp[0].weight
@@ -219,7 +223,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         if model.attention:
             m = _rowscale(m, torch.sigmoid(_lin(m, g.att_mlp[0].weight, 0, Hn, g.att_mlp[0].bias)))
         # ---- edge_mode_virtual (:111-119): rows (n, c); input cat[h, Hv[b], vr, m_X[b][:, c]]
-        cm = _small_segment_sum(x, batch, B) * inv_cnt_b.unsqueeze(1)               # global_mean_pool(coord)
+        cm = _segment_sum(x, batch, B) * inv_cnt_b.unsqueeze(1)               # global_mean_pool(coord)
         mX = Z - cm.unsqueeze(-1)
         mX = torch.einsum('bij,bjk->bik', mX.permute(0, 2, 1), mX)                  # [B, C, C]
         Wv = g.edge_mlp_virtual[0].weight
@@ -231,7 +235,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
             v = _rowscale(v, torch.sigmoid(_lin(v, g.att_mlp_virtual[0].weight, 0, Hn, g.att_mlp_virtual[0].bias)))
         # ---- coord_model_vel (:122-145)
         trans = cd * head(g.coord_mlp_r, m)
-        agg = _small_segment_sum(trans, row, N)
+        agg = _segment_sum(trans, row, N)
         x_new = x + (agg if coords_sum else agg * inv_cnt_row.unsqueeze(1))
         x_new = x_new + torch.mean(-vcd * head(g.coord_mlp_r_virtual, v).reshape(N, 1, C), dim=-1)
         x_new = x_new + scalar_head(g.coord_mlp_vel, h) * vel
@@ -239,7 +243,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
             x_new = x_new + scalar_head(g.gravity_mlp, h) * gravity
         # ---- coord_model_virtual (:147-151)
         transX = vcd * head(g.coord_mlp_v_virtual, v).reshape(N, 1, C)
-        Z_new = Z + (_small_segment_sum(transX.reshape(N, 3 * C), batch, B) * inv_cnt_b.unsqueeze(1)).reshape(B, 3, C)
+        Z_new = Z + (_segment_sum(transX.reshape(N, 3 * C), batch, B) * inv_cnt_b.unsqueeze(1)).reshape(B, 3, C)
         # ---- node_model (:154-166): Linear over cat[h, agg, flat(v), node_attr]; flat(v) of the reference is (h, c)-ordered
         aggm = _rowscale(_ScatterAdd.apply(m, row, N), inv_cnt_row)
         W3 = g.node_mlp[0].weight

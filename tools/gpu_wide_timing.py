@@ -1,7 +1,8 @@
 """one-off measurement of the WIDE path (hidden_nf = 128): fwd + loss + bwd on a Water-3D-like frame, eager launches.
 usage: python tools/gpu_wide_timing.py [nodes] [channels] [hidden]"""
 import sys, time, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import fastegnn_amd
 from bench import make_frame, loss_fn
 
