@@ -19,7 +19,9 @@ from .model import SortedGraph, _PadParams, _PtrTable, _activation_kind, _carve,
 H = K.H
 
 
-def _base_mlp(i, h, o, act, last_act=False):
+def _base_mlp(i, h, o, act, last_act=False, flat=False):
+    if flat:   # BaseMLP(flat=True), basic.py:176-178
+        act, h = nn.Tanh(), 4 * h
     mods = [nn.Linear(i, h), act, nn.Linear(h, o)] + ([act] if last_act else [])
     m = nn.Module()
     m.mlp = nn.Sequential(*mods)
@@ -29,13 +31,13 @@ def _base_mlp(i, h, o, act, last_act=False):
 class EGNN_Layer(nn.Module):
     """Parameter holder; construction order of models/basic.py:286-300."""
 
-    def __init__(self, in_edge_nf, hidden_nf, activation, with_v):
+    def __init__(self, in_edge_nf, hidden_nf, activation, with_v, flat=False):
         super().__init__()
         self.edge_message_net = nn.Module()
-        self.edge_message_net.scalar_net = _base_mlp(1 + 2 * hidden_nf + in_edge_nf, hidden_nf, hidden_nf, activation, True)
-        self.coord_net = _base_mlp(hidden_nf, hidden_nf, 1, activation)
-        self.node_net = _base_mlp(2 * hidden_nf, hidden_nf, hidden_nf, activation)
-        self.node_v_net = _base_mlp(hidden_nf, hidden_nf, 1, activation) if with_v else None
+        self.edge_message_net.scalar_net = _base_mlp(1 + 2 * hidden_nf + in_edge_nf, hidden_nf, hidden_nf, activation, True, flat)
+        self.coord_net = _base_mlp(hidden_nf, hidden_nf, 1, activation, False, flat)
+        self.node_net = _base_mlp(2 * hidden_nf, hidden_nf, hidden_nf, activation, False, flat)
+        self.node_v_net = _base_mlp(hidden_nf, hidden_nf, 1, activation, False, flat) if with_v else None
 
 
 _SLOT_OF = {   # FASTEGNN_P_* slot name -> reference key suffix inside layers.<i>
@@ -168,24 +170,27 @@ class EGNN(nn.Module):
     def __init__(self, n_layers, in_node_nf, in_edge_nf, hidden_nf, activation=nn.SiLU(), device='cpu', with_v=False,
                  flat=False, norm=False):
         super().__init__()
-        if not 1 <= hidden_nf <= H or flat:
-            raise NotImplementedError("fastegnn_amd.EGNN: hidden_nf<=64 (narrower runs zero-padded), flat=False only "
-                                      "(flat=True means 256-wide Tanh MLPs)")
+        # hidden_nf <= 64 with flat=False: the fused kernels (FASTEGNN_F_EGNN wiring).  flat=True (Tanh MLPs with 4 x hidden inner
+        # units, basic.py:176-178) or 64 < hidden_nf <= 256: the unfused wide path (fastegnn_amd/wide.py: generic-width operators)
+        if not 1 <= hidden_nf <= 256:
+            raise NotImplementedError(f"fastegnn_amd.EGNN: hidden_nf must be at most 256 in this build (got {hidden_nf})")
+        self._wide = bool(flat) or hidden_nf > H
+        self.flat = bool(flat)
         # `activation` (basic.py:324; BaseMLP puts it behind every first layer and behind the message MLP, :181-192): the same
         # kinds as FastEGNN's act_fn, on the generic-activation build of the library when it is not SiLU
         self._act = _activation_kind(activation)
-        if self._act[0] in (K.ACT_SIGMOID, K.ACT_SOFTPLUS) and hidden_nf < H:
+        if self._act[0] in (K.ACT_SIGMOID, K.ACT_SOFTPLUS) and hidden_nf < H and not self._wide:
             raise NotImplementedError("fastegnn_amd.EGNN: hidden_nf < 64 runs zero-padded, which needs activation(0) = 0")
         self.hidden_nf = hidden_nf
         self.norm = bool(norm)
-        if in_edge_nf > 7 or in_node_nf > 8:
+        if not self._wide and (in_edge_nf > 7 or in_node_nf > 8):
             raise NotImplementedError("fastegnn_amd.EGNN: in_edge_nf<=7, in_node_nf<=8")
         self.n_layers, self.with_v = n_layers, with_v
         self.in_node_nf, self.in_edge_nf = in_node_nf, in_edge_nf
         self.layers = nn.ModuleList()                      # registered first, filled after the embedding (basic.py:327-335)
         self.embedding = nn.Linear(in_node_nf, hidden_nf)
         for _ in range(n_layers):
-            self.layers.append(EGNN_Layer(in_edge_nf, hidden_nf, activation, with_v))
+            self.layers.append(EGNN_Layer(in_edge_nf, hidden_nf, activation, with_v, flat))
         self._spec = None
         self._graph_cache = {}
         self.deterministic = bool(K.deterministic_default())   # see fastegnn_amd.FastEGNN.deterministic (set before the first call)
@@ -215,6 +220,12 @@ class EGNN(nn.Module):
     def forward(self, x, h, edge_index, edge_fea, v=None):
         if not x.is_cuda:
             raise RuntimeError("fastegnn_amd.EGNN runs on a gfx950 GPU only (no CPU fallback)")
+        if self._wide:
+            from . import wide
+            if edge_fea is not None and edge_fea.size(1) == 0:
+                edge_fea = None
+            x_out, h_out = wide.egnn_forward(self, x, h, edge_index, edge_fea, v)
+            return (x_out, v, h_out) if v is not None else (x_out, h_out)
         if self._spec is None:
             self._build_spec()
         N = x.size(0)

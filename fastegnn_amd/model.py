@@ -529,9 +529,8 @@ class FastEGNN(nn.Module):
         self._wide = hidden_nf > H
         if not 1 <= hidden_nf <= 256:
             raise NotImplementedError(f"fastegnn_amd: hidden_nf must be at most 256 in this build (got {hidden_nf})")
-        if self._wide and (mlp_dtype != torch.float32 or (self._extra_flags & (K.F_RF | K.F_EGNN))):
-            raise NotImplementedError("fastegnn_amd: hidden_nf > 64 (the unfused wide path) is built for FastEGNN with fp32 "
-                                      "operands only")
+        if self._wide and mlp_dtype != torch.float32:
+            raise NotImplementedError("fastegnn_amd: hidden_nf > 64 (the unfused wide path) is built for fp32 operands only")
         self._act = _activation_kind(act_fn)
         if self._act[0] in (K.ACT_SIGMOID, K.ACT_SOFTPLUS) and hidden_nf < H:
             raise NotImplementedError("fastegnn_amd: hidden_nf < 64 runs zero-padded, which needs act_fn(0) = 0")

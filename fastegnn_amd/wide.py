@@ -191,6 +191,8 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
     idx_bc = (batch.unsqueeze(1) * C + ar_c.unsqueeze(0)).reshape(-1)              # row n*C + c -> b(n)*C + c
     gravity = torch.tensor(model.gravity, **ones) if model.gravity is not None else None
     coords_sum = bool(getattr(model, "_extra_flags", 0) & K.F_COORDS_SUM)         # E_GCL_vel(coords_agg='sum'), :126
+    rf = bool(getattr(model, "_extra_flags", 0) & K.F_RF)   # FastRF (models/FastRF.py:155-186): no node_model / node_model_virtual,
+    #                                                         the velocity head reads ||vel|| (detached, :169) instead of h
 
     x, vel = node_loc.float(), node_vel.float()
     Z = loc_mean.float()                                                            # virtual_node_loc [B, 3, C]
@@ -202,8 +204,11 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         s = _lin(act(_lin(X, seq[0].weight, 0, Hn, seq[0].bias)), seq[2].weight, 0, Hn, None)
         return torch.tanh(s) if model.tanh else s
 
+    def scalar_head_in(seq, X):   # Linear(w, H), act, Linear(H, 1) over an input of any width w
+        return _lin(act(_lin(X, seq[0].weight, 0, X.size(1), seq[0].bias)), seq[2].weight, 0, Hn, seq[2].bias)
+
     def scalar_head(seq, X):   # Linear(H, H), act, Linear(H, 1)   (:75-88)
-        return _lin(act(_lin(X, seq[0].weight, 0, Hn, seq[0].bias)), seq[2].weight, 0, Hn, seq[2].bias)
+        return scalar_head_in(seq, X)
 
     for i in range(model.n_layers):
         g = getattr(model, "gcl_%d" % i)
@@ -238,12 +243,18 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         agg = _segment_sum(trans, row, N)
         x_new = x + (agg if coords_sum else agg * inv_cnt_row.unsqueeze(1))
         x_new = x_new + torch.mean(-vcd * head(g.coord_mlp_r_virtual, v).reshape(N, 1, C), dim=-1)
-        x_new = x_new + scalar_head(g.coord_mlp_vel, h) * vel
+        if rf:
+            x_new = x_new + scalar_head_in(g.coord_mlp_vel, torch.norm(vel, p=2, dim=-1).unsqueeze(-1).detach()) * vel
+        else:
+            x_new = x_new + scalar_head(g.coord_mlp_vel, h) * vel
         if gravity is not None:
             x_new = x_new + scalar_head(g.gravity_mlp, h) * gravity
         # ---- coord_model_virtual (:147-151)
         transX = vcd * head(g.coord_mlp_v_virtual, v).reshape(N, 1, C)
         Z_new = Z + (_segment_sum(transX.reshape(N, 3 * C), batch, B) * inv_cnt_b.unsqueeze(1)).reshape(B, 3, C)
+        if rf:   # the features of real and virtual nodes pass through (FastRF.py:186)
+            x, Z = x_new, Z_new
+            continue
         # ---- node_model (:154-166): Linear over cat[h, agg, flat(v), node_attr]; flat(v) of the reference is (h, c)-ordered
         aggm = _rowscale(_ScatterAdd.apply(m, row, N), inv_cnt_row)
         W3 = g.node_mlp[0].weight
@@ -260,3 +271,47 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         HvT = _lin(act(zv), g.node_mlp_virtual[2].weight, 0, Hn, g.node_mlp_virtual[2].bias, HvT if model.residual else None)
         h, x, Z = h_new, x_new, Z_new
     return x, Z
+
+
+def egnn_forward(model, x, h, edge_index, edge_fea, v=None):
+    """EGNN.forward (models/basic.py:337-341 over EGNN_Layer.forward :302-320) on the wide operators: hidden_nf > 64, or
+    flat=True (every BaseMLP a Tanh MLP with 4 x hidden inner units, :176-178) -> (x, h)."""
+    dev = x.device
+    Hn = model.hidden_nf
+    kind, p = (K.ACT_TANH, 0.0) if model.flat else model._act
+    act = lambda z: _Act.apply(z, kind, p)                       # noqa: E731
+    N = x.size(0)
+    row, col = edge_index[0].contiguous().long(), edge_index[1].contiguous().long()
+    f32 = dict(dtype=torch.float32, device=dev)
+    inv_cnt = 1.0 / torch.zeros(N, **f32).index_add_(0, row, torch.ones(row.numel(), **f32)).clamp(min=1)   # aggregate(aggr='mean'), :27-52
+    x = x.float()
+    vv = v.float() if v is not None else None
+    h = _lin(h.float(), model.embedding.weight, 0, model.in_node_nf, model.embedding.bias)
+
+    def mlp(net, X, base_first=None):   # BaseMLP without last_act: Linear, act, Linear
+        return _lin(act(_lin(X, net.mlp[0].weight, 0, X.size(1), net.mlp[0].bias) if base_first is None else base_first),
+                    net.mlp[2].weight, 0, net.mlp[2].weight.size(1), net.mlp[2].bias)
+
+    for layer in model.layers:
+        rij = _rows(x, row) - _rows(x, col)
+        scalar = (rij * rij).sum(1, keepdim=True)                                   # 1 x 1 Gram of the single vector, :268-270
+        if model.norm:
+            scalar = torch.nn.functional.normalize(scalar, p=2, dim=-1)
+        # edge_message_net: BaseMLP(last_act=True) over cat(scalar, h[row], h[col], edge_fea)  (:313, :259-261)
+        net = layer.edge_message_net.scalar_net.mlp
+        W0 = net[0].weight
+        pre = _lin(scalar, W0, 0, 1)
+        if edge_fea is not None:
+            pre = _lin(edge_fea.float(), W0, 1 + 2 * Hn, edge_fea.size(1), None, pre)
+        pre = _GatherAdd.apply(_lin(h, W0, 1 + Hn, Hn), col, _GatherAdd.apply(_lin(h, W0, 1, Hn, net[0].bias), row, pre))
+        message = act(_lin(act(pre), net[2].weight, 0, net[2].weight.size(1), net[2].bias))     # [E, H]
+        f = rij * mlp(layer.coord_net, message)
+        tot_f = torch.clamp(_segment_sum(f, row, N) * inv_cnt.unsqueeze(1), min=-100, max=100)
+        x_new = x + tot_f
+        if vv is not None:
+            x_new = x_new + mlp(layer.node_v_net, h) * vv
+        tot_message = _rowscale(_ScatterAdd.apply(message, row, N), inv_cnt)
+        Wn = layer.node_net.mlp[0].weight
+        h = mlp(layer.node_net, None, _lin(tot_message, Wn, Hn, Hn, None, _lin(h, Wn, 0, Hn, layer.node_net.mlp[0].bias)))
+        x = x_new
+    return x, h

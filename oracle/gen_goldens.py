@@ -330,10 +330,10 @@ def egnn_cases():
     sys.path.insert(0, REF)
     from models.basic import EGNN
 
-    def case(name, seed, with_v, coord_scale=1.0, L=2, loc_scale=2.0, norm=False):
+    def case(name, seed, with_v, coord_scale=1.0, L=2, loc_scale=2.0, norm=False, hidden=64, flat=False):
         torch.manual_seed(seed)
         gen = torch.Generator().manual_seed(seed + 100)
-        model = EGNN(n_layers=L, in_node_nf=2, in_edge_nf=2, hidden_nf=64, device="cpu", with_v=with_v, norm=norm)
+        model = EGNN(n_layers=L, in_node_nf=2, in_edge_nf=2, hidden_nf=hidden, device="cpu", with_v=with_v, norm=norm, flat=flat)
         with torch.no_grad():
             for k, v in model.named_parameters():
                 if "coord_net.mlp.2" in k:
@@ -349,7 +349,7 @@ def egnn_cases():
         out = model(**{**inp, **leaf})
         x_out, h_out = out[0], out[-1]
         target = inp["x"] + torch.randn(N, 3, generator=gen)
-        wh = torch.randn(N, 64, generator=gen)
+        wh = torch.randn(N, hidden, generator=gen)
         loss = torch.nn.functional.mse_loss(x_out, target) + 0.05 * (h_out * wh).sum() / N
         loss.backward()
         rec = {f"in/{k}": v.numpy() for k, v in inp.items()}
@@ -362,11 +362,16 @@ def egnn_cases():
         for k, v in leaf.items():
             rec[f"gin/{k}"] = v.grad.numpy()
         rec["meta/with_v"], rec["meta/L"], rec["meta/norm"] = np.array(int(with_v)), np.array(L), np.array(int(norm))
+        rec["meta/flat"], rec["meta/hidden"] = np.array(int(flat)), np.array(hidden)
         path = os.path.join(OUT, f"{name}.npz")
         np.savez_compressed(path, **rec)
         clamped = float((x_out.detach() - inp["x"]).abs().max())
         print(f"{name}: N={N} E={ei.size(1)} loss={loss.item():.5f} max|dx|={clamped:.2f} -> {os.path.getsize(path)/1024:.0f} KiB")
 
+    if "--egnn-wide" in sys.argv:   # the unfused wide path of the sibling: flat=True (Tanh MLPs of 4 x hidden, basic.py:176-178), hidden > 64
+        case("egnn_flat", 25, True, coord_scale=3.0, hidden=32, flat=True)
+        case("egnn_h128", 26, True, coord_scale=3.0, hidden=128)
+        return
     case("egnn_with_v", 21, True)
     case("egnn_no_v", 22, False)
     case("egnn_clamped", 23, True, coord_scale=4000.0, loc_scale=6.0)    # tot_f hits the +-100 clamp (:310)
@@ -437,13 +442,13 @@ def fastrf_cases():
     sys.path.insert(0, REF)
     from models.FastRF import FastRF
 
-    def case(name, seed, L=2, C=4, coord_scale=300.0, **flags):
+    def case(name, seed, L=2, C=4, coord_scale=300.0, hidden=64, **flags):
         torch.manual_seed(seed); random.seed(seed); np.random.seed(seed)
         gen = torch.Generator().manual_seed(seed)
         sizes, edges = [7, 4, 9], [25, 10, 25]
         ei, batch = _rand_graph_batch(gen, sizes, edges, isolate=(2, 3))
         N = sum(sizes)
-        model = FastRF(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=64, virtual_channels=C, n_layers=L, **flags)
+        model = FastRF(node_feat_nf=2, node_attr_nf=0, edge_attr_nf=2, hidden_nf=hidden, virtual_channels=C, n_layers=L, **flags)
         with torch.no_grad():
             for k, prm in model.named_parameters():
                 if k.endswith(("coord_mlp_r.2.weight", "coord_mlp_r_virtual.2.weight", "coord_mlp_v_virtual.2.weight")):
@@ -466,7 +471,7 @@ def fastrf_cases():
             out[f"gin/{k}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
         out["out/loc"], out["out/vloc"] = loc.detach().numpy(), vloc.detach().numpy()
         g = flags.get("gravity")
-        meta = dict(nf=2, na=0, ea=2, H=64, C=C, L=L, residual=1, attention=int(flags.get("attention", False)),
+        meta = dict(nf=2, na=0, ea=2, H=hidden, C=C, L=L, residual=1, attention=int(flags.get("attention", False)),
                     normalize=int(flags.get("normalize", False)), tanh=int(flags.get("tanh", False)),
                     has_gravity=int(g is not None), gravity=np.array(g if g is not None else [0, 0, 0], dtype=np.float32))
         for k, v in meta.items():
@@ -474,19 +479,22 @@ def fastrf_cases():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
         print(name, "loss", float(loss))
 
+    if "--fastrf-wide" in sys.argv:   # hidden_nf above 64: the sibling on the unfused wide path
+        case("fastrf_h128", 24, hidden=128, attention=True, gravity=[0, -1, 0])
+        return
     case("fastrf_plain", 21)
     case("fastrf_allflags", 22, attention=True, normalize=True, tanh=True, gravity=[0, -1, 0])
     case("fastrf_c16", 23, C=16, coord_scale=100.0, gravity=[0, -1, 0])
 
 
 def main():
-    if "--fastrf" in sys.argv:
+    if "--fastrf" in sys.argv or "--fastrf-wide" in sys.argv:
         fastrf_cases()
         return
     if "--dataset" in sys.argv:
         dataset_case()
         return
-    if "--egnn" in sys.argv:
+    if "--egnn" in sys.argv or "--egnn-wide" in sys.argv:
         egnn_cases()
         return
     FastEGNN = _import_reference()

@@ -126,8 +126,7 @@ def test_error_behaviour():
         fastegnn_amd.FastEGNN(2, 0, 2, 257, 3)                # beyond the wide path's range
     with pytest.raises(NotImplementedError):
         fastegnn_amd.FastEGNN(2, 0, 2, 128, 3, mlp_dtype=torch.bfloat16)   # the wide path is fp32 only
-    with pytest.raises(NotImplementedError):
-        fastegnn_amd.FastRF(2, 0, 2, 128, 3)                  # ... and FastEGNN only
+    assert fastegnn_amd.FastRF(2, 0, 2, 128, 3)._wide and fastegnn_amd.EGNN(2, 2, 2, 16, flat=True)._wide   # the siblings too
     with pytest.raises(NotImplementedError):
         fastegnn_amd.FastEGNN(2, 0, 2, 64, 3, act_fn=torch.nn.Hardswish())      # not one of the eight kinds of the C ABI
     with pytest.raises(NotImplementedError):

@@ -6,7 +6,7 @@ import torch
 from oracle import fastrf_ref as RF
 from tests.helpers import Golden, golden_loss, rel_err
 
-CASES = ["fastrf_plain", "fastrf_allflags", "fastrf_c16"]
+CASES = ["fastrf_plain", "fastrf_allflags", "fastrf_c16", "fastrf_h128"]   # fastrf_h128: hidden_nf = 128, the unfused wide path
 
 
 @pytest.mark.parametrize("name", CASES)

