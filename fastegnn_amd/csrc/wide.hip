@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_smalln_kernel(const float *A, int ld
 
 // dW[o*ldw + c0 + k] += sum_m G[m*ldg + o] * X[m*ldx + k]  over the workgroup's row range (blockIdx.z), fp32 atomics into dW
 __global__ __launch_bounds__(256) void tn_tile_kernel(const float *G, int ldg, const float *X, int ldx, long M, int O, int Kd,
-                                                      float *dW, int ldw, int c0, long rows_per_split) {
+                                                      float *dW, int ldw, int c0, long rows_per_split, float *db) {
   __shared__ float Gs[BK][BM + 16];   // [row][o]
   __shared__ float Xs[BK][BN + 16];   // [row][k]
   const int o0 = blockIdx.x * BM, k0 = blockIdx.y * BN;
@@ -129,6 +129,10 @@ __global__ __launch_bounds__(256) void tn_tile_kernel(const float *G, int ldg, c
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // db (bias gradient, may be null): the column sums of G ride along in the workgroups of the first k-block -- thread c < 64 adds
+  // the 16 rows of its column from the staged tile (in double: cancelling sums over up to 10^6 rows)
+  const bool do_bias = db != nullptr && blockIdx.y == 0 && tid < BM;
+  double bsum = 0.0;
   for (long r0 = r_lo; r0 < r_hi; r0 += BK) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -138,6 +142,12 @@ __global__ __launch_bounds__(256) void tn_tile_kernel(const float *G, int ldg, c
       Xs[r][c] = (m < r_hi && k0 + c < Kd) ? X[(size_t)m * ldx + k0 + c] : 0.f;
     }
     __syncthreads();
+    if (do_bias) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < BK; ++r) t += Gs[r][tid];
+      bsum += (double)t;
+    }
 #pragma unroll
     for (int rs = 0; rs < BK; rs += 4) {
       const float a0 = Gs[rs + lk][wr + li], a1 = Gs[rs + lk][wr + 16 + li];
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(256) void tn_tile_kernel(const float *G, int ldg, c
         if (k < Kd) atomicAdd(dW + (size_t)o * ldw + c0 + k, acc[bi][bj][r]);
       }
     }
+  if (do_bias && o0 + tid < O) atomicAdd(db + o0 + tid, (float)bsum);
 }
 
 // out[s*so + l*sl] += sum_m S[m*lds + s] * L[m*ldl + l]   with a SMALL side (ns <= 8 columns): the [1, H] heads' weight gradients
@@ -215,6 +226,27 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(float *table, const in
     const size_t m = i / W, w = i - m * W;
     atomicAdd(table + (size_t)idx[m] * W + w, rows[i]);
   }
+}
+// the same for wide rows (W >= 32): thread = one column, workgroup = a range of rows walked in order with a running sum that is
+// flushed (one atomic) whenever the target changes -- sorted or grouped indices (segment sums by graph, the C channel rows of a
+// node) cost one atomic per run instead of one per row; unsorted ones cost what scatter_add_kernel costs
+__global__ __launch_bounds__(256) void scatter_add_runs_kernel(float *table, const int64_t *idx, long M, int W, const float *rows,
+                                                               long rows_per_wg) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const long m_lo = (long)blockIdx.y * rows_per_wg, m_hi = m_lo + rows_per_wg < M ? m_lo + rows_per_wg : M;
+  if (w >= W || m_lo >= m_hi) return;
+  int64_t cur = idx[m_lo];
+  float acc = 0.f;
+  for (long m = m_lo; m < m_hi; ++m) {
+    const int64_t i = idx[m];
+    if (i != cur) {
+      atomicAdd(table + (size_t)cur * W + w, acc);
+      acc = 0.f;
+      cur = i;
+    }
+    acc += rows[(size_t)m * W + w];
+  }
+  atomicAdd(table + (size_t)cur * W + w, acc);
 }
 // Y[m, :] = X[m, :] * s[m]
 __global__ __launch_bounds__(256) void rowscale_kernel(const float *X, const float *s, long M, int W, float *Y) {
@@ -303,7 +335,8 @@ int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O
       const int gx = cdiv(O, BM), gy = cdiv(K, BN), ns = row_splits(M, (long)gx * gy);
       long rows = cdiv(M, ns);
       rows = (rows + BK - 1) / BK * BK;
-      hipLaunchKernelGGL(tn_tile_kernel, dim3(gx, gy, (unsigned)cdiv(M, rows)), dim3(256), 0, st, G, O, X, K, (long)M, O, K, dW, ldw, c0, rows);
+      hipLaunchKernelGGL(tn_tile_kernel, dim3(gx, gy, (unsigned)cdiv(M, rows)), dim3(256), 0, st, G, O, X, K, (long)M, O, K, dW, ldw, c0, rows, db);
+      db = nullptr;   // done inside
     }
     int rc = check_launch("fastegnn_wide_linear_dw");
     if (rc) return rc;
@@ -345,7 +378,15 @@ int fastegnn_wide_scatter_add(float *table, const int64_t *idx, int64_t M, int32
   FE_REQUIRE(M >= 0 && W >= 1, "fastegnn_wide_scatter_add: bad sizes");
   if (M == 0) return FASTEGNN_OK;
   FE_REQUIRE(table && idx && rows, "fastegnn_wide_scatter_add: null pointer");
-  hipLaunchKernelGGL(scatter_add_kernel, dim3(grid1d((size_t)M * W)), dim3(256), 0, (hipStream_t)stream, table, idx, (long)M, W, rows);
+  if (W >= 32) {
+    const int gx = cdiv(W, 256);
+    long rows_per_wg = 64;   // enough workgroups to fill the chip, runs long enough to pay
+    while (rows_per_wg < 1024 && (long)gx * cdiv(M, rows_per_wg) > 16384) rows_per_wg *= 2;
+    hipLaunchKernelGGL(scatter_add_runs_kernel, dim3(gx, (unsigned)cdiv(M, rows_per_wg)), dim3(256), 0, (hipStream_t)stream, table, idx,
+                       (long)M, W, rows, rows_per_wg);
+  } else {
+    hipLaunchKernelGGL(scatter_add_kernel, dim3(grid1d((size_t)M * W)), dim3(256), 0, (hipStream_t)stream, table, idx, (long)M, W, rows);
+  }
   return check_launch("fastegnn_wide_scatter_add");
 }
 // Y[m, :] = X[m, :] * s[m]                                (attention gates, 1 / count of the segment means)

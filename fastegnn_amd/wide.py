@@ -186,9 +186,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
     ones = dict(dtype=torch.float32, device=dev)
     inv_cnt_row = 1.0 / torch.zeros(N, **ones).index_add_(0, row, torch.ones(row.numel(), **ones)).clamp(min=1)
     inv_cnt_b = 1.0 / torch.zeros(B, **ones).index_add_(0, batch, torch.ones(N, **ones)).clamp(min=1)
-    ar_c = torch.arange(C, device=dev)
     idx_n = torch.arange(N, device=dev).repeat_interleave(C)                       # row n*C + c -> n
-    idx_bc = (batch.unsqueeze(1) * C + ar_c.unsqueeze(0)).reshape(-1)              # row n*C + c -> b(n)*C + c
     gravity = torch.tensor(model.gravity, **ones) if model.gravity is not None else None
     coords_sum = bool(getattr(model, "_extra_flags", 0) & K.F_COORDS_SUM)         # E_GCL_vel(coords_agg='sum'), :126
     rf = bool(getattr(model, "_extra_flags", 0) & K.F_RF)   # FastRF (models/FastRF.py:155-186): no node_model / node_model_virtual,
@@ -233,8 +231,10 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         mX = torch.einsum('bij,bjk->bik', mX.permute(0, 2, 1), mX)                  # [B, C, C]
         Wv = g.edge_mlp_virtual[0].weight
         Bc = _lin(mX.permute(0, 2, 1).reshape(B * C, C), Wv, 2 * Hn + 1, C, None, _lin(HvT, Wv, Hn, Hn))
-        pv = _GatherAdd.apply(Bc, idx_bc, _GatherAdd.apply(_lin(h, Wv, 0, Hn, g.edge_mlp_virtual[0].bias), idx_n,
-                                                           _lin(vr.reshape(N * C, 1), Wv, 2 * Hn, 1)))
+        # rows (n, c) <- A[n] + Bc[b(n), c]: the second gather moves whole [C*H] rows by graph (its adjoint is then a segment sum
+        # over sorted indices instead of N*C atomics onto B*C rows)
+        pv = _GatherAdd.apply(_lin(h, Wv, 0, Hn, g.edge_mlp_virtual[0].bias), idx_n, _lin(vr.reshape(N * C, 1), Wv, 2 * Hn, 1))
+        pv = _GatherAdd.apply(Bc.view(B, C * Hn), batch, pv.view(N, C * Hn)).view(N * C, Hn)
         v = act(_lin(act(pv), g.edge_mlp_virtual[2].weight, 0, Hn, g.edge_mlp_virtual[2].bias))   # [N*C, H]
         if model.attention:
             v = _rowscale(v, torch.sigmoid(_lin(v, g.att_mlp_virtual[0].weight, 0, Hn, g.att_mlp_virtual[0].bias)))
