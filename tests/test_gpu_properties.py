@@ -260,7 +260,7 @@ def test_narrow_hidden_nf_vs_oracle(hidden, C):
     _, m = _models(cfg, seed=1)
     assert m.gcl_0.node_mlp[0].weight.shape == (hidden, 2 * hidden + hidden * C + 2)
     with pytest.raises(NotImplementedError):
-        fastegnn_amd.FastEGNN(2, 0, 2, 128, 4, device="cuda")
+        fastegnn_amd.FastEGNN(2, 0, 2, 257, 4, device="cuda")    # (64, 256]: the unfused wide path, tests/test_gpu_wide.py
 
 
 def test_coords_agg_sum_vs_oracle():

@@ -154,3 +154,13 @@ def test_wide_model_matches_reference_golden():
     G = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
     msgs = check_parity(g, loc.detach(), vloc.detach(), G, {k: v.grad for k, v in leaf.items()})
     assert not msgs, msgs
+
+
+def test_wide_model_without_edges():
+    """E = 0 (every node isolated): the edge operators see empty inputs, segment means of nothing are zero (count.clamp(min=1))"""
+    hidden, C_ = 96, 2
+    cfg = R.Config(2, 0, 2, hidden, C_, n_layers=2, gravity=[0, -1, 0])
+    inp = _batch([9, 5], 3, C_, seed=4)
+    inp["edge_index"] = torch.zeros(2, 0, dtype=torch.long)
+    inp["edge_attr"] = torch.zeros(0, 2)
+    _check_vs_oracle(cfg, inp, seed=4, case="wide_no_edges")
