@@ -21,6 +21,24 @@ from .model import _stream
 MAX_WIDE = 256
 
 
+class HipOps:
+    """The operators on libfastegnn_hip.so (the product path).  tests/test_wide_cpu.py drives the same orchestration through a
+    torch restatement of these nine calls on CPU (test infrastructure, as tests/cpu_stage_backend.py does for the sharded path)."""
+
+    @staticmethod
+    def call(name, *args):
+        dev = next(a.device for a in args if torch.is_tensor(a))
+        K.check(getattr(K.lib(), "fastegnn_wide_" + name)(*[K.ptr(a) if torch.is_tensor(a) or a is None else a for a in args],
+                                                          _stream(dev)), "fastegnn_wide_" + name)
+
+
+_OPS = HipOps
+
+
+def _call(name, *args):
+    _OPS.call(name, *args)
+
+
 def _f32(t):
     return t.contiguous().float()
 
@@ -35,8 +53,7 @@ class _Linear(torch.autograd.Function):
         out = torch.empty(M, O, dtype=torch.float32, device=X.device)
         b = _f32(bias) if bias is not None else None
         bs = _f32(base) if base is not None else None
-        K.check(K.lib().fastegnn_wide_linear(K.ptr(X), M, Kc, K.ptr(W), W.size(1), c0, K.ptr(b), K.ptr(bs), K.ptr(out), O,
-                                             _stream(X.device)), "fastegnn_wide_linear")
+        _call("linear", X, M, Kc, W, W.size(1), c0, b, bs, out, O)
         ctx.save_for_backward(X, W)
         ctx.meta = (c0, Kc, bias is not None, base is not None)
         return out
@@ -47,17 +64,15 @@ class _Linear(torch.autograd.Function):
         c0, Kc, has_bias, has_base = ctx.meta
         g = _f32(g)
         M, O = g.shape
-        lib, st = K.lib(), _stream(g.device)
         gX = gW = gb = None
         if ctx.needs_input_grad[0]:
             gX = torch.empty(M, Kc, dtype=torch.float32, device=g.device)
-            K.check(lib.fastegnn_wide_linear_dx(K.ptr(g), M, O, K.ptr(W), W.size(1), c0, Kc, K.ptr(gX), 0, st), "fastegnn_wide_linear_dx")
+            _call("linear_dx", g, M, O, W, W.size(1), c0, Kc, gX, 0)
         want_w, want_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[4]
         if want_w or want_b:
             gW = torch.zeros_like(W) if want_w else None
             gb = torch.zeros(O, dtype=torch.float32, device=g.device) if want_b else None
-            K.check(lib.fastegnn_wide_linear_dw(K.ptr(g), K.ptr(X), M, O, Kc, K.ptr(gW), W.size(1), c0, K.ptr(gb), st),
-                    "fastegnn_wide_linear_dw")
+            _call("linear_dw", g, X, M, O, Kc, gW, W.size(1), c0, gb)
         return gX, gW, None, None, gb, (g if has_base else None)
 
 
@@ -66,7 +81,7 @@ class _Act(torch.autograd.Function):
     def forward(ctx, z, kind, p):
         z = _f32(z)
         y = torch.empty_like(z)
-        K.check(K.lib().fastegnn_wide_act(K.ptr(z), z.numel(), kind, p, K.ptr(y), _stream(z.device)), "fastegnn_wide_act")
+        _call("act", z, z.numel(), kind, p, y)
         ctx.save_for_backward(z)
         ctx.meta = (kind, p)
         return y
@@ -76,8 +91,7 @@ class _Act(torch.autograd.Function):
         (z,) = ctx.saved_tensors
         g = _f32(g)
         dz = torch.empty_like(z)
-        K.check(K.lib().fastegnn_wide_act_backward(K.ptr(z), K.ptr(g), z.numel(), ctx.meta[0], ctx.meta[1], K.ptr(dz),
-                                                   _stream(z.device)), "fastegnn_wide_act_backward")
+        _call("act_backward", z, g, z.numel(), ctx.meta[0], ctx.meta[1], dz)
         return dz, None, None
 
 
@@ -90,8 +104,7 @@ class _GatherAdd(torch.autograd.Function):
         M, W = idx.numel(), X.size(1)
         out = torch.empty(M, W, dtype=torch.float32, device=X.device)
         bs = _f32(base) if base is not None else None
-        K.check(K.lib().fastegnn_wide_gather_add(K.ptr(X), K.ptr(idx), M, W, K.ptr(bs), K.ptr(out), _stream(X.device)),
-                "fastegnn_wide_gather_add")
+        _call("gather_add", X, idx, M, W, bs, out)
         ctx.save_for_backward(idx)
         ctx.meta = (X.size(0), base is not None)
         return out
@@ -103,8 +116,7 @@ class _GatherAdd(torch.autograd.Function):
         gX = None
         if ctx.needs_input_grad[0]:
             gX = torch.zeros(ctx.meta[0], g.size(1), dtype=torch.float32, device=g.device)
-            K.check(K.lib().fastegnn_wide_scatter_add(K.ptr(gX), K.ptr(idx), idx.numel(), g.size(1), K.ptr(g), _stream(g.device)),
-                    "fastegnn_wide_scatter_add")
+            _call("scatter_add", gX, idx, idx.numel(), g.size(1), g)
         return gX, None, (g if ctx.meta[1] else None)
 
 
@@ -115,8 +127,7 @@ class _ScatterAdd(torch.autograd.Function):
     def forward(ctx, rows, idx, R):
         rows = _f32(rows)
         table = torch.zeros(R, rows.size(1), dtype=torch.float32, device=rows.device)
-        K.check(K.lib().fastegnn_wide_scatter_add(K.ptr(table), K.ptr(idx), idx.numel(), rows.size(1), K.ptr(rows),
-                                                  _stream(rows.device)), "fastegnn_wide_scatter_add")
+        _call("scatter_add", table, idx, idx.numel(), rows.size(1), rows)
         ctx.save_for_backward(idx)
         return table
 
@@ -125,8 +136,7 @@ class _ScatterAdd(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         g = _f32(g)
         out = torch.empty(idx.numel(), g.size(1), dtype=torch.float32, device=g.device)
-        K.check(K.lib().fastegnn_wide_gather_add(K.ptr(g), K.ptr(idx), idx.numel(), g.size(1), None, K.ptr(out), _stream(g.device)),
-                "fastegnn_wide_gather_add")
+        _call("gather_add", g, idx, idx.numel(), g.size(1), None, out)
         return out, None, None
 
 
@@ -137,8 +147,7 @@ class _RowScale(torch.autograd.Function):
     def forward(ctx, X, s):
         X, s = _f32(X), _f32(s)
         Y = torch.empty_like(X)
-        K.check(K.lib().fastegnn_wide_rowscale(K.ptr(X), K.ptr(s), X.size(0), X.size(1), K.ptr(Y), _stream(X.device)),
-                "fastegnn_wide_rowscale")
+        _call("rowscale", X, s, X.size(0), X.size(1), Y)
         ctx.save_for_backward(X, s)
         return Y
 
@@ -146,14 +155,13 @@ class _RowScale(torch.autograd.Function):
     def backward(ctx, g):
         X, s = ctx.saved_tensors
         g = _f32(g)
-        lib, st = K.lib(), _stream(g.device)
         gX = gs = None
         if ctx.needs_input_grad[0]:
             gX = torch.empty_like(X)
-            K.check(lib.fastegnn_wide_rowscale(K.ptr(g), K.ptr(s), X.size(0), X.size(1), K.ptr(gX), st), "fastegnn_wide_rowscale")
+            _call("rowscale", g, s, X.size(0), X.size(1), gX)
         if ctx.needs_input_grad[1]:
             gs = torch.empty(X.size(0), dtype=torch.float32, device=g.device)
-            K.check(lib.fastegnn_wide_rowdot(K.ptr(g), K.ptr(X), X.size(0), X.size(1), K.ptr(gs), st), "fastegnn_wide_rowdot")
+            _call("rowdot", g, X, X.size(0), X.size(1), gs)
         return gX, gs
 
 

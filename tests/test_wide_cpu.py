@@ -1,0 +1,121 @@
+"""CPU: the orchestration of the wide path (fastegnn_amd/wide.py: hidden_nf > 64, EGNN flat=True) through a torch restatement of
+the nine fastegnn_wide_* operators -- TEST INFRASTRUCTURE standing in for csrc/wide.hip, as tests/cpu_stage_backend.py does for
+the sharded path -- against the goldens captured from the reference classes.  What this pins without a GPU: the op sequence, the
+column-block bookkeeping of every Linear over a torch.cat, the (n, c) row layouts, the autograd wiring.  The operators themselves
+are checked against the same torch arithmetic on the GPU (tests/test_gpu_wide.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import fastegnn_amd
+from fastegnn_amd import _lib as K
+from fastegnn_amd import wide
+from tests.helpers import Golden, check_parity, golden_loss, rel_err
+
+
+def _fn(kind, p):
+    return {K.ACT_SILU: F.silu, K.ACT_RELU: F.relu, K.ACT_LEAKY_RELU: lambda z: F.leaky_relu(z, p), K.ACT_TANH: torch.tanh,
+            K.ACT_SIGMOID: torch.sigmoid, K.ACT_ELU: lambda z: F.elu(z, p), K.ACT_GELU: F.gelu,
+            K.ACT_SOFTPLUS: lambda z: F.softplus(z, beta=p, threshold=20.0)}[kind]
+
+
+class TorchOps:
+    """include/fastegnn_hip.h "the WIDE path", one method per entry point, same argument order"""
+
+    @staticmethod
+    def call(name, *a):
+        getattr(TorchOps, name)(*a)
+
+    @staticmethod
+    def linear(X, M, Kc, W, ldw, c0, bias, base, out, O):
+        assert W.shape == (O, ldw) and X.shape == (M, Kc) and out.shape == (M, O)
+        r = X @ W[:, c0:c0 + Kc].t()
+        out.copy_(r + (bias if bias is not None else 0) + (base if base is not None else 0))
+
+    @staticmethod
+    def linear_dx(G, M, O, W, ldw, c0, Kc, dX, accumulate):
+        r = G @ W[:, c0:c0 + Kc]
+        dX.copy_(dX + r if accumulate else r)
+
+    @staticmethod
+    def linear_dw(G, X, M, O, Kc, dW, ldw, c0, db):
+        if dW is not None:
+            dW[:, c0:c0 + Kc] += G.t() @ X
+        if db is not None:
+            db += G.sum(0)
+
+    @staticmethod
+    def act(z, n, kind, p, y):
+        y.copy_(_fn(kind, p)(z))
+
+    @staticmethod
+    def act_backward(z, dy, n, kind, p, dz):
+        with torch.enable_grad():
+            zz = z.detach().clone().requires_grad_(True)
+            _fn(kind, p)(zz).backward(dy)
+        dz.copy_(zz.grad)
+
+    @staticmethod
+    def gather_add(X, idx, M, W, base, out):
+        out.copy_(X[idx] + (base if base is not None else 0))
+
+    @staticmethod
+    def scatter_add(table, idx, M, W, rows):
+        table.index_add_(0, idx, rows)
+
+    @staticmethod
+    def rowscale(X, s, M, W, Y):
+        Y.copy_(X * s.unsqueeze(1))
+
+    @staticmethod
+    def rowdot(A, B, M, W, out):
+        out.copy_((A * B).sum(1))
+
+
+@pytest.fixture
+def torch_ops(monkeypatch):
+    monkeypatch.setattr(wide, "_OPS", TorchOps)
+
+
+def test_wide_fastegnn_orchestration_matches_reference_golden(torch_ops):
+    from tests.gpu_util import model_from_golden
+    g = Golden("wide_h128_two_graphs")
+    m = model_from_golden(g, device="cpu")
+    kw, target, wv = g.model_kwargs()
+    leaf = {k: kw[k].clone().requires_grad_(True) for k in ("node_feat", "node_loc", "node_vel", "loc_mean")}
+    kw.update(leaf)
+    loc, vloc = wide.forward(m, **kw)
+    golden_loss(loc, vloc, target, wv).backward()
+    G = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+    msgs = check_parity(g, loc.detach(), vloc.detach(), G, {k: v.grad for k, v in leaf.items()})
+    assert not msgs, msgs
+
+
+def test_wide_fastrf_orchestration_matches_reference_golden(torch_ops):
+    from tests.gpu_util import model_from_golden
+    g = Golden("fastrf_h128")
+    m = model_from_golden(g, device="cpu", cls=fastegnn_amd.FastRF)
+    kw, target, wv = g.model_kwargs()
+    kw.pop("node_attr")
+    loc, vloc = wide.forward(m, **kw)
+    assert rel_err(loc, g.out["loc"]) < 1e-5 and rel_err(vloc, g.out["vloc"]) < 1e-5
+    golden_loss(loc, vloc, target, wv).backward()
+    for k, p in m.named_parameters():
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert rel_err(got, g.gp[k]) < 5e-5, (k, rel_err(got, g.gp[k]))
+
+
+@pytest.mark.parametrize("name", ["egnn_flat", "egnn_h128"])
+def test_wide_egnn_orchestration_matches_reference_golden(torch_ops, name):
+    from tests.test_egnn_oracle_cpu import egnn_loss, load_egnn
+    g = load_egnn(name)
+    m = fastegnn_amd.EGNN(n_layers=int(g["meta"]["L"]), in_node_nf=2, in_edge_nf=2, hidden_nf=int(g["meta"]["hidden"]),
+                          with_v=bool(int(g["meta"]["with_v"])), norm=bool(int(g["meta"]["norm"])), flat=bool(int(g["meta"]["flat"])))
+    m.load_state_dict(g["p"], strict=True)
+    i = g["in"]
+    x, h = wide.egnn_forward(m, i["x"], i["h"], i["edge_index"], i["edge_fea"], i.get("v"))
+    assert rel_err(x, g["out"]["x"]) < 1e-5 and rel_err(h, g["out"]["h"]) < 2e-5
+    egnn_loss(x, h, i["target"], i["wh"]).backward()
+    for k, p in m.named_parameters():
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert rel_err(got, g["gp"][k]) < 5e-5, (k, rel_err(got, g["gp"][k]))
