@@ -608,6 +608,8 @@ class FastEGNN(nn.Module):
             raise ValueError("node_attr width does not match node_attr_nf")
         if self._wide:
             from . import wide
+            if isinstance(edge_index, SortedGraph):
+                raise TypeError("fastegnn_amd: the wide path (hidden_nf > 64) takes edge_index as the reference does, an int64 [2, E] tensor")
             if _DEBUG_CHECKS:
                 _check_indices(edge_index, data_batch, node_loc.size(0), loc_mean.size(0))
             if edge_attr is not None and edge_attr.size(1) == 0:
