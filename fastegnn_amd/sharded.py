@@ -142,11 +142,11 @@ class HipBackend:
     def stage(self, name, spec, N, B, graph, t: Dict[str, torch.Tensor], params, grads=None, flags=0):
         L = _new_layer(spec, N, B, graph)
         L.flags |= flags
-        ptab = _PtrTable(params)
+        ptab = params.ptab() if isinstance(params, _LayerList) else _PtrTable(params)
         keep = [ptab]
         _fill(L, params=ptab.addr(), **{k: v for k, v in t.items() if v is not None})
         if grads is not None:
-            gtab = _PtrTable(grads)
+            gtab = grads.ptab() if isinstance(grads, _LayerList) else _PtrTable(grads)
             keep.append(gtab)
             _fill(L, grads=gtab.addr())
         K.check(getattr(self.lib, "fastegnn_" + name)(C.byref(L), _stream(self.dev)), "fastegnn_" + name)
@@ -607,8 +607,24 @@ class _Comm:
         return _Timed(dist.reduce_scatter_tensor(out, inp, group=self.group, async_op=not self.sync) or _Done(), rec)
 
 
+class _LayerList(list):
+    """The FASTEGNN_P_* ordered tensors of one layer.  The host array of their device pointers is built once and lives with the
+    list (a stage call needs it; a layer makes 6 forward / 7 backward stage calls with the same list -- 38 data_ptr() calls each)."""
+
+    _ptab = None
+
+    def ptab(self):
+        if self._ptab is None:
+            self._ptab = _PtrTable(self)
+            # no reference back to the list: a cycle would keep the gradient views alive past the backward, and autograd's
+            # AccumulateGrad then CLONES them instead of adopting the slices of the one flat buffer (dist.allreduce_gradients
+            # reduces that buffer in place)
+            self._ptab.keep = None
+        return self._ptab
+
+
 def _layer_lists(spec: _Spec, params, i):
-    return [params[s] if s is not None else None for s in spec.layer_slots[i]]
+    return _LayerList(params[s] if s is not None else None for s in spec.layer_slots[i])
 
 
 class _Part:
