@@ -119,3 +119,40 @@ def test_wide_egnn_orchestration_matches_reference_golden(torch_ops, name):
     for k, p in m.named_parameters():
         got = p.grad if p.grad is not None else torch.zeros_like(p)
         assert rel_err(got, g["gp"][k]) < 5e-5, (k, rel_err(got, g["gp"][k]))
+
+
+@pytest.mark.parametrize("flags", [dict(tanh=True, normalize=True, gravity=[0.2, -1, 0.1]), dict(residual=False, attention=True),
+                                   dict(act="elu", act_param=1.3, gravity=[0, -1, 0]), dict(coords_agg="sum")])
+def test_wide_fastegnn_flags_match_the_oracle(torch_ops, flags):
+    """every constructor flag (and coords_agg='sum', node_attr, a non-SiLU activation) through the wide orchestration against the
+    oracle, fp32 torch arithmetic on both sides: only wiring differences would show"""
+    from oracle import fastegnn_ref as R
+    from tests.gpu_util import act_module
+    hidden, C_, na = 72, 3, 2
+    cfg = R.Config(2, na, 2, hidden, C_, n_layers=2, **flags)
+    g = torch.Generator().manual_seed(3)
+    sizes = [9, 6]
+    N = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(2), torch.tensor(sizes))
+    ei = torch.cat([torch.randint(0, 9, (2, 30), generator=g), 9 + torch.randint(0, 6, (2, 14), generator=g)], 1)
+    loc = torch.randn(N, 3, generator=g)
+    cm = torch.zeros(2, 3).index_add_(0, batch, loc) / torch.tensor(sizes).unsqueeze(1)
+    inp = dict(node_feat=torch.rand(N, 2, generator=g), node_loc=loc, node_vel=torch.randn(N, 3, generator=g) * 0.3, edge_index=ei,
+               data_batch=batch, loc_mean=cm.unsqueeze(-1).repeat(1, 1, C_), edge_attr=torch.rand(ei.size(1), 2, generator=g),
+               node_attr=torch.rand(N, na, generator=g))
+    p = R.init_params(cfg, seed=5, coord_gain=0.05)
+    kw = {k: v for k, v in flags.items() if k not in ("act", "act_param", "coords_agg")}
+    m = fastegnn_amd.FastEGNN(2, na, 2, hidden, C_, n_layers=2, act_fn=act_module(cfg), **kw)
+    m.load_state_dict(p, strict=True)
+    if flags.get("coords_agg") == "sum":
+        m._extra_flags |= K.F_COORDS_SUM
+    loc_w, vloc_w = wide.forward(m, **inp)
+    (loc_w.pow(2).mean() + vloc_w.pow(2).mean()).backward()
+    pp = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    l, v = R.forward(pp, cfg, **inp)
+    (l.pow(2).mean() + v.pow(2).mean()).backward()
+    assert rel_err(loc_w, l) < 2e-6 and rel_err(vloc_w, v) < 2e-6
+    for k, prm in m.named_parameters():
+        ref = pp[k].grad if pp[k].grad is not None else torch.zeros_like(pp[k])
+        got = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+        assert rel_err(got, ref) < 2e-4, (k, rel_err(got, ref))
