@@ -179,3 +179,24 @@ def test_weight_gradient_slab_planning_never_exhausts_its_share():
     out = (C.c_int32 * 3)()
     rc = L.fastegnn_selftest_wgrad_plan((C.c_int64 * 3)(10 ** 6, 10 ** 6, 10 ** 6), (C.c_int32 * 3)(1, 1, 1), 3, 0, 0, 384, 2, out)
     assert rc != 0
+
+
+def test_layer_list_pointer_table_does_not_outlive_its_tensors():
+    """fastegnn_amd.sharded._LayerList caches the host pointer table of a layer's tensors.  It must not form a reference cycle:
+    the gradient views of a backward have to die with the backward, or autograd's AccumulateGrad clones them instead of adopting
+    the slices of the one flat buffer that dist.allreduce_gradients reduces in place (the 2-rank GPU tests caught exactly that)."""
+    import gc
+    import weakref
+    from fastegnn_amd.sharded import _LayerList
+    gc.collect()
+    gc.disable()
+    try:
+        flat = torch.zeros(64)
+        lst = _LayerList([flat[0:8], None, flat[8:16]] + [None] * (K.P_COUNT - 3))
+        ref = weakref.ref(lst[0])
+        tab = lst.ptab()
+        assert tab is lst.ptab() and tab.arr[0] == flat.data_ptr() and tab.arr[1] is None
+        del lst, tab
+        assert ref() is None          # freed by reference counting alone (the collector is off)
+    finally:
+        gc.enable()
