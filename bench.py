@@ -33,8 +33,6 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak (= fp32 vector peak)
 PEAK_MFMA_BF16_TFLOPS = 2500.0 # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak
-BF16X3_CEILING_TFLOPS = 224.0  # measured chain of bf16x3 64x64 products (fp32-equivalent FLOPs), DESIGN.md section 4
-F16X2_CEILING_TFLOPS = 314.0   # the same chain (split + product + SiLU, 4 waves / SIMD) on f16x2 products: tools/gpu_bf3.py, round 4
 H = 64
 UNIT = 2 * H * H               # FLOPs of one 64x64 mat-vec
 
@@ -388,6 +386,34 @@ def latest_traffic():
     return json.load(open(files[-1])), os.path.basename(files[-1])
 
 
+def latest_sq_counters():
+    """Per-launch SQ counters of the fused kernels from the newest tracked capture (tools/gpu_sq.sh -> profiles/sq_counters_rNN.json):
+    what the matrix pipe really executed (SQ_INSTS_VALU_MFMA_MOPS_*: 512 FLOP per count) and how busy it was."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "sq_counters_r*.json")))
+    if not files:
+        return {}, None
+    return json.load(open(files[-1])), os.path.basename(files[-1])
+
+
+# profiler ids (fastegnn_profile_name) -> kernel names of the counter capture
+_SQ_NAMES = {"virt_bwd_kernel": "fe::virt_bwd_pc_kernel", "edge_bwd_kernel": "fe::edge_bwd_pc_kernel", "edge_fwd_kernel": "fe::edge_fwd_kernel",
+             "virt_fwd_kernel": "fe::virt_fwd_kernel", "node_pre_fwd_kernel": "fe::node_pre_fwd_kernel",
+             "node_pre_bwd_kernel": "fe::node_pre_bwd_kernel", "virt_bwd_node_kernel": "fe::virt_bwd_node_kernel",
+             "virt_bwd_gv_kernel": "fe::virt_bwd_gv_kernel"}
+
+
+def matrix_pipe(sq, name, launch_s):
+    """(matrix_pipe_util, mfma_busy) of a kernel: the 16-bit MFMA work the counters saw per launch / this run's launch duration /
+    the dense 16-bit peak, and the tracked busy share of the matrix pipe.  None when the capture has no such kernel."""
+    c = sq.get(_SQ_NAMES.get(name, name))
+    if not c:
+        return None, None
+    mops = c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0) + c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
+    util = mops * 512.0 / launch_s / (PEAK_MFMA_BF16_TFLOPS * 1e12)
+    return round(util, 4), (round(c["mfma_busy"], 4) if c.get("mfma_busy") is not None else None)
+
+
 # ------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -639,6 +665,9 @@ def main():
         km = kernel_model(kN, kE, B, C, L, gravity=cfg["gravity"] is not None)
         ob = operand_bytes(kN, kE, B, C, gravity=cfg["gravity"] is not None)
         kernels = {}
+        rfree = recompute_free_units(kN, kE, B, C)
+        sq, sq_file = latest_sq_counters() if (args.config == "cfg4" and not sharded and dtype != "bf16") else ({}, None)
+        sq_meta = sq.get("_meta", {}) if sq else {}
         for name, (ms, cnt) in prof.items():
             per_step = ms / prof_steps
             launch_s = ms / cnt * 1e-3
@@ -646,38 +675,45 @@ def main():
                    "avg_launch_ms": round(ms / cnt, 5)}
             if name in km:
                 fl, by = km[name]
-                ent["tflops"] = round(fl / launch_s / 1e12, 3)                 # algorithmic FLOPs per launch / launch duration
+                # fp32-EQUIVALENT rate: algorithmic 64x64 products per launch (recomputed ones included) x 8192 FLOP / launch duration.
+                # The products run as 16-bit MFMAs (f16x2 / bf16x3 splits): this is not a fraction of any pipe's peak and may exceed
+                # the 157.3 TFLOP/s of the fp32-input MFMA; what the matrix pipe did is `matrix_pipe_util`
+                ent["fp32_equivalent_tflops"] = round(fl / launch_s / 1e12, 3)
                 if by is not None:
                     ent["gbs"] = round(by / launch_s / 1e9, 1)                   # SURVEY 8d algorithmic bytes per launch
+                util, busy = matrix_pipe(sq, name, launch_s)
+                if util is not None:
+                    ent["matrix_pipe_util"] = util
+                    ent["mfma_busy"] = busy
             if name == "edge_col_reduce_kernel":
                 ent["operand_gbs"] = round(ob[name] / launch_s / 1e9, 1)
-            if name == "wgrad_tn_kernel":   # two launches per layer: the layer-wide batch and the per-channel node_mlp.0 job
+            if name == "wgrad_tn_kernel":   # the layer-wide batch (and, before round 5, the per-channel node_mlp.0 job)
                 tot = ob["wgrad_tn_kernel[layer batch]"] + ob["wgrad_tn_kernel[v job]"]
                 ent["operand_gbs"] = round(tot / (2 * launch_s) / 1e9, 1)
             kernels[name] = ent
         dom = max((n for n in kernels if n in km), key=lambda n: kernels[n]["ms_per_step"])
         fl, by = km[dom]
+        fl_alg = rfree.get(dom, fl)            # without the forward products a backward kernel recomputes (bwd = 2 x fwd)
+        launch_s = kernels[dom]["avg_launch_ms"] * 1e-3
         peak_mfma = PEAK_MFMA_BF16_TFLOPS if dtype == "bf16" else PEAK_MFMA_F32_TFLOPS
         t_mfma = fl / (peak_mfma * 1e12)
         t_hbm = (by or 0) / (PEAK_HBM_GBS * 1e9)
         tr, tr_file = latest_traffic()
         traffic = tr.get(dom, {}).get("hbm_bytes_per_launch") if (args.config == "cfg4" and not sharded) else None
         if t_mfma >= t_hbm:
-            roof = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak_mfma,
-                    "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / peak_mfma, 4), "traffic": traffic}
-            # the same fraction without the forward products a backward kernel recomputes (3 of virt_bwd's 9 units per (node,
-            # channel), 2 of edge_bwd's 6 per edge): `frac` counts executed algorithmic work, this one useful work
-            rf = recompute_free_units(kN, kE, B, C).get(dom)
-            roof["frac_algorithmic"] = round((rf / fl) * roof["frac"], 4) if rf else roof["frac"]
-            if dtype != "bf16":
-                # the fp32-grade products of this kernel are bf16x3 on the matrix pipe; a bare chain of them reaches
-                # 224 TFLOP/s fp32-equivalent on this part (tools/gpu_bf3.py): the kernel's real ceiling
-                roof["frac_of_bf16x3_ceiling"] = round(kernels[dom]["tflops"] / BF16X3_CEILING_TFLOPS, 4)
-                roof["frac_algorithmic_of_bf16x3_ceiling"] = round(roof["frac_algorithmic"] * peak_mfma / BF16X3_CEILING_TFLOPS, 4)
-                # since round 4 the producers of the fused kernels multiply on f16x2 products (3 MFMAs instead of 6), whose bare
-                # chain reaches 314 TFLOP/s fp32-equivalent: the fractions against THAT ceiling are the honest ones
-                roof["frac_of_f16x2_ceiling"] = round(kernels[dom]["tflops"] / F16X2_CEILING_TFLOPS, 4)
-                roof["frac_algorithmic_of_f16x2_ceiling"] = round(roof["frac_algorithmic"] * peak_mfma / F16X2_CEILING_TFLOPS, 4)
+            # achieved = ALGORITHMIC FLOPs (the transposed products and the weight-gradient contractions of a backward
+            # kernel, NOT its recomputed forward products) per launch / the launch duration measured in this run; peak = the dense
+            # MFMA peak of the arithmetic type (fp32: 157.3 TFLOP/s).  Recomputation and the 16-bit split products therefore show up
+            # as lost efficiency, never as achieved work.
+            ach = fl_alg / launch_s / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": peak_mfma,
+                    "unit": "TFLOP/s", "frac": round(ach / peak_mfma, 4), "traffic": traffic,
+                    "algorithmic_flops_per_launch": fl_alg, "executed_product_flops_per_launch": fl}
+            util, busy = matrix_pipe(sq, dom, launch_s)
+            roof["matrix_pipe_util"] = util      # 16-bit MFMA FLOPs the counters saw / duration / 2.5 PFLOP/s dense
+            roof["mfma_busy"] = busy             # SQ_VALU_MFMA_BUSY_CYCLES / the SIMDs' time, from the tracked capture
+            roof["counters_source"] = (f"profiles/{sq_file}: rocprofv3 --pmc passes (tools/gpu_sq.sh) of commit "
+                                       f"{sq_meta.get('commit', '?')}, not of this run; durations are this run's") if util is not None else None
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["gbs"], "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic}
@@ -688,8 +724,8 @@ def main():
         if es:
             edge_scatter = {"kernel": "edge_fwd_kernel", "algorithmic_bytes_per_launch": 280 * kE + 540 * kN,
                             "achieved_GBs": es["gbs"], "frac_of_hbm_peak": round(es["gbs"] / PEAK_HBM_GBS, 4),
-                            "achieved_TFLOPs": es["tflops"],
-                            "frac_of_mfma_f32_peak": round(es["tflops"] / PEAK_MFMA_F32_TFLOPS, 4)}
+                            "fp32_equivalent_tflops": es["fp32_equivalent_tflops"],
+                            "matrix_pipe_util": es.get("matrix_pipe_util"), "mfma_busy": es.get("mfma_busy")}
         if sharded:
             par = f"row-owner sharding of ONE batch over {world} GPU(s) (fastegnn_amd/sharded.py), strong scaling"
         elif world > 1:

@@ -9,16 +9,32 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FASTEGNN_SAFE_WAITS=1 loads the -DFE_SAFE_WAITS build of the same sources (csrc/Makefile): every hand-counted wait,
+# FASTEGNN_SAFE_WAITS=1 loads the -DFE_SAFE_WAITS build of the same sources (csrc/Makefile, `make safe`): every hand-counted wait,
 # LDS-DMA copy and relaxed LDS flag in its conservative form.  Same ABI, same results; a diagnostic, not a fallback.
 SAFE_WAITS = os.environ.get("FASTEGNN_SAFE_WAITS", "0") not in ("", "0")
-# FASTEGNN_WIDE_RANGE=1 loads the build without the f16x2 products (csrc/Makefile: libfastegnn_hip_x3.so, the bf16x3 arithmetic of
-# rounds 1-3): fp32's exponent range for every operand, ~6 % slower.  The default build's f16x2 operands overflow beyond 65 504.
-WIDE_RANGE = os.environ.get("FASTEGNN_WIDE_RANGE", "0") not in ("", "0")
-LIB_PATH = os.path.join(_HERE, "libfastegnn_hip_safe.so" if SAFE_WAITS else
-                        ("libfastegnn_hip_x3.so" if WIDE_RANGE else "libfastegnn_hip.so"))
+# Operand range.  The default build multiplies on 2-part fp16 splits (f16x2): hidden activations and [64,64] weights must stay below
+# 65 504 in magnitude, which the reference's plain fp32 (models/FastEGNN.py:102-119) does not require.  The modules therefore guard
+# every eager forward (fastegnn_check_finite on the outputs) and re-run a call that left the range on the wide-range build
+# (libfastegnn_hip_x3.so / _act_x3.so: 3-part bf16 splits, fp32's exponent range, ~8 % slower), staying there.
+#   FASTEGNN_WIDE_RANGE unset : automatic (above)        =1 : wide-range build from the first call        =0 : f16x2 build, overflow raises
+_wr = os.environ.get("FASTEGNN_WIDE_RANGE", "")
+WIDE_RANGE = None if _wr == "" else _wr != "0"
+if SAFE_WAITS and WIDE_RANGE:
+    raise RuntimeError("fastegnn_amd: FASTEGNN_SAFE_WAITS=1 (a diagnostic build of the f16x2 arithmetic) cannot be combined with "
+                       "FASTEGNN_WIDE_RANGE=1")
 
-ABI_VERSION = 104   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
+
+def lib_path(act: bool = False, wide: bool = False) -> str:
+    if SAFE_WAITS:
+        if act:
+            raise RuntimeError("fastegnn_amd: FASTEGNN_SAFE_WAITS=1 has no generic-activation build (act_fn must be SiLU)")
+        return os.path.join(_HERE, "libfastegnn_hip_safe.so")
+    return os.path.join(_HERE, "libfastegnn_hip" + ("_act" if act else "") + ("_x3" if wide else "") + ".so")
+
+
+LIB_PATH = lib_path(False, bool(WIDE_RANGE))   # the library the stage-independent helpers (CSR, graphs, training step, comm) use
+
+ABI_VERSION = 105   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
 H = 64
 QX_LD = 68
 FEATW = 8
@@ -85,17 +101,18 @@ class LayerT(C.Structure):
 
 
 _libs = {}
-ACT_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfastegnn_hip_act.so")
+ACT_LIB_PATH = lib_path(True, bool(WIDE_RANGE)) if not SAFE_WAITS else None
 # activation kinds of the FASTEGNN_F_ACT bits (include/fastegnn_hip.h)
 F_ACT_SHIFT = 11
 ACT_SILU, ACT_RELU, ACT_LEAKY_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU, ACT_GELU, ACT_SOFTPLUS = range(8)
 
 
-def lib(act: bool = False):
-    """Load the HIP library; raises (never falls back) when it is missing.  act=True: the generic-activation build
-    (libfastegnn_hip_act.so, -DFE_ACT_GENERIC) -- the layer / stage calls of a model whose act_fn is not SiLU go there;
-    the default library rejects their flags."""
-    path = ACT_LIB_PATH if act else LIB_PATH
+def lib(act: bool = False, wide=None):
+    """Load a build of the HIP library; raises (never falls back to a CPU path) when it is missing.
+    act=True: the generic-activation build (-DFE_ACT_GENERIC) -- the layer / stage calls of a model whose act_fn is not SiLU go
+    there; the default library rejects their flags.  wide: True = the wide-range (bf16x3) form, False = the f16x2 form,
+    None = what FASTEGNN_WIDE_RANGE selects (f16x2 unless it is 1)."""
+    path = lib_path(act, bool(WIDE_RANGE) if wide is None else bool(wide))
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
@@ -105,6 +122,8 @@ def lib(act: bool = False):
     L = C.CDLL(path)
     if bool(L.fastegnn_generic_activations()) != act:
         raise RuntimeError(f"fastegnn_amd: {path} is not the {'generic-activation' if act else 'SiLU'} build")
+    if bool(L.fastegnn_f16_operands()) == path.endswith("_x3.so"):
+        raise RuntimeError(f"fastegnn_amd: {path} was not built with the arithmetic its name says (csrc/Makefile)")
     L.fastegnn_last_error.restype = C.c_char_p
     L.fastegnn_version.restype = C.c_int
     if L.fastegnn_version() != ABI_VERSION:
@@ -171,6 +190,7 @@ def lib(act: bool = False):
     L.fastegnn_comm_all_gather.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp]
     L.fastegnn_comm_reduce_scatter.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp]
     L.fastegnn_comm_all_to_all_v.argtypes = [_vp, _vp, C.POINTER(C.c_int64), _vp, C.POINTER(C.c_int64), _i32, _vp]
+    L.fastegnn_check_finite.argtypes = [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp]
     L.fastegnn_gather_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_scatter_add_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_wg_slab_floats.restype = C.c_size_t
@@ -214,7 +234,7 @@ STAGE_FUNCS = [
 # every symbol include/fastegnn_hip.h declares (checked by tests/test_abi_cpu.py)
 EXPORTED = STAGE_FUNCS + [
     "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_wg_edge_floats", "fastegnn_wg_virt_floats", "fastegnn_wg_virt_floats_for", "fastegnn_backward_scratch_floats_for", "fastegnn_wg_node_floats", "fastegnn_backward_scratch_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes", "fastegnn_chunk_rows", "fastegnn_chunk_edges",
-    "fastegnn_build_csr", "fastegnn_pad_params", "fastegnn_generic_activations", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
+    "fastegnn_build_csr", "fastegnn_pad_params", "fastegnn_generic_activations", "fastegnn_f16_operands", "fastegnn_check_finite", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_rm", "fastegnn_selftest_jreduce", "fastegnn_selftest_lane_sums", "fastegnn_selftest_wgrad", "fastegnn_selftest_wgrad_plan", "fastegnn_selftest_wgrad_guard", "fastegnn_selftest_stream", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
     "fastegnn_augment_edge_attr", "fastegnn_loss_mse_mmd", "fastegnn_adam_step",

@@ -176,9 +176,28 @@ __global__ void scatter_add_rows_kernel(float *table, const int64_t *ids, long n
   if (i >= n * w) return;
   atomicAdd(&table[ids[i / w] * w + i % w], rows[i]);
 }
+// *flag |= 1 when a value of a / b is Inf or NaN (the exponent field is all ones); grid-stride, one atomic per offending wave
+__global__ __launch_bounds__(256) void check_finite_kernel(const unsigned *a, long na, const unsigned *b, long nb, int *flag) {
+  bool bad = false;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) bad |= (a[i] & 0x7f800000u) == 0x7f800000u;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) bad |= (b[i] & 0x7f800000u) == 0x7f800000u;
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
 }  // namespace fe
 
 extern "C" {
+int fastegnn_f16_operands(void) { return (FE_FWD_F16 | FE_BWD_F16) != 0 ? 1 : 0; }
+int fastegnn_check_finite(const float *a, int64_t na, const float *b, int64_t nb, int32_t *flag, void *stream) {
+  FE_REQUIRE(flag && (a || na == 0) && (b || nb == 0) && na >= 0 && nb >= 0, "fastegnn_check_finite: null pointer");
+  if (na + nb == 0) return FASTEGNN_OK;
+  long n = na > nb ? na : nb;
+  int grid = fe::cdiv(n, 256 * 8);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(fe::check_finite_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned *>(a),
+                     (long)na, reinterpret_cast<const unsigned *>(b), (long)nb, flag);
+  return fe::check_launch("check_finite_kernel");
+}
 int fastegnn_gather_rows(const float *table, const int64_t *ids, int64_t n, int32_t width, float *out, void *stream) {
   FE_REQUIRE(width > 0 && width % 4 == 0, "fastegnn_gather_rows: width must be a multiple of 4");
   if (n == 0) return FASTEGNN_OK;

@@ -361,6 +361,14 @@ struct Stamp {
 #define FE_T(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long _t = __builtin_amdgcn_s_memtime(); \
                   _st.acc[i] += _t - _st.prev; _st.prev = _t; __builtin_amdgcn_sched_barrier(0); }
 #define FE_TEND() if (lane_id() == 0) { for (int _k = 0; _k < 12; ++_k) atomicAdd(&g_stamps[_k], _st.acc[_k]); }
+#elif defined(FE_ISA_MARK)
+// assembly-only builds of tools/isa_budget.py: the phase boundaries as comments in the instruction stream (between scheduling
+// fences, so that a phase's instructions stay between its marks); never linked into a library
+#define FE_TP
+#define FE_TA
+#define FE_T0()
+#define FE_T(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("; FE_MARK " #i); __builtin_amdgcn_sched_barrier(0); }
+#define FE_TEND()
 #else
 #define FE_TP
 #define FE_TA
@@ -821,19 +829,42 @@ __device__ __forceinline__ void gemm64_f2(const unsigned *img3, const Split2 &in
 // = silu(z) log2 e needs no scale, and the factor rides along: the NEXT product takes the scaled activation with unscaled
 // weights and a scaled bias, head vectors and the aggregation's 1/deg absorb 1 / log2 e.  The scaled image is split from the
 // double-precision product w * log2(e), so no weight is rounded twice.
+// Bit 1 (round 5): the FIRST layer as well -- node_pre_fwd stores P and Q in units of ln 2 (its W1a / W1b images and b1 are pre-scaled,
+// pack.hip), the edge kernels scale the radial / edge_attr features of the rank-3 update by log2(e), so the first SiLU of a tile takes
+// its argument as it arrives (16 vector multiplies per 16-edge tile less: profiles/r05_edge_fwd_instruction_budget.txt).  The factor
+// rides through the first product: W2's image is then UNSCALED (its input is already log2(e) too large).  The backward kernels read the
+// same P / Q and multiply by ln 2 where the forward multiplied by log2(e) (silu_both2): no instruction more.  Gradients are taken
+// with respect to the TRUE P / Q (the scaled storage is a representation), so node_pre_bwd and the weight gradients are untouched.
 #ifndef FE_LOG2E_FOLD
-#define FE_LOG2E_FOLD 1   // adopted in round 4 (edge_fwd 0.870 -> 0.854 ms per step, parity green; profiles/r04_lever_f16x2_fwd_bwd_fold.txt)
+#define FE_LOG2E_FOLD 3   // bit 0 adopted in round 4 (edge_fwd 0.870 -> 0.854 ms per step; profiles/r04_lever_f16x2_fwd_bwd_fold.txt), bit 1 in round 5
 #endif
 // (the generic-activation build keeps the plain form: the fold is a property of SiLU)
 #ifdef FE_ACT_GENERIC
 constexpr bool LOG2E_FOLD_EDGE = false;
+constexpr bool LOG2E_FOLD_FIRST = false;
 #else
 constexpr bool LOG2E_FOLD_EDGE = (FE_LOG2E_FOLD & 1) != 0;
+constexpr bool LOG2E_FOLD_FIRST = (FE_LOG2E_FOLD & 2) != 0;
+static_assert(!LOG2E_FOLD_FIRST || LOG2E_FOLD_EDGE, "FE_LOG2E_FOLD: bit 1 (first layer) needs bit 0");
 #endif
 constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
 constexpr double LOG2E_D = 1.4426950408889634074;
 __device__ __forceinline__ float silu2_f(float z2) { return z2 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z2)); }
 __device__ __forceinline__ Vec vsilu2(const Vec &a) { return vmap(a, [](float z) { return silu2_f(z); }); }
+// y = silu(z), z <- silu'(z) from a pre-activation given in units of ln 2 (z2 = z log2 e): the backward's reading of a folded P + Q
+__device__ __forceinline__ Vec vsilu_keep_d2(Vec &z2) {
+  Vec y;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z2.t[t][r]));
+      const float yy = (z2.t[t][r] * LN2_F) * s;
+      y.t[t][r] = yy;
+      z2.t[t][r] = s + yy * (1.0f - s);
+    }
+  return y;
+}
 // word of a split image from two DOUBLE values (a scaled weight): parts as part_pack / part2_pack make them, the residuals
 // taken in double
 __device__ __forceinline__ unsigned split_word_d(double w0, double w1, int part, bool f16) {
@@ -940,6 +971,116 @@ __device__ __forceinline__ void gemm64_f2_rm_(const char *img, const Split2 &in,
       acc.t[t] = hi;
     }
   }
+}
+
+// ---- f16x2 for the in-workgroup WEIGHT-GRADIENT consumers (round 5): sticky power-of-two scale, 32x32x16 MFMAs ----------------
+// dW[o][k] += sum over the 16 rows of a ring ticket of G[row][o] T[row][k].  A contraction over ROWS cannot take the per-item scale
+// of vsplit2_scaled; it takes a scale per operand STREAM instead: S = 2^k chosen so that the largest magnitude seen so far sits in
+// [2^14, 2^15), lowered (never raised) when a larger tile arrives -- the accumulator is multiplied by the ratio then, a rare
+// wave-uniform branch.  Errors are 2^-23 of the stream's largest row, which is what an fp32 sum over rows gives too.  Near 2^14 the
+// residual x S - fp16(x S) is itself a normal fp16 number down to |x S| = 1/4 (absolute error 2^-25 below that: 2^-39 of the
+// largest element), so the low part needs NO 2^11 scale and all three products -- (h,h), (l,h), (h,l) -- accumulate into ONE
+// register set: 12 MFMAs and no fold per ticket and weight where the bf16x3 form took 48 MFMAs per ticket.
+// v_mfma_f32_32x32x16_f16: K = 16 rows = exactly one ticket (no pairing of tickets), and the instruction holds the vector issue port
+// for 8 of its 32 cycles instead of 8 of 16 (MI355X_MICROARCH.md, constants table).
+// Operand layout: lane (i = lane & 31, half = lane >> 5) supplies rows 8 half + e (e = 0..7) of feature 32 b + i for block b = 0, 1
+// -- of G as the A operand, of T as the B operand.  Accumulator block (bo, bk), register 4 g + r of lane (n, half):
+// dW[32 bo + 8 g + 4 half + r][32 bk + n].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct WgAcc32 {
+  f32x16 c[2][2];
+};
+struct WgOp32 {
+  u32x4 h[2], l[2];   // [block]: 8 fp16 per lane
+};
+__device__ __forceinline__ void wg32_zero(WgAcc32 &a) {
+#pragma unroll
+  for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+    for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a.c[bo][bk][e] = 0.f;
+}
+// x[b][e] = tile[(8 half + e) * RS + 32 b + i]: conflict-free b32 reads (32 consecutive floats per half, the halves 8 rows apart)
+template <int RS>
+__device__ __forceinline__ void wg32_read(const float *tile, float (&x)[2][8]) {
+  const int l = lane_id(), i = l & 31, hf = l >> 5;
+  const float *p = tile + (8 * hf) * RS + i;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[b][e] = p[e * RS + 32 * b];
+}
+// largest magnitude of the tile, the same value in every lane (DPP row rotations, then the two permlane swaps)
+__device__ __forceinline__ float wg32_absmax(const float (&x)[2][8]) {
+  float m = 0.f;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(x[b][e]));
+  m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x128, 0xf, 0xf, false)));  // row_ror:8
+  m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x124, 0xf, 0xf, false)));  // row_ror:4
+  m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x122, 0xf, 0xf, false)));  // row_ror:2
+  m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x121, 0xf, 0xf, false)));  // row_ror:1
+  return qmax(m);
+}
+// sticky scale of one operand stream: `se` = exponent field of S (0: no tile seen yet).  Returns the factor the accumulators of the
+// stream must be multiplied by (1 unless the scale had to come down); the caller applies it.
+struct WgScale {
+  int se;
+  __device__ __forceinline__ float scale() const { return __builtin_bit_cast(float, (unsigned)(se > 0 ? se : 127) << 23); }
+  __device__ __forceinline__ float inv() const { return __builtin_bit_cast(float, (unsigned)(254 - (se > 0 ? se : 127)) << 23); }
+  // m: the tile's largest magnitude (wave-uniform)
+  __device__ __forceinline__ float update(float m) {
+    const int em = __builtin_amdgcn_readfirstlane((int)(f2u(m) >> 23));   // biased exponent; 0 for a zero (or subnormal) tile
+    if (em == 0 || em == 255) return 1.f;                                 // nothing to scale; Inf / NaN tiles poison the sum as in fp32
+    int want = 268 - em;                                                  // m S in [2^14, 2^15)
+    want = want > 254 ? 254 : (want < 1 ? 1 : want);
+    if (se == 0) { se = want; return 1.f; }
+    if (want >= se) return 1.f;                                           // the tile fits under the current scale
+    const float f = __builtin_bit_cast(float, (unsigned)(127 - (se - want)) << 23);   // 2^(want - se) < 1
+    se = want;
+    return f;
+  }
+};
+// the 16 values of a lane -> fp16 parts of x S: h = fp16(x S) (RNE), l = fp16(x S - h)
+__device__ __forceinline__ WgOp32 wg32_split(const float (&x)[2][8], float sc) {
+  WgOp32 O;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float a0 = x[b][2 * w], a1 = x[b][2 * w + 1];
+      unsigned h;
+      float r0, r1;
+      asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(h) : "v"(a0), "v"(a1), "v"(sc));
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(sc), "v"(h));
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(sc), "v"(h));
+      O.h[b][w] = h;
+      O.l[b][w] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
+    }
+  return O;
+}
+__device__ __forceinline__ void wg32_scale_acc(WgAcc32 &a, float f) {
+#pragma unroll
+  for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+    for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a.c[bo][bk][e] *= f;
+}
+// acc += G^T T over the 16 rows: smallest terms first
+__device__ __forceinline__ void wg32_mma(WgAcc32 &acc, const WgOp32 &G, const WgOp32 &T) {
+#pragma unroll
+  for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+    for (int bk = 0; bk < 2; ++bk) {
+      f32x16 c = acc.c[bo][bk];
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, G.l[bo]), __builtin_bit_cast(f16x8, T.h[bk]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, G.h[bo]), __builtin_bit_cast(f16x8, T.l[bk]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, G.h[bo]), __builtin_bit_cast(f16x8, T.h[bk]), c, 0, 0, 0);
+      acc.c[bo][bk] = c;
+    }
 }
 
 // Which forward kernels run on f16x2 images (bit 0 edge_fwd, bit 1 virt_fwd, bit 2 node_pre_fwd); pack_kernel writes the

@@ -235,6 +235,11 @@ struct EdgeBwdArgs {
 constexpr int PC_WAVES = 8;
 constexpr int PC_CONS = 3, PC_CONS2 = 7;
 constexpr int PC_PROD = 6;                  // producer waves
+// Round 5, f16x2 build: the consumers contract on f16x2 products with a sticky scale and 32x32x16 MFMAs (common.h, WgAcc32), one
+// ticket (16 edges) per step.  -DFE_PC_CONS32=0 restores the bf16x3 consumers.
+#ifndef FE_PC_CONS32
+#define FE_PC_CONS32 1
+#endif
 // (round 4, with the f16x2 producers, two repeats on one box, tools/gpu_ab_rings2.sh: 2 slots 3.23-3.26, 3 slots 3.16-3.20,
 //  4 slots 3.25-3.27, 5 slots 3.24 ms per step; round 2 had gone from 2 to 4 with the bf16x3 producers)
 #ifndef FE_PC_RING
@@ -325,7 +330,84 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // lgkmcnt(0): the tile is in LDS before the flag
     if (l == 0) lds_st(&ctrl[PC_FILLED + kind * PC_RING + sl], round + 1);
   };
-  if (consumer) {
+  constexpr bool CONS32 = MODE == GM_F16 && FE_PC_CONS32 != 0;
+  if (CONS32 && consumer) {
+    if constexpr (CONS32) {
+#if FE_PC_PRIO
+    __builtin_amdgcn_s_setprio(FE_PC_PRIO);
+#endif
+    // f16x2 consumer (common.h: WgAcc32 / WgScale): ring `ckind`, one ticket per step, the slot handed back as soon as its values are
+    // in registers; sticky power-of-two scales per operand stream; running sums in TRUE units in this wave's scratch tile
+    const int total = lds_ld(&ctrl[PC_TOTAL]);
+    WgAcc32 acc;
+    wg32_zero(acc);
+    WgScale sG{0}, sT{0};
+    double bs[2] = {0., 0.};
+    auto scp = [&](int blk, int e4) {
+      char *b = reinterpret_cast<char *>(A.cons_scratch + ((size_t)blockIdx.x * 2 + ckind) * IMG) + (size_t)((blk * 4 + e4) * 64 * 16);
+      asm volatile("" : "+s"(b));
+      return reinterpret_cast<f32x4 *>(b + (unsigned)l * 16u);
+    };
+    bool flushed = false;
+    const size_t sl = (size_t)(ckind == 0 ? A.slab_w2 : A.slab_wx1) + blockIdx.x;
+    auto flush = [&](bool last) {
+      const float ig = sG.inv(), it = sT.inv();
+      float *slab_dst = A.slab + sl * IMG;
+#pragma unroll
+      for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (acc.c[bo][bk][4 * e4 + r] * ig) * it;
+            f32x4 *d = scp(bo * 2 + bk, e4);
+            if (flushed) v += *d;
+            if (!last) {
+              *d = v;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) slab_dst[(32 * bo + 8 * e4 + 4 * (l >> 5) + r) * H + 32 * bk + (l & 31)] = v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.c[bo][bk][4 * e4 + r] = 0.f;
+          }
+    };
+    int since = 0;
+    for (int done = 0; done < total; ++done) {
+      const int s0 = done % PC_RING, r0w = done / PC_RING;
+      while (lds_ld(&ctrl[PC_FILLED + ckind * PC_RING + s0]) != r0w + 1) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      const float *g0 = ring + (ckind * PC_RING + s0) * PC_SLOT;
+      float xg[2][8], xt[2][8];
+      wg32_read<PC_RS>(g0, xg);
+      wg32_read<PC_RS>(g0 + 16 * PC_RS, xt);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (l == 0) lds_st(&ctrl[PC_DRAINED + ckind * PC_RING + s0], r0w + 1);
+      const float f = sG.update(wg32_absmax(xg)) * sT.update(wg32_absmax(xt));
+      if (f != 1.f) wg32_scale_acc(acc, f);
+      const WgOp32 G = wg32_split(xg, sG.scale()), T = wg32_split(xt, sT.scale());
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        bs[b] += (double)(((xg[b][0] + xg[b][1]) + (xg[b][2] + xg[b][3])) + ((xg[b][4] + xg[b][5]) + (xg[b][6] + xg[b][7])));
+      wg32_mma(acc, G, T);
+      if (++since >= PC_FLUSH && done + 1 < total) {
+        flush(false);
+        flushed = true;
+        since = 0;
+      }
+    }
+    flush(true);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      double s0 = bs[b];
+      s0 += __shfl_xor(s0, 32);
+      if (l < 32) A.slab_b[sl * H + 32 * b + l] = (float)s0;
+    }
+    }
+  } else if (consumer) {
 #if FE_PC_PRIO
     __builtin_amdgcn_s_setprio(FE_PC_PRIO);   // the consumer must never be the slower side: it wins issue arbitration on its SIMD
 #endif

@@ -29,7 +29,9 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodeP
   float *vec = lds + 5 * IMG3;                         // b1 bv0 wv2 bg0 wg2 wv0
   const int nimg = a.gravity ? 5 : 4;
   load_images_x3(img, wpack_x3(a.wpack, a.C, I_W1A), nimg);
-  load_floats(vec + 0 * H, a.b1, H);
+  // (P in units of ln 2 when the edge stage's first layer is folded: the W1a / W1b images carry log2(e), pack.hip)
+  if constexpr (edge_fold_first<MODE>()) { for (int i = threadIdx.x; i < H; i += blockDim.x) vec[i] = a.b1 ? a.b1[i] * LOG2E_F : 0.f; }
+  else load_floats(vec + 0 * H, a.b1, H);
   load_floats(vec + 1 * H, a.bv0, H);
   load_floats(vec + 2 * H, a.wv2, H);
   load_floats(vec + 3 * H, a.bg0, H);
@@ -246,6 +248,9 @@ constexpr int EDGE_FWD_IMG_FLOATS = 2 * IMG3;
 template <int MODE>
 __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs a, int C) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef FE_ISA_CONST   // assembly-only builds of tools/isa_budget.py: the layer flags as a constant (straight-line code of ONE configuration)
+  a.flags = FE_ISA_CONST; a.ea_dim = 2; a.bx2 = nullptr; a.attw = nullptr;
+#endif
   float *img = lds;                              // W2, WX1 (fp32 or split images)
   float *vec = lds + EDGE_FWD_IMG_FLOATS;        // EV_COUNT vectors
   float *tiles = vec + EV_COUNT * H;             // per wave: [16][TS] + [16][4]

@@ -96,7 +96,9 @@ __device__ __forceinline__ void pack_image(const PackArgs &a, int id) {
   for (int idx = threadIdx.x; idx < IMG / 2; idx += 256) {
     int o = idx >> 5, k = (idx & 31) * 2;
     const float w0 = at(o, k), w1 = at(o, k + 1);
-    if (!a.bf16 && LOG2E_FOLD_EDGE && id == I_W2) {   // edge_fwd's first in-kernel product delivers z * log2(e) (common.h)
+    // log2(e) folds of the edge stage (common.h): with the FIRST layer folded, node_pre_fwd's W1a / W1b carry the factor (P and Q in
+    // units of ln 2) and W2 takes an activation that is already log2(e) too large -- its image is plain; without it, W2 carries it
+    if (!a.bf16 && LOG2E_FOLD_EDGE && (LOG2E_FOLD_FIRST ? (id == I_W1A || id == I_W1B) : id == I_W2)) {
       const bool f16 = img_is_f16(id, a.C);
       for (int p = 0; p < 3; ++p) d3[img3_index(p, o, k)] = split_word_d((double)w0 * LOG2E_D, (double)w1 * LOG2E_D, p, f16);
       continue;

@@ -148,6 +148,8 @@ __device__ __forceinline__ void gemm_e(const void *img, const Vec &in, Vec &acc)
 }
 
 // part 1: consumes the gathered operands (geometry + first-layer pre-activation)
+// FOLD1: P and Q arrive in units of ln 2 (common.h, FE_LOG2E_FOLD bit 1) -- the scalar features of the rank-3 update are scaled to match
+template <bool FOLD1>
 __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *vec, const EdgeIdx &I, const EdgeRows &G,
                                               int q, EdgeFwdState &S, Vec &pre FE_TP) {
   S.row = I.row;
@@ -171,6 +173,7 @@ __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *ve
 #pragma unroll
   for (int k = 0; k < 8; ++k) S.eav[k] = I.eav[k];
 #ifdef FE_EDGE_PRE_VALU   // rounds 1-3: one vector fma per element and scalar feature
+  static_assert(!FOLD1, "FE_EDGE_PRE_VALU is the unfolded form");
   vaxpy(pre, S.rf, vload_vec(vec + EV_WR * H, q));
 #pragma unroll
   for (int k = 0; k < 8; ++k)
@@ -191,6 +194,7 @@ __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *ve
     f0 = q == 2 ? e1 : f0;
     f0 = q == 1 ? e0 : f0;
     f0 = q == 0 ? r_ : f0;
+    if constexpr (FOLD1) f0 *= LOG2E_F;
     const float *w0 = vec + q * H + j;
 #pragma unroll
     for (int t = 0; t < 4; ++t) pre.t[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[16 * t], f0, pre.t[t], 0, 0, 0);
@@ -200,6 +204,7 @@ __device__ __forceinline__ void edge_tile_pre(const EdgeArgs &a, const float *ve
       f1 = q == 2 ? e5 : f1;
       f1 = q == 1 ? e4 : f1;
       f1 = q == 0 ? e3 : f1;
+      if constexpr (FOLD1) f1 *= LOG2E_F;
       const float *w1 = w0 + 4 * H;
 #pragma unroll
       for (int t = 0; t < 4; ++t) pre.t[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[16 * t], f1, pre.t[t], 0, 0, 0);
@@ -214,11 +219,17 @@ template <bool KEEP_D, int MODE, bool RM>
 constexpr bool edge_fold() {
   return !KEEP_D && !RM && (MODE == GM_X3 || MODE == GM_F16) && LOG2E_FOLD_EDGE;
 }
+// are P and Q stored in units of ln 2?  (every fp32-grade form of the SiLU build; pack.hip and node_pre_fwd decide by the same rule)
+template <int MODE>
+constexpr bool edge_fold_first() { return (MODE == GM_X3 || MODE == GM_F16) && LOG2E_FOLD_FIRST; }
 template <bool KEEP_D, int MODE = GM_F32, bool RM = false>
 __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img, const float *vec, int q, EdgeFwdState &S,
                                               Vec &pre FE_TP) {
   constexpr bool FOLD = edge_fold<KEEP_D, MODE, RM>();   // S.mp, S.m0, S.m, S.up, S.u are then log2(e) x their values
-  S.t = KEEP_D ? vsilu_keep_d(pre FE_ACT(a)) : vsilu(pre FE_ACT(a));
+  constexpr bool FOLD1 = edge_fold_first<MODE>();        // pre arrives as log2(e) x the pre-activation; forward: S.t is log2(e) x t too
+  static_assert(!FOLD1 || KEEP_D || FOLD, "a folded first layer needs the folded forward chain");
+  if constexpr (FOLD1) S.t = KEEP_D ? vsilu_keep_d2(pre) : vsilu2(pre);
+  else S.t = KEEP_D ? vsilu_keep_d(pre FE_ACT(a)) : vsilu(pre FE_ACT(a));
   FE_T(2)   // silu 1
   S.mp = vload_vec(vec + EV_B2 * H, q);
 #ifdef FE_EDGE_T2   // diagnostic lever: two-part split of the first chained layer's operand (forward kernel, fp32 mode)
@@ -251,7 +262,7 @@ __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const void 
                                                   const EdgeIdx &I, int q, EdgeFwdState &S, Vec &pre FE_TP) {
   EdgeRows G;
   edge_gather(a, I, q, G);
-  edge_tile_pre(a, vec, I, G, q, S, pre FE_TA);
+  edge_tile_pre<edge_fold_first<MODE>()>(a, vec, I, G, q, S, pre FE_TA);
   edge_tile_mlp<KEEP_D, MODE, RM>(a, img, vec, q, S, pre FE_TA);
 }
 

@@ -185,6 +185,16 @@ constexpr int VB_WAVES = 8;
 // Waves w and w + 4 of a workgroup share a SIMD.  Consumers: waves 3 and 7 (a SIMD of their own) and wave 6 (beside
 // producer wave 2); producers: waves 0, 1, 2, 4, 5.
 constexpr int VB_CONS_X = 3, VB_CONS_XX = 7, VB_CONS_V2 = 6;
+// Round 5, f16x2 build: the consumers contract on f16x2 products with a sticky scale and 32x32x16 MFMAs (common.h, WgAcc32) -- a quarter
+// of the matrix-pipe time and half the operand-split work of the bf16x3 form -- so TWO waves carry the three contractions: wave 3
+// takes (g_ux, v) and (g_uX, v) (one split of v serves both), wave 7 takes (g_vp, t); wave 6 becomes the sixth producer.
+// -DFE_VB_CONS32=0 restores the bf16x3 consumers (and with them the 5 + 3 split); -DFE_VB_6P=0 keeps 5 + 3 with the new consumers.
+#ifndef FE_VB_CONS32
+#define FE_VB_CONS32 1
+#endif
+#ifndef FE_VB_6P
+#define FE_VB_6P 1
+#endif
 constexpr int VB_RS = 68;                     // row stride of a ring tile
 constexpr int VB_TILE = 16 * VB_RS;           // floats per 16 x 64 tile
 constexpr int VB_SLOT_A = 3 * VB_TILE;        // g_ux | g_uX | v   (read by consumers X and XX)
@@ -259,7 +269,9 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
   if (threadIdx.x < VBC_CTRL) ctrl[threadIdx.x] = 0;
   __syncthreads();
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
-  const bool consumer = wv == VB_CONS_X || wv == VB_CONS_XX || wv == VB_CONS_V2;
+  constexpr bool CONS32 = SM == GM_F16 && FE_VB_CONS32 != 0;   // f16x2 / 32x32x16 consumers (the bf16 mode and the x3 build keep theirs)
+  constexpr bool SIXP = CONS32 && FE_VB_6P != 0;               // 6 producers + 2 consumers
+  const bool consumer = wv == VB_CONS_X || wv == VB_CONS_XX || (!SIXP && wv == VB_CONS_V2);
   const int ntiles = (a.N + 15) >> 4;
   const int t_lo = (int)((long)blockIdx.x * ntiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   const int n_fine = min(t_hi - t_lo, VB_FINE_TILES), n_coarse = t_hi - t_lo - n_fine;
@@ -272,10 +284,127 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
   const int cur = a.batch[t_lo * 16];             // graph whose pools this workgroup accumulates in LDS
   const bool tanh_on = a.flags & FASTEGNN_F_TANH;
 
+  if (CONS32 && consumer) {
+    if constexpr (CONS32) {
+    // ---------------------------------------------------------------------------------------------------------
+    // consumers, f16x2 form (common.h: WgAcc32 / WgScale): one ticket (16 rows) per step, no pairing.
+    //   SIXP : wave 3 = roles 0 + 1 (X and XX, both from ring A, v split once), wave 7 = role 2 (V2, ring B)
+    //   else : wave 3 = role 0, wave 7 = role 1, wave 6 = role 2 (one accumulator each, as the bf16x3 consumers)
+    // ---------------------------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);
+    const bool ringA_wave = SIXP ? wv == VB_CONS_X : wv != VB_CONS_V2;
+    const int role0 = SIXP ? (wv == VB_CONS_X ? 0 : 2) : (wv == VB_CONS_X ? 0 : (wv == VB_CONS_XX ? 1 : 2));
+    const bool two_acc = SIXP && wv == VB_CONS_X;
+    const int RING = ringA_wave ? A.ringA : A.ringB;
+    const int slot_f = ringA_wave ? VB_SLOT_A : VB_SLOT_B;
+    const float *ring = ringA_wave ? ringA : ringB;
+    const int g_off0 = role0 == 1 ? VB_TILE : 0, g_off1 = VB_TILE, t_off = ringA_wave ? 2 * VB_TILE : VB_TILE;
+    const int *filled = ctrl + VBC_FILLED + (ringA_wave ? 0 : VB_MAXRING);
+    int *drained0 = ctrl + VBC_DRAINED + role0 * VB_MAXRING;
+    int *drained1 = ctrl + VBC_DRAINED + 1 * VB_MAXRING;   // second flag of a ring-A slot (set by this wave when it holds both roles)
+    WgAcc32 acc0, acc1;
+    wg32_zero(acc0);
+    wg32_zero(acc1);
+    WgScale sG0{0}, sG1{0}, sT{0};
+    double bs0[2] = {0., 0.}, bs1[2] = {0., 0.};          // bias column sums of this lane's rows: feature 32 b + i, double across tickets
+    // running sums in TRUE units, accumulator order, in this wave's scratch tiles (L2 resident): [role][block (bo, bk)][16 regs][64 lanes]
+    auto scp = [&](int role, int blk, int e4) {
+      char *b = reinterpret_cast<char *>(A.cons_scratch + ((size_t)blockIdx.x * 3 + role) * IMG) + (size_t)((blk * 4 + e4) * 64 * 16);
+      asm volatile("" : "+s"(b));
+      return reinterpret_cast<f32x4 *>(b + (unsigned)l * 16u);
+    };
+    bool flushed = false;
+    auto flush_one = [&](WgAcc32 &acc, const WgScale &sg, int role, bool last, float *slab_dst) {
+      const float ig = sg.inv(), it = sT.inv();
+#pragma unroll
+      for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (acc.c[bo][bk][4 * e4 + r] * ig) * it;
+            f32x4 *d = scp(role, bo * 2 + bk, e4);
+            if (flushed) v += *d;
+            if (!last) {
+              *d = v;
+            } else {
+              // [o][k] row-major slab: o = 32 bo + 8 e4 + 4 half + r, k = 32 bk + (lane & 31)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) slab_dst[(32 * bo + 8 * e4 + 4 * (l >> 5) + r) * H + 32 * bk + (l & 31)] = v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.c[bo][bk][4 * e4 + r] = 0.f;
+          }
+    };
+    int since = 0;
+    for (int done = 0; done < total; ++done) {
+      const int s0 = done % RING, r0w = done / RING;
+      while (vb_ld(&filled[s0]) != r0w + 1) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");   // the slot reads stay behind the flag read
+      const float *g0 = ring + s0 * slot_f;
+      float xt[2][8], xg0[2][8], xg1[2][8];
+      wg32_read<VB_RS>(g0 + t_off, xt);
+      wg32_read<VB_RS>(g0 + g_off0, xg0);
+      if (two_acc) wg32_read<VB_RS>(g0 + g_off1, xg1);
+      // every read of the slot has returned (lgkmcnt(0)) and none of them may sink below the hand-back
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (l == 0) {
+        vb_st(&drained0[s0], r0w + 1);
+        if (two_acc) vb_st(&drained1[s0], r0w + 1);
+      }
+      // sticky scales: a larger tile lowers the stream's scale and rescales what the accumulators hold (rare, wave-uniform)
+      {
+        const float fT = sT.update(wg32_absmax(xt));
+        const float f0 = sG0.update(wg32_absmax(xg0)) * fT;
+        if (f0 != 1.f) wg32_scale_acc(acc0, f0);
+        if (two_acc) {
+          const float f1 = sG1.update(wg32_absmax(xg1)) * fT;
+          if (f1 != 1.f) wg32_scale_acc(acc1, f1);
+        }
+      }
+      const WgOp32 T = wg32_split(xt, sT.scale());
+      {
+        const WgOp32 G = wg32_split(xg0, sG0.scale());
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          bs0[b] += (double)(((xg0[b][0] + xg0[b][1]) + (xg0[b][2] + xg0[b][3])) + ((xg0[b][4] + xg0[b][5]) + (xg0[b][6] + xg0[b][7])));
+        wg32_mma(acc0, G, T);
+      }
+      if (two_acc) {
+        const WgOp32 G = wg32_split(xg1, sG1.scale());
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          bs1[b] += (double)(((xg1[b][0] + xg1[b][1]) + (xg1[b][2] + xg1[b][3])) + ((xg1[b][4] + xg1[b][5]) + (xg1[b][6] + xg1[b][7])));
+        wg32_mma(acc1, G, T);
+      }
+      if (++since >= VB_FLUSH && done + 1 < total) {   // the accumulators leave the registers every VB_FLUSH tickets (cancelling sums)
+        flush_one(acc0, sG0, role0, false, nullptr);
+        if (two_acc) flush_one(acc1, sG1, 1, false, nullptr);
+        flushed = true;
+        since = 0;
+      }
+    }
+    // one partial slab per workgroup and weight ([o][k] row-major) + its bias column sums
+    auto finish = [&](WgAcc32 &acc, const WgScale &sg, int role, double (&bs)[2]) {
+      const size_t sl = (size_t)(role == 0 ? A.slab_x : (role == 1 ? A.slab_X : A.slab_v2)) + blockIdx.x;
+      flush_one(acc, sg, role, true, A.slab + sl * IMG);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        double s0 = bs[b];
+        s0 += __shfl_xor(s0, 32);   // the two row halves of the feature
+        if (l < 32) A.slab_b[sl * H + 32 * b + l] = (float)s0;
+      }
+    };
+    finish(acc0, sG0, role0, bs0);
+    if (two_acc) finish(acc1, sG1, 1, bs1);
+    }
 #ifdef VB_NO_CONS
-  if (false) {
+  } else if (false) {
 #else
-  if (consumer) {
+  } else if (consumer) {
 #endif
     // ---------------------------------------------------------------------------------------------------------
     // consumers (as in edge_bwd_pc_kernel): one 64x64 accumulator each, two tickets of the ring per step (K = 32 rows),

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import _lib as K
-from .model import SortedGraph, _PadParams, _PtrTable, _activation_kind, _carve, _fill, _new_layer, _stream
+from .model import RangeGuard, SortedGraph, _PadParams, _PtrTable, _activation_kind, _carve, _fill, _new_layer, _stream
 
 H = K.H
 
@@ -78,7 +78,8 @@ def _egnn_pad_layout(name: str, shape, h: int):
 class _EGNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, graph, edge_fea, x, h_in, v, *params):
-        lib = K.lib(act=spec.act_kind != K.ACT_SILU)
+        lib = K.lib(act=spec.act_kind != K.ACT_SILU, wide=spec.wide)
+        ctx.wide = spec.wide
         # edge_fea is a differentiable input (basic.py:313 concatenates it into the message MLP's input): its gradient is
         # accumulated by the edge backward kernel in sorted-edge order when asked for
         ea_sorted = graph.permute(edge_fea.detach() if edge_fea is not None else None)
@@ -116,7 +117,7 @@ class _EGNNFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_x, g_h):
         spec, graph, saved = ctx.spec, ctx.graph, ctx.saved
-        lib = K.lib(act=spec.act_kind != K.ACT_SILU)
+        lib = K.lib(act=spec.act_kind != K.ACT_SILU, wide=ctx.wide)
         batch, ea_sorted, h_in, v, params = ctx.misc
         dev = v.device
         st = _stream(dev)
@@ -193,6 +194,7 @@ class EGNN(nn.Module):
             self.layers.append(EGNN_Layer(in_edge_nf, hidden_nf, activation, with_v, flat))
         self._spec = None
         self._graph_cache = {}
+        self._range = RangeGuard()   # automatic wide-range fallback (fastegnn_amd.model.RangeGuard)
         self.deterministic = bool(K.deterministic_default())   # see fastegnn_amd.FastEGNN.deterministic (set before the first call)
         self.to(device)
 
@@ -215,7 +217,7 @@ class EGNN(nn.Module):
                                      flags=K.F_EGNN | (K.F_EGNN_NORM if self.norm else 0) | (K.F_DETERMINISTIC if self.deterministic else 0)
                                      | (self._act[0] << K.F_ACT_SHIFT),
                                      act_kind=self._act[0], act_param=self._act[1], gravity=[0.0, 0.0, 0.0],
-                                     layer_slots=layer_slots, names=names)
+                                     layer_slots=layer_slots, names=names, wide=False)
 
     def forward(self, x, h, edge_index, edge_fea, v=None):
         if not x.is_cuda:
@@ -243,7 +245,17 @@ class EGNN(nn.Module):
         plist = self._plist
         if self.hidden_nf < H:   # 64-wide images of the parameters (fastegnn_pad_params; the reverse mode slices the gradients back)
             plist = list(_PadParams.apply(tuple(self._spec.names), self.hidden_nf, 0, _egnn_pad_layout, *plist))
-        x_out, h_out = _EGNNFunction.apply(self._spec, graph, edge_fea, x, h, vv, *plist)
+        guard, spec = self._range, self._spec
+        if guard.pending and not guard.wide and guard.tripped(x.device):
+            guard.switch("EGNN", "a replayed HIP graph of this module")
+        spec.wide = guard.wide
+        x_out, h_out = _EGNNFunction.apply(spec, graph, edge_fea, x, h, vv, *plist)
+        if not guard.wide:
+            guard.launch(K.lib(act=spec.act_kind != K.ACT_SILU, wide=False), x_out, h_out)
+            if guard.tripped(x.device):
+                guard.switch("EGNN")
+                spec.wide = True
+                x_out, h_out = _EGNNFunction.apply(spec, graph, edge_fea, x, h, vv, *plist)
         if self.hidden_nf < H:
             h_out = h_out[:, :self.hidden_nf]     # the padded features are identically zero
         return (x_out, v, h_out) if v is not None else (x_out, h_out)

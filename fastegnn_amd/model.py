@@ -64,6 +64,75 @@ class E_GCL_vel(nn.Module):
 _DEBUG_CHECKS = os.environ.get("FASTEGNN_DEBUG_CHECKS", "0") not in ("", "0")
 
 
+class RangeGuard:
+    """Automatic wide-range fallback of one module (FastEGNN / FastRF / EGNN / ShardedFastEGNN).
+
+    The default library multiplies on 2-part fp16 splits: a hidden activation or a [64,64] weight beyond 65 504 overflows there
+    and the outputs turn non-finite, where the reference's plain fp32 (models/FastEGNN.py:102-119) stays finite.  Every forward on
+    the f16x2 build is therefore followed by ONE capturable launch (fastegnn_check_finite) that ORs a device word when an output is
+    Inf / NaN.  An eager forward reads the word before it returns (one 4-byte copy: the only synchronisation, ~0.3 % of a cfg4
+    step) and, if it is set, re-runs the call on the wide-range build (libfastegnn_hip_x3.so / _act_x3.so), warns once and stays
+    there.  Inside a HIP-graph capture nothing can be read: the launch is captured with the step, the word accumulates over the
+    replays and the next eager forward of the module looks at it first.  FASTEGNN_WIDE_RANGE=1 starts on the wide-range build,
+    =0 pins the f16x2 build and turns the overflow into a FloatingPointError."""
+
+    def __init__(self):
+        self.forced = K.WIDE_RANGE            # None: automatic
+        self.wide = bool(K.WIDE_RANGE)        # the build in use
+        self._flags: Dict[torch.device, torch.Tensor] = {}
+        self.pending = False                  # a guard launch was captured into a HIP graph and has not been read since
+        self.warned = False
+
+    def flag(self, dev) -> torch.Tensor:
+        f = self._flags.get(dev)
+        if f is None:
+            f = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._flags[dev] = f
+        return f
+
+    def launch(self, lib, a: torch.Tensor, b: Optional[torch.Tensor] = None):
+        """queue the check of up to two fp32 tensors on the current stream"""
+        dev = a.device
+        a = a.detach()
+        b = b.detach() if b is not None else None
+        K.check(lib.fastegnn_check_finite(K.ptr(a), a.numel(), K.ptr(b), b.numel() if b is not None else 0,
+                                          K.ptr(self.flag(dev)), _stream(dev)), "fastegnn_check_finite")
+
+    def tripped(self, dev, group=None) -> bool:
+        """Eager: read (and clear) the device word -- over all ranks of `group` when given.  Capturing: defer."""
+        if torch.cuda.is_current_stream_capturing():
+            self.pending = True
+            return False
+        f = self.flag(dev)
+        if group is not None:
+            import torch.distributed as dist
+            g = f if dist.get_backend(group) == "nccl" else f.cpu()
+            dist.all_reduce(g, op=dist.ReduceOp.MAX, group=group)
+            hit = bool(int(g.item()))
+        else:
+            hit = bool(int(f.item()))
+        self.pending = False
+        if hit:
+            f.zero_()
+        return hit
+
+    def switch(self, who: str, why: str = "a forward pass"):
+        if self.forced is False:
+            raise FloatingPointError(
+                f"fastegnn_amd.{who}: {why} produced non-finite outputs on the f16x2 build (operands beyond 65 504) and "
+                "FASTEGNN_WIDE_RANGE=0 pins that build; unset it (automatic fallback) or set FASTEGNN_WIDE_RANGE=1")
+        if K.SAFE_WAITS:
+            raise FloatingPointError(f"fastegnn_amd.{who}: {why} left the fp16 operand range; the FASTEGNN_SAFE_WAITS=1 diagnostic "
+                                     "build has no wide-range form")
+        self.wide = True
+        if not self.warned:
+            import warnings
+            warnings.warn(f"fastegnn_amd.{who}: {why} left the operand range of the default f16x2 arithmetic (|x| > 65 504); this "
+                          "module now runs on the wide-range build (bf16x3 products, fp32's exponent range, ~8 % slower). "
+                          "FASTEGNN_WIDE_RANGE=1 selects it from the start.", RuntimeWarning, stacklevel=3)
+            self.warned = True
+
+
 
 # ------------------------------------------------------------------------------------------
 # sorted graph handle
@@ -210,6 +279,7 @@ class _Spec:
         self.act_kind, self.act_param = getattr(model, "_act", (K.ACT_SILU, 0.0))
         flags |= self.act_kind << K.F_ACT_SHIFT
         self.flags = flags | model._extra_flags
+        self.wide = False      # the build the NEXT call runs on (set by the module from its RangeGuard before every call)
         self.gravity = [float(v) for v in model.gravity] if model.gravity is not None else [0.0, 0.0, 0.0]
         # parameter order handed to the autograd function
         self.names = ["virtual_node_feat", "embedding_in.weight", "embedding_in.bias"]
@@ -362,7 +432,8 @@ class _FastEGNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec: _Spec, graph: SortedGraph, batch32, gptr, edge_attr, node_attr,
                 node_feat, node_loc, node_vel, loc_mean, *params):
-        lib = K.lib(act=spec.act_kind != K.ACT_SILU)
+        lib = K.lib(act=spec.act_kind != K.ACT_SILU, wide=spec.wide)
+        ctx.wide = spec.wide   # the backward reads what this build saved (P / Q in units of ln 2 on the f16x2 build): same build
         # edge_attr / node_attr are differentiable inputs (the reference harness detaches them, utils/train.py:33,46-47,
         # but the module itself is differentiable in them): their gradients are accumulated by the edge / virtual backward
         # kernels when asked for
@@ -429,7 +500,7 @@ class _FastEGNNFunction(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_loc, g_vloc):
-        lib = K.lib(act=ctx.spec.act_kind != K.ACT_SILU)
+        lib = K.lib(act=ctx.spec.act_kind != K.ACT_SILU, wide=ctx.wide)
         spec, graph, saved = ctx.spec, ctx.graph, ctx.saved
         if saved is None or any(b is None for b in saved):
             raise RuntimeError("fastegnn_amd: backward through the graph a second time: the saved stage products are "
@@ -553,6 +624,7 @@ class FastEGNN(nn.Module):
                                                           attention, tanh, gravity))
         self._graph_cache: Dict[tuple, SortedGraph] = {}
         self.cache_graphs = True
+        self._range = RangeGuard()
         self._deterministic = K.deterministic_default()
         self._spec = None      # built lazily (after .to(device) / load_state_dict), parameters are fixed objects
         self._plist = None
@@ -638,11 +710,22 @@ class FastEGNN(nn.Module):
         if self.hidden_nf < H:
             rf = bool(spec.flags & K.F_RF)
             plist = list(_PadParams.apply(tuple(spec.names), self.hidden_nf, spec.C, rf, *plist))
-        out = _FastEGNNFunction.apply(spec, graph, batch32, gptr, edge_attr, node_attr, node_feat, node_loc, node_vel,
-                                      loc_mean, *plist)
+        guard, who = self._range, type(self).__name__
+        if guard.pending and not guard.wide and guard.tripped(dev):
+            guard.switch(who, "a replayed HIP graph of this module")
+        spec.wide = guard.wide
+
+        def run():
+            return _FastEGNNFunction.apply(spec, graph, batch32, gptr, edge_attr, node_attr, node_feat, node_loc, node_vel,
+                                           loc_mean, *plist)
+        out = run()
+        if not guard.wide and spec.flags & K.F_BF16 == 0:   # (the bf16 operand mode has fp32's exponent range)
+            guard.launch(K.lib(act=spec.act_kind != K.ACT_SILU, wide=False), out[0], out[1])
+            if guard.tripped(dev):
+                guard.switch(who)
+                spec.wide = True
+                out = run()        # the same call on the wide-range build; what it returns is what fp32 gives
         if _DEBUG_CHECKS and not (bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[1]).all())):
-            raise FloatingPointError(
-                "fastegnn_amd: non-finite outputs.  The default library multiplies on 2-part fp16 splits: hidden activations "
-                "and [64,64] weights beyond 65 504 overflow there (the reference's fp32 does not).  FASTEGNN_WIDE_RANGE=1 loads "
-                "libfastegnn_hip_x3.so, the same kernels on 3-part bf16 splits with fp32's exponent range.")
+            raise FloatingPointError("fastegnn_amd: non-finite outputs (on the wide-range build as well: the inputs or the "
+                                     "weights themselves overflow fp32)" if guard.wide else "fastegnn_amd: non-finite outputs")
         return out

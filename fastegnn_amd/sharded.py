@@ -55,9 +55,9 @@ H = K.H
 class HipBackend:
     """Stage calls on libfastegnn_hip.so (the product path)."""
 
-    def __init__(self, device, act: bool = False):
+    def __init__(self, device, act: bool = False, wide: bool = False):
         self.dev = device
-        self.lib = K.lib(act)   # act: the generic-activation build (a model whose act_fn is not SiLU)
+        self.lib = K.lib(act, wide=wide)   # act: the generic-activation build (a model whose act_fn is not SiLU); wide: its bf16x3 form
 
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.dev)
@@ -942,7 +942,16 @@ class ShardedFastEGNN(torch.nn.Module):
             m._spec = _Spec(m)
             pidx = m._param_index
             m._plist = [pidx[n] for n in m._spec.names]
-        be = self.backend or HipBackend(local["node_loc"].device, act=m._spec.act_kind != K.ACT_SILU)
+        # the range guard of the wrapped module decides the build (fastegnn_amd.model.RangeGuard); a caller-supplied backend
+        # (the CPU stage backend of the gloo tests) is used as it is
+        guard = m._range
+        dev = local["node_loc"].device
+        guarded = self.backend is None and not (m._spec.flags & K.F_BF16)
+        world, _ = self._world_rank()
+        group = (self.group if self.group is not None else dist.group.WORLD) if (dist.is_initialized() and self.emulate is None and world > 1) else None
+        if guarded and guard.pending and not guard.wide and guard.tripped(dev, group):
+            guard.switch("ShardedFastEGNN", "a replayed HIP graph of this module")
+        be = self.backend or HipBackend(dev, act=m._spec.act_kind != K.ACT_SILU, wide=guard.wide)
         spec = m._spec
         csc = bool(m._spec.flags & K.F_DETERMINISTIC)
         if csc and len(plan.parts) > 1:
@@ -964,9 +973,19 @@ class ShardedFastEGNN(torch.nn.Module):
         plist = m._plist
         if m.hidden_nf < K.H:
             plist = be.pad_params(spec.names, m.hidden_nf, spec.C, bool(spec.flags & K.F_RF), plist)
-        return _ShardedFunction.apply(be, self.comm(), spec, plan, parts, batch32, gptr, ea,
-                                      local["node_attr"], local["node_feat"], local["node_loc"], local["node_vel"],
-                                      local["loc_mean"], *plist)
+        def run(be_):
+            return _ShardedFunction.apply(be_, self.comm(), spec, plan, parts, batch32, gptr, ea,
+                                          local["node_attr"], local["node_feat"], local["node_loc"], local["node_vel"],
+                                          local["loc_mean"], *plist)
+        out = run(be)
+        if guarded and not guard.wide:
+            # every rank checks ITS rows and the replicated virtual coordinates; the decision is taken over all ranks (one 4-byte
+            # all-reduce) so that they switch builds together
+            guard.launch(be.lib, out[0], out[1])
+            if guard.tripped(dev, group):
+                guard.switch("ShardedFastEGNN")
+                out = run(HipBackend(dev, act=spec.act_kind != K.ACT_SILU, wide=True))
+        return out
 
     def forward(self, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None,
                 node_attr=None):

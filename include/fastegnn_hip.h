@@ -244,7 +244,7 @@ const char *fastegnn_last_error(void);
  * fastegnn_layer_t / fastegnn_graph_t or the meaning of an argument changes (round 3 inserted act_param: 100 -> 101; round 4 appended wgrad_batch and added fastegnn_pack_weights_all / FASTEGNN_F_WPACK_READY: 103; the fastegnn_wide_* entry points: 104).
  * A binding MUST compare it with the FASTEGNN_ABI_VERSION it was written against AND check fastegnn_sizeof_layer() /
  * fastegnn_sizeof_graph() against its own mirror of the descriptors before the first call (fastegnn_amd/_lib.py does). */
-#define FASTEGNN_ABI_VERSION 104
+#define FASTEGNN_ABI_VERSION 105
 int fastegnn_version(void);
 /* floats of the packed weight-image buffer for C virtual channels */
 size_t fastegnn_wpack_floats(int32_t C);
@@ -315,6 +315,14 @@ typedef struct {
 int fastegnn_pad_params(const fastegnn_pad_desc_t *desc, int32_t n, int32_t h, int32_t reverse, void *stream);
 /* 1 when the library evaluates every FASTEGNN_ACT_* kind (libfastegnn_hip_act.so), 0 for the SiLU-only build */
 int fastegnn_generic_activations(void);
+/* 1 if the fp32-grade products of this build run on 2-part fp16 splits (operands must stay below 65 504 in magnitude: the default
+ * library), 0 if on 3-part bf16 splits with fp32's exponent range (libfastegnn_hip_x3.so / _act_x3.so).  ABI revision 105. */
+int fastegnn_f16_operands(void);
+/* Range guard of the f16x2 build (the reference is plain fp32, models/FastEGNN.py:102-119: it has no such limit): *flag |= 1 if any
+ * of a[0..na) / b[0..nb) is not finite.  One capturable launch on `stream`, no host synchronisation; the caller reads the device
+ * word when it may (fastegnn_amd.FastEGNN: after every eager forward -- a set flag re-runs the call on the wide-range library).
+ * Either array may be NULL with its count 0.  ABI revision 105. */
+int fastegnn_check_finite(const float *a, int64_t na, const float *b, int64_t nb, int32_t *flag, void *stream);
 /* batch int64 [N] (ascending) -> batch int32 [N], gptr int32 [B+1] */
 int fastegnn_build_batch(const int64_t *batch64, int32_t N, int32_t B, int32_t *batch, int32_t *gptr,
                          void *stream);

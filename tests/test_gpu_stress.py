@@ -20,7 +20,13 @@ ITERS = int(os.environ.get("FASTEGNN_STRESS_ITERS", "100"))
 
 
 def _run(tmp, safe):
+    if safe and not os.path.exists(os.path.join(ROOT, "fastegnn_amd", "libfastegnn_hip_safe.so")):
+        # the conservative-synchronisation build is a diagnostic, not a product library: built here, on demand (csrc/Makefile `safe`)
+        b = subprocess.run(["make", "-C", os.path.join(ROOT, "fastegnn_amd", "csrc"), "-j8", "safe"], capture_output=True, text=True,
+                           timeout=1500)
+        assert b.returncode == 0, b.stderr[-2000:]
     env = dict(os.environ, FASTEGNN_SAFE_WAITS="1" if safe else "0")
+    env.pop("FASTEGNN_WIDE_RANGE", None)
     out = subprocess.run([sys.executable, "-m", "tests.stress_runner", str(ITERS), str(tmp)], cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=1500)
     line = [l for l in out.stdout.splitlines() if l.startswith("STRESS ")]

@@ -1,8 +1,12 @@
 """Child process of tests/test_gpu_wide_range.py: one golden through the HIP module with its hidden features scaled up, under
-the library the environment selects (FASTEGNN_WIDE_RANGE, FASTEGNN_DEBUG_CHECKS); prints one JSON line."""
+the library policy the environment selects (FASTEGNN_WIDE_RANGE unset / 0 / 1); prints one JSON line.
+
+    python -m tests.wide_range_runner <scale> [golden name]
+"""
 import json
 import os
 import sys
+import warnings
 
 import torch
 
@@ -13,26 +17,42 @@ if ROOT not in sys.path:
 
 def main():
     scale = float(sys.argv[1])
+    name = sys.argv[2] if len(sys.argv) > 2 else "c16_two_graphs"
     from fastegnn_amd import _lib as K
     from oracle import fastegnn_ref as R
     from tests.gpu_util import model_from_golden
-    from tests.helpers import Golden, rel_err
-    g = Golden("c16_two_graphs")
+    from tests.helpers import Golden, golden_loss, rel_err
+    g = Golden(name)
     m = model_from_golden(g, device="cuda")
     with torch.no_grad():      # hidden features of ~scale: beyond fp16's range for scale >> 65 504
         m.embedding_in.weight.mul_(scale)
         m.embedding_in.bias.mul_(scale)
     kw, target, wv = g.model_kwargs(device="cuda")
-    out = dict(lib=os.path.basename(K.LIB_PATH), raised=None)
+    out = dict(lib=os.path.basename(K.LIB_PATH), raised=None, warned=False)
     try:
-        loc, vloc = m(**kw)
-        out["finite"] = bool(torch.isfinite(loc).all() and torch.isfinite(vloc).all())
-        p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            loc, vloc = m(**kw)
+            golden_loss(loc, vloc, target, wv).backward()
+            loc2, _ = m(**kw)                  # a second call stays on the build the first one ended on, silently
+        out["warned"] = sum("wide-range" in str(w.message) for w in wlist)
+        out["wide"] = bool(m._range.wide)
+        out["finite"] = bool(torch.isfinite(loc).all() and torch.isfinite(vloc).all() and torch.isfinite(loc2).all())
+        p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
         rl, rv = R.forward(p, g.cfg, **{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in kw.items()})
         out["ref_finite"] = bool(torch.isfinite(rl).all())
-        out["err_loc"] = rel_err(loc.detach().cpu(), rl) if out["finite"] else None
+        out["err_loc"] = rel_err(loc.detach().cpu(), rl.detach()) if out["finite"] else None
+        if out["finite"] and out["ref_finite"]:
+            golden_loss(rl, rv, target.cpu(), wv.cpu() if torch.is_tensor(wv) else wv).backward()
+            gm = dict(m.named_parameters())
+            errs = {}
+            for k in ("embedding_in.weight", "gcl_0.edge_mlp.0.weight", "gcl_1.edge_mlp_virtual.2.weight", "virtual_node_feat"):
+                if gm[k].grad is not None and p[k].grad is not None:
+                    errs[k] = rel_err(gm[k].grad.cpu(), p[k].grad)
+            out["grad_finite"] = all(bool(torch.isfinite(q.grad).all()) for q in gm.values() if q.grad is not None)
+            out["err_grad_max"] = max(errs.values()) if errs else None
     except FloatingPointError as e:
-        out["raised"] = str(e)[:80]
+        out["raised"] = str(e)[:160]
     print(json.dumps(out))
 
 

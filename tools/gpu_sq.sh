@@ -14,7 +14,7 @@ run p2 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE
 run p3 SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT
 cd $R
 python - <<PY | tee gpurun_out/$tag/sq_counters.txt
-import csv, glob, collections, subprocess
+import csv, glob, collections, subprocess, json, os
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
 for n in ("p1", "p2", "p3"):
     fs = glob.glob("gpurun_out/$tag/%s/*/*counter_collection.csv" % n)
@@ -27,6 +27,7 @@ for n in ("p1", "p2", "p3"):
 print("# rocprofv3 --pmc (three passes, kernel trace only) of: python3 bench.py --layers 1 --steps 1 --warmup 1 --hipgraph off")
 print("# cfg4 frame (100 000 nodes, 1.92 M edges, C = 16), ONE layer, fp32 mode; values are per-LAUNCH averages summed over the chip.")
 print("# commit:", subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "(snapshot without .git)")
+OUT = {}
 names = ["fe::edge_fwd_kernel", "fe::virt_fwd_kernel", "fe::edge_bwd_pc_kernel", "fe::virt_bwd_pc_kernel", "fe::virt_bwd_gv_kernel",
          "fe::virt_bwd_node_kernel", "fe::node_pre_fwd_kernel", "fe::node_pre_bwd_kernel", "fe::wgrad_tn_kernel", "fe::wgrad_reduce_kernel"]
 for k in names:
@@ -57,4 +58,15 @@ for k in names:
     print(f"  waiting (any)   WAIT_INST_ANY / WAVE_CYCLES                {v['SQ_WAIT_INST_ANY'] / wc:8.3f}")
     print(f"  waiting on LDS  WAIT_INST_LDS / WAVE_CYCLES                {v['SQ_WAIT_INST_LDS'] / wc:8.3f}")
     print(f"  LDS bank conflicts  LDS_BANK_CONFLICT / ACTIVE_INST_LDS    {v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_ACTIVE_INST_LDS'], 1):8.3f}")
+    J = dict(v)
+    J["waves_per_simd"] = wps
+    J["mfma_busy"] = (v["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * wc / wps)) if wps else None
+    J["valu_issue_share_of_simd"] = share * wps if wps else None
+    J["lds_bank_conflict_ratio"] = v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_ACTIVE_INST_LDS"], 1)
+    J["launches_sampled"] = len(cnt[(k, "p1")])
+    OUT[k] = J
+OUT["_meta"] = {"commit": os.environ.get("GRAFT_COMMIT", ""), "what": "rocprofv3 --pmc, three passes, kernel trace only (tools/gpu_sq.sh): per-LAUNCH "
+                "averages summed over the chip, ONE layer of the cfg4 frame, fp32 mode; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / the SIMDs' time; "
+                "SQ_INSTS_VALU_MFMA_MOPS_* count 512 FLOP each"}
+json.dump(OUT, open("gpurun_out/$tag/sq_counters.json", "w"), indent=1)
 PY
