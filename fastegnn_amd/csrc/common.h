@@ -132,11 +132,13 @@ __device__ __forceinline__ float expm1_f(float z) {   // exp(z) - 1 without canc
 // y = f(z), d = f'(z)
 __device__ __forceinline__ void act_both(float z, Act a, float &y, float &d) {
   switch (a.kind) {
-    case FASTEGNN_ACT_RELU: y = fmaxf(z, 0.f); d = z > 0.f ? 1.f : 0.f; break;
+    // (every kind propagates NaN like torch does -- fmaxf / fminf would launder a NaN into a finite value, and the range guard of the
+    //  f16x2 build, fastegnn_check_finite, reads the OUTPUTS: an overflow must stay visible there)
+    case FASTEGNN_ACT_RELU: y = z < 0.f ? 0.f : z; d = z > 0.f ? 1.f : 0.f; break;
     case FASTEGNN_ACT_LEAKY_RELU: y = z > 0.f ? z : a.p * z; d = z > 0.f ? 1.f : a.p; break;
     case FASTEGNN_ACT_TANH: y = tanh_f(z); d = 1.0f - y * y; break;
     case FASTEGNN_ACT_SIGMOID: y = sigmoid_f(z); d = y * (1.0f - y); break;
-    case FASTEGNN_ACT_ELU: { const float e = a.p * expm1_f(fminf(z, 0.f)); y = z > 0.f ? z : e; d = z > 0.f ? 1.f : e + a.p; break; }
+    case FASTEGNN_ACT_ELU: { const float e = a.p * expm1_f(z < 0.f ? z : 0.f); y = z <= 0.f ? e : z; d = z > 0.f ? 1.f : e + a.p; break; }
     case FASTEGNN_ACT_GELU: {
       const float c = 0.5f * (1.0f + erff(z * 0.70710678f));
       y = z * c;
@@ -146,7 +148,7 @@ __device__ __forceinline__ void act_both(float z, Act a, float &y, float &d) {
     case FASTEGNN_ACT_SOFTPLUS: {   // torch.nn.Softplus(beta, threshold = 20)
       const float bz = a.p * z;
       const float s = sigmoid_f(bz);
-      y = bz > 20.f ? z : log1pf(__expf(fminf(bz, 20.f))) / a.p;
+      y = bz <= 20.f ? log1pf(__expf(bz)) / a.p : z;
       d = bz > 20.f ? 1.f : s;
       break;
     }
@@ -1024,10 +1026,27 @@ __device__ __forceinline__ float wg32_absmax(const float (&x)[2][8]) {
   m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x121, 0xf, 0xf, false)));  // row_ror:1
   return qmax(m);
 }
+// does the tile fit under scale exponent `se`?  One lane-local maximum and a ballot -- no cross-lane reduction on the consumer's
+// critical path; the full maximum (wg32_absmax) is taken only when this says no (the first tile of a stream, or a larger one).
+__device__ __forceinline__ bool wg32_fits(const float (&x)[2][8], int se) {
+  float m = 0.f;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(x[b][e]));
+  // |x| S < 2^15  <=>  exponent(x) + se - 127 <= 141; written on the bits: (bits(|x|) >> 23) <= 268 - se
+  const bool over = (int)(f2u(m) >> 23) > 268 - se;
+  return se != 0 && __builtin_amdgcn_ballot_w64(over) == 0ull;
+}
 // sticky scale of one operand stream: `se` = exponent field of S (0: no tile seen yet).  Returns the factor the accumulators of the
 // stream must be multiplied by (1 unless the scale had to come down); the caller applies it.
 struct WgScale {
   int se;
+  // the common case costs a lane-local maximum and one ballot
+  __device__ __forceinline__ float update_lazy(const float (&x)[2][8]) {
+    if (wg32_fits(x, se)) return 1.f;
+    return update(wg32_absmax(x));
+  }
   __device__ __forceinline__ float scale() const { return __builtin_bit_cast(float, (unsigned)(se > 0 ? se : 127) << 23); }
   __device__ __forceinline__ float inv() const { return __builtin_bit_cast(float, (unsigned)(254 - (se > 0 ? se : 127)) << 23); }
   // m: the tile's largest magnitude (wave-uniform)

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       __builtin_amdgcn_s_waitcnt(0xc07f);
       if (l == 0) lds_st(&ctrl[PC_DRAINED + ckind * PC_RING + s0], r0w + 1);
-      const float f = sG.update(wg32_absmax(xg)) * sT.update(wg32_absmax(xt));
+      const float f = sG.update_lazy(xg) * sT.update_lazy(xt);
       if (f != 1.f) wg32_scale_acc(acc, f);
       const WgOp32 G = wg32_split(xg, sG.scale()), T = wg32_split(xt, sT.scale());
 #pragma unroll

@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             float ax = a.aggx[(size_t)n * 3 + k];
-            if (clamp_aggx) ax = fminf(fmaxf(ax, -100.f), 100.f);
+            if (clamp_aggx) ax = ax > 100.f ? 100.f : (ax < -100.f ? -100.f : ax);   // (NaN stays NaN, as torch.clamp: basic.py:310)
             a.x_out[(size_t)n * 3 + k] = xi[k] + ax + transv[k] * invC + sv * a.vel[(size_t)n * 3 + k] + sg * a.g[k];
           }
         }

@@ -188,6 +188,8 @@ constexpr int VB_CONS_X = 3, VB_CONS_XX = 7, VB_CONS_V2 = 6;
 // Round 5, f16x2 build: the consumers contract on f16x2 products with a sticky scale and 32x32x16 MFMAs (common.h, WgAcc32) -- a quarter
 // of the matrix-pipe time and half the operand-split work of the bf16x3 form -- so TWO waves carry the three contractions: wave 3
 // takes (g_ux, v) and (g_uX, v) (one split of v serves both), wave 7 takes (g_vp, t); wave 6 becomes the sixth producer.
+// Measured on one box each (profiles/r05_lever_cons32.txt): bf16x3 consumers 3.209 ms per step; f16x2 consumers, 5 + 3: 3.131; the same
+// with the lane-local scale check (WgScale::update_lazy) 3.056; 6 + 2 with it 2.903 (without it 3.151: wave 3 paced the ring).
 // -DFE_VB_CONS32=0 restores the bf16x3 consumers (and with them the 5 + 3 split); -DFE_VB_6P=0 keeps 5 + 3 with the new consumers.
 #ifndef FE_VB_CONS32
 #define FE_VB_CONS32 1
@@ -357,11 +359,11 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
       }
       // sticky scales: a larger tile lowers the stream's scale and rescales what the accumulators hold (rare, wave-uniform)
       {
-        const float fT = sT.update(wg32_absmax(xt));
-        const float f0 = sG0.update(wg32_absmax(xg0)) * fT;
+        const float fT = sT.update_lazy(xt);
+        const float f0 = sG0.update_lazy(xg0) * fT;
         if (f0 != 1.f) wg32_scale_acc(acc0, f0);
         if (two_acc) {
-          const float f1 = sG1.update(wg32_absmax(xg1)) * fT;
+          const float f1 = sG1.update_lazy(xg1) * fT;
           if (f1 != 1.f) wg32_scale_acc(acc1, f1);
         }
       }
