@@ -1141,6 +1141,25 @@ __device__ __forceinline__ typename OperandOf<MODE>::type make_operand(const Vec
   else if constexpr (MODE == GM_F16) return vsplit2(v);
   else return v;
 }
+// ---- the 32-edge forward kernel (edge_fwd32.hip): does this build have it, and where its images live ----
+// Measured, NOT adopted (profiles/r05_lever_edge_fwd32.txt): the 32-edge kernel issues 11 % fewer cycles per edge but runs two waves per
+// SIMD (242-256 registers) where the 16-edge kernel runs four, and loses more to exposed MFMA / LDS latency than it saves:
+// 0.837 against 0.797 ms per step on one box.  -DFE_EDGE_FWD32=1 builds it in (and makes pack_kernel write its images).
+#ifndef FE_EDGE_FWD32
+#define FE_EDGE_FWD32 0
+#endif
+#ifdef FE_ACT_GENERIC
+constexpr bool EDGE_FWD32 = false;
+#else
+constexpr bool EDGE_FWD32 = FE_EDGE_FWD32 != 0 && (FE_FWD_F16 & 1) != 0 && LOG2E_FOLD_FIRST;
+#endif
+// u32 index (two fp16: contraction indices k, k + 1, k even) of W[o][k] in an f16x2 image of the 32x32x16 operand layout:
+// part h at 0, part l at 2048; lane (i, hf) of output block bo, k-step s reads its 8 values as one 16-byte word group
+__host__ __device__ inline int img32_word(int part, int o, int k) {
+  const int bo = o >> 5, i = o & 31, b = k >> 5, g = (k >> 3) & 3, hf = (k >> 2) & 1, r = k & 3;
+  const int s = 2 * b + (g >> 1), e = 4 * (g & 1) + r;
+  return part * 2048 + ((bo * 4 + s) * 64 + hf * 32 + i) * 4 + (e >> 1);
+}
 // image i of a resident image array (fp32 images for GM_F32, split images otherwise)
 template <int MODE>
 __device__ __forceinline__ void gemm_op(const void *img, int i, const typename OperandOf<MODE>::type &in, Vec &acc) {

@@ -92,6 +92,9 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st);
 int graph_xsum(const fastegnn_layer_t *L, hipStream_t st);
 int graph_pre_forward(const fastegnn_layer_t *L, hipStream_t st);
 int edge_forward(const fastegnn_layer_t *L, hipStream_t st);
+// edge_fwd32.hip: the same stage on 32-edge tiles / 32x32x16 MFMAs (default build, fp32-grade SiLU mode)
+bool edge_forward32_applies(const fastegnn_layer_t *L);
+int edge_forward32(const fastegnn_layer_t *L, hipStream_t st);
 int virt_forward(const fastegnn_layer_t *L, hipStream_t st);
 int graph_post_forward(const fastegnn_layer_t *L, hipStream_t st);
 // `shared`: a weight-gradient batch that outlives the stage (fastegnn_layer_backward: ONE contraction launch and ONE

@@ -369,6 +369,7 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
   EdgeArgs a = make_edge_args(L);
   FE_REQUIRE((size_t)L->N * QXLD < (1u << 30) && (size_t)g.n_src * QXLD < (1u << 30) && (size_t)g.n_edges * 8 < (1u << 30),
              "edge_forward: tables exceed the 32-bit offset range of the gather path");
+  if (edge_forward32_applies(L)) return edge_forward32(L, st);   // 32-edge tiles (edge_fwd32.hip)
   // one workgroup per CU once there are >= 256 x 16 row chunks; small graphs spread their chunks (32 edges) over as
   // many waves as there are chunks instead of serialising them in a few workgroups (the N-body mini-batches)
   int grid = cdiv(g.n_chunks, EDGE_FWD_WAVES);

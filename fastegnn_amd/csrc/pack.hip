@@ -88,9 +88,22 @@ __device__ __forceinline__ void pack_image(const PackArgs &a, int id) {
     const float w = d.transposed ? d.src[(size_t)k * d.ld + d.c0 + o * d.ks] : d.src[(size_t)o * d.ld + d.c0 + k * d.ks];
     return a.bf16 ? round_bf(w) : w;   // bf16 operand mode: every image holds the bf16-rounded weights
   };
-  for (int idx = threadIdx.x; idx < IMG; idx += 256) {
-    int o = idx >> 6, k = idx & 63;
-    dst[img_index(o, k)] = at(o, k);
+  if (EDGE_FWD32 && !a.bf16 && (id == I_W2 || id == I_WX1)) {
+    // nothing reads the fp32 images of W2 / WX1 (the edge kernels multiply on split images): their slots hold the f16x2 images of the
+    // 32-edge forward kernel in the 32x32x16 operand layout (common.h, img32_word; edge_fwd32.hip).  Both plain: with the first layer
+    // folded, W2's input already carries log2(e)
+    unsigned *d32 = reinterpret_cast<unsigned *>(dst);
+    for (int idx = threadIdx.x; idx < IMG / 2; idx += 256) {
+      const int o = idx >> 5, k = (idx & 31) * 2;
+      const float w0 = at(o, k), w1 = at(o, k + 1);
+      d32[img32_word(0, o, k)] = split2_word(w0, w1, 0);
+      d32[img32_word(1, o, k)] = split2_word(w0, w1, 1);
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < IMG; idx += 256) {
+      int o = idx >> 6, k = idx & 63;
+      dst[img_index(o, k)] = at(o, k);
+    }
   }
   // split images: one word = two consecutive k of the same tile row (k even)
   for (int idx = threadIdx.x; idx < IMG / 2; idx += 256) {
