@@ -72,6 +72,9 @@ struct WgradBatch {
   // only the fixed-order reduction into dW / db runs here.  *slab_begin receives the first slab index.
   int plan();
   int add_slabs(float *dW, int lddw, int c0, int ks, float *db, int nsplit, int *slab_begin);
+  // the same for `nb` weights whose partial slabs the caller keeps in an array of its OWN: ext[(b * nsplit + split) * 4096], no bias;
+  // weight b adds into dW + b * sW
+  int add_slabs_ext(const float *ext, float *dW, int lddw, int c0, int ks, int nsplit, int nb, long sW);
   int finish();
   // The contractions are deferred to finish(): a job's operand rows must stay untouched until then.  A stage that is about
   // to write `n` floats at `p` while the batch is open declares it here; an overlap with an operand of a queued job is an
@@ -105,6 +108,9 @@ int graph_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *sh
 int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
 // virt_bwd.hip: floats of wg_virt for B4 (1 <= C <= 64)
 size_t virt_pc_wg_floats(size_t N, size_t C);
+// the channel-phased form of B4 (virt_bwd_cs_kernel): does it run for this shape, and its share of wg_virt
+bool virt_cs_applies(long N, int C, int flags);
+size_t virt_cs_wg_floats(size_t C);
 int edge_col_reduce(const fastegnn_layer_t *L, hipStream_t st);
 int node_pre_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared = nullptr);
 // operand regions of the node-level / graph-level weight gradients inside wg_node (disjoint, so that the jobs of a whole

@@ -821,14 +821,15 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
 // two consumer waves per workgroup (256 x 2 tiles of 64x64)
 extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { (void)E; return (size_t)256 * 2 * fe::IMG; }
 // weight-gradient operand workspaces of the virtual / node-level stages (layouts: virt_backward in virt_bwd.hip,
-// graph_post_backward, graph_pre_backward, node_pre_backward above).  One form of B4 serves every wiring since round 4
-// (v / Gv + the per-group parts of g_A / g_x + consumer scratch); the _for variant is kept for ABI stability.
+// graph_post_backward, graph_pre_backward, node_pre_backward above).  The flag-less query is the upper bound over both forms of B4
+// (the tile-major form: v / Gv + the per-group parts of g_A / g_x + consumer scratch); the _for variant sizes by the form that runs.
 extern "C" size_t fastegnn_wg_virt_floats(int32_t N, int32_t C) {
   const size_t n = C >= 1 ? fe::virt_pc_wg_floats((size_t)(N > 0 ? N : 0), (size_t)C) : 0;
   return n > 4 ? n : 4;
 }
 extern "C" size_t fastegnn_wg_virt_floats_for(int32_t N, int32_t C, int32_t flags) {
-  (void)flags;
+  // the channel-phased form of B4 (round 5) keeps no [C][N][64] array: consumer scratch + the partial slabs of dW3c only
+  if (fe::virt_cs_applies(N, C, flags)) return fe::virt_cs_wg_floats((size_t)C);
   return fastegnn_wg_virt_floats(N, C);
 }
 extern "C" size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C) {

@@ -517,7 +517,11 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
   float *dW = a.dW + (size_t)bidx * a.sW;
   const int e = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const bool bias_block = blockIdx.z == IMG / H;      // last z-block reduces the bias slabs
-  const float *base = bias_block ? tab.slab_b + s0 * H + e : tab.slab + s0 * IMG + blockIdx.z * H + e;
+  // (a slab job may keep its slabs in an array of the caller: add_slabs_ext stores its base in the unused operand pointer)
+  const bool ext = a.T == nullptr && a.G != nullptr;
+  const float *slabs = ext ? a.G : tab.slab;
+  const size_t sx = ext ? (size_t)bidx * a.nsplit : s0;
+  const float *base = bias_block ? tab.slab_b + s0 * H + e : slabs + sx * IMG + blockIdx.z * H + e;
   const size_t stride = bias_block ? H : IMG;
   if (bias_block && !a.db) return;
   double s[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
@@ -601,17 +605,17 @@ int WgradBatch::plan() {
   if (planned) return FASTEGNN_OK;
   long want = 0;
   for (int k = 0; k < tab.n_jobs; ++k)
-    if (tab.job[k].G) want += (long)tab.job[k].nsplit * tab.job[k].nb;
+    if (tab.job[k].T) want += (long)tab.job[k].nsplit * tab.job[k].nb;   // (T == null: a slab job, whose slabs its caller's kernel wrote)
   const long avail = (long)slab_top - slab_base;
   long need_min = 0;
   for (int k = 0; k < tab.n_jobs; ++k)
-    if (tab.job[k].G) need_min += tab.job[k].nb;
+    if (tab.job[k].T) need_min += tab.job[k].nb;
   FE_REQUIRE(need_min <= avail, "wgrad: slab workspace exhausted");
   n_wg = 0;
   n_slab = slab_base;
   for (int k = 0; k < tab.n_jobs; ++k) {
     WgJob &j = tab.job[k];
-    if (!j.G) { j.wg_begin = n_wg; continue; }   // slab job: contributes no workgroups to wgrad_tn_kernel
+    if (!j.T) { j.wg_begin = n_wg; continue; }   // slab job: contributes no workgroups to wgrad_tn_kernel
     long nsplit = j.nsplit;
     if (want > avail) {   // every job gives up the same fraction (at least one slab per batch slice stays)
       nsplit = nsplit * (avail - need_min) / want;
@@ -665,6 +669,20 @@ int WgradBatch::add_slabs(float *dW, int lddw, int c0, int ks, float *db, int ns
   j.round = 0;
   j.wg_begin = -1; j.slab_begin = slab_top;
   *slab_begin = slab_top;
+  return FASTEGNN_OK;
+}
+
+int WgradBatch::add_slabs_ext(const float *ext, float *dW, int lddw, int c0, int ks, int nsplit, int nb, long sW) {
+  FE_REQUIRE(ext && dW && nsplit > 0 && nb > 0 && sW != 0, "wgrad: add_slabs_ext arguments");
+  FE_REQUIRE(tab.n_jobs < WG_MAX_JOBS, "wgrad: too many jobs in one batch");
+  FE_REQUIRE(!planned, "wgrad: add_slabs_ext() after the batch has been planned");
+  WgJob &j = tab.job[tab.n_jobs++];
+  j.G = ext; j.T = nullptr; j.dW = dW; j.db = nullptr; j.M = 0; j.sG = j.sT = 0; j.sW = sW;
+  j.ldg = j.ldt = H; j.lddw = lddw; j.c0 = c0; j.ks = ks; j.kmax = 64;
+  j.rows_per_wg = 0; j.nsplit = nsplit; j.nb = nb;
+  j.round = 0;
+  j.wg_begin = -1; j.slab_begin = 0;
+  if (nb > max_nb) max_nb = nb;
   return FASTEGNN_OK;
 }
 

@@ -870,14 +870,692 @@ __global__ __launch_bounds__(256) void virt_bwd_combine_kernel(float *g_A, float
   }
 }
 
+// =====================================================================================
+// B4c', channel-PHASED form (round 5): Gv and v never reach HBM
+// =====================================================================================
+// The form above keeps two [C][N][64] arrays in HBM per launch: Gv = g_poolV + W3c^T g_np (written by virt_bwd_gv_kernel, read back
+// here) and v (written here, read back by wgrad_tn for the per-channel node_mlp.0 blocks) -- 1.6 GB of a launch's 1.1 + 0.5 GB of
+// traffic at cfg4, two extra kernels (0.49 + 0.48 ms per step).  Both need ONE 64x64 object per channel -- the image of W3c[c]^T, the
+// accumulator of dW3c[c] -- which a tile-major walk over 16 channels cannot keep on chip.  Here a workgroup keeps its tile range and
+// walks it CHANNEL-major: units are (channel c, tile) pairs taken from a ticket counter in that order, so at any time the producers
+// work on one channel (two around a boundary):
+//   * W3c[c]^T sits in an LDS stage of two slots (slot c & 1); the wave that finishes the last unit of channel c - 1 refills that
+//     slot with channel c + 1 while the others work on channel c -- no workgroup barrier, one flag per channel;
+//   * Gv is formed in registers: g_poolV[b, c] + W3c[c]^T g_np (one more f16x2 product per unit);
+//   * the consumer that owns dW3c holds ONE accumulator for the channel in flight (flushed to its scratch tile when a ticket of
+//     the other parity arrives, written out as that channel's partial slab when the channel's last ticket has been contracted);
+//     g_np rides along in the ring slot of (g_ux, g_uX, v);
+//   * g_A / g_x of a tile accumulate through memory from channel to channel (read-modify-write of the tile's rows by whichever
+//     producer holds the unit: workgroup-scope release / acquire at unit boundaries; a tile recurs every ntiles-per-workgroup units, far
+//     outside the window of units in flight -- the launcher requires >= 12 tiles per workgroup);
+//   * pools and the rank-1 gradients as above, the LDS pool rows by channel parity, flushed by the wave that closes the channel.
+// Waves: producers 0, 1, 2, 4, 5; wave 3 contracts (g_ux, v) and (g_uX, v), wave 7 (g_vp, t), wave 6 (g_np, v).
+// Everything a workgroup needs from its neighbours is gone: no part tiles, no combine kernel, no atomics on g_A.
+#ifndef FE_VB_CS
+#define FE_VB_CS 1
+#endif
+#ifndef FE_VBS_5P
+#define FE_VBS_5P 1
+#endif
+constexpr int VBS_SLOT_A = 4 * VB_TILE;        // g_ux | g_uX | v | g_np
+constexpr int VBS_W3_WORDS = 4096;             // one f16x2 image of W3c^T (img3 layout, parts h | l)
+constexpr int VBS_MIN_TILES = 12;              // tiles per workgroup below which the tile-major form runs instead
+constexpr int VBS_MAXC = 64;
+constexpr int VBS_MAXTILES = 256;              // tiles per workgroup the per-tile sequence flags cover (1 M nodes on 256 workgroups)
+// control words: unit ticket, ring heads A / B | per ring slot: filled, drained (ring A: two readers), channel of a ring-A slot |
+// per channel: image ready, units done
+enum { VBSC_UNIT = 0, VBSC_HEAD = 1, VBSC_FILLED = 4, VBSC_DRAINED = 4 + 2 * VB_MAXRING, VBSC_SLOTCH = 4 + 5 * VB_MAXRING,
+       VBSC_READY = 4 + 6 * VB_MAXRING, VBSC_DONE = 4 + 6 * VB_MAXRING + VBS_MAXC, VBSC_TSEQ = 4 + 6 * VB_MAXRING + 2 * VBS_MAXC,
+       VBSC_CTRL = 4 + 6 * VB_MAXRING + 2 * VBS_MAXC + VBS_MAXTILES };
+
+struct VirtCsArgs {
+  VirtArgs f;
+  const float *g_x_out, *g_poolX, *g_poolV, *g_np;
+  float *g_x, *g_A, *g_Bc, *g_Zp;
+  float *cons_scratch;        // [grid][5][64*64]: running sums of X, XX, V2 and of the two parities of W (accumulator order)
+  float *w_slab;              // [C][grid][64*64] partial slabs of dW3c, [o][k] row-major
+  float *d_wxv2, *d_wxx2, *d_wvr, *d_attw, *d_attb;
+  int ld_v0;
+  float *slab, *slab_b;
+  int slab_x, slab_X, slab_v2;
+  int ringA, ringB, nbank;
+};
+inline size_t vbs_lds_floats(int ringA, int ringB, int nbank) {
+  return (size_t)3 * (rm_lds_bytes<GM_F16>() / 4) + 2 * VBS_W3_WORDS + VV_COUNT * H + (size_t)nbank * VB_RACC + 2 * H + 8 +
+         (size_t)ringA * VBS_SLOT_A + (size_t)ringB * VB_SLOT_B + VBSC_CTRL;
+}
+
+// acc += W x on an f16x2 image (img3 layout) with a per-item scaled gradient operand (Split2s): as gemm64_f2_rm_<.., true>
+__device__ __forceinline__ void gemm64_f2_scaled(const unsigned *img3, const Split2s &in, Vec &acc) {
+  const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + lane_id();
+  const f16x8 xh0 = __builtin_bit_cast(f16x8, in.s.p[0][0]), xh1 = __builtin_bit_cast(f16x8, in.s.p[0][1]);
+  const f16x8 xl0 = __builtin_bit_cast(f16x8, in.s.p[1][0]), xl1 = __builtin_bit_cast(f16x8, in.s.p[1][1]);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f16x8 ah0 = __builtin_bit_cast(f16x8, ip[(t * 2 + 0) * 64]), ah1 = __builtin_bit_cast(f16x8, ip[(t * 2 + 1) * 64]);
+    const f16x8 al0 = __builtin_bit_cast(f16x8, ip[512 + (t * 2 + 0) * 64]), al1 = __builtin_bit_cast(f16x8, ip[512 + (t * 2 + 1) * 64]);
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, xh0, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xl0, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, xh1, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xl1, lo, 0, 0, 0);
+    f32x4 hi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hi[r] = lo[r] * F2_DOWN;
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh0, hi, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh1, hi, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc.t[t][r] = __builtin_fmaf(hi[r], in.inv, acc.t[t][r]);
+  }
+}
+
+// diagnostic (-DFE_VBS_WATCHDOG): every spin of the channel-phased kernel gives up after ~0.2 s and leaves its number in g_vbs_dog
+#ifdef FE_VBS_WATCHDOG
+__device__ int g_vbs_dog[64];
+#define VBS_SPIN(id, cond, sl) { long _n = 0; while (cond) { __builtin_amdgcn_s_sleep(sl); if (++_n > 3000000) { if (lane_id() == 0) { atomicAdd(&g_vbs_dog[id], 1); if (blockIdx.x == 0 && g_vbs_dog[48 + wave_id()] == 0) g_vbs_dog[48 + wave_id()] = (id) * 1000000 + _mark; } break; } } }
+#define VBS_MARK(x) _mark = (x)
+#else
+#define VBS_SPIN(id, cond, sl) while (cond) __builtin_amdgcn_s_sleep(sl)
+#define VBS_MARK(x)
+#endif
+template <bool ATT>
+__global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A) {
+  constexpr int SM = GM_F16;
+  typedef typename OperandOf<SM>::type SOp;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef FE_VBS_WATCHDOG
+  int _mark = 0;
+#endif
+  const VirtArgs &a = A.f;
+  const int C = a.C;
+  constexpr int RMS = rm_lds_bytes<SM>();
+  char *rmimg = reinterpret_cast<char *>(lds);                      // V2 | WXV0 | WXX0 (row-major f16x2: product and transpose)
+  unsigned *w3 = reinterpret_cast<unsigned *>(lds) + 3 * (RMS / 4);   // W3c[c]^T of the channel in flight (slot c & 1) and of the next
+  float *vec = lds + 3 * (RMS / 4) + 2 * VBS_W3_WORDS;
+  float *racc0 = vec + VV_COUNT * H;                                // [nbank][5][64]
+  float *gBc_l = racc0 + A.nbank * VB_RACC;                         // [2][64]: pool rows of graph `cur`, by channel parity
+  float *gZ_l = gBc_l + 2 * H;                                      // [2][4]
+  float *ringA = gZ_l + 8;
+  float *ringB = ringA + A.ringA * VBS_SLOT_A;
+  int *ctrl = reinterpret_cast<int *>(ringB + A.ringB * VB_SLOT_B);
+  const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
+  // one wave copies the image of channel c into its stage slot (16 KB: sixteen 16-byte pieces per lane)
+  auto stage_w3 = [&](int c) {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_x3(a.wpack, C, img_w3ct(C, c)));
+    u32x4 *dst = reinterpret_cast<u32x4 *>(w3 + (c & 1) * VBS_W3_WORDS);
+    u32x4 tmp[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tmp[i] = src[l + 64 * i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[l + 64 * i] = tmp[i];
+  };
+  {
+    const char *src = wpack_rm(a.wpack, C, RM_F16);
+    for (int i = threadIdx.x; i < 3 * (RMS / 16); i += blockDim.x) {
+      const int im = i / (RMS / 16), k = i % (RMS / 16);
+      reinterpret_cast<u32x4 *>(rmimg + im * RMS)[k] = reinterpret_cast<const u32x4 *>(src + (size_t)im * RM_BYTES)[k];
+    }
+  }
+  virt_load_vecs(vec, a);
+  for (int i = threadIdx.x; i < A.nbank * VB_RACC + 2 * H + 8; i += blockDim.x) racc0[i] = 0.f;
+  if (threadIdx.x < VBSC_CTRL) ctrl[threadIdx.x] = 0;
+  if (wv == 0) stage_w3(0);
+  if (wv == 1 && C > 1) stage_w3(1);
+  __syncthreads();
+  if (threadIdx.x < 2 && threadIdx.x < C) ctrl[VBSC_READY + threadIdx.x] = 1;
+  __syncthreads();
+  // -DFE_VBS_5P=1 (default): wave 6 is a third consumer that takes the dW3c contraction off wave 7 -- with six producers wave 7's two
+  // contractions from two rings paced the kernel (virt_bwd 4.41 ms per step; 3.47 with the dW3c products skipped: gpurun_out/cs3)
+  constexpr bool FIVEP = FE_VBS_5P != 0;
+  const bool consumer = wv == VB_CONS_X || wv == VB_CONS_XX || (FIVEP && wv == VB_CONS_V2);
+  const int ntiles = (a.N + 15) >> 4;
+  const int t_lo = (int)((long)blockIdx.x * ntiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  const int nt = t_hi - t_lo;
+  const int total = nt * C;                       // units = tickets per ring
+  const int cur = a.batch[t_lo * 16];             // graph whose pools this workgroup accumulates in LDS
+  const bool tanh_on = a.flags & FASTEGNN_F_TANH;
+
+  if (consumer) {
+    __builtin_amdgcn_s_setprio(3);
+    const bool wx = wv == VB_CONS_X;              // wave 3: X + XX (ring A);  wave 7: V2 (ring B) + W (ring A)
+    auto scp = [&](int slot, int blk, int e4) {
+      char *b = reinterpret_cast<char *>(A.cons_scratch + ((size_t)blockIdx.x * 5 + slot) * IMG) + (size_t)((blk * 4 + e4) * 64 * 16);
+      asm volatile("" : "+s"(b));
+      return reinterpret_cast<f32x4 *>(b + (unsigned)l * 16u);
+    };
+    // acc (in units of the streams' scales) -> true units, added to the running sum of scratch tile `slot`; last: out as a [o][k] slab
+    auto flush_one = [&](WgAcc32 &acc, float ig, float it, int slot, bool have, bool last, float *slab_dst) {
+#pragma unroll
+      for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (acc.c[bo][bk][4 * e4 + r] * ig) * it;
+            f32x4 *d = scp(slot, bo * 2 + bk, e4);
+            if (have) v += *d;
+            if (!last) {
+              *d = v;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) slab_dst[(32 * bo + 8 * e4 + 4 * (l >> 5) + r) * H + 32 * bk + (l & 31)] = v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.c[bo][bk][4 * e4 + r] = 0.f;
+          }
+    };
+    auto bias_out = [&](double (&bs)[2], size_t sl) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        double s0 = bs[b];
+        s0 += __shfl_xor(s0, 32);
+        if (l < 32) A.slab_b[sl * H + 32 * b + l] = (float)s0;
+      }
+    };
+    auto rowsum8 = [](const float (&x)[2][8], int b) {
+      return (double)(((x[b][0] + x[b][1]) + (x[b][2] + x[b][3])) + ((x[b][4] + x[b][5]) + (x[b][6] + x[b][7])));
+    };
+    WgAcc32 acc0, acc1;      // wave 3: X, XX;  wave 7: V2, W
+    wg32_zero(acc0);
+    wg32_zero(acc1);
+    const int *filledA = ctrl + VBSC_FILLED, *filledB = ctrl + VBSC_FILLED + VB_MAXRING;
+    if (wx) {
+      WgScale sG0{0}, sG1{0}, sT{0};
+      double bs0[2] = {0., 0.}, bs1[2] = {0., 0.};
+      bool flushed = false;
+      int since = 0;
+      int *drained = ctrl + VBSC_DRAINED;
+      for (int done = 0; done < total; ++done) {
+        VBS_MARK(done);
+        const int s0 = done % A.ringA, r0w = done / A.ringA;
+        VBS_SPIN(1, vb_ld(&filledA[s0]) != r0w + 1, 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        const float *g0 = ringA + s0 * VBS_SLOT_A;
+        float xt[2][8], xg0[2][8], xg1[2][8];
+        wg32_read<VB_RS>(g0 + 2 * VB_TILE, xt);
+        wg32_read<VB_RS>(g0, xg0);
+        wg32_read<VB_RS>(g0 + VB_TILE, xg1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (l == 0) vb_st(&drained[s0], r0w + 1);
+        const float fT = sT.update_lazy(xt);
+        const float f0 = sG0.update_lazy(xg0) * fT, f1 = sG1.update_lazy(xg1) * fT;
+        if (f0 != 1.f) wg32_scale_acc(acc0, f0);
+        if (f1 != 1.f) wg32_scale_acc(acc1, f1);
+        const WgOp32 T = wg32_split(xt, sT.scale());
+        {
+          const WgOp32 G = wg32_split(xg0, sG0.scale());
+          bs0[0] += rowsum8(xg0, 0); bs0[1] += rowsum8(xg0, 1);
+          wg32_mma(acc0, G, T);
+        }
+        {
+          const WgOp32 G = wg32_split(xg1, sG1.scale());
+          bs1[0] += rowsum8(xg1, 0); bs1[1] += rowsum8(xg1, 1);
+          wg32_mma(acc1, G, T);
+        }
+        if (++since >= VB_FLUSH && done + 1 < total) {
+          flush_one(acc0, sG0.inv(), sT.inv(), 0, flushed, false, nullptr);
+          flush_one(acc1, sG1.inv(), sT.inv(), 1, flushed, false, nullptr);
+          flushed = true;
+          since = 0;
+        }
+      }
+      const size_t slx = (size_t)A.slab_x + blockIdx.x, slX = (size_t)A.slab_X + blockIdx.x;
+      flush_one(acc0, sG0.inv(), sT.inv(), 0, flushed, true, A.slab + slx * IMG);
+      flush_one(acc1, sG1.inv(), sT.inv(), 1, flushed, true, A.slab + slX * IMG);
+      bias_out(bs0, slx);
+      bias_out(bs1, slX);
+    } else {
+      WgScale sGv{0}, sTv{0}, sGw{0}, sTw{0};      // streams: g_vp, t (ring B);  g_np, v (ring A)
+      double bsv[2] = {0., 0.};
+      bool flushed_v = false;
+      int since_v = 0, doneA = 0, doneB = 0;
+      int w_ch = -1;                               // channel whose products acc1 holds
+      int w_cnt[2] = {0, 0};                       // tickets of the channel of each parity contracted so far
+      bool w_have[2] = {false, false};             // the parity's scratch tile holds a partial sum
+      int since_w = 0;
+      int *drainedA = ctrl + VBSC_DRAINED + VB_MAXRING, *drainedB = ctrl + VBSC_DRAINED + 2 * VB_MAXRING;
+      const bool doV2 = wv == VB_CONS_XX, doW = FIVEP ? wv == VB_CONS_V2 : wv == VB_CONS_XX;
+      // acc1 -> the running sum of its channel (scratch tile 3 + parity)
+      auto park_w = [&]() {
+        if (w_ch < 0) return;
+        flush_one(acc1, sGw.inv(), sTw.inv(), 3 + (w_ch & 1), w_have[w_ch & 1], false, nullptr);
+        w_have[w_ch & 1] = true;
+      };
+#ifdef FE_VBS_WATCHDOG
+      long dog = 0;
+#endif
+      while ((doW && doneA < total) || (doV2 && doneB < total)) {
+        bool did = false;
+        if (doV2 && doneB < total) {
+          const int s0 = doneB % A.ringB, r0w = doneB / A.ringB;
+          if (vb_ld(&filledB[s0]) == r0w + 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            const float *g0 = ringB + s0 * VB_SLOT_B;
+            float xg[2][8], xt[2][8];
+            wg32_read<VB_RS>(g0, xg);
+            wg32_read<VB_RS>(g0 + VB_TILE, xt);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (l == 0) vb_st(&drainedB[s0], r0w + 1);
+            const float f = sGv.update_lazy(xg) * sTv.update_lazy(xt);
+            if (f != 1.f) wg32_scale_acc(acc0, f);
+            const WgOp32 G = wg32_split(xg, sGv.scale()), T = wg32_split(xt, sTv.scale());
+            bsv[0] += rowsum8(xg, 0); bsv[1] += rowsum8(xg, 1);
+            wg32_mma(acc0, G, T);
+            ++doneB;
+            if (++since_v >= VB_FLUSH && doneB < total) {
+              flush_one(acc0, sGv.inv(), sTv.inv(), 2, flushed_v, false, nullptr);
+              flushed_v = true;
+              since_v = 0;
+            }
+            did = true;
+          }
+        }
+        if (doW && doneA < total) {
+          const int s0 = doneA % A.ringA, r0w = doneA / A.ringA;
+          if (vb_ld(&filledA[s0]) == r0w + 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            const float *g0 = ringA + s0 * VBS_SLOT_A;
+            const int ch = __builtin_amdgcn_readfirstlane(ctrl[VBSC_SLOTCH + s0]);
+            float xg[2][8], xt[2][8];
+            wg32_read<VB_RS>(g0 + 3 * VB_TILE, xg);   // g_np
+            wg32_read<VB_RS>(g0 + 2 * VB_TILE, xt);   // v
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (l == 0) vb_st(&drainedA[s0], r0w + 1);
+            if (ch != w_ch) {                          // a ticket of the other channel: park what acc1 holds
+              park_w();
+              w_ch = ch;
+              since_w = 0;
+            }
+#ifndef VBS_DIAG_NO_W   // diagnostic: wave 7 only drains its ring-A tickets (results are wrong without the contraction)
+            const float f = sGw.update_lazy(xg) * sTw.update_lazy(xt);
+            if (f != 1.f) wg32_scale_acc(acc1, f);
+            const WgOp32 G = wg32_split(xg, sGw.scale()), T = wg32_split(xt, sTw.scale());
+            wg32_mma(acc1, G, T);
+#endif
+            ++doneA;
+            const int par = ch & 1;
+            if (++w_cnt[par] == nt) {                  // the channel is complete: its partial slab, [o][k] row-major
+              flush_one(acc1, sGw.inv(), sTw.inv(), 3 + par, w_have[par], true, A.w_slab + ((size_t)ch * gridDim.x + blockIdx.x) * IMG);
+              w_have[par] = false;
+              w_cnt[par] = 0;
+              w_ch = -1;
+            } else if (++since_w >= VB_FLUSH) {        // cancelling sums: the accumulator leaves the registers every 768 rows
+              park_w();
+              since_w = 0;
+            }
+            did = true;
+          }
+        }
+        if (!did) {
+          __builtin_amdgcn_s_sleep(1);
+#ifdef FE_VBS_WATCHDOG
+          if (++dog > 6000000) { if (l == 0) { atomicAdd(&g_vbs_dog[6], 1); if (blockIdx.x == 0) { g_vbs_dog[38] = doneA; g_vbs_dog[39] = doneB; g_vbs_dog[40] = total; g_vbs_dog[41] = ctrl[VBSC_UNIT]; g_vbs_dog[42] = ctrl[VBSC_HEAD]; g_vbs_dog[43] = ctrl[VBSC_HEAD + 1]; for (int _k = 0; _k < 8; ++_k) { g_vbs_dog[8 + _k] = ctrl[VBSC_READY + _k]; g_vbs_dog[16 + _k] = ctrl[VBSC_DONE + _k]; } } } break; }
+#endif
+        }
+      }
+      if (doV2) {
+        const size_t sl = (size_t)A.slab_v2 + blockIdx.x;
+        flush_one(acc0, sGv.inv(), sTv.inv(), 2, flushed_v, true, A.slab + sl * IMG);
+        bias_out(bsv, sl);
+      }
+    }
+  } else {
+    // ---------------------------------------------------------------------------------------------------------
+    // producers
+    // ---------------------------------------------------------------------------------------------------------
+    const float invC = 1.0f / (float)C;
+    const float attb0 = ATT ? a.attb[0] : 0.f;
+    float *racc = racc0 + ((wv > 3 ? wv - 1 : wv) % A.nbank) * VB_RACC;
+    auto mm = [&](int which, const SOp &op, Vec &acc) { gemm_rm<SM, false>(rmimg + which * RMS, op, acc); };
+    auto mmT = [&](int which, const Vec &g, Vec &acc) {
+      const auto op = make_grad_operand<SM>(g);
+      gemm_rm_g<SM, true>(rmimg + which * RMS, op, acc);
+    };
+    int pend_tile = -1, pend_c = 0;   // the unit whose rows this wave stored last: not yet handed on
+    for (;;) {
+      int u = 0;
+      if (l == 0) u = atomicAdd(&ctrl[VBSC_UNIT], 1);
+      u = __builtin_amdgcn_readfirstlane(u);
+      if (u >= total) {
+        if (pend_tile >= 0) {   // (units of other waves may still wait for this wave's last rows)
+          __builtin_amdgcn_s_waitcnt(0x0f70);
+          asm volatile("" ::: "memory");
+          if (l == 0) __hip_atomic_store(&ctrl[VBSC_TSEQ + pend_tile], pend_c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        break;
+      }
+      const int c = u / nt, tile = t_lo + (u - c * nt);
+      VBS_MARK(u);
+      if (pend_tile >= 0 && (vb_ld(&ctrl[VBSC_READY + c]) == 0 || vb_ld(&ctrl[VBSC_TSEQ + (tile - t_lo)]) < c)) {
+        // about to wait (rare): hand this wave's last rows on first -- a wave that waits must not hold back what others wait for
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        asm volatile("" ::: "memory");
+        if (l == 0) __hip_atomic_store(&ctrl[VBSC_TSEQ + pend_tile], pend_c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        pend_tile = -1;
+      }
+      VBS_SPIN(2, vb_ld(&ctrl[VBSC_READY + c]) == 0, 2);   // W3c[c]^T is in slot c & 1, the parity's pool rows are clear
+      // the tile's g_A / g_x rows were last written by whichever wave of THIS workgroup held (c - 1, tile): workgroup scope -- the waves
+      // of a workgroup share their CU's vector L1, so acquire / release cost a wait, no cache maintenance (agent scope writes the L2
+      // back and invalidates the L1 on this multi-XCD part: measured 4.1 instead of 0.7 ms per launch)
+      // TSEQ[tile] = c once the rows of (c - 1, tile) are in memory -- published by their writer lazily, behind its NEXT unit's first
+      // loads (below), so nobody ever waits for a store: this spin practically never turns
+      VBS_SPIN(7, vb_ld(&ctrl[VBSC_TSEQ + (tile - t_lo)]) < c, 1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int n0 = tile * 16, nend = min(a.N, n0 + 16);
+      // (one graph in the batch -- the frames this form is for: no batch lookups at the head of the dependent-load chain)
+      const int b0 = a.B == 1 ? 0 : a.batch[n0], b1 = a.B == 1 ? 0 : a.batch[nend - 1];
+      const int pmode = b0 != b1 ? 2 : (b0 == cur ? 0 : 1);
+      const int n = n0 + j;
+      const bool valid = n < nend;
+      const int nc = valid ? n : nend - 1;
+      const int b = a.B == 1 ? 0 : a.batch[nc];
+      const unsigned offB = (unsigned)b * C * H + 4u * q + (unsigned)c * H;   // [B,C,64] arrays
+      const unsigned offN = (unsigned)nc * H + 4u * q;                        // [N,64] arrays
+      const unsigned offZ = (unsigned)b * 3u * C;
+      float gxn[3], xi[3], gx[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gxn[k] = valid ? A.g_x_out[(size_t)nc * 3 + k] : 0.f;
+        xi[k] = a.x[(size_t)nc * 3 + k];
+        // the tile's g_x accumulates through memory; the direct path x' = x + ... is counted once, with channel 0
+        gx[k] = c == 0 ? gxn[k] : (valid ? A.g_x[(size_t)nc * 3 + k] : 0.f);
+      }
+      float vd[3], gpX[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        vd[k] = (a.Z + (k * C + c))[offZ] - xi[k];
+        gpX[k] = valid ? (A.g_poolX + (k * C + c))[offZ] : 0.f;
+      }
+      const float vr = sqrt_f(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
+      Vec vp = vload_vec(vec + VV_C2 * H, q);
+      Vec d_pre = vload_u(a.A, offN);
+      vadd(d_pre, vload_u(a.Bc, offB));
+      vaxpy(d_pre, vr, vload_vec(vec + VV_WVR * H, q));
+      const Vec t = vsilu_keep_d(d_pre FE_ACT(a));        // d_pre <- silu'(pre)
+      if (pend_tile >= 0) {
+        // every load of this unit's head has returned, and the vector memory counter runs in order: the g_A / g_x rows the PREVIOUS
+        // unit of this wave stored are in memory.  Its tile may now be taken up in the next channel.
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+        asm volatile("" ::: "memory");
+        if (l == 0) __hip_atomic_store(&ctrl[VBSC_TSEQ + pend_tile], pend_c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+      }
+      mm(0, make_operand<SM>(t), vp);
+      const Vec v0 = vsilu_keep_d(vp FE_ACT(a));          // vp <- silu'(vp)
+      float att = 1.f;
+      Vec v = v0;
+      if constexpr (ATT) {
+        att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + attb0);
+        v = vscale(v0, att);
+      }
+      float sx, sX;
+      Vec g_ux, g_uX;
+      {
+        Vec uxp = vload_vec(vec + VV_BXV0 * H, q), uXp = vload_vec(vec + VV_BXX0 * H, q);
+        {
+          const SOp vs = make_operand<SM>(v);
+          mm(1, vs, uxp);
+          mm(2, vs, uXp);
+        }
+        {
+          Vec ux = vsilu_keep_d(uxp FE_ACT(a));
+          const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
+          sx = tanh_on ? tanh_f(sr) : sr;
+          float g_sx = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) g_sx -= vd[k] * invC * gxn[k];
+          const float g_sr = tanh_on ? g_sx * (1.f - sx * sx) : g_sx;
+          vb_accum_items(racc + 0 * H, vscale(ux, g_sr), j, q);
+          g_ux = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
+        }
+        {
+          Vec uX = vsilu_keep_d(uXp FE_ACT(a));
+          const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
+          sX = tanh_on ? tanh_f(sr) : sr;
+          float g_sX = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) g_sX += vd[k] * gpX[k];
+          const float g_sr = tanh_on ? g_sX * (1.f - sX * sX) : g_sX;
+          vb_accum_items(racc + 1 * H, vscale(uX, g_sr), j, q);
+          g_uX = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
+        }
+      }
+      // Gv = g_poolV[b, c] + W3c[c]^T g_np is formed in registers; the g_np row also rides to wave 7 in the ring slot
+      const Vec gnp = vb_mask(vload_u(A.g_np, offN), valid);
+      {   // (g_ux, v), (g_uX, v), (g_np, v) to waves 3 and 7: one slot of ring A, free once both have drained it
+        int tk = 0;
+        if (l == 0) tk = atomicAdd(&ctrl[VBSC_HEAD + 0], 1);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        const int sl = tk % A.ringA, round = tk / A.ringA;
+        VBS_SPIN(4, vb_ld(&ctrl[VBSC_DRAINED + 0 * VB_MAXRING + sl]) != round, 2);
+        VBS_SPIN(5, vb_ld(&ctrl[VBSC_DRAINED + 1 * VB_MAXRING + sl]) != round, 2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        float *slot = ringA + sl * VBS_SLOT_A;
+        vb_tile_store(slot, j, q, g_ux);
+        vb_tile_store(slot + VB_TILE, j, q, g_uX);
+        vb_tile_store(slot + 2 * VB_TILE, j, q, valid ? v : vzero());
+        vb_tile_store(slot + 3 * VB_TILE, j, q, gnp);
+        if (l == 0) ctrl[VBSC_SLOTCH + sl] = c;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (l == 0) vb_st(&ctrl[VBSC_FILLED + sl], round + 1);
+        asm volatile("" ::: "memory");
+      }
+      Vec g_v = vb_mask(vload_u(A.g_poolV, offB), valid);
+      gemm64_f2_scaled(w3 + (c & 1) * VBS_W3_WORDS, vsplit2_scaled(gnp), g_v);
+      mmT(1, g_ux, g_v);
+      mmT(2, g_uX, g_v);
+      float g_vd[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g_vd[k] = -sx * invC * gxn[k] + sX * gpX[k];
+      Vec g_v0 = g_v;
+      if constexpr (ATT) {
+        const float g_a = vdot(g_v, v0);
+        const float g_z = g_a * att * (1.f - att);
+        vb_accum_items(racc + 3 * H, vscale(v0, g_z), j, q);
+        const float sz = jsum(q == 0 ? g_z : 0.f);
+        if (l == 0) atomicAdd(&racc[4 * H], sz);
+        g_v0 = vscale(g_v, att);
+        vaxpy(g_v0, g_z, vload_vec(vec + VV_ATT * H, q));
+      }
+      Vec g_t = vzero();
+      Vec ga = vzero();
+      {
+        const Vec g_vp = vmul(g_v0, vp);
+        {   // (g_vp, t) to wave 7
+          int tk = 0;
+          if (l == 0) tk = atomicAdd(&ctrl[VBSC_HEAD + 1], 1);
+          tk = __builtin_amdgcn_readfirstlane(tk);
+          const int sl = tk % A.ringB, round = tk / A.ringB;
+          VBS_SPIN(3, vb_ld(&ctrl[VBSC_DRAINED + 2 * VB_MAXRING + sl]) != round, 2);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+          float *slot = ringB + sl * VB_SLOT_B;
+          vb_tile_store(slot, j, q, g_vp);
+          vb_tile_store(slot + VB_TILE, j, q, t);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+          if (l == 0) vb_st(&ctrl[VBSC_FILLED + VB_MAXRING + sl], round + 1);
+          asm volatile("" ::: "memory");
+        }
+        if (c > 0) ga = vload_u(A.g_A, offN);     // requested here, consumed after the product: the tile's running g_A
+        mmT(0, g_vp, g_t);
+      }
+      const Vec g_pre = vmul(g_t, d_pre);
+      vadd(ga, g_pre);
+      if (valid) vstore_u(A.g_A, offN, ga);
+      vb_accum_items(racc + 2 * H, vscale(g_pre, vr), j, q);
+      const float g_vr = vdot(g_pre, vload_vec(vec + VV_WVR * H, q));
+      const float ivr = vr > 0.f ? g_vr * rcp_f(vr) : 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        g_vd[k] += ivr * vd[k];
+        gx[k] -= g_vd[k];
+      }
+      if (valid && q == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) A.g_x[(size_t)n * 3 + k] = gx[k];
+      }
+      // pools over the nodes of the tile: g_Bc[b,c,:] += g_pre, g_Zp[b,:,c] += g_vd
+      if (pmode < 2) {
+        float pz[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pz[k] = jsum((valid && q == 0) ? g_vd[k] : 0.f);
+        vb_accum_items(pmode == 0 ? gBc_l + (c & 1) * H : A.g_Bc + ((size_t)b0 * C + c) * H, g_pre, j, q);
+        if (l < 3) {
+          const float pzl = l == 0 ? pz[0] : (l == 1 ? pz[1] : pz[2]);
+          if (pmode == 0) atomicAdd(&gZ_l[(c & 1) * 4 + l], pzl);
+          else atomicAdd(&A.g_Zp[((size_t)b0 * 3 + l) * C + c], pzl);
+        }
+      } else {
+        if (valid && q == 0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) atomicAdd(&A.g_Zp[((size_t)b * 3 + k) * C + c], g_vd[k]);
+        }
+        if (valid) {
+#pragma unroll
+          for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              atomicAdd(&A.g_Bc[((size_t)b * C + c) * H + 16 * t2 + 4 * q + r], g_pre.t[t2][r]);
+        }
+      }
+      // unit done.  Its pool atomics (LDS) are out before the channel's counter moves; its g_A / g_x rows are handed on lazily (TSEQ)
+      pend_tile = tile - t_lo;
+      pend_c = c;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      int dn = 0;
+      if (l == 0) dn = atomicAdd(&ctrl[VBSC_DONE + c], 1);
+      dn = __builtin_amdgcn_readfirstlane(dn);
+      if (dn == nt - 1) {
+        // this wave closes channel c: the parity's pool rows go out and are cleared, the stage slot takes channel c + 2
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        const float pb = gBc_l[(c & 1) * H + l];
+        atomicAdd(&A.g_Bc[((size_t)cur * C + c) * H + l], pb);
+        gBc_l[(c & 1) * H + l] = 0.f;
+        if (l < 3) {
+          atomicAdd(&A.g_Zp[((size_t)cur * 3 + l) * C + c], gZ_l[(c & 1) * 4 + l]);
+          gZ_l[(c & 1) * 4 + l] = 0.f;
+        }
+        if (c + 2 < C) {
+          stage_w3(c + 2);
+          // (a RELEASE store at workgroup scope between compiler barriers: as a relaxed store behind a fence the compiler sank it out
+          // of the unit loop -- legal for a relaxed atomic, fatal here: this very wave goes on to spin on the flag of a later channel
+          // while the others wait for this one.  Found with the spin watchdog of -DFE_VBS_WATCHDOG, tools/gpu_vbs_dog.py)
+          asm volatile("" ::: "memory");
+          if (l == 0) __hip_atomic_store(&ctrl[VBSC_READY + c + 2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < H) {
+    const int o = threadIdx.x;
+    float s5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int bk = 0; bk < A.nbank; ++bk) {
+      const float *r = racc0 + bk * VB_RACC;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s5[k] += r[k * H + o];
+      s5[4] += r[4 * H];
+    }
+    atomicAdd(&A.d_wxv2[o], s5[0]);
+    atomicAdd(&A.d_wxx2[o], s5[1]);
+    atomicAdd(&A.d_wvr[(size_t)o * A.ld_v0], s5[2]);
+    if constexpr (ATT) {
+      atomicAdd(&A.d_attw[o], s5[3]);
+      if (o == 0) atomicAdd(A.d_attb, s5[4]);
+    }
+  }
+}
+
+// does the channel-phased form run this layer's B4?  (default build, fp32-grade SiLU-or-generic activations, FastEGNN wiring, enough
+// tiles per workgroup; FASTEGNN_VIRT_CS=0 in the environment keeps the tile-major form -- an A/B switch)
+// workgroups of the channel-phased form: one per CU while every workgroup keeps >= VBS_MIN_TILES tiles (the g_A / g_x rows of a tile
+// pass from unit (c, tile) to unit (c + 1, tile) through memory: the two must never be in flight together)
+static int virt_cs_grid(long N) {
+  const long g = ((N + 15) / 16) / VBS_MIN_TILES;
+  return (int)(g > 256 ? 256 : g);
+}
+// the form runs when that fills the chip; FASTEGNN_VIRT_CS_MIN_GRID lowers the bar (tests: the oracle comparisons at 20 000 nodes)
+static int virt_cs_min_grid() {
+  static const int v = getenv("FASTEGNN_VIRT_CS_MIN_GRID") ? atoi(getenv("FASTEGNN_VIRT_CS_MIN_GRID")) : 256;
+  return v < 1 ? 1 : v;
+}
+bool virt_cs_applies(long N, int C, int flags) {
+  if (!(FE_VB_CS && GM_VIRT_BWD == GM_F16 && FE_VB_CONS32)) return false;
+  static const bool off = getenv("FASTEGNN_VIRT_CS") && atoi(getenv("FASTEGNN_VIRT_CS")) == 0;
+  if (off || (flags & (FASTEGNN_F_BF16 | FASTEGNN_F_RF | FASTEGNN_F_EGNN)) || C < 1 || C > VBS_MAXC) return false;
+  const int grid = virt_cs_grid(N);
+  // Upper bound on the tiles per workgroup: every channel pass re-reads the range's A / g_np / g_A rows (12 KB per tile), which must
+  // come from the L2 / Infinity Cache for the form to pay.  Measured (profiles/r05_lever_virt_cs.txt): at 24 tiles per workgroup
+  // (cfg4) the two forms tie on time and this one keeps 1.6 GB per launch out of HBM; at 244 (cfg5: 770 MB of rows, beyond the
+  // 256 MB cache) it re-streams them from HBM 32 times and loses 7 % -- the tile-major form runs there.  FASTEGNN_VIRT_CS_MAX_TILES
+  // moves the bound (a blocked walk -- channel-major inside blocks of ~32 tiles -- is the open end of this design).
+  static const int max_tiles = getenv("FASTEGNN_VIRT_CS_MAX_TILES") ? atoi(getenv("FASTEGNN_VIRT_CS_MAX_TILES")) : 64;
+  const long nt = ((N + 15) / 16 + grid - 1) / grid;
+  return grid >= virt_cs_min_grid() && nt <= VBS_MAXTILES && nt <= max_tiles;
+}
+size_t virt_cs_wg_floats(size_t C) { return (size_t)256 * (5 + C) * IMG; }
+
 // floats of wg_virt: Gv, overwritten row by row with v ([C][N + pad][64]) | parts of g_A and g_x | consumer scratch
 size_t virt_pc_wg_floats(size_t N, size_t C) {
   const size_t NGF = (C + VB_GF - 1) / VB_GF;
   return (N + WGV_PAD) * C * H + (size_t)256 * VB_FINE_TILES * (NGF - 1) * 16 * (H + 4) + (size_t)256 * 3 * IMG;
 }
 
+// B4c': the (node, channel) part in the channel-phased form -- one kernel, then the fixed-order reduction of its partial slabs
+static int virt_backward_channels_cs(const fastegnn_layer_t *L, hipStream_t st, float *wg_gnp) {
+  const int C = L->C;
+  const bool att = has(L, FASTEGNN_F_ATTENTION);
+  float *const *g = L->grads;
+  const int grid = virt_cs_grid(L->N);
+  FE_REQUIRE(L->g_poolV, "virt_backward: g_poolV null");
+  WgradBatch bb(L->wg_slab, st, false, WG_SLABS / 2, WG_SLABS / 2);
+  VirtCsArgs A;
+  A.f = make_virt_args(L);
+  A.g_x_out = L->g_x_out; A.g_poolX = L->g_poolX; A.g_poolV = L->g_poolV; A.g_np = wg_gnp;
+  A.g_x = L->g_x; A.g_A = L->g_A; A.g_Bc = L->g_Bc; A.g_Zp = L->g_Zp;
+  A.cons_scratch = L->wg_virt;
+  A.w_slab = L->wg_virt + (size_t)grid * 5 * IMG;
+  A.ld_v0 = 2 * H + 1 + C;
+  A.d_wxv2 = g[FASTEGNN_P_CRV2_W]; A.d_wxx2 = g[FASTEGNN_P_CVV2_W];
+  A.d_wvr = g[FASTEGNN_P_VIRT0_W] + 2 * H;
+  A.d_attw = g[FASTEGNN_P_ATTV_W]; A.d_attb = g[FASTEGNN_P_ATTV_B];
+  int rc;
+  if ((rc = bb.add_slabs(g[FASTEGNN_P_CRV0_W], H, 0, 1, g[FASTEGNN_P_CRV0_B], grid, &A.slab_x))) return rc;
+  if ((rc = bb.add_slabs(g[FASTEGNN_P_CVV0_W], H, 0, 1, g[FASTEGNN_P_CVV0_B], grid, &A.slab_X))) return rc;
+  if ((rc = bb.add_slabs(g[FASTEGNN_P_VIRT2_W], H, 0, 1, g[FASTEGNN_P_VIRT2_B], grid, &A.slab_v2))) return rc;
+  A.slab = bb.tab.slab; A.slab_b = bb.tab.slab_b;
+  // rings: 3 slots of (g_ux | g_uX | v | g_np) + 2 of (g_vp | t) are what the 160 KB leave beside five images; FE_VBS_RING overrides
+  static const int ring_want = getenv("FE_VBS_RING") ? atoi(getenv("FE_VBS_RING")) : 32;
+  A.ringA = ring_want / 10; A.ringB = ring_want % 10; A.nbank = 1;
+  if (A.ringA < 2 || A.ringA > VB_MAXRING) A.ringA = 3;
+  if (A.ringB < 2 || A.ringB > VB_MAXRING) A.ringB = 2;
+  while (vbs_lds_floats(A.ringA, A.ringB, 1) * sizeof(float) > 160 * 1024 && A.ringB > 2) --A.ringB;
+  while (vbs_lds_floats(A.ringA, A.ringB, 1) * sizeof(float) > 160 * 1024 && A.ringA > 2) --A.ringA;
+  while (A.nbank < VB_MAXBANK && vbs_lds_floats(A.ringA, A.ringB, A.nbank + 1) * sizeof(float) <= 160 * 1024) ++A.nbank;
+  const size_t lds = vbs_lds_floats(A.ringA, A.ringB, A.nbank) * sizeof(float);
+  FE_REQUIRE(lds <= 160 * 1024, "virt_backward: LDS budget exceeded");
+  {
+    ProfScope ps(K_VIRT_BWD, st);
+    const dim3 g3(grid), b3(64 * VB_WAVES);
+    if (att) hipLaunchKernelGGL((virt_bwd_cs_kernel<true>), g3, b3, lds, st, A);
+    else hipLaunchKernelGGL((virt_bwd_cs_kernel<false>), g3, b3, lds, st, A);
+  }
+  if ((rc = check_launch("virt_bwd_cs_kernel"))) return rc;
+  // node_mlp.0 block of channel c (column 2H + k C + c, k = feature of v): one slab set per channel, written by wave 7
+  const int ld_n0 = 2 * H + H * C + L->na;
+  if ((rc = bb.add_slabs_ext(A.w_slab, g[FASTEGNN_P_NODE0_W], ld_n0, 2 * H, C, grid, C, 1))) return rc;
+  return bb.finish();
+}
+
 // B4b + B4c: the (node, channel) part -- Gv, then the producer / consumer kernel and its weight gradients
 static int virt_backward_channels(const fastegnn_layer_t *L, hipStream_t st, float *wg_gnp) {
+  if (virt_cs_applies(L->N, L->C, L->flags)) return virt_backward_channels_cs(L, st, wg_gnp);
   const int N = L->N, C = L->C, ntiles = cdiv(N, 16);
   const bool bf = has(L, FASTEGNN_F_BF16), att = has(L, FASTEGNN_F_ATTENTION), rf = has(L, FASTEGNN_F_RF);
   float *const *g = L->grads;
@@ -1020,6 +1698,17 @@ extern "C" int fastegnn_debug_read_vb2_stamps(unsigned long long *out, int reset
   if (reset) {
     unsigned long long z[32] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(fe::g_vb2_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
+
+#ifdef FE_VBS_WATCHDOG
+extern "C" int fastegnn_debug_read_vbs_dog(int *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::g_vbs_dog), sizeof(int) * 64) != hipSuccess) return -1;
+  if (reset) {
+    int z[64] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(fe::g_vbs_dog), z, sizeof(z));
   }
   return 0;
 }

@@ -1,0 +1,61 @@
+"""-m gpu: the channel-PHASED form of the virtual backward (virt_bwd_cs_kernel: Gv and v never in HBM; csrc/virt_bwd.hip) against the
+oracle.  By default it runs from ~49 000 nodes up (one workgroup per CU with >= 12 tiles each), where the suite only holds property
+tests; FASTEGNN_VIRT_CS_MIN_GRID lowers the bar so that the oracle comparisons of tests/test_gpu_properties.py at 20 000 - 37 000
+nodes -- the headline shape (C = 16, gravity), the cfg5 shape (C = 32), three graphs in one batch (pools of several graphs per
+workgroup), odd channel counts, the deterministic edge backward -- run through it.  A child process: the switch is read once."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SUBSET = ("test_cfg4_headline_shape_vs_oracle or test_cfg5_shape_c32_vs_oracle or test_many_tiles_per_workgroup_vs_oracle or "
+          "test_many_tiles_odd_channel_counts_vs_oracle or test_deterministic_backward_matches_atomic_scatter")
+
+
+def _pytest(env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_properties.py", "-m", "gpu", "-q", "-x", "-k", SUBSET],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = "\n".join(r.stdout.splitlines()[-25:])
+    assert r.returncode == 0, tail + "\n" + r.stderr[-1500:]
+    return tail
+
+
+def test_oracle_comparisons_through_the_channel_phased_backward():
+    tail = _pytest({"FASTEGNN_VIRT_CS_MIN_GRID": "64", "FASTEGNN_VIRT_CS_REPORT": "1"})
+    assert "passed" in tail
+
+
+def test_the_switch_really_selects_the_kernel():
+    """the same frame under both forms: the channel-phased kernel is what ran (profiler ids), and the two agree"""
+    code = r'''
+import sys, json, torch
+sys.path.insert(0, ".")
+import fastegnn_amd
+from fastegnn_amd import _lib as K
+from bench import make_frame, loss_fn
+torch.manual_seed(43)
+m = fastegnn_amd.FastEGNN(2, 0, 2, 64, 16, device="cuda", n_layers=2, gravity=[0, -1, 0])
+frame, target = make_frame(20000, 16, 43, "cuda")
+K.lib().fastegnn_profile_enable(1)
+loc, vloc = m(**frame)
+loss_fn(loc, vloc, target).backward()
+torch.cuda.synchronize()
+prof = K.profile_collect()
+g = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+print("RESULT " + json.dumps({"gv": prof.get("virt_bwd_gv_kernel", (0, 0))[1], "vb": prof.get("virt_bwd_kernel", (0, 0))[1],
+                              "gsum": float(g.double().abs().sum()), "loc": float(loc.double().abs().sum())}))
+'''
+    import json
+    res = {}
+    for tag, env in (("cs", {"FASTEGNN_VIRT_CS_MIN_GRID": "64"}), ("tile", {"FASTEGNN_VIRT_CS": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["cs"]["gv"] == 0 and res["cs"]["vb"] == 2, res       # no Gv kernel: the phased form ran both layers
+    assert res["tile"]["gv"] == 2, res
+    assert abs(res["cs"]["gsum"] - res["tile"]["gsum"]) <= 1e-4 * res["tile"]["gsum"], res

@@ -5,9 +5,11 @@ tag=$1; shift
 O=gpurun_out/$tag; mkdir -p $O
 i=0
 for extra in "$@"; do
+  envv=""
+  case "$extra" in ENV:*) envv="${extra#ENV:}"; extra="";; esac
   ( cd fastegnn_amd/csrc && rm -f *.o && make -j16 ../libfastegnn_hip.so EXTRA="$extra" > /dev/null 2>&1 ) || { echo "build failed: $extra"; continue; }
-  python bench.py --steps 40 --warmup 3 --no-cpu-baseline ${BENCH_ARGS} 2>$O/v$i.err | grep '{"metric"' > $O/v$i.json || tail -3 $O/v$i.err
-  python - "$extra" $O/v$i.json <<'PY'
+  env $envv timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline ${BENCH_ARGS} 2>$O/v$i.err | grep '{"metric"' > $O/v$i.json || tail -3 $O/v$i.err
+  python - "$extra$envv" $O/v$i.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))
 k = d["kernels"]
