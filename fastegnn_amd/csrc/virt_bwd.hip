@@ -1490,6 +1490,7 @@ bool virt_cs_applies(long N, int C, int flags) {
   static const bool off = getenv("FASTEGNN_VIRT_CS") && atoi(getenv("FASTEGNN_VIRT_CS")) == 0;
   if (off || (flags & (FASTEGNN_F_BF16 | FASTEGNN_F_RF | FASTEGNN_F_EGNN)) || C < 1 || C > VBS_MAXC) return false;
   const int grid = virt_cs_grid(N);
+  if (grid < 1) return false;
   // Upper bound on the tiles per workgroup: every channel pass re-reads the range's A / g_np / g_A rows (12 KB per tile), which must
   // come from the L2 / Infinity Cache for the form to pay.  Measured (profiles/r05_lever_virt_cs.txt): at 24 tiles per workgroup
   // (cfg4) the two forms tie on time and this one keeps 1.6 GB per launch out of HBM; at 244 (cfg5: 770 MB of rows, beyond the
