@@ -382,6 +382,7 @@ int fastegnn_wide_scatter_add(float *table, const int64_t *idx, int64_t M, int32
     const int gx = cdiv(W, 256);
     long rows_per_wg = 64;   // enough workgroups to fill the chip, runs long enough to pay
     while (rows_per_wg < 1024 && (long)gx * cdiv(M, rows_per_wg) > 16384) rows_per_wg *= 2;
+    while (cdiv(M, rows_per_wg) > 65535) rows_per_wg *= 2;   // grid.y is a 16-bit quantity: beyond 67 M rows the ranges grow instead
     hipLaunchKernelGGL(scatter_add_runs_kernel, dim3(gx, (unsigned)cdiv(M, rows_per_wg)), dim3(256), 0, (hipStream_t)stream, table, idx,
                        (long)M, W, rows, rows_per_wg);
   } else {

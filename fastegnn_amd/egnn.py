@@ -224,6 +224,9 @@ class EGNN(nn.Module):
             raise RuntimeError("fastegnn_amd.EGNN runs on a gfx950 GPU only (no CPU fallback)")
         if self._wide:
             from . import wide
+            from .model import _DEBUG_CHECKS, _check_indices
+            if _DEBUG_CHECKS:   # FASTEGNN_DEBUG_CHECKS=1: an out-of-range row / col would be an out-of-bounds gather or atomic
+                _check_indices(edge_index, torch.zeros(x.size(0), dtype=torch.long, device=x.device), x.size(0), 1)
             if edge_fea is not None and edge_fea.size(1) == 0:
                 edge_fea = None
             x_out, h_out = wide.egnn_forward(self, x, h, edge_index, edge_fea, v)

@@ -262,7 +262,7 @@ def _fill(layer: K.LayerT, **tensors):
 class _Spec:
     """Static description shared by forward and backward."""
 
-    def __init__(self, model: "FastEGNN"):
+    def __init__(self, model: "FastEGNN", deterministic: Optional[bool] = None):
         self.C = model.virtual_channels
         self.n_layers = model.n_layers
         self.ea = model.edge_attr_nf
@@ -275,7 +275,8 @@ class _Spec:
         flags |= K.F_RESIDUAL if model.residual else 0
         flags |= K.F_GRAVITY if model.gravity is not None else 0
         flags |= K.F_BF16 if getattr(model, "mlp_dtype", torch.float32) == torch.bfloat16 else 0
-        flags |= K.F_DETERMINISTIC if getattr(model, "deterministic", False) else 0
+        det = getattr(model, "deterministic", False) if deterministic is None else deterministic
+        flags |= K.F_DETERMINISTIC if det else 0
         self.act_kind, self.act_param = getattr(model, "_act", (K.ACT_SILU, 0.0))
         flags |= self.act_kind << K.F_ACT_SHIFT
         self.flags = flags | model._extra_flags
@@ -627,6 +628,7 @@ class FastEGNN(nn.Module):
         self._range = RangeGuard()
         self._deterministic = K.deterministic_default()
         self._spec = None      # built lazily (after .to(device) / load_state_dict), parameters are fixed objects
+        self._spec_det = None  # the same with FASTEGNN_F_DETERMINISTIC, for the small graphs that take it by default
         self._plist = None
         self.to(self.device)
 
@@ -651,17 +653,30 @@ class FastEGNN(nn.Module):
     def deterministic(self, value):
         self._deterministic = None if value is None else bool(value)
         self._spec = None
+        self._spec_det = None
         self._graph_cache = {}
 
-    def sorted_graph(self, edge_index: torch.Tensor, n_nodes: int) -> SortedGraph:
+    # graphs of at most this many edges take the col-keyed (order-independent) sum unless told otherwise: on a graph of a few dozen
+    # nodes the arrival order of the atomic scatter moves the input gradients between runs at the level of the parity floor, and the
+    # reference's CPU scatter_add_ is run-to-run exact; the extra index sort and reduce launch cost nothing measurable there
+    SMALL_GRAPH_EDGES = 512
+
+    def deterministic_for(self, n_edges: int) -> bool:
+        """the form of the edge backward a call with `n_edges` edges takes (see `deterministic`)"""
+        if self._deterministic is None and n_edges <= self.SMALL_GRAPH_EDGES:
+            return True
+        return self.deterministic
+
+    def sorted_graph(self, edge_index: torch.Tensor, n_nodes: int, deterministic: Optional[bool] = None) -> SortedGraph:
         """CSR of `edge_index`, cached (``self.cache_graphs``, 8 entries) under (data_ptr, size, torch's version counter,
         n_nodes).  Caveat: a writer that bypasses torch's version counter -- a raw-pointer kernel such as this library's
         own ``fastegnn_radius_graph_fill`` refilling a reused buffer -- is not seen; pass a fresh tensor, or set
         ``cache_graphs = False``, when edge lists are rewritten in place that way."""
-        key = (edge_index.data_ptr(), edge_index.size(1), edge_index._version, n_nodes, n_nodes, 0, self.deterministic)
+        det = self.deterministic_for(edge_index.size(1)) if deterministic is None else deterministic
+        key = (edge_index.data_ptr(), edge_index.size(1), edge_index._version, n_nodes, n_nodes, 0, det)
         g = self._graph_cache.get(key) if self.cache_graphs else None
         if g is None:
-            g = SortedGraph(edge_index, n_nodes, csc=self.deterministic)
+            g = SortedGraph(edge_index, n_nodes, csc=det)
             if self.cache_graphs:
                 if len(self._graph_cache) >= 8:
                     self._graph_cache.pop(next(iter(self._graph_cache)))
@@ -693,8 +708,15 @@ class FastEGNN(nn.Module):
             self._spec = _Spec(self)
             pidx = self._param_index
             self._plist = [pidx[n] for n in self._spec.names]
-        spec = self._spec
         graph = edge_index if isinstance(edge_index, SortedGraph) else self.sorted_graph(edge_index, N)
+        spec = self._spec
+        # a graph that came with its col-keyed index (small graphs by default, `deterministic` otherwise) takes the order-independent sum
+        if graph.cscptr is not None and not spec.flags & K.F_DETERMINISTIC:
+            if getattr(self, "_spec_det", None) is None:
+                self._spec_det = _Spec(self, deterministic=True)
+            spec = self._spec_det
+        elif graph.cscptr is None and spec.flags & K.F_DETERMINISTIC:
+            raise ValueError("fastegnn_amd: deterministic=True needs a SortedGraph built with csc=True")
         lib = K.lib()
         if data_batch.dtype != torch.int64:      # the C entry point reads int64 (what PyG collate emits)
             data_batch = data_batch.long()

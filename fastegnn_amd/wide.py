@@ -182,8 +182,25 @@ def _segment_sum(t, idx, R):
     return _ScatterAdd.apply(t, idx, R)
 
 
+_WARNED_DET = False
+
+
+def _warn_deterministic(model):
+    """the wide path's segment sums and weight gradients are fp32 atomics in arrival order: say so once when the module was asked for
+    reproducible sums (`deterministic = True` is honoured by the fused kernels only)"""
+    global _WARNED_DET
+    # FastEGNN / FastRF keep the request in `_deterministic` (None: not asked), EGNN in a plain `deterministic` attribute
+    asked = model._deterministic if hasattr(model, "_deterministic") else getattr(model, "deterministic", False)
+    if asked is True and not _WARNED_DET:
+        import warnings
+        warnings.warn("fastegnn_amd: hidden_nf > 64 (or EGNN flat=True) runs on the unfused wide path, whose sums are fp32 atomics: "
+                      "results vary at rounding level from run to run although deterministic=True was requested", RuntimeWarning, stacklevel=3)
+        _WARNED_DET = True
+
+
 def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_mean, edge_attr=None, node_attr=None):
     """FastEGNN.forward (models/FastEGNN.py:255-276) for hidden_nf > 64 -> (node_loc, virtual_node_loc)."""
+    _warn_deterministic(model)
     dev = node_loc.device
     Hn, C = model.hidden_nf, model.virtual_channels
     kind, p = model._act
@@ -284,6 +301,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
 def egnn_forward(model, x, h, edge_index, edge_fea, v=None):
     """EGNN.forward (models/basic.py:337-341 over EGNN_Layer.forward :302-320) on the wide operators: hidden_nf > 64, or
     flat=True (every BaseMLP a Tanh MLP with 4 x hidden inner units, :176-178) -> (x, h)."""
+    _warn_deterministic(model)
     dev = x.device
     Hn = model.hidden_nf
     kind, p = (K.ACT_TANH, 0.0) if model.flat else model._act

@@ -102,6 +102,9 @@ GRAD_FLOOR = 1e-6
 # kernels) each sit at a random point of the same rounding-noise band, so "2 x the reference's own draw" is not a
 # bound; the floor granted is the measured band, never more than 1.5e-5.
 GRAD_EXCEPTIONS = [
+    # Round 5: the entry for the input gradients of the 17-node activation goldens ("^act_", "^gin/", floor 2.5e-6) is gone: graphs of
+    # at most 512 edges take the order-independent col-keyed sum by default (FastEGNN.deterministic_for), and over five runs on the
+    # default and on the wide-range build no such comparison exceeds the plain rule (worst 1.59e-6 / 1.37e-6: gpurun_out/actgin, tools/gpu_r5_act_gin.sh)
     # Round 4 (f16x2 products, double-precision slab reduce / bias totals / embedding sums; profiles/r04_gradient_tolerance_report.txt:
     # 4 385 comparisons over the whole -m gpu suite, 27 beyond 2 x ref + 1e-6, none beyond what is granted here): the entries for
     # the layer-0 bias sums of the virtual coordinate heads on the cfg4 / cfg5 shapes (factor 4 until round 3: now 0.35-0.69 of
@@ -153,11 +156,6 @@ GRAD_EXCEPTIONS = [
      "then across tiles in LDS -- a different association of a cancelling sum: 5.81e-6 over 2 x ref "
      "(ragged3_attention, gcl_0.att_mlp_virtual.0.bias 9.60e-6 vs 1.89e-6; 1.26e-5 / 1.36e-5 and floor 1e-5 with the "
      "truncating split)"),
-    (r"^act_", r"^gin/", 2.0, 2.5e-6,
-     "input gradients of the 17-node activation goldens (generic-activation library): the end of the whole backward chain on "
-     "a graph whose sums have a dozen terms -- max error over 34-51 numbers, 6.1e-7 .. 1.69e-6 over six builds / runs of round "
-     "4 (the col-side scatter's atomic order moves it between runs) where the reference sits at 2.7e-7: at the 1e-6 floor of the "
-     "plain rule, not above its factor"),
     (r"act_mid", r"\.bias$", 2.0, 5e-6,
      "activations other than SiLU at 4 000 nodes: bias gradients are column sums over 32 k - 48 k rows behind erf / exp / "
      "log1p evaluations of 2-4 ulp; measured 4.64e-6 against 2 x ref + 1e-6 = 2.96e-6 (act_mid_gelu, "
