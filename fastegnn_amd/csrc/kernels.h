@@ -72,8 +72,8 @@ struct WgradBatch {
   // only the fixed-order reduction into dW / db runs here.  *slab_begin receives the first slab index.
   int plan();
   int add_slabs(float *dW, int lddw, int c0, int ks, float *db, int nsplit, int *slab_begin);
-  // the same for `nb` weights whose partial slabs the caller keeps in an array of its OWN: ext[(b * nsplit + split) * 4096], no bias;
-  // weight b adds into dW + b * sW
+  // the same for `nb` weights whose partial slabs the caller keeps in an array of its OWN: ext[(b * nsplit + split) * 4096], no bias,
+  // elements in the accumulator order of the 32x32 MFMA blocks (common.h, WgAcc32); weight b adds into dW + b * sW
   int add_slabs_ext(const float *ext, float *dW, int lddw, int c0, int ks, int nsplit, int nb, long sW);
   int finish();
   // The contractions are deferred to finish(): a job's operand rows must stay untouched until then.  A stage that is about

@@ -521,7 +521,13 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
   const bool ext = a.T == nullptr && a.G != nullptr;
   const float *slabs = ext ? a.G : tab.slab;
   const size_t sx = ext ? (size_t)bidx * a.nsplit : s0;
-  const float *base = bias_block ? tab.slab_b + s0 * H + e : slabs + sx * IMG + blockIdx.z * H + e;
+  // (ext slabs come in the accumulator order of the 32x32 MFMA blocks -- common.h, WgAcc32: element (o, k) of the [64][64] weight)
+  size_t eoff = (size_t)blockIdx.z * H + e;
+  if (ext && !bias_block) {
+    const int o = blockIdx.z, k = e;
+    eoff = (size_t)(((((o >> 5) * 2 + (k >> 5)) * 4 + ((o >> 3) & 3)) * 64 + ((o >> 2) & 1) * 32 + (k & 31)) * 4 + (o & 3));
+  }
+  const float *base = bias_block ? tab.slab_b + s0 * H + e : slabs + sx * IMG + eoff;
   const size_t stride = bias_block ? H : IMG;
   if (bias_block && !a.db) return;
   double s[8] = {0., 0., 0., 0., 0., 0., 0., 0.};

@@ -902,23 +902,33 @@ constexpr int VBS_W3_WORDS = 4096;             // one f16x2 image of W3c^T (img3
 constexpr int VBS_MIN_TILES = 12;              // tiles per workgroup below which the tile-major form runs instead
 constexpr int VBS_MAXC = 64;
 constexpr int VBS_MAXTILES = 256;              // tiles per workgroup the per-tile sequence flags cover (1 M nodes on 256 workgroups)
+// A long tile range is walked in BLOCKS of VBS_BLOCK tiles (VirtCsArgs::block), channel-major inside a block: every channel pass re-reads the block's A /
+// g_np / g_A rows (12 KB per tile), and they must still be in the L2 / Infinity Cache when the next pass comes (cfg5, 244 tiles per
+// workgroup, un-blocked: 770 MB of rows re-streamed from HBM 32 times -- 77.7 against 72.2 ms per step of the tile-major form).  A
+// PHASE is one (block, channel) pair; phases alternate between the two stage slots / pool rows like channels did.
+#ifndef FE_VBS_BLOCK
+#define FE_VBS_BLOCK 24
+#endif
+constexpr int VBS_BLOCK = FE_VBS_BLOCK;
+constexpr int VBS_NPH = 64;                    // phase flags live modulo this (at most three phases are in flight)
 // control words: unit ticket, ring heads A / B | per ring slot: filled, drained (ring A: two readers), channel of a ring-A slot |
 // per channel: image ready, units done
 enum { VBSC_UNIT = 0, VBSC_HEAD = 1, VBSC_FILLED = 4, VBSC_DRAINED = 4 + 2 * VB_MAXRING, VBSC_SLOTCH = 4 + 5 * VB_MAXRING,
-       VBSC_READY = 4 + 6 * VB_MAXRING, VBSC_DONE = 4 + 6 * VB_MAXRING + VBS_MAXC, VBSC_TSEQ = 4 + 6 * VB_MAXRING + 2 * VBS_MAXC,
-       VBSC_CTRL = 4 + 6 * VB_MAXRING + 2 * VBS_MAXC + VBS_MAXTILES };
+       VBSC_READY = 4 + 6 * VB_MAXRING, VBSC_DONE = 4 + 6 * VB_MAXRING + VBS_NPH, VBSC_TSEQ = 4 + 6 * VB_MAXRING + 2 * VBS_NPH,
+       VBSC_CTRL = 4 + 6 * VB_MAXRING + 2 * VBS_NPH + VBS_MAXTILES };
 
 struct VirtCsArgs {
   VirtArgs f;
   const float *g_x_out, *g_poolX, *g_poolV, *g_np;
   float *g_x, *g_A, *g_Bc, *g_Zp;
   float *cons_scratch;        // [grid][5][64*64]: running sums of X, XX, V2 and of the two parities of W (accumulator order)
-  float *w_slab;              // [C][grid][64*64] partial slabs of dW3c, [o][k] row-major
+  float *w_slab;              // [C][grid][64*64] partial sums of dW3c per workgroup, in ACCUMULATOR order (WgAcc32), summed over the blocks
   float *d_wxv2, *d_wxx2, *d_wvr, *d_attw, *d_attb;
   int ld_v0;
   float *slab, *slab_b;
   int slab_x, slab_X, slab_v2;
   int ringA, ringB, nbank;
+  int block;                  // tiles per block of the walk (VBS_BLOCK; FASTEGNN_VIRT_CS_BLOCK overrides it -- tests)
 };
 inline size_t vbs_lds_floats(int ringA, int ringB, int nbank) {
   return (size_t)3 * (rm_lds_bytes<GM_F16>() / 4) + 2 * VBS_W3_WORDS + VV_COUNT * H + (size_t)nbank * VB_RACC + 2 * H + 8 +
@@ -980,9 +990,10 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
   int *ctrl = reinterpret_cast<int *>(ringB + A.ringB * VB_SLOT_B);
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
   // one wave copies the image of channel c into its stage slot (16 KB: sixteen 16-byte pieces per lane)
-  auto stage_w3 = [&](int c) {
+  auto stage_w3 = [&](int ph) {   // image of channel ph % C into the slot of phase ph
+    const int c = ph % C;
     const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_x3(a.wpack, C, img_w3ct(C, c)));
-    u32x4 *dst = reinterpret_cast<u32x4 *>(w3 + (c & 1) * VBS_W3_WORDS);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(w3 + (ph & 1) * VBS_W3_WORDS);
     u32x4 tmp[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) tmp[i] = src[l + 64 * i];
@@ -999,18 +1010,20 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
   virt_load_vecs(vec, a);
   for (int i = threadIdx.x; i < A.nbank * VB_RACC + 2 * H + 8; i += blockDim.x) racc0[i] = 0.f;
   if (threadIdx.x < VBSC_CTRL) ctrl[threadIdx.x] = 0;
+  const int ntiles = (a.N + 15) >> 4;
+  const int t_lo = (int)((long)blockIdx.x * ntiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  const int nt = t_hi - t_lo;
+  const int BT = A.block;
+  const int nblk = (nt + BT - 1) / BT, nphase = nblk * C;
   if (wv == 0) stage_w3(0);
-  if (wv == 1 && C > 1) stage_w3(1);
+  if (wv == 1 && nphase > 1) stage_w3(1);
   __syncthreads();
-  if (threadIdx.x < 2 && threadIdx.x < C) ctrl[VBSC_READY + threadIdx.x] = 1;
+  if (threadIdx.x < 2 && (int)threadIdx.x < nphase) ctrl[VBSC_READY + threadIdx.x] = threadIdx.x + 1;   // READY[ph % NPH] == ph + 1: phase ph may run
   __syncthreads();
   // -DFE_VBS_5P=1 (default): wave 6 is a third consumer that takes the dW3c contraction off wave 7 -- with six producers wave 7's two
   // contractions from two rings paced the kernel (virt_bwd 4.41 ms per step; 3.47 with the dW3c products skipped: gpurun_out/cs3)
   constexpr bool FIVEP = FE_VBS_5P != 0;
   const bool consumer = wv == VB_CONS_X || wv == VB_CONS_XX || (FIVEP && wv == VB_CONS_V2);
-  const int ntiles = (a.N + 15) >> 4;
-  const int t_lo = (int)((long)blockIdx.x * ntiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
-  const int nt = t_hi - t_lo;
   const int total = nt * C;                       // units = tickets per ring
   const int cur = a.batch[t_lo * 16];             // graph whose pools this workgroup accumulates in LDS
   const bool tanh_on = a.flags & FASTEGNN_F_TANH;
@@ -1118,11 +1131,32 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
       int since_w = 0;
       int *drainedA = ctrl + VBSC_DRAINED + VB_MAXRING, *drainedB = ctrl + VBSC_DRAINED + 2 * VB_MAXRING;
       const bool doV2 = wv == VB_CONS_XX, doW = FIVEP ? wv == VB_CONS_V2 : wv == VB_CONS_XX;
+      // acc (+ the parity's scratch tile) -> the channel's running sum over the blocks, ACCUMULATOR order, plain read-modify-write
+      // (the slab is this wave's own; the reduction kernel reads that order: WgJob::acc32)
+      auto flush_w = [&](WgAcc32 &acc, float ig, float it, int slot, bool have, float *dst, bool add) {
+#pragma unroll
+        for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+          for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              f32x4 v;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = (acc.c[bo][bk][4 * e4 + r] * ig) * it;
+              if (have) v += *scp(slot, bo * 2 + bk, e4);
+              f32x4 *d = reinterpret_cast<f32x4 *>(dst + (size_t)(((bo * 2 + bk) * 4 + e4) * 64 * 4)) + l;
+              if (add) v += *d;
+              *d = v;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc.c[bo][bk][4 * e4 + r] = 0.f;
+            }
+      };
       // acc1 -> the running sum of its channel (scratch tile 3 + parity)
+      int w_par = 0;                               // phase parity of what acc1 holds
       auto park_w = [&]() {
         if (w_ch < 0) return;
-        flush_one(acc1, sGw.inv(), sTw.inv(), 3 + (w_ch & 1), w_have[w_ch & 1], false, nullptr);
-        w_have[w_ch & 1] = true;
+        flush_one(acc1, sGw.inv(), sTw.inv(), 3 + w_par, w_have[w_par], false, nullptr);
+        w_have[w_par] = true;
       };
 #ifdef FE_VBS_WATCHDOG
       long dog = 0;
@@ -1159,16 +1193,19 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
           if (vb_ld(&filledA[s0]) == r0w + 1) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             const float *g0 = ringA + s0 * VBS_SLOT_A;
-            const int ch = __builtin_amdgcn_readfirstlane(ctrl[VBSC_SLOTCH + s0]);
+            const int chw = __builtin_amdgcn_readfirstlane(ctrl[VBSC_SLOTCH + s0]);
+            const int ch = chw & 0xff, nb_ph = (chw >> 8) & 0xfff, first_blk = chw >> 20;   // channel | tiles of its phase | block
+            const int par = (first_blk * C + ch) & 1;     // PHASE parity: neighbouring phases differ in it (channels need not: odd C)
             float xg[2][8], xt[2][8];
             wg32_read<VB_RS>(g0 + 3 * VB_TILE, xg);   // g_np
             wg32_read<VB_RS>(g0 + 2 * VB_TILE, xt);   // v
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __builtin_amdgcn_s_waitcnt(0xc07f);
             if (l == 0) vb_st(&drainedA[s0], r0w + 1);
-            if (ch != w_ch) {                          // a ticket of the other channel: park what acc1 holds
+            if (ch != w_ch || par != w_par) {          // a ticket of the other phase: park what acc1 holds
               park_w();
               w_ch = ch;
+              w_par = par;
               since_w = 0;
             }
 #ifndef VBS_DIAG_NO_W   // diagnostic: wave 7 only drains its ring-A tickets (results are wrong without the contraction)
@@ -1178,9 +1215,8 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
             wg32_mma(acc1, G, T);
 #endif
             ++doneA;
-            const int par = ch & 1;
-            if (++w_cnt[par] == nt) {                  // the channel is complete: its partial slab, [o][k] row-major
-              flush_one(acc1, sGw.inv(), sTw.inv(), 3 + par, w_have[par], true, A.w_slab + ((size_t)ch * gridDim.x + blockIdx.x) * IMG);
+            if (++w_cnt[par] == nb_ph) {               // the phase is complete: into the channel's running sum of this workgroup
+              flush_w(acc1, sGw.inv(), sTw.inv(), 3 + par, w_have[par], A.w_slab + ((size_t)ch * gridDim.x + blockIdx.x) * IMG, first_blk != 0);
               w_have[par] = false;
               w_cnt[par] = 0;
               w_ch = -1;
@@ -1229,9 +1265,15 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
         }
         break;
       }
-      const int c = u / nt, tile = t_lo + (u - c * nt);
+      // unit -> (block, channel, tile): blocks of VBS_BLOCK tiles (the last one shorter), channel-major inside a block
+      const int per_blk = BT * C;
+      const int blk = min(u / per_blk, nblk - 1);
+      const int nb = min(BT, nt - blk * BT);                        // tiles of this block
+      const int ru = u - blk * per_blk;
+      const int c = ru / nb, tile = t_lo + blk * BT + (ru - c * nb);
+      const int ph = blk * C + c;                                   // phase: stage slot / pool rows ph & 1, flags ph % VBS_NPH
       VBS_MARK(u);
-      if (pend_tile >= 0 && (vb_ld(&ctrl[VBSC_READY + c]) == 0 || vb_ld(&ctrl[VBSC_TSEQ + (tile - t_lo)]) < c)) {
+      if (pend_tile >= 0 && (vb_ld(&ctrl[VBSC_READY + ph % VBS_NPH]) != ph + 1 || vb_ld(&ctrl[VBSC_TSEQ + (tile - t_lo)]) < c)) {
         // about to wait (rare): hand this wave's last rows on first -- a wave that waits must not hold back what others wait for
         __builtin_amdgcn_s_waitcnt(0x0f70);
         asm volatile("" ::: "memory");
@@ -1239,7 +1281,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
         asm volatile("" ::: "memory");
         pend_tile = -1;
       }
-      VBS_SPIN(2, vb_ld(&ctrl[VBSC_READY + c]) == 0, 2);   // W3c[c]^T is in slot c & 1, the parity's pool rows are clear
+      VBS_SPIN(2, vb_ld(&ctrl[VBSC_READY + ph % VBS_NPH]) != ph + 1, 2);   // W3c[c]^T is in slot ph & 1, the parity's pool rows are clear
       // the tile's g_A / g_x rows were last written by whichever wave of THIS workgroup held (c - 1, tile): workgroup scope -- the waves
       // of a workgroup share their CU's vector L1, so acquire / release cost a wait, no cache maintenance (agent scope writes the L2
       // back and invalidates the L1 on this multi-XCD part: measured 4.1 instead of 0.7 ms per launch)
@@ -1341,13 +1383,13 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
         vb_tile_store(slot + VB_TILE, j, q, g_uX);
         vb_tile_store(slot + 2 * VB_TILE, j, q, valid ? v : vzero());
         vb_tile_store(slot + 3 * VB_TILE, j, q, gnp);
-        if (l == 0) ctrl[VBSC_SLOTCH + sl] = c;
+        if (l == 0) ctrl[VBSC_SLOTCH + sl] = c | (nb << 8) | (blk << 20);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if (l == 0) vb_st(&ctrl[VBSC_FILLED + sl], round + 1);
         asm volatile("" ::: "memory");
       }
       Vec g_v = vb_mask(vload_u(A.g_poolV, offB), valid);
-      gemm64_f2_scaled(w3 + (c & 1) * VBS_W3_WORDS, vsplit2_scaled(gnp), g_v);
+      gemm64_f2_scaled(w3 + (ph & 1) * VBS_W3_WORDS, vsplit2_scaled(gnp), g_v);
       mmT(1, g_ux, g_v);
       mmT(2, g_uX, g_v);
       float g_vd[3];
@@ -1404,10 +1446,10 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
         float pz[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) pz[k] = jsum((valid && q == 0) ? g_vd[k] : 0.f);
-        vb_accum_items(pmode == 0 ? gBc_l + (c & 1) * H : A.g_Bc + ((size_t)b0 * C + c) * H, g_pre, j, q);
+        vb_accum_items(pmode == 0 ? gBc_l + (ph & 1) * H : A.g_Bc + ((size_t)b0 * C + c) * H, g_pre, j, q);
         if (l < 3) {
           const float pzl = l == 0 ? pz[0] : (l == 1 ? pz[1] : pz[2]);
-          if (pmode == 0) atomicAdd(&gZ_l[(c & 1) * 4 + l], pzl);
+          if (pmode == 0) atomicAdd(&gZ_l[(ph & 1) * 4 + l], pzl);
           else atomicAdd(&A.g_Zp[((size_t)b0 * 3 + l) * C + c], pzl);
         }
       } else {
@@ -1428,25 +1470,26 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
       pend_c = c;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       int dn = 0;
-      if (l == 0) dn = atomicAdd(&ctrl[VBSC_DONE + c], 1);
+      if (l == 0) dn = atomicAdd(&ctrl[VBSC_DONE + ph % VBS_NPH], 1);
       dn = __builtin_amdgcn_readfirstlane(dn);
-      if (dn == nt - 1) {
+      if (dn == nb - 1) {
         // this wave closes channel c: the parity's pool rows go out and are cleared, the stage slot takes channel c + 2
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        const float pb = gBc_l[(c & 1) * H + l];
+        const float pb = gBc_l[(ph & 1) * H + l];
         atomicAdd(&A.g_Bc[((size_t)cur * C + c) * H + l], pb);
-        gBc_l[(c & 1) * H + l] = 0.f;
+        gBc_l[(ph & 1) * H + l] = 0.f;
         if (l < 3) {
-          atomicAdd(&A.g_Zp[((size_t)cur * 3 + l) * C + c], gZ_l[(c & 1) * 4 + l]);
-          gZ_l[(c & 1) * 4 + l] = 0.f;
+          atomicAdd(&A.g_Zp[((size_t)cur * 3 + l) * C + c], gZ_l[(ph & 1) * 4 + l]);
+          gZ_l[(ph & 1) * 4 + l] = 0.f;
         }
-        if (c + 2 < C) {
-          stage_w3(c + 2);
+        if (l == 0) ctrl[VBSC_DONE + ph % VBS_NPH] = 0;   // (the flag slot is reused VBS_NPH phases later)
+        if (ph + 2 < nphase) {
+          stage_w3(ph + 2);
           // (a RELEASE store at workgroup scope between compiler barriers: as a relaxed store behind a fence the compiler sank it out
           // of the unit loop -- legal for a relaxed atomic, fatal here: this very wave goes on to spin on the flag of a later channel
           // while the others wait for this one.  Found with the spin watchdog of -DFE_VBS_WATCHDOG, tools/gpu_vbs_dog.py)
           asm volatile("" ::: "memory");
-          if (l == 0) __hip_atomic_store(&ctrl[VBSC_READY + c + 2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (l == 0) __hip_atomic_store(&ctrl[VBSC_READY + (ph + 2) % VBS_NPH], ph + 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
           asm volatile("" ::: "memory");
         }
       }
@@ -1491,11 +1534,10 @@ bool virt_cs_applies(long N, int C, int flags) {
   if (off || (flags & (FASTEGNN_F_BF16 | FASTEGNN_F_RF | FASTEGNN_F_EGNN)) || C < 1 || C > VBS_MAXC) return false;
   const int grid = virt_cs_grid(N);
   if (grid < 1) return false;
-  // Upper bound on the tiles per workgroup: every channel pass re-reads the range's A / g_np / g_A rows (12 KB per tile), which must
-  // come from the L2 / Infinity Cache for the form to pay.  Measured (profiles/r05_lever_virt_cs.txt): at 24 tiles per workgroup
-  // (cfg4) the two forms tie on time and this one keeps 1.6 GB per launch out of HBM; at 244 (cfg5: 770 MB of rows, beyond the
-  // 256 MB cache) it re-streams them from HBM 32 times and loses 7 % -- the tile-major form runs there.  FASTEGNN_VIRT_CS_MAX_TILES
-  // moves the bound (a blocked walk -- channel-major inside blocks of ~32 tiles -- is the open end of this design).
+  // Upper bound on the tiles per workgroup (default 64): measured (profiles/r05_lever_virt_cs.txt), at 24 tiles per workgroup (cfg4) the
+  // two forms tie on time and this one keeps 1.6 GB per launch out of HBM; at 244 (cfg5, walked in blocks of 24) it needs 12.2 instead
+  // of 20.3 GB and is 1.6 % slower per step (its units pay a g_np split and a g_A read-modify-write per channel) -- the tile-major
+  // form runs there unless FASTEGNN_VIRT_CS_MAX_TILES=256 asks for the smaller footprint.
   static const int max_tiles = getenv("FASTEGNN_VIRT_CS_MAX_TILES") ? atoi(getenv("FASTEGNN_VIRT_CS_MAX_TILES")) : 64;
   const long nt = ((N + 15) / 16 + grid - 1) / grid;
   return grid >= virt_cs_min_grid() && nt <= VBS_MAXTILES && nt <= max_tiles;
@@ -1533,6 +1575,8 @@ static int virt_backward_channels_cs(const fastegnn_layer_t *L, hipStream_t st, 
   A.slab = bb.tab.slab; A.slab_b = bb.tab.slab_b;
   // rings: 3 slots of (g_ux | g_uX | v | g_np) + 2 of (g_vp | t) are what the 160 KB leave beside five images; FE_VBS_RING overrides
   static const int ring_want = getenv("FE_VBS_RING") ? atoi(getenv("FE_VBS_RING")) : 32;
+  static const int block_want = getenv("FASTEGNN_VIRT_CS_BLOCK") ? atoi(getenv("FASTEGNN_VIRT_CS_BLOCK")) : VBS_BLOCK;
+  A.block = block_want < 1 ? 1 : (block_want > 0xfff ? 0xfff : block_want);
   A.ringA = ring_want / 10; A.ringB = ring_want % 10; A.nbank = 1;
   if (A.ringA < 2 || A.ringA > VB_MAXRING) A.ringA = 3;
   if (A.ringB < 2 || A.ringB > VB_MAXRING) A.ringB = 2;

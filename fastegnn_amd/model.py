@@ -598,18 +598,19 @@ class FastEGNN(nn.Module):
         assert virtual_channels > 0, f'Channels of virtual node must greater than 0 (got {virtual_channels})'
         # hidden_nf < 64 runs zero-padded on the 64-wide tiles (_pad_param); 64 < hidden_nf <= 256 takes the unfused WIDE path
         # (fastegnn_amd/wide.py: the reference's op sequence on generic-width HIP operators; FastEGNN, fp32 only)
-        self._wide = hidden_nf > H
+        # ... and so does a model beyond the fused kernels' argument ceilings (virtual_channels > 64, edge_attr_nf > 7, node_feat_nf > 8):
+        # the reference has none (models/FastEGNN.py:227-263), and the wide path's operators are generic in every width
+        self._wide = hidden_nf > H or virtual_channels > 64 or edge_attr_nf > 7 or node_feat_nf > 8
         if not 1 <= hidden_nf <= 256:
             raise NotImplementedError(f"fastegnn_amd: hidden_nf must be at most 256 in this build (got {hidden_nf})")
         if self._wide and mlp_dtype != torch.float32:
-            raise NotImplementedError("fastegnn_amd: hidden_nf > 64 (the unfused wide path) is built for fp32 operands only")
+            raise NotImplementedError("fastegnn_amd: hidden_nf > 64, virtual_channels > 64, edge_attr_nf > 7 or node_feat_nf > 8 run on "
+                                      "the unfused wide path, which is built for fp32 operands only")
         self._act = _activation_kind(act_fn)
         if self._act[0] in (K.ACT_SIGMOID, K.ACT_SOFTPLUS) and hidden_nf < H:
             raise NotImplementedError("fastegnn_amd: hidden_nf < 64 runs zero-padded, which needs act_fn(0) = 0")
         if self._act[0] != K.ACT_SILU and mlp_dtype != torch.float32:
             raise NotImplementedError("fastegnn_amd: the bf16 operand mode is built for SiLU only")
-        if not self._wide and (virtual_channels > 64 or edge_attr_nf > 7 or node_feat_nf > 8):   # (the wide path has no such limits)
-            raise NotImplementedError("fastegnn_amd: supports virtual_channels<=64, edge_attr_nf<=7, node_feat_nf<=8")
         self.hidden_nf = hidden_nf
         self.device = device
         self.n_layers = n_layers

@@ -127,6 +127,9 @@ def test_error_behaviour():
     with pytest.raises(NotImplementedError):
         fastegnn_amd.FastEGNN(2, 0, 2, 128, 3, mlp_dtype=torch.bfloat16)   # the wide path is fp32 only
     assert fastegnn_amd.FastRF(2, 0, 2, 128, 3)._wide and fastegnn_amd.EGNN(2, 2, 2, 16, flat=True)._wide   # the siblings too
+    # beyond the fused kernels' argument ceilings the wide path takes over as well (the reference has no such limits)
+    assert fastegnn_amd.FastEGNN(9, 0, 2, 64, 3)._wide and fastegnn_amd.FastEGNN(2, 0, 8, 64, 3)._wide and fastegnn_amd.FastEGNN(2, 0, 2, 64, 65)._wide
+    assert not fastegnn_amd.FastEGNN(8, 0, 7, 64, 64)._wide
     with pytest.raises(NotImplementedError):
         fastegnn_amd.FastEGNN(2, 0, 2, 64, 3, act_fn=torch.nn.Hardswish())      # not one of the eight kinds of the C ABI
     with pytest.raises(NotImplementedError):

@@ -1,8 +1,9 @@
 """-m gpu: the channel-PHASED form of the virtual backward (virt_bwd_cs_kernel: Gv and v never in HBM; csrc/virt_bwd.hip) against the
 oracle.  By default it runs from ~49 000 nodes up (one workgroup per CU with >= 12 tiles each), where the suite only holds property
 tests; FASTEGNN_VIRT_CS_MIN_GRID lowers the bar so that the oracle comparisons of tests/test_gpu_properties.py at 20 000 - 37 000
-nodes -- the headline shape (C = 16, gravity), the cfg5 shape (C = 32), three graphs in one batch (pools of several graphs per
-workgroup), odd channel counts, the deterministic edge backward -- run through it.  A child process: the switch is read once."""
+nodes -- the headline shape (C = 16, gravity), three graphs in one batch (pools of several graphs per workgroup), the deterministic
+edge backward; with blocks of 5 tiles (what a 1 M-node frame does with blocks of 24) the cfg5 shape (C = 32) and odd channel counts
+-- run through it.  A child process: the switch is read once."""
 import os
 import subprocess
 import sys
@@ -12,13 +13,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SUBSET = ("test_cfg4_headline_shape_vs_oracle or test_cfg5_shape_c32_vs_oracle or test_many_tiles_per_workgroup_vs_oracle or "
-          "test_many_tiles_odd_channel_counts_vs_oracle or test_deterministic_backward_matches_atomic_scatter")
+SUBSET = ("test_cfg4_headline_shape_vs_oracle or test_many_tiles_per_workgroup_vs_oracle or "
+          "test_deterministic_backward_matches_atomic_scatter")
+SUBSET_BLOCKED = "test_cfg5_shape_c32_vs_oracle or test_many_tiles_odd_channel_counts_vs_oracle"
 
 
-def _pytest(env_extra):
+def _pytest(env_extra, subset=SUBSET):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_properties.py", "-m", "gpu", "-q", "-x", "-k", SUBSET],
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_properties.py", "-m", "gpu", "-q", "-x", "-k", subset],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = "\n".join(r.stdout.splitlines()[-25:])
     assert r.returncode == 0, tail + "\n" + r.stderr[-1500:]
@@ -26,7 +28,14 @@ def _pytest(env_extra):
 
 
 def test_oracle_comparisons_through_the_channel_phased_backward():
-    tail = _pytest({"FASTEGNN_VIRT_CS_MIN_GRID": "64", "FASTEGNN_VIRT_CS_REPORT": "1"})
+    tail = _pytest({"FASTEGNN_VIRT_CS_MIN_GRID": "64"})
+    assert "passed" in tail
+
+
+def test_oracle_comparisons_through_the_blocked_walk():
+    """the same with blocks of 5 tiles: the 12 - 13 tiles of a workgroup become three blocks (5, 5, 2 / 3), i.e. what a 1 M-node
+    frame does with its 244 tiles per workgroup and blocks of 24 -- phases wrap the two stage slots, dW3c sums over blocks"""
+    tail = _pytest({"FASTEGNN_VIRT_CS_MIN_GRID": "64", "FASTEGNN_VIRT_CS_BLOCK": "5"}, SUBSET_BLOCKED)
     assert "passed" in tail
 
 

@@ -103,6 +103,15 @@ def test_wide_model_vs_oracle(hidden, flags):
     _check_vs_oracle(cfg, _batch([300, 141, 77], 6, C_, seed=hidden), seed=hidden, case=f"wide_h{hidden}")
 
 
+@pytest.mark.parametrize("nf,ea,C_", [(9, 2, 3), (2, 9, 3), (2, 2, 70)])
+def test_beyond_the_fused_kernels_argument_ceilings_vs_oracle(nf, ea, C_):
+    """hidden_nf = 64 with node_feat_nf > 8, edge_attr_nf > 7 or virtual_channels > 64: the reference has no such limits
+    (models/FastEGNN.py:227-263); the module routes these shapes to the wide path instead of refusing them."""
+    cfg = R.Config(nf, 0, ea, 64, C_, n_layers=2, gravity=[0, -1, 0])
+    assert fastegnn_amd.FastEGNN(nf, 0, ea, 64, C_)._wide
+    _check_vs_oracle(cfg, _batch([150, 60], 5, C_, seed=nf + ea + C_, nf=nf, ea=ea), seed=nf + ea + C_, case="wide_ceilings")
+
+
 def test_wide_model_normalize_vs_oracle():
     """normalize=True (:181-183) on a graph WITHOUT self loops: d / (|d| + 1e-8) at d = 0 amplifies rounding noise by 1e8 (the
     reference's own fp32 gradients sit 1e-3 from exact arithmetic on such edges -- tests/helpers.py, the ragged3_normalize entry),
