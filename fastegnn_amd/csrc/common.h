@@ -1229,6 +1229,7 @@ __host__ __device__ inline int img_w3c(int c) { return I_FIXED + c; }
 __host__ __device__ inline bool img_is_f16(int id, int C) {
   if (id == I_W2 || id == I_WX1) return (FE_FWD_F16 & 1) != 0;
   if (id == I_V2 || id == I_WXV0 || id == I_WXX0 || (id >= I_FIXED && id < I_FIXED + C)) return (FE_FWD_F16 & 2) != 0;
+  if (id == I_W3A || id == I_W3B || id == I_W4) return (FE_FWD_F16 & 2) != 0;   // node_model's three products at the tail of virt_fwd
   if (id >= I_W1A && id <= I_WG0) return (FE_FWD_F16 & 4) != 0;
   if (id >= I_FIXED + C && id < I_FIXED + 2 * C) return (FE_BWD_F16 & 2) != 0;   // W3c[c]^T: read by virt_bwd_cs_kernel only
   return false;

@@ -606,29 +606,29 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       // the waves that own a tile run the products (read straight from global memory these three products cost more
       // than the whole channel loop of a tile, cf. the phase stamps of virt_bwd).
       const bool mine = active && own;
-      float *fstage = reinterpret_cast<float *>(stage);
-      constexpr int NSTG = IMG / 4 / (64 * VIRT_WAVES);
-      static_assert(NSTG * 4 * 64 * VIRT_WAVES == IMG, "stage copy must tile the fp32 image");
+      // (round 5: the SPLIT images of the three weights -- f16x2 / bf16x3 / bf16 products on the matrix pipe like every other product of
+      //  this kernel, where rounds 1-4 ran them as fp32-input MFMAs from the fp32 images: 3 x 64 MFMAs of 32 cycles per tile, a
+      //  fifth of the kernel's matrix-pipe time, against 3 x 24 of 16)
       auto stage_image = [&](int id) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (size_t)id * IMG);
-        f32x4 tmp[NSTG];
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(wpack_x3(a.wpack, C, id));
+        u32x4 tmp[STG];
 #pragma unroll
-        for (int i = 0; i < NSTG; ++i) tmp[i] = src[threadIdx.x + i * 64 * VIRT_WAVES];
+        for (int i = 0; i < STG; ++i) tmp[i] = src[threadIdx.x + i * 64 * VIRT_WAVES];
         __syncthreads();          // every wave is done with the previous content of the stage
-        f32x4 *dst = reinterpret_cast<f32x4 *>(fstage);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(stage);
 #pragma unroll
-        for (int i = 0; i < NSTG; ++i) dst[threadIdx.x + i * 64 * VIRT_WAVES] = tmp[i];
+        for (int i = 0; i < STG; ++i) dst[threadIdx.x + i * 64 * VIRT_WAVES] = tmp[i];
         __syncthreads();
       };
       Vec hv = vzero();
       stage_image(I_W3A);
       if (mine) {
         hv = vload_row(a.h + (size_t)nc * H, q);
-        gemm64_m<MODE>(fstage, hv, nodeacc);
+        gemm_i<MODE>(stage, 0, hv, nodeacc);
       }
       stage_image(I_W3B);
       if (mine) {
-        gemm64_m<MODE>(fstage, vload_row(a.aggm + (size_t)nc * H, q), nodeacc);
+        gemm_i<MODE>(stage, 0, vload_row(a.aggm + (size_t)nc * H, q), nodeacc);
         if (a.na > 0) {
           const int ld = 2 * H + H * C + a.na;
           for (int k = 0; k < a.na; ++k) {
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       stage_image(I_W4);
       if (mine) {
         Vec out = vload_vec(vec + VV_B4 * H, q);
-        gemm64_m<MODE>(fstage, vsilu(nodeacc FE_ACT(a)), out);
+        gemm_i<MODE>(stage, 0, vsilu(nodeacc FE_ACT(a)), out);
         if (a.flags & FASTEGNN_F_RESIDUAL) vadd(out, hv);
         if (valid) vstore_row(a.h_out + (size_t)n * H, q, out);
       }

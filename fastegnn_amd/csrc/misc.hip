@@ -521,11 +521,15 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
   const bool ext = a.T == nullptr && a.G != nullptr;
   const float *slabs = ext ? a.G : tab.slab;
   const size_t sx = ext ? (size_t)bidx * a.nsplit : s0;
-  // (ext slabs come in the accumulator order of the 32x32 MFMA blocks -- common.h, WgAcc32: element (o, k) of the [64][64] weight)
-  size_t eoff = (size_t)blockIdx.z * H + e;
+  // (ext slabs come in the accumulator order of the 32x32 MFMA blocks -- common.h, WgAcc32.  The 64 threads of a z-block read 64
+  //  CONSECUTIVE floats of that order and decode which (o, k) each of them is: float ((((bo 2 + bk) 4 + e4) 64 + lane) 4 + r)
+  //  holds element (32 bo + 8 e4 + 4 (lane >> 5) + r, 32 bk + (lane & 31)))
+  const size_t eoff = (size_t)blockIdx.z * H + e;
+  int o_ = blockIdx.z, k_ = e;
   if (ext && !bias_block) {
-    const int o = blockIdx.z, k = e;
-    eoff = (size_t)(((((o >> 5) * 2 + (k >> 5)) * 4 + ((o >> 3) & 3)) * 64 + ((o >> 2) & 1) * 32 + (k & 31)) * 4 + (o & 3));
+    const int idx = (int)eoff, ln = (idx >> 2) & 63;
+    o_ = 32 * (idx >> 11) + 8 * ((idx >> 8) & 3) + 4 * (ln >> 5) + (idx & 3);
+    k_ = 32 * ((idx >> 10) & 1) + (ln & 31);
   }
   const float *base = bias_block ? tab.slab_b + s0 * H + e : slabs + sx * IMG + eoff;
   const size_t stride = bias_block ? H : IMG;
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(WgTable tab) {
     if (bias_block) {
       atomicAdd(&a.db[e], (float)t);
     } else {
-      const int o = blockIdx.z, k = e;
+      const int o = o_, k = k_;
       if (k < a.kmax) atomicAdd(dW + (size_t)o * a.lddw + a.c0 + (size_t)k * a.ks, (float)t);
     }
   }
