@@ -407,6 +407,8 @@ def matrix_pipe(sq, name, launch_s):
     """(matrix_pipe_util, mfma_busy) of a kernel: the 16-bit MFMA work the counters saw per launch / this run's launch duration /
     the dense 16-bit peak, and the tracked busy share of the matrix pipe.  None when the capture has no such kernel."""
     c = sq.get(_SQ_NAMES.get(name, name))
+    if name == "virt_bwd_kernel" and sq.get("fe::virt_bwd_cs_kernel"):   # the channel-phased form of the same stage (csrc/virt_bwd.hip)
+        c = sq["fe::virt_bwd_cs_kernel"]
     if not c:
         return None, None
     mops = c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0) + c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)

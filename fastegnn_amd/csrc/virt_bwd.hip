@@ -1133,7 +1133,11 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
       bool w_have[2] = {false, false};             // the parity's scratch tile holds a partial sum
       int since_w = 0;
       int *drainedA = ctrl + VBSC_DRAINED + VB_MAXRING, *drainedB = ctrl + VBSC_DRAINED + 2 * VB_MAXRING;
+#ifdef FE_VBS_SWAP   // measured alternative: the light (g_vp, t) contraction beside producer 2 on SIMD 2, (g_np, v) beside wave 3 on SIMD 3
+      const bool doV2 = FIVEP ? wv == VB_CONS_V2 : wv == VB_CONS_XX, doW = wv == VB_CONS_XX;
+#else
       const bool doV2 = wv == VB_CONS_XX, doW = FIVEP ? wv == VB_CONS_V2 : wv == VB_CONS_XX;
+#endif
       // acc (+ the parity's scratch tile) -> the channel's running sum over the blocks, ACCUMULATOR order, plain read-modify-write
       // (the slab is this wave's own; the reduction kernel reads that order: WgJob::acc32)
       auto flush_w = [&](WgAcc32 &acc, float ig, float it, int slot, bool have, float *dst, bool add) {

@@ -28,7 +28,7 @@ print("# rocprofv3 --pmc (three passes, kernel trace only) of: python3 bench.py 
 print("# cfg4 frame (100 000 nodes, 1.92 M edges, C = 16), ONE layer, fp32 mode; values are per-LAUNCH averages summed over the chip.")
 print("# commit:", subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "(snapshot without .git)")
 OUT = {}
-names = ["fe::edge_fwd_kernel", "fe::virt_fwd_kernel", "fe::edge_bwd_pc_kernel", "fe::virt_bwd_pc_kernel", "fe::virt_bwd_gv_kernel",
+names = ["fe::edge_fwd_kernel", "fe::virt_fwd_kernel", "fe::edge_bwd_pc_kernel", "fe::virt_bwd_cs_kernel", "fe::virt_bwd_pc_kernel", "fe::virt_bwd_gv_kernel",
          "fe::virt_bwd_node_kernel", "fe::node_pre_fwd_kernel", "fe::node_pre_bwd_kernel", "fe::wgrad_tn_kernel", "fe::wgrad_reduce_kernel"]
 for k in names:
     if k not in agg: continue
@@ -45,7 +45,7 @@ for k in names:
     # Units (checked on edge_fwd: 5.85 M MFMAs x 16 cycles = VALU_MFMA_BUSY_CYCLES exactly): *_BUSY_CYCLES in cycles; WAVE_CYCLES,
     # ACTIVE_INST_* and WAIT_INST_* in units of 4 cycles, summed over waves.  ACTIVE_INST_VALU / WAVE_CYCLES is the share of a wave's
     # resident time in which it issues vector / MFMA instructions; times the waves per SIMD it is the SIMD's vector-issue utilisation.
-    wps = {"fe::edge_fwd_kernel": 4, "fe::virt_fwd_kernel": 2, "fe::edge_bwd_pc_kernel": 2, "fe::virt_bwd_pc_kernel": 2,
+    wps = {"fe::edge_fwd_kernel": 4, "fe::virt_fwd_kernel": 2, "fe::edge_bwd_pc_kernel": 2, "fe::virt_bwd_pc_kernel": 2, "fe::virt_bwd_cs_kernel": 2,
            "fe::node_pre_fwd_kernel": 2, "fe::node_pre_bwd_kernel": 2}.get(k)
     wc = v["SQ_WAVE_CYCLES"] or 1
     share = v["SQ_ACTIVE_INST_VALU"] / wc

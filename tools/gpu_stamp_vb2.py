@@ -7,7 +7,8 @@ from bench import make_frame, loss_fn
 L = K.lib()
 torch.manual_seed(43)
 m = fastegnn_amd.FastEGNN(2, 0, 2, 64, 16, device="cuda", n_layers=4, gravity=[0, -1, 0])
-frame, target = make_frame(100000, 16, 43, "cuda")
+NN = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+frame, target = make_frame(NN, 16, 43, "cuda")
 def step():
     for p in m.parameters(): p.grad = None
     loc, vloc = m(**frame)
@@ -21,7 +22,7 @@ for _ in range(NS): step()
 torch.cuda.synchronize(); L.fastegnn_debug_read_vb2_stamps(out, 1)
 prof = K.profile_collect()
 v = list(out)
-units = NS * 4 * 6250 * 16          # (tile, channel) pairs stamped
+units = NS * 4 * ((NN + 15) // 16) * 16          # (tile, channel) pairs stamped
 names = ["bookkeeping", "rows arrive, pre", "silu + split + V2", "silu, v store", "head x fwd + rank-1", "head X fwd + rank-1",
          "publish ring A", "Gv row + 2 transposed heads", "g_vp + publish ring B", "V2^T", "g_pre consumers", "final barrier wait"]
 tot = sum(v[:12])

@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if k.startswith("fe::") and r["Counter_Name"] == c:
-            k = k.replace("fe::", "").split("<")[0].replace("_pc_kernel", "_kernel")   # profiler ids: one name per stage
+            k = k.replace("fe::", "").split("<")[0].replace("_pc_kernel", "_kernel").replace("_cs_kernel", "_kernel")   # profiler ids: one name per stage
             agg[k].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         out[k][c] = sum(v) / len(v)
