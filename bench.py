@@ -242,7 +242,7 @@ def loss_fn(loc, vloc, target):
     return torch.nn.functional.mse_loss(loc, target) + 0.01 * vloc.pow(2).mean()
 
 
-def kernel_model(N, E, B, C, L, gravity=True):
+def kernel_model(N, E, B, C, L, gravity=True, phased=False):
     """Per-LAUNCH algorithmic work of each kernel: name -> (FLOPs, bytes or None).
 
     FLOPs: the 64x64 contractions the stage requires, no tile padding (UNIT = one 64x64 mat-vec).
@@ -261,6 +261,10 @@ def kernel_model(N, E, B, C, L, gravity=True):
     # virtual backward (producer/consumer form): 3 recomputed + 3 transposed products + 3 in-workgroup weight gradients
     # per (node, channel); the W3c^T product and the node-MLP adjoint are kernels of their own
     f["virt_bwd_kernel"] = (NC * 9 * UNIT, 2 * 820 * N)
+    if phased:
+        # the channel-phased form (round 5) contains the W3c^T product and the dW3c contraction as well: 3 recomputed + 4 transposed
+        # products + 4 in-workgroup weight gradients per (node, channel); no virt_bwd_gv kernel, no per-channel wgrad job
+        f["virt_bwd_kernel"] = (NC * 11 * UNIT, 2 * 820 * N)
     f["virt_bwd_gv_kernel"] = (NC * UNIT, None)
     f["virt_bwd_node_kernel"] = (N * 3 * UNIT, None)
     f["node_pre_fwd_kernel"] = (N * (3 + heads) * UNIT, None)
@@ -268,12 +272,12 @@ def kernel_model(N, E, B, C, L, gravity=True):
     return f
 
 
-def recompute_free_units(N, E, B, C):
+def recompute_free_units(N, E, B, C, phased=False):
     """FLOPs per launch WITHOUT the forward products a backward kernel recomputes (SURVEY 8d's convention: backward = 2 x
     forward -- the transposed products and the weight-gradient contractions): what `roofline.frac_algorithmic` is computed
     from, so that recomputation shows up as lost efficiency instead of as achieved FLOPs."""
     NC = N * C
-    return {"edge_bwd_kernel": E * 4 * UNIT, "virt_bwd_kernel": NC * 6 * UNIT}
+    return {"edge_bwd_kernel": E * 4 * UNIT, "virt_bwd_kernel": NC * (8 if phased else 6) * UNIT}
 
 
 def operand_bytes(N, E, B, C, gravity=True):
@@ -664,10 +668,11 @@ def main():
         value = units_per_step * args.steps / dt
         # kernel model of what THIS rank ran (sharded: its 1/world share of the rows and edges)
         kN, kE = (shard["plan"].nloc, shard["edge_index"].size(1)) if sharded else (N, E)
-        km = kernel_model(kN, kE, B, C, L, gravity=cfg["gravity"] is not None)
+        phased = "virt_bwd_kernel" in prof and "virt_bwd_gv_kernel" not in prof      # which form of the virtual backward ran
+        km = kernel_model(kN, kE, B, C, L, gravity=cfg["gravity"] is not None, phased=phased)
         ob = operand_bytes(kN, kE, B, C, gravity=cfg["gravity"] is not None)
         kernels = {}
-        rfree = recompute_free_units(kN, kE, B, C)
+        rfree = recompute_free_units(kN, kE, B, C, phased=phased)
         sq, sq_file = latest_sq_counters() if (args.config == "cfg4" and not sharded and dtype != "bf16") else ({}, None)
         sq_meta = sq.get("_meta", {}) if sq else {}
         for name, (ms, cnt) in prof.items():
