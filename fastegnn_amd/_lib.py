@@ -34,7 +34,7 @@ def lib_path(act: bool = False, wide: bool = False) -> str:
 
 LIB_PATH = lib_path(False, bool(WIDE_RANGE))   # the library the stage-independent helpers (CSR, graphs, training step, comm) use
 
-ABI_VERSION = 105   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
+ABI_VERSION = 106   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
 H = 64
 QX_LD = 68
 FEATW = 8
@@ -105,6 +105,7 @@ ACT_LIB_PATH = lib_path(True, bool(WIDE_RANGE)) if not SAFE_WAITS else None
 # activation kinds of the FASTEGNN_F_ACT bits (include/fastegnn_hip.h)
 F_ACT_SHIFT = 11
 ACT_SILU, ACT_RELU, ACT_LEAKY_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU, ACT_GELU, ACT_SOFTPLUS = range(8)
+ACT_NONE = -1   # fastegnn_wide_linear / _dx / _dw: no fused activation
 
 
 def lib(act: bool = False, wide=None):
@@ -198,9 +199,9 @@ def lib(act: bool = False, wide=None):
     L.fastegnn_wgrad_batch_open.argtypes = [C.POINTER(LayerT), _vp, C.POINTER(_vp)]
     L.fastegnn_wgrad_batch_close.argtypes = [_vp]
     _i64, _f = C.c_int64, C.c_float   # the wide path (include/fastegnn_hip.h "the WIDE path")
-    L.fastegnn_wide_linear.argtypes = [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]
-    L.fastegnn_wide_linear_dx.argtypes = [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]
-    L.fastegnn_wide_linear_dw.argtypes = [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp]
+    L.fastegnn_wide_linear.argtypes = [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _f, _vp]
+    L.fastegnn_wide_linear_dx.argtypes = [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _f, _vp]
+    L.fastegnn_wide_linear_dw.argtypes = [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _f, _vp]
     L.fastegnn_wide_act.argtypes = [_vp, _i64, _i32, _f, _vp, _vp]
     L.fastegnn_wide_act_backward.argtypes = [_vp, _vp, _i64, _i32, _f, _vp, _vp]
     L.fastegnn_wide_gather_add.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp, _vp]

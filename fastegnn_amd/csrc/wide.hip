@@ -2,195 +2,167 @@
 // main_nbody.py:27, models/FastEGNN.py:28-99).  The fused stage kernels of this library are built on 64-wide register
 // tiles; a wider model runs UNFUSED on the operators below -- the op sequence of models/FastEGNN.py:102-223 with every
 // hidden-sized tensor op as one of these launches (fastegnn_amd/wide.py assembles them, autograd composes the backward from
-// the *_dx / *_dw / *_bwd entry points).  Correctness first: plain fp32 arithmetic (v_mfma_f32_16x16x4_f32 in the two
-// LDS-tiled 64x64 GEMM kernels, vector FMAs elsewhere; no operand splits), fp32 atomics for the row-keyed sums.
-// DESIGN.md section 9 prices this path; the tuned path is hidden_nf <= 64.
+// the *_dx / *_dw / *_bwd entry points).  The two GEMM kernels (wide_gemm.h) run fp32-grade products as bf16x3 splits on the
+// matrix pipe, with the activation of a Linear's input and the activation backward of its input gradient fused in; vector
+// FMAs elsewhere, fp32 atomics for the row-keyed sums.  DESIGN.md section 9 prices this path; the tuned path is hidden_nf <= 64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #ifndef FE_ACT_GENERIC
 #define FE_ACT_GENERIC   // this translation unit always carries every activation kind (act_both)
 #endif
 #include "kernels.h"
+#include "wide_gemm.h"
 
 namespace fe {
 namespace wide {
 
-constexpr int BM = 64, BN = 64, BK = 16;
-
-// C[m, n] = (base ? base[m*ldc + n] : 0) + (bias ? bias[n] : 0) + sum_k A[m*lda + k] * B(k, n),   B(k, n) = Bp[k*sbk + n*sbn]
-// (forward of a Linear: B(k, o) = W[o*ldw + c0 + k]; its input gradient: B(o, k) = W[o*ldw + c0 + k])
-// 256 threads = 4 waves, one 64 x 64 tile per workgroup, operands staged through LDS, fp32 products on the matrix pipe.
-__global__ __launch_bounds__(256) void gemm_tile_kernel(const float *A, int lda, long M, int Kd, const float *Bp, long sbk, long sbn,
-                                                        int N, const float *bias, const float *base, float *C, int ldc,
-                                                        int accumulate) {
-  __shared__ float As[BK][BM + 16];
-  __shared__ float Bs[BK][BN + 16];
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int tid = threadIdx.x;
-  // wave w owns the 32 x 32 quadrant (w >> 1, w & 1) of the tile as 2 x 2 blocks of v_mfma_f32_16x16x4_f32 (fp32 products):
-  // lane (lk, li) supplies A[row li][k lk] and B[k lk][column li] of a block and holds rows 4 lk .. 4 lk + 3 of column li of D
-  const int wave = tid >> 6, li = tid & 15, lk = (tid >> 4) & 3;
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < Kd; k0 += BK) {
-    // A tile: 64 rows x 16 k -- thread loads rows (tid >> 4) + 16 i, k = tid & 15 (consecutive k of a row: coalesced)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (tid >> 4) + 16 * i, k = tid & 15;
-      const long m = m0 + r;
-      As[k][r] = (m < M && k0 + k < Kd) ? A[(size_t)m * lda + k0 + k] : 0.f;
-    }
-    // B tile: 16 k x 64 n.  Walk the faster-varying index of B with the fast thread index.
-    if (sbn == 1) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = (tid >> 6) + 4 * i, n = tid & 63;
-        Bs[k][n] = (k0 + k < Kd && n0 + n < N) ? Bp[(size_t)(k0 + k) * sbk + (size_t)(n0 + n)] : 0.f;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n = (tid >> 4) + 16 * i, k = tid & 15;
-        Bs[k][n] = (k0 + k < Kd && n0 + n < N) ? Bp[(size_t)(k0 + k) * sbk + (size_t)(n0 + n) * sbn] : 0.f;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < BK; ks += 4) {
-      const float a0 = As[ks + lk][wr + li], a1 = As[ks + lk][wr + 16 + li];
-      const float b0 = Bs[ks + lk][wc + li], b1 = Bs[ks + lk][wc + 16 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long m = m0 + wr + 16 * bi + 4 * lk + r;
-      if (m >= M) continue;
-#pragma unroll
-      for (int bj = 0; bj < 2; ++bj) {
-        const int n = n0 + wc + 16 * bj + li;
-        if (n >= N) continue;
-        float v = acc[bi][bj][r];
-        if (bias) v += bias[n];
-        if (base) v += base[(size_t)m * ldc + n];
-        float *dst = C + (size_t)m * ldc + n;
-        *dst = accumulate ? *dst + v : v;
-      }
-    }
-}
-
-// the same product for N <= 8 columns (the [1, H] heads and their input gradients, the rank-1 radial columns): sixteen lanes per
-// row, each summing every 16th k, combined with a butterfly
+// C[m, n] = epi(sum_k pro(A[m, k]) * B(k, n) + bias[n]) + base[m, n],  B(k, n) = Bp[k*sbk + n*sbn]   (forward of a Linear:
+// B(k, o) = W[o*ldw + c0 + k]; its input gradient: B(o, k) = W[o*ldw + c0 + k]; epi = * act'(Z[m, n])) for N <= 8 columns (the
+// [1, H] heads and their input gradients, the rank-1 radial columns): 32 lanes per row, each taking every 32nd group of four
+// consecutive k (one 512-byte line of a 128-wide row per instruction), combined with a butterfly
+template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemm_smalln_kernel(const float *A, int lda, long M, int Kd, const float *Bp, long sbk, long sbn,
                                                           int N, const float *bias, const float *base, float *C, int ldc,
-                                                          int accumulate) {
-  const long m = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int sub = threadIdx.x & 15;
+                                                          int accumulate, Act pro, const float *Z, int ldz, Act epi) {
+  const long m = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int sub = threadIdx.x & 31;
   const bool live = m < M;
-  for (int n = 0; n < N; ++n) {
-    float s = 0.f;
-    if (live)
-      for (int k = sub; k < Kd; k += 16) s += A[(size_t)m * lda + k] * Bp[(size_t)k * sbk + (size_t)n * sbn];
+  const bool vec = (lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
+  float s[8] = {};
+  if (live) {
+    const float *a = A + (size_t)m * lda;
+    const int k4n = vec ? Kd >> 2 : 0;
+    for (int k4 = sub; k4 < k4n; k4 += 32) {
+      const float4 v = *reinterpret_cast<const float4 *>(a + 4 * k4);
+      const float x[4] = {pro_t<PRO>(v.x, pro), pro_t<PRO>(v.y, pro), pro_t<PRO>(v.z, pro), pro_t<PRO>(v.w, pro)};
 #pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) s += __shfl_xor(s, d, 16);
+      for (int n = 0; n < 8; ++n)
+        if (n < N) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[n] += x[j] * Bp[(size_t)(4 * k4 + j) * sbk + (size_t)n * sbn];
+        }
+    }
+    for (int k = 4 * k4n + sub; k < Kd; k += 32) {
+      const float x = pro_t<PRO>(a[k], pro);
+#pragma unroll
+      for (int n = 0; n < 8; ++n)
+        if (n < N) s[n] += x * Bp[(size_t)k * sbk + (size_t)n * sbn];
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    if (n >= N) break;
+    float t = s[n];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) t += __shfl_xor(t, d, 32);
     if (live && sub == 0) {
-      float v = s;
+      float v = t;
       if (bias) v += bias[n];
+      if constexpr (EPI != AM_NONE) v *= dact_t<EPI>(Z[(size_t)m * ldz + n], epi);
       if (base) v += base[(size_t)m * ldc + n];
       float *dst = C + (size_t)m * ldc + n;
       *dst = accumulate ? *dst + v : v;
     }
   }
 }
-
-// dW[o*ldw + c0 + k] += sum_m G[m*ldg + o] * X[m*ldx + k]  over the workgroup's row range (blockIdx.z), fp32 atomics into dW
-__global__ __launch_bounds__(256) void tn_tile_kernel(const float *G, int ldg, const float *X, int ldx, long M, int O, int Kd,
-                                                      float *dW, int ldw, int c0, long rows_per_split, float *db) {
-  __shared__ float Gs[BK][BM + 16];   // [row][o]
-  __shared__ float Xs[BK][BN + 16];   // [row][k]
-  const int o0 = blockIdx.x * BM, k0 = blockIdx.y * BN;
-  const long r_lo = (long)blockIdx.z * rows_per_split, r_hi = r_lo + rows_per_split < M ? r_lo + rows_per_split : M;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, li = tid & 15, lk = (tid >> 4) & 3;   // as gemm_tile_kernel, the contraction runs over the rows
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-  f32x4 acc[2][2];
+// the same for a contraction of Kd <= 8 terms (the first layer's few feature columns, the input gradient of a [1, H] head): thread =
+// four consecutive columns of a row when the shapes allow (N, ldc, ldz multiples of 4), bound by the write of C
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void gemm_smallk_kernel(const float *A, int lda, long M, int Kd, const float *Bp, long sbk, long sbn,
+                                                          int N, const float *bias, const float *base, float *C, int ldc,
+                                                          int accumulate, Act pro, const float *Z, int ldz, Act epi, int vec) {
+  const int nv = vec ? N >> 2 : N, wv = vec ? 4 : 1;
+  const size_t total = (size_t)M * nv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t m = i / nv;
+    const int n = (int)(i - m * nv) * wv;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < Kd; ++k) {
+      const float x = pro_t<PRO>(A[m * lda + k], pro);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // db (bias gradient, may be null): the column sums of G ride along in the workgroups of the first k-block -- thread c < 64 adds
-  // the 16 rows of its column from the staged tile (in double: cancelling sums over up to 10^6 rows)
-  const bool do_bias = db != nullptr && blockIdx.y == 0 && tid < BM;
-  double bsum = 0.0;
-  for (long r0 = r_lo; r0 < r_hi; r0 += BK) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (tid >> 6) + 4 * i, c = tid & 63;
-      const long m = r0 + r;
-      Gs[r][c] = (m < r_hi && o0 + c < O) ? G[(size_t)m * ldg + o0 + c] : 0.f;
-      Xs[r][c] = (m < r_hi && k0 + c < Kd) ? X[(size_t)m * ldx + k0 + c] : 0.f;
+      for (int j = 0; j < 4; ++j)
+        if (j < wv) v[j] += x * Bp[(size_t)k * sbk + (size_t)(n + j) * sbn];
     }
-    __syncthreads();
-    if (do_bias) {
-      float t = 0.f;
-#pragma unroll
-      for (int r = 0; r < BK; ++r) t += Gs[r][tid];
-      bsum += (double)t;
-    }
-#pragma unroll
-    for (int rs = 0; rs < BK; rs += 4) {
-      const float a0 = Gs[rs + lk][wr + li], a1 = Gs[rs + lk][wr + 16 + li];
-      const float b0 = Xs[rs + lk][wc + li], b1 = Xs[rs + lk][wc + 16 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int o = o0 + wr + 16 * bi + 4 * lk + r;
-      if (o >= O) continue;
-#pragma unroll
-      for (int bj = 0; bj < 2; ++bj) {
-        const int k = k0 + wc + 16 * bj + li;
-        if (k < Kd) atomicAdd(dW + (size_t)o * ldw + c0 + k, acc[bi][bj][r]);
+    float z[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+    const float *bsrc = base ? base : (accumulate ? C : nullptr);
+    if (vec) {
+      if constexpr (EPI != AM_NONE) {
+        const float4 t = *reinterpret_cast<const float4 *>(Z + m * ldz + n);
+        z[0] = t.x; z[1] = t.y; z[2] = t.z; z[3] = t.w;
       }
+      if (bsrc) {
+        const float4 t = *reinterpret_cast<const float4 *>(bsrc + m * ldc + n);
+        bs[0] = t.x; bs[1] = t.y; bs[2] = t.z; bs[3] = t.w;
+      }
+    } else {
+      if constexpr (EPI != AM_NONE) z[0] = Z[m * ldz + n];
+      if (bsrc) bs[0] = bsrc[m * ldc + n];
     }
-  if (do_bias && o0 + tid < O) atomicAdd(db + o0 + tid, (float)bsum);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < wv) {
+        if (bias) v[j] += bias[n + j];
+        if constexpr (EPI != AM_NONE) v[j] *= dact_t<EPI>(z[j], epi);
+        v[j] += bs[j];
+      }
+    if (vec) *reinterpret_cast<float4 *>(C + m * ldc + n) = float4{v[0], v[1], v[2], v[3]};
+    else C[m * ldc + n] = v[0];
+  }
 }
 
-// out[s*so + l*sl] += sum_m S[m*lds + s] * L[m*ldl + l]   with a SMALL side (ns <= 8 columns): the [1, H] heads' weight gradients
-// (S = G, L = X) and the few feature columns of a first layer (S = X, L = G).  Thread = one column l, rows of the workgroup's range.
+// out[s*so + l*sl] += sum_m proS(S[m*lds + s]) * proL(L[m*ldl + l])   with a SMALL side (NS <= 8 columns): the [1, H] heads' weight
+// gradients (S = G, L = X) and the few feature columns of a first layer (S = X, L = G); the activation applies to the side that is
+// X.  Thread = VW (4 or 1) consecutive columns l in one of the workgroup's row slots; a workgroup walks its row range with every
+// slot, the slots' partials (double: cancelling column sums over up to 10^6 rows) meet in LDS, one fp32 atomic per column and range.
+template <int NS, int VW, int PS, int PL>
 __global__ __launch_bounds__(256) void tn_small_kernel(const float *S, int lds_, int ns, const float *L, int ldl, int nl, long M,
-                                                       float *out, long so, long sl, long rows_per_split) {
+                                                       float *out, long so, long sl, long rows_per_split, int cols_per_wg, Act proS,
+                                                       Act proL) {
+  __shared__ double red[256 * VW];
   const long r_lo = (long)blockIdx.y * rows_per_split, r_hi = r_lo + rows_per_split < M ? r_lo + rows_per_split : M;
-  const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= nl) return;
-  double acc[8] = {};   // (cancelling column sums over up to 10^6 rows: the range's partial in double, one fp32 atomic per range)
-  for (long m = r_lo; m < r_hi; ++m) {
-    const double x = L[(size_t)m * ldl + l];
+  const int slots = 256 / cols_per_wg, slot = threadIdx.x / cols_per_wg, cw = threadIdx.x % cols_per_wg;
+  const int l = (blockIdx.x * cols_per_wg + cw) * VW;
+  const bool live = l < nl;
+  double acc[NS][VW];
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-      if (s < ns) acc[s] += (double)S[(size_t)m * lds_ + s] * x;
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int j = 0; j < VW; ++j) acc[s][j] = 0.0;
+  if (live) {
+#pragma unroll 4
+    for (long m = r_lo + slot; m < r_hi; m += slots) {
+      float x[VW];
+      if constexpr (VW == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(L + (size_t)m * ldl + l);
+        x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+      } else x[0] = L[(size_t)m * ldl + l];
+#pragma unroll
+      for (int j = 0; j < VW; ++j) x[j] = pro_t<PL>(x[j], proL);
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        if (s < ns) {
+          const double sv = (double)pro_t<PS>(S[(size_t)m * lds_ + s], proS);
+#pragma unroll
+          for (int j = 0; j < VW; ++j) acc[s][j] += sv * (double)x[j];
+        }
+    }
   }
 #pragma unroll
-  for (int s = 0; s < 8; ++s)
-    if (s < ns) atomicAdd(out + (size_t)s * so + (size_t)l * sl, (float)acc[s]);
+  for (int s = 0; s < NS; ++s) {
+    if (s >= ns) break;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VW; ++j) red[(slot * cols_per_wg + cw) * VW + j] = acc[s][j];
+    __syncthreads();
+    if (slot == 0 && live) {
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        double t = 0.0;
+        for (int q = 0; q < slots; ++q) t += red[(q * cols_per_wg + cw) * VW + j];
+        atomicAdd(out + (size_t)s * so + (size_t)(l + j) * sl, (float)t);
+      }
+    }
+  }
 }
 
 // db[o] += sum_m G[m*ldg + o]
@@ -269,26 +241,85 @@ inline int grid1d(size_t n) {
   const size_t g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
 }
-// row ranges of the reductions over M: enough workgroups to fill the chip, at least 512 rows each
-inline int row_splits(long M, long other_wgs) {
-  long want = (2048 + other_wgs - 1) / (other_wgs > 0 ? other_wgs : 1);
-  long most = (M + 511) / 512;
+// row ranges of the reductions over M: enough workgroups to fill the chip, at least `min_rows` rows each
+inline int row_splits(long M, long other_wgs, long min_rows = 512, long target = 2048) {
+  long want = (target + other_wgs - 1) / (other_wgs > 0 ? other_wgs : 1);
+  long most = (M + min_rows - 1) / min_rows;
   if (want > most) want = most;
   if (want < 1) want = 1;
-  if (want > 4096) want = 4096;
+  if (want > 16384) want = 16384;
   return (int)want;
 }
+inline int pow2_at_least(int n) {
+  int p = 1;
+  while (p < n) p *= 2;
+  return p;
+}
+inline bool act_ok(int kind) { return kind >= ACT_NONE && kind <= FASTEGNN_ACT_SOFTPLUS; }
 
 static int gemm(const float *A, int lda, long M, int Kd, const float *Bp, long sbk, long sbn, int N, const float *bias,
-                const float *base, float *C, int ldc, int accumulate, hipStream_t st, const char *what) {
+                const float *base, float *C, int ldc, int accumulate, Act pro, const float *Z, int ldz, Act epi, hipStream_t st,
+                const char *what) {
   if (M == 0 || N == 0) return FASTEGNN_OK;
+  const int pm = am_of(pro.kind), em = Z ? am_of(epi.kind) : AM_NONE;
+  FE_REQUIRE(!(pm && em) && !(base && accumulate), "wide gemm: unsupported combination of fused steps");
+// one launch per (prologue, epilogue) mode: the two never meet in one call
+#define FE_MODES(LAUNCH)                                 \
+  do {                                                   \
+    if (pm == AM_SILU) { LAUNCH(AM_SILU, AM_NONE); }     \
+    else if (pm == AM_GEN) { LAUNCH(AM_GEN, AM_NONE); }  \
+    else if (em == AM_SILU) { LAUNCH(AM_NONE, AM_SILU); } \
+    else if (em == AM_GEN) { LAUNCH(AM_NONE, AM_GEN); }  \
+    else { LAUNCH(AM_NONE, AM_NONE); }                   \
+  } while (0)
   if (N <= 8) {
-    hipLaunchKernelGGL(gemm_smalln_kernel, dim3((unsigned)cdiv(M, 16)), dim3(256), 0, st, A, lda, M, Kd, Bp, sbk, sbn, N, bias, base, C,
-                       ldc, accumulate);
+#define FE_SMALLN(P_, E_)                                                                                                            \
+  hipLaunchKernelGGL((gemm_smalln_kernel<P_, E_>), dim3((unsigned)cdiv(M, 8)), dim3(256), 0, st, A, lda, M, Kd, Bp, sbk, sbn, N, bias, \
+                     base, C, ldc, accumulate, pro, Z, ldz, epi)
+    FE_MODES(FE_SMALLN);
+#undef FE_SMALLN
+  } else if (Kd <= 8 || (lda & 3) || (Kd & 3) || (reinterpret_cast<size_t>(A) & 15)) {
+    // few terms -- or a row stride the streaming GEMM's 16-byte loads cannot take (K not a multiple of 4: rare, any speed will do)
+    const int vec = (N & 3) == 0 && (ldc & 3) == 0 && (!Z || (ldz & 3) == 0) && (reinterpret_cast<size_t>(C) & 15) == 0 &&
+                    (reinterpret_cast<size_t>(base) & 15) == 0 && (reinterpret_cast<size_t>(Z) & 15) == 0;
+#define FE_SMALLK(P_, E_)                                                                                                              \
+  hipLaunchKernelGGL((gemm_smallk_kernel<P_, E_>), dim3(grid1d((size_t)M * (vec ? N / 4 : N))), dim3(256), 0, st, A, lda, M, Kd, Bp, sbk, \
+                     sbn, N, bias, base, C, ldc, accumulate, pro, Z, ldz, epi, vec)
+    FE_MODES(FE_SMALLK);
+#undef FE_SMALLK
   } else {
-    hipLaunchKernelGGL(gemm_tile_kernel, dim3((unsigned)cdiv(M, BM), (unsigned)cdiv(N, BN)), dim3(256), 0, st, A, lda, M, Kd, Bp, sbk,
-                       sbn, N, bias, base, C, ldc, accumulate);
+    // column blocks of 32 NQ <= 128 columns, as even as the width allows (160 = 96 + 64, not 128 + 32)
+    const int nquads = cdiv(N, 32), nblocks = cdiv(nquads, 4), nq = cdiv(nquads, nblocks), gy = cdiv(nquads, nq);
+    const long units = cdiv(M, 32);
+    const int wgs_per_cu = x3_lds_bytes(nq) * 2 <= 160 * 1024 ? 2 : 1;
+    long gx = cdiv(units, XWAVES);
+    if (gx > 256 * wgs_per_cu) gx = 256 * wgs_per_cu;
+    GemmX3 g{A, lda, M, Kd, Bp, sbk, sbn, N, bias, base, C, ldc, accumulate, pro, Z, ldz, epi, (int)cdiv(units, gx * XWAVES)};
+    const dim3 grid((unsigned)gx, (unsigned)gy), block(XWAVES * 64);
+    const bool deep = nq == 4 && Kd % 128 == 0;   // (the four-buffer prefetch: whole 128-wide panels of a full-width column block)
+#define FE_X3_LAUNCH(NQ_, P_, E_)                                                                                  \
+  do {                                                                                                             \
+    if (NQ_ == 4 && deep) hipLaunchKernelGGL((gemm_x3_kernel<4, P_, E_, true>), grid, block, x3_lds_bytes(4), st, g); \
+    else hipLaunchKernelGGL((gemm_x3_kernel<NQ_, P_, E_, false>), grid, block, x3_lds_bytes(NQ_), st, g);          \
+  } while (0)
+#define FE_X3_MODES(NQ_)                                         \
+  do {                                                           \
+    if (pm == AM_SILU) FE_X3_LAUNCH(NQ_, AM_SILU, AM_NONE);      \
+    else if (pm == AM_GEN) FE_X3_LAUNCH(NQ_, AM_GEN, AM_NONE);   \
+    else if (em == AM_SILU) FE_X3_LAUNCH(NQ_, AM_NONE, AM_SILU); \
+    else if (em == AM_GEN) FE_X3_LAUNCH(NQ_, AM_NONE, AM_GEN);   \
+    else FE_X3_LAUNCH(NQ_, AM_NONE, AM_NONE);                    \
+  } while (0)
+    switch (nq) {
+      case 1: FE_X3_MODES(1); break;
+      case 2: FE_X3_MODES(2); break;
+      case 3: FE_X3_MODES(3); break;
+      default: FE_X3_MODES(4); break;
+    }
+#undef FE_X3_MODES
+#undef FE_X3_LAUNCH
   }
+#undef FE_MODES
   return check_launch(what);
 }
 
@@ -300,42 +331,81 @@ using namespace fe::wide;
 
 extern "C" {
 
-// out[M, O] = (base ? base : 0) + X[M, K] . W[:, c0 : c0 + K]^T + bias        (models/FastEGNN.py: every nn.Linear; a Linear over a
-// torch.cat of inputs is the sum of these calls over the weight's column blocks, chained through `base`)
+// out[M, O] = (base ? base : 0) + act(X)[M, K] . W[:, c0 : c0 + K]^T + bias        (models/FastEGNN.py: every nn.Linear; a Linear over
+// a torch.cat of inputs is the sum of these calls over the weight's column blocks, chained through `base`).  act_kind >= 0: X is
+// the PRE-activation of the Linear's input (nn.Sequential(Linear, act, Linear): the activation runs in this kernel's prologue and
+// its output never reaches memory); FASTEGNN_ACT_NONE: X as is.
 int fastegnn_wide_linear(const float *X, int64_t M, int32_t K, const float *W, int32_t ldw, int32_t c0, const float *bias,
-                         const float *base, float *out, int32_t O, void *stream) {
-  FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0, "fastegnn_wide_linear: bad sizes");
+                         const float *base, float *out, int32_t O, int32_t act_kind, float act_p, void *stream) {
+  FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0 && act_ok(act_kind), "fastegnn_wide_linear: bad arguments");
   FE_REQUIRE((X || M == 0) && W && (out || M == 0), "fastegnn_wide_linear: null pointer");
-  return gemm(X, K, M, K, W + c0, 1, ldw, O, bias, base, out, O, 0, (hipStream_t)stream, "fastegnn_wide_linear");
+  return gemm(X, K, M, K, W + c0, 1, ldw, O, bias, base, out, O, 0, Act{act_kind, act_p}, nullptr, 0, Act{ACT_NONE, 0.f},
+              (hipStream_t)stream, "fastegnn_wide_linear");
 }
-// dX[M, K] (+)= G[M, O] . W[:, c0 : c0 + K]
+// dX[M, K] (+)= (G[M, O] . W[:, c0 : c0 + K]) * act'(Z[M, K])      (Z may be null: no activation; with Z the result is the
+// gradient of the PRE-activation Z that fastegnn_wide_linear took with the same act_kind)
 int fastegnn_wide_linear_dx(const float *G, int64_t M, int32_t O, const float *W, int32_t ldw, int32_t c0, int32_t K, float *dX,
-                            int32_t accumulate, void *stream) {
-  FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0, "fastegnn_wide_linear_dx: bad sizes");
+                            int32_t accumulate, const float *Z, int32_t act_kind, float act_p, void *stream) {
+  FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0 && act_ok(act_kind), "fastegnn_wide_linear_dx: bad arguments");
   FE_REQUIRE((G || M == 0) && W && (dX || M == 0), "fastegnn_wide_linear_dx: null pointer");
-  return gemm(G, O, M, O, W + c0, ldw, 1, K, nullptr, nullptr, dX, K, accumulate, (hipStream_t)stream, "fastegnn_wide_linear_dx");
+  FE_REQUIRE(!Z || act_kind >= 0, "fastegnn_wide_linear_dx: Z needs an activation kind");
+  return gemm(G, O, M, O, W + c0, ldw, 1, K, nullptr, nullptr, dX, K, accumulate, Act{ACT_NONE, 0.f}, Z, K, Act{act_kind, act_p},
+              (hipStream_t)stream, "fastegnn_wide_linear_dx");
 }
-// dW[:, c0 : c0 + K] += G[M, O]^T . X[M, K];  db[O] += column sums of G (db may be null)
+// dW[:, c0 : c0 + K] += G[M, O]^T . act(X)[M, K];  db[O] += column sums of G (db may be null)
 int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O, int32_t K, float *dW, int32_t ldw, int32_t c0,
-                            float *db, void *stream) {
-  FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0, "fastegnn_wide_linear_dw: bad sizes");
+                            float *db, int32_t act_kind, float act_p, void *stream) {
+  FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0 && act_ok(act_kind), "fastegnn_wide_linear_dw: bad arguments");
   FE_REQUIRE((G && X) || M == 0, "fastegnn_wide_linear_dw: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) return FASTEGNN_OK;
+  const Act pro{act_kind, act_p};
   if (dW) {
-    if (O <= 8) {          // small side = G's columns, long side = X's
-      const int gx = cdiv(K, 256), ns = row_splits(M, gx);
-      hipLaunchKernelGGL(tn_small_kernel, dim3(gx, ns), dim3(256), 0, st, G, O, O, X, K, K, (long)M, dW + c0, (long)ldw, (long)1,
-                         (long)cdiv(M, ns));
-    } else if (K <= 8) {   // small side = X's columns
-      const int gx = cdiv(O, 256), ns = row_splits(M, gx);
-      hipLaunchKernelGGL(tn_small_kernel, dim3(gx, ns), dim3(256), 0, st, X, K, K, G, O, O, (long)M, dW + c0, (long)1, (long)ldw,
-                         (long)cdiv(M, ns));
+    if (O <= 8 || K <= 8) {
+      // small side S = G's columns and long side L = X's, or the other way round; the activation belongs to the X side
+      const bool g_small = O <= 8;
+      const float *S = g_small ? G : X, *Lg = g_small ? X : G;
+      const int nsm = g_small ? O : K, nl = g_small ? K : O;
+      const long so = g_small ? ldw : 1, sl = g_small ? 1 : ldw;
+      const int vw = ((nl & 3) == 0 && (reinterpret_cast<size_t>(Lg) & 15) == 0) ? 4 : 1;
+      const int nlv = nl / vw;
+      const int cols = nlv >= 256 ? 256 : pow2_at_least(nlv);
+      const int gx = cdiv(nlv, cols), nsplit = row_splits(M, gx, 256 / cols * 64, 1024);
+      const dim3 grid(gx, nsplit);
+      const long rps = cdiv(M, nsplit);
+      const int am = am_of(act_kind), ps = g_small ? AM_NONE : am, pl = g_small ? am : AM_NONE;
+#define FE_TNS(NS_, VW_, PS_, PL_)                                                                                                    \
+  hipLaunchKernelGGL((tn_small_kernel<NS_, VW_, PS_, PL_>), grid, dim3(256), 0, st, S, nsm, nsm, Lg, nl, nl, (long)M, dW + c0, so, sl, rps, \
+                     cols, pro, pro)
+#define FE_TNS_ACT(NS_, VW_)                                           \
+  do {                                                                 \
+    if (ps == AM_SILU) FE_TNS(NS_, VW_, AM_SILU, AM_NONE);             \
+    else if (ps == AM_GEN) FE_TNS(NS_, VW_, AM_GEN, AM_NONE);          \
+    else if (pl == AM_SILU) FE_TNS(NS_, VW_, AM_NONE, AM_SILU);        \
+    else if (pl == AM_GEN) FE_TNS(NS_, VW_, AM_NONE, AM_GEN);          \
+    else FE_TNS(NS_, VW_, AM_NONE, AM_NONE);                           \
+  } while (0)
+      if (vw == 4) {
+        if (nsm == 1) FE_TNS_ACT(1, 4);
+        else if (nsm <= 4) FE_TNS_ACT(4, 4);
+        else FE_TNS_ACT(8, 4);
+      } else {
+        if (nsm == 1) FE_TNS_ACT(1, 1);
+        else FE_TNS_ACT(8, 1);
+      }
+#undef FE_TNS_ACT
+#undef FE_TNS
     } else {
-      const int gx = cdiv(O, BM), gy = cdiv(K, BN), ns = row_splits(M, (long)gx * gy);
+      const int gx = cdiv(O, TB), gy = cdiv(K, TB), ns = row_splits(M, (long)gx * gy, 256, 512);
       long rows = cdiv(M, ns);
-      rows = (rows + BK - 1) / BK * BK;
-      hipLaunchKernelGGL(tn_tile_kernel, dim3(gx, gy, (unsigned)cdiv(M, rows)), dim3(256), 0, st, G, O, X, K, (long)M, O, K, dW, ldw, c0, rows, db);
+      rows = (rows + 31) / 32 * 32;
+      TnX3 t{G, O, X, K, (long)M, O, K, dW, ldw, c0, rows, db, pro};
+      const dim3 grid(gx, gy, (unsigned)cdiv(M, rows));
+      switch (am_of(act_kind)) {
+        case AM_SILU: hipLaunchKernelGGL(tn_x3_kernel<AM_SILU>, grid, dim3(256), 0, st, t); break;
+        case AM_GEN: hipLaunchKernelGGL(tn_x3_kernel<AM_GEN>, grid, dim3(256), 0, st, t); break;
+        default: hipLaunchKernelGGL(tn_x3_kernel<AM_NONE>, grid, dim3(256), 0, st, t); break;
+      }
       db = nullptr;   // done inside
     }
     int rc = check_launch("fastegnn_wide_linear_dw");

@@ -13,6 +13,8 @@ several times slower per FLOP than the fused one -- DESIGN.md section 9 -- and e
 reference's whole ``hidden_nf`` range.  No CPU fallback: the library is loaded on first use and its absence raises."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as K
@@ -44,36 +46,39 @@ def _f32(t):
 
 
 class _Linear(torch.autograd.Function):
-    """out = (base) + X . W[:, c0:c0+K]^T (+ bias)"""
+    """out = (base) + act(X) . W[:, c0:c0+K]^T (+ bias).  `act` = (kind, p) makes X the PRE-activation of the Linear's input: the
+    activation runs in the GEMM's prologue (act(X) is never stored), its backward in the epilogue of the input gradient."""
 
     @staticmethod
-    def forward(ctx, X, W, c0, Kc, bias, base):
+    def forward(ctx, X, W, c0, Kc, bias, base, act):
         X, W = _f32(X), W.contiguous()
         M, O = X.size(0), W.size(0)
         out = torch.empty(M, O, dtype=torch.float32, device=X.device)
         b = _f32(bias) if bias is not None else None
         bs = _f32(base) if base is not None else None
-        _call("linear", X, M, Kc, W, W.size(1), c0, b, bs, out, O)
+        kind, p = act if act is not None else (K.ACT_NONE, 0.0)
+        _call("linear", X, M, Kc, W, W.size(1), c0, b, bs, out, O, kind, p)
         ctx.save_for_backward(X, W)
-        ctx.meta = (c0, Kc, bias is not None, base is not None)
+        ctx.meta = (c0, Kc, bias is not None, base is not None, act)
         return out
 
     @staticmethod
     def backward(ctx, g):
         X, W = ctx.saved_tensors
-        c0, Kc, has_bias, has_base = ctx.meta
+        c0, Kc, has_bias, has_base, act = ctx.meta
+        kind, p = act if act is not None else (K.ACT_NONE, 0.0)
         g = _f32(g)
         M, O = g.shape
         gX = gW = gb = None
         if ctx.needs_input_grad[0]:
             gX = torch.empty(M, Kc, dtype=torch.float32, device=g.device)
-            _call("linear_dx", g, M, O, W, W.size(1), c0, Kc, gX, 0)
+            _call("linear_dx", g, M, O, W, W.size(1), c0, Kc, gX, 0, X if act is not None else None, kind, p)
         want_w, want_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[4]
         if want_w or want_b:
             gW = torch.zeros_like(W) if want_w else None
             gb = torch.zeros(O, dtype=torch.float32, device=g.device) if want_b else None
-            _call("linear_dw", g, X, M, O, Kc, gW, W.size(1), c0, gb)
-        return gX, gW, None, None, gb, (g if has_base else None)
+            _call("linear_dw", g, X, M, O, Kc, gW, W.size(1), c0, gb, kind, p)
+        return gX, gW, None, None, gb, (g if has_base else None), None
 
 
 class _Act(torch.autograd.Function):
@@ -169,8 +174,16 @@ def _rowscale(X, s):
     return _RowScale.apply(X, s.reshape(-1))
 
 
-def _lin(X, W, c0=0, Kc=None, bias=None, base=None):
-    return _Linear.apply(X, W, c0, W.size(1) - c0 if Kc is None else Kc, bias, base)
+# FASTEGNN_WIDE_FUSE=0: every activation as its own launch (the unfused form of round 4; A/B lever)
+FUSE_ACT = os.environ.get("FASTEGNN_WIDE_FUSE", "1") != "0"
+
+
+def _lin(X, W, c0=0, Kc=None, bias=None, base=None, act=None):
+    """act = (kind, p): the Linear of act(X), X the pre-activation"""
+    Kc = W.size(1) - c0 if Kc is None else Kc
+    if act is not None and not FUSE_ACT:
+        return _Linear.apply(_Act.apply(X, act[0], act[1]), W, c0, Kc, bias, base, None)
+    return _Linear.apply(X, W, c0, Kc, bias, base, act)
 
 
 def _rows(X, idx):
@@ -206,6 +219,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
     kind, p = model._act
     N, B = node_loc.size(0), loc_mean.size(0)
     act = lambda z: _Act.apply(z, kind, p)                       # noqa: E731
+    A = (kind, p)                                                # _lin(Z, ..., act=A): the Linear of act(Z), fused
     row, col = edge_index[0].contiguous().long(), edge_index[1].contiguous().long()
     batch = data_batch.contiguous().long()
     ones = dict(dtype=torch.float32, device=dev)
@@ -224,11 +238,11 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
     h = _lin(node_feat.float(), model.embedding_in.weight, 0, model.node_feat_nf, model.embedding_in.bias)
 
     def head(seq, X):   # coord_mlp: Linear(H, H), act, Linear(H, 1, bias=False) [, Tanh]   (:55-67)
-        s = _lin(act(_lin(X, seq[0].weight, 0, Hn, seq[0].bias)), seq[2].weight, 0, Hn, None)
+        s = _lin(_lin(X, seq[0].weight, 0, Hn, seq[0].bias), seq[2].weight, 0, Hn, None, None, A)
         return torch.tanh(s) if model.tanh else s
 
     def scalar_head_in(seq, X):   # Linear(w, H), act, Linear(H, 1) over an input of any width w
-        return _lin(act(_lin(X, seq[0].weight, 0, X.size(1), seq[0].bias)), seq[2].weight, 0, Hn, seq[2].bias)
+        return _lin(_lin(X, seq[0].weight, 0, X.size(1), seq[0].bias), seq[2].weight, 0, Hn, seq[2].bias, None, A)
 
     def scalar_head(seq, X):   # Linear(H, H), act, Linear(H, 1)   (:75-88)
         return scalar_head_in(seq, X)
@@ -247,7 +261,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         feat = radial if edge_attr is None else torch.cat([radial, edge_attr.float()], 1)
         pre = _GatherAdd.apply(_lin(h, W1, Hn, Hn), col,
                                _GatherAdd.apply(_lin(h, W1, 0, Hn, g.edge_mlp[0].bias), row, _lin(feat, W1, 2 * Hn, feat.size(1))))
-        m = act(_lin(act(pre), g.edge_mlp[2].weight, 0, Hn, g.edge_mlp[2].bias))   # [E, H]
+        m = act(_lin(pre, g.edge_mlp[2].weight, 0, Hn, g.edge_mlp[2].bias, None, A))   # [E, H]
         if model.attention:
             m = _rowscale(m, torch.sigmoid(_lin(m, g.att_mlp[0].weight, 0, Hn, g.att_mlp[0].bias)))
         # ---- edge_mode_virtual (:111-119): rows (n, c); input cat[h, Hv[b], vr, m_X[b][:, c]]
@@ -260,7 +274,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         # over sorted indices instead of N*C atomics onto B*C rows)
         pv = _GatherAdd.apply(_lin(h, Wv, 0, Hn, g.edge_mlp_virtual[0].bias), idx_n, _lin(vr.reshape(N * C, 1), Wv, 2 * Hn, 1))
         pv = _GatherAdd.apply(Bc.view(B, C * Hn), batch, pv.view(N, C * Hn)).view(N * C, Hn)
-        v = act(_lin(act(pv), g.edge_mlp_virtual[2].weight, 0, Hn, g.edge_mlp_virtual[2].bias))   # [N*C, H]
+        v = act(_lin(pv, g.edge_mlp_virtual[2].weight, 0, Hn, g.edge_mlp_virtual[2].bias, None, A))   # [N*C, H]
         if model.attention:
             v = _rowscale(v, torch.sigmoid(_lin(v, g.att_mlp_virtual[0].weight, 0, Hn, g.att_mlp_virtual[0].bias)))
         # ---- coord_model_vel (:122-145)
@@ -288,12 +302,12 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         npre = _lin(v.view(N, C * Hn), W3v, 0, C * Hn, None, npre)
         if node_attr is not None:
             npre = _lin(node_attr.float(), W3, 2 * Hn + Hn * C, node_attr.size(1), None, npre)
-        h_new = _lin(act(npre), g.node_mlp[2].weight, 0, Hn, g.node_mlp[2].bias, h if model.residual else None)
+        h_new = _lin(npre, g.node_mlp[2].weight, 0, Hn, g.node_mlp[2].bias, h if model.residual else None, A)
         # ---- node_model_virtual (:168-178)
         poolV = _rowscale(_ScatterAdd.apply(v.view(N, C * Hn), batch, B), inv_cnt_b).view(B * C, Hn)
         Wn = g.node_mlp_virtual[0].weight
         zv = _lin(poolV, Wn, Hn, Hn, None, _lin(HvT, Wn, 0, Hn, g.node_mlp_virtual[0].bias))
-        HvT = _lin(act(zv), g.node_mlp_virtual[2].weight, 0, Hn, g.node_mlp_virtual[2].bias, HvT if model.residual else None)
+        HvT = _lin(zv, g.node_mlp_virtual[2].weight, 0, Hn, g.node_mlp_virtual[2].bias, HvT if model.residual else None, A)
         h, x, Z = h_new, x_new, Z_new
     return x, Z
 
@@ -306,6 +320,7 @@ def egnn_forward(model, x, h, edge_index, edge_fea, v=None):
     Hn = model.hidden_nf
     kind, p = (K.ACT_TANH, 0.0) if model.flat else model._act
     act = lambda z: _Act.apply(z, kind, p)                       # noqa: E731
+    A = (kind, p)
     N = x.size(0)
     row, col = edge_index[0].contiguous().long(), edge_index[1].contiguous().long()
     f32 = dict(dtype=torch.float32, device=dev)
@@ -315,8 +330,8 @@ def egnn_forward(model, x, h, edge_index, edge_fea, v=None):
     h = _lin(h.float(), model.embedding.weight, 0, model.in_node_nf, model.embedding.bias)
 
     def mlp(net, X, base_first=None):   # BaseMLP without last_act: Linear, act, Linear
-        return _lin(act(_lin(X, net.mlp[0].weight, 0, X.size(1), net.mlp[0].bias) if base_first is None else base_first),
-                    net.mlp[2].weight, 0, net.mlp[2].weight.size(1), net.mlp[2].bias)
+        return _lin(_lin(X, net.mlp[0].weight, 0, X.size(1), net.mlp[0].bias) if base_first is None else base_first,
+                    net.mlp[2].weight, 0, net.mlp[2].weight.size(1), net.mlp[2].bias, None, A)
 
     for layer in model.layers:
         rij = _rows(x, row) - _rows(x, col)
@@ -330,7 +345,7 @@ def egnn_forward(model, x, h, edge_index, edge_fea, v=None):
         if edge_fea is not None:
             pre = _lin(edge_fea.float(), W0, 1 + 2 * Hn, edge_fea.size(1), None, pre)
         pre = _GatherAdd.apply(_lin(h, W0, 1 + Hn, Hn), col, _GatherAdd.apply(_lin(h, W0, 1, Hn, net[0].bias), row, pre))
-        message = act(_lin(act(pre), net[2].weight, 0, net[2].weight.size(1), net[2].bias))     # [E, H]
+        message = act(_lin(pre, net[2].weight, 0, net[2].weight.size(1), net[2].bias, None, A))     # [E, H]
         f = rij * mlp(layer.coord_net, message)
         tot_f = torch.clamp(_segment_sum(f, row, N) * inv_cnt.unsqueeze(1), min=-100, max=100)
         x_new = x + tot_f

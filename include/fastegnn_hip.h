@@ -93,6 +93,7 @@ enum {
 #define FASTEGNN_F_ACT_SHIFT 11
 #define FASTEGNN_F_ACT_MASK 15
 enum {
+  FASTEGNN_ACT_NONE = -1,        /* fastegnn_wide_linear*: no fused activation */
   FASTEGNN_ACT_SILU = 0,
   FASTEGNN_ACT_RELU = 1,
   FASTEGNN_ACT_LEAKY_RELU = 2,   /* act_param = negative_slope */
@@ -241,10 +242,11 @@ typedef struct {
 /* ---- library ---- */
 const char *fastegnn_last_error(void);
 /* ABI revision: FASTEGNN_ABI_VERSION of the header the library was built from.  It changes whenever the layout of
- * fastegnn_layer_t / fastegnn_graph_t or the meaning of an argument changes (round 3 inserted act_param: 100 -> 101; round 4 appended wgrad_batch and added fastegnn_pack_weights_all / FASTEGNN_F_WPACK_READY: 103; the fastegnn_wide_* entry points: 104).
+ * fastegnn_layer_t / fastegnn_graph_t or the meaning of an argument changes (round 3 inserted act_param: 100 -> 101; round 4 appended wgrad_batch and added fastegnn_pack_weights_all / FASTEGNN_F_WPACK_READY: 103; the fastegnn_wide_* entry points: 104;
+ * round 5: fastegnn_f16_operands / fastegnn_check_finite: 105; the fused activation arguments of fastegnn_wide_linear / _dx / _dw: 106).
  * A binding MUST compare it with the FASTEGNN_ABI_VERSION it was written against AND check fastegnn_sizeof_layer() /
  * fastegnn_sizeof_graph() against its own mirror of the descriptors before the first call (fastegnn_amd/_lib.py does). */
-#define FASTEGNN_ABI_VERSION 105
+#define FASTEGNN_ABI_VERSION 106
 int fastegnn_version(void);
 /* floats of the packed weight-image buffer for C virtual channels */
 size_t fastegnn_wpack_floats(int32_t C);
@@ -430,22 +432,26 @@ int fastegnn_scatter_add_rows(float *table, const int64_t *ids, int64_t n, int32
 /* ---- the WIDE path: 64 < hidden_nf <= 256 (models/FastEGNN.py:28-99 takes any hidden_nf; main_nbody.py:27 --dim_hidden) ----
  * The fused stage kernels above are built on 64-wide tiles.  A wider model runs unfused: the op sequence of
  * models/FastEGNN.py:102-223 with every hidden-sized tensor op as ONE of the launches below (fastegnn_amd/wide.py; autograd
- * composes the backward from the _dx / _dw / _backward entry points).  fp32 FMA arithmetic, row-major contiguous operands,
- * int64 indices as the reference's edge_index / data['batch'] hold them.  ABI revision 104.
- *   linear      out[M,O] = (base ? base : 0) + X[M,K] . W[:, c0:c0+K]^T + bias      -- nn.Linear; a Linear over a torch.cat of
+ * composes the backward from the _dx / _dw / _backward entry points).  fp32-grade arithmetic (the GEMMs as bf16x3 splits on the
+ * matrix pipe, csrc/wide_gemm.h), row-major contiguous operands, int64 indices as the reference's edge_index / data['batch']
+ * hold them.  ABI revision 104; revision 106 added the fused activation arguments of the three linear entry points:
+ * act_kind = FASTEGNN_ACT_* makes X the PRE-activation of the Linear's input (nn.Sequential(Linear, act, Linear),
+ * models/FastEGNN.py:41-99: act(X) is formed in the kernel and never stored), FASTEGNN_ACT_NONE takes X as is.
+ *   linear      out[M,O] = (base ? base : 0) + act(X)[M,K] . W[:, c0:c0+K]^T + bias -- nn.Linear; a Linear over a torch.cat of
  *               inputs is the sum of these calls over the weight's column blocks (W row stride ldw), chained through `base`
- *   linear_dx   dX[M,K] (+)= G[M,O] . W[:, c0:c0+K]
- *   linear_dw   dW[:, c0:c0+K] += G^T X,  db += column sums of G (either may be NULL); fp32 atomics over row ranges
+ *   linear_dx   dX[M,K] (+)= (G[M,O] . W[:, c0:c0+K]) * act'(Z[M,K])   -- Z NULL: no activation factor; with Z the result is the
+ *               gradient of the pre-activation Z that `linear` took
+ *   linear_dw   dW[:, c0:c0+K] += G^T act(X),  db += column sums of G (either may be NULL); fp32 atomics over row ranges
  *   act         y = act_fn(z), kind = FASTEGNN_ACT_*, p = its parameter;  act_backward  dz = dy * act_fn'(z)
  *   gather_add  out[m,:] = (base ? base[m,:] : 0) + X[idx[m],:]      -- node_feat[row], virtual_node_feat[data_batch]
  *   scatter_add table[idx[m],:] += rows[m,:]                         -- unsorted_segment_sum / global_mean_pool sums (atomics)
  *   rowscale    Y[m,:] = X[m,:] * s[m];  rowdot  out[m] = <A[m,:], B[m,:]>   -- gates, 1/count of the segment means */
 int fastegnn_wide_linear(const float *X, int64_t M, int32_t K, const float *W, int32_t ldw, int32_t c0, const float *bias,
-                         const float *base, float *out, int32_t O, void *stream);
+                         const float *base, float *out, int32_t O, int32_t act_kind, float act_p, void *stream);
 int fastegnn_wide_linear_dx(const float *G, int64_t M, int32_t O, const float *W, int32_t ldw, int32_t c0, int32_t K, float *dX,
-                            int32_t accumulate, void *stream);
+                            int32_t accumulate, const float *Z, int32_t act_kind, float act_p, void *stream);
 int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O, int32_t K, float *dW, int32_t ldw, int32_t c0,
-                            float *db, void *stream);
+                            float *db, int32_t act_kind, float act_p, void *stream);
 int fastegnn_wide_act(const float *z, int64_t n, int32_t kind, float p, float *y, void *stream);
 int fastegnn_wide_act_backward(const float *z, const float *dy, int64_t n, int32_t kind, float p, float *dz, void *stream);
 int fastegnn_wide_gather_add(const float *X, const int64_t *idx, int64_t M, int32_t W, const float *base, float *out, void *stream);

@@ -27,20 +27,28 @@ class TorchOps:
         getattr(TorchOps, name)(*a)
 
     @staticmethod
-    def linear(X, M, Kc, W, ldw, c0, bias, base, out, O):
+    def _pro(X, kind, p):
+        return X if kind == K.ACT_NONE else _fn(kind, p)(X)
+
+    @staticmethod
+    def linear(X, M, Kc, W, ldw, c0, bias, base, out, O, kind, p):
         assert W.shape == (O, ldw) and X.shape == (M, Kc) and out.shape == (M, O)
-        r = X @ W[:, c0:c0 + Kc].t()
+        r = TorchOps._pro(X, kind, p) @ W[:, c0:c0 + Kc].t()
         out.copy_(r + (bias if bias is not None else 0) + (base if base is not None else 0))
 
     @staticmethod
-    def linear_dx(G, M, O, W, ldw, c0, Kc, dX, accumulate):
+    def linear_dx(G, M, O, W, ldw, c0, Kc, dX, accumulate, Z, kind, p):
         r = G @ W[:, c0:c0 + Kc]
+        if Z is not None:
+            d = torch.empty_like(Z)
+            TorchOps.act_backward(Z, r, Z.numel(), kind, p, d)
+            r = d
         dX.copy_(dX + r if accumulate else r)
 
     @staticmethod
-    def linear_dw(G, X, M, O, Kc, dW, ldw, c0, db):
+    def linear_dw(G, X, M, O, Kc, dW, ldw, c0, db, kind, p):
         if dW is not None:
-            dW[:, c0:c0 + Kc] += G.t() @ X
+            dW[:, c0:c0 + Kc] += G.t() @ TorchOps._pro(X, kind, p)
         if db is not None:
             db += G.sum(0)
 
