@@ -7,6 +7,7 @@
 // FMAs elsewhere, fp32 atomics for the row-keyed sums.  DESIGN.md section 9 prices this path; the tuned path is hidden_nf <= 64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #ifndef FE_ACT_GENERIC
 #define FE_ACT_GENERIC   // this translation unit always carries every activation kind (act_both)
 #endif
@@ -24,44 +25,66 @@ template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemm_smalln_kernel(const float *A, int lda, long M, int Kd, const float *Bp, long sbk, long sbn,
                                                           int N, const float *bias, const float *base, float *C, int ldc,
                                                           int accumulate, Act pro, const float *Z, int ldz, Act epi) {
-  const long m = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  constexpr int RU = 4;   // rows per 32-lane group, their loads in flight together (one row at a time ran at 2 TB/s)
+  const long mg = ((long)blockIdx.x * 8 + (threadIdx.x >> 5)) * RU;
   const int sub = threadIdx.x & 31;
-  const bool live = m < M;
   const bool vec = (lda & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
-  float s[8] = {};
-  if (live) {
-    const float *a = A + (size_t)m * lda;
-    const int k4n = vec ? Kd >> 2 : 0;
-    for (int k4 = sub; k4 < k4n; k4 += 32) {
-      const float4 v = *reinterpret_cast<const float4 *>(a + 4 * k4);
-      const float x[4] = {pro_t<PRO>(v.x, pro), pro_t<PRO>(v.y, pro), pro_t<PRO>(v.z, pro), pro_t<PRO>(v.w, pro)};
+  float s[RU][8];
+#pragma unroll
+  for (int u = 0; u < RU; ++u)
+#pragma unroll
+    for (int n = 0; n < 8; ++n) s[u][n] = 0.f;
+  const int k4n = vec ? Kd >> 2 : 0;
+  for (int k4 = sub; k4 < k4n; k4 += 32) {
+    float4 v[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const long m = mg + u < M ? mg + u : M - 1;
+      v[u] = *reinterpret_cast<const float4 *>(A + (size_t)m * lda + 4 * k4);
+    }
+    float b[4][8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j][n] = n < N ? Bp[(size_t)(4 * k4 + j) * sbk + (size_t)n * sbn] : 0.f;
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const float x[4] = {pro_t<PRO>(v[u].x, pro), pro_t<PRO>(v[u].y, pro), pro_t<PRO>(v[u].z, pro), pro_t<PRO>(v[u].w, pro)};
 #pragma unroll
       for (int n = 0; n < 8; ++n)
         if (n < N) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) s[n] += x[j] * Bp[(size_t)(4 * k4 + j) * sbk + (size_t)n * sbn];
+          for (int j = 0; j < 4; ++j) s[u][n] += x[j] * b[j][n];
         }
     }
-    for (int k = 4 * k4n + sub; k < Kd; k += 32) {
-      const float x = pro_t<PRO>(a[k], pro);
+  }
+  for (int k = 4 * k4n + sub; k < Kd; k += 32) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const long m = mg + u < M ? mg + u : M - 1;
+      const float x = pro_t<PRO>(A[(size_t)m * lda + k], pro);
 #pragma unroll
       for (int n = 0; n < 8; ++n)
-        if (n < N) s[n] += x * Bp[(size_t)k * sbk + (size_t)n * sbn];
+        if (n < N) s[u][n] += x * Bp[(size_t)k * sbk + (size_t)n * sbn];
     }
   }
 #pragma unroll
-  for (int n = 0; n < 8; ++n) {
-    if (n >= N) break;
-    float t = s[n];
+  for (int u = 0; u < RU; ++u) {
+    const long m = mg + u;
 #pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) t += __shfl_xor(t, d, 32);
-    if (live && sub == 0) {
-      float v = t;
-      if (bias) v += bias[n];
-      if constexpr (EPI != AM_NONE) v *= dact_t<EPI>(Z[(size_t)m * ldz + n], epi);
-      if (base) v += base[(size_t)m * ldc + n];
-      float *dst = C + (size_t)m * ldc + n;
-      *dst = accumulate ? *dst + v : v;
+    for (int n = 0; n < 8; ++n) {
+      if (n >= N) break;
+      float t = s[u][n];
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) t += __shfl_xor(t, d, 32);
+      if (m < M && sub == 0) {
+        float v = t;
+        if (bias) v += bias[n];
+        if constexpr (EPI != AM_NONE) v *= dact_t<EPI>(Z[(size_t)m * ldz + n], epi);
+        if (base) v += base[(size_t)m * ldc + n];
+        float *dst = C + (size_t)m * ldc + n;
+        *dst = accumulate ? *dst + v : v;
+      }
     }
   }
 }
@@ -182,13 +205,51 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *z, const floa
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dz[i] = dy[i] * dact_f(z[i], a);
 }
 
-// out[m, :] = (base ? base[m, :] : 0) + X[idx[m], :]
-__global__ __launch_bounds__(256) void gather_add_kernel(const float *X, const int64_t *idx, long M, int W, const float *base, float *out) {
-  const size_t n = (size_t)M * W;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const size_t m = i / W, w = i - m * W;
-    const float v = X[(size_t)idx[m] * W + w];
-    out[i] = base ? base[i] + v : v;
+// out[m, :] = (base ? base[m, :] : 0) + P[i1[m], :] + (Q ? Q[i2[m], :] : 0) + sum_{k < nf} feat[m, k] * Wf[w*ldw + k]
+// The first Linear of edge_model / edge_mode_virtual over its torch.cat input (models/FastEGNN.py:102-119) after the node-sized
+// products: P[row] + Q[col] + radial / edge_attr columns in ONE pass that only writes [M, W] (three launches and two
+// read-modify-write passes before).  Thread = VW (4 or 1) consecutive columns, the workgroup's threads tile rows x column groups.
+template <int VW>
+__global__ __launch_bounds__(256) void gather2_kernel(const float *P, const int64_t *i1, const float *Q, const int64_t *i2, const float *feat,
+                                                      int nf, const float *Wf, int ldw, const float *base, float *out, long M, int W,
+                                                      int cols_per_wg) {
+  const int slots = 256 / cols_per_wg, slot = threadIdx.x / cols_per_wg, cw = threadIdx.x % cols_per_wg;
+  const int w = (blockIdx.y * cols_per_wg + cw) * VW;   // (rows wider than a workgroup: column blocks on grid.y)
+  if (w >= W) return;
+  float wf[8][VW];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < VW; ++j) wf[k][j] = (feat && k < nf) ? Wf[(size_t)(w + j) * ldw + k] : 0.f;
+  auto ld = [&](const float *p, float (&v)[VW]) {
+    if constexpr (VW == 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(p);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else v[0] = *p;
+  };
+  const long stride = (long)gridDim.x * slots;
+#pragma unroll 2
+  for (long m = (long)blockIdx.x * slots + slot; m < M; m += stride) {
+    float a[VW], b[VW], c[VW];
+    ld(P + (size_t)i1[m] * W + w, a);
+    if (Q) ld(Q + (size_t)i2[m] * W + w, b);
+    if (base) ld(base + (size_t)m * W + w, c);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      if (Q) a[j] += b[j];
+      if (base) a[j] += c[j];
+    }
+    if (feat) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < nf) {
+          const float f = feat[(size_t)m * nf + k];
+#pragma unroll
+          for (int j = 0; j < VW; ++j) a[j] += f * wf[k][j];
+        }
+    }
+    if constexpr (VW == 4) *reinterpret_cast<float4 *>(out + (size_t)m * W + w) = float4{a[0], a[1], a[2], a[3]};
+    else out[(size_t)m * W + w] = a[0];
   }
 }
 // table[idx[m], :] += rows[m, :]
@@ -199,26 +260,54 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(float *table, const in
     atomicAdd(table + (size_t)idx[m] * W + w, rows[i]);
   }
 }
-// the same for wide rows (W >= 32): thread = one column, workgroup = a range of rows walked in order with a running sum that is
-// flushed (one atomic) whenever the target changes -- sorted or grouped indices (segment sums by graph, the C channel rows of a
-// node) cost one atomic per run instead of one per row; unsorted ones cost what scatter_add_kernel costs
-__global__ __launch_bounds__(256) void scatter_add_runs_kernel(float *table, const int64_t *idx, long M, int W, const float *rows,
-                                                               long rows_per_wg) {
-  const int w = blockIdx.x * 256 + threadIdx.x;
-  const long m_lo = (long)blockIdx.y * rows_per_wg, m_hi = m_lo + rows_per_wg < M ? m_lo + rows_per_wg : M;
+// table[idx[m], :] += rows[perm ? perm[m] : m, :] for wide rows: thread = VW consecutive columns in one of the workgroup's row slots;
+// a slot walks its contiguous share of the workgroup's row range in order with a running sum that is flushed (one atomic per column)
+// whenever the target changes -- sorted or grouped indices (segment sums by graph, by edge row, the C channel rows of a node) cost
+// one atomic per run instead of one per row.  An UNSORTED index (the edge columns) gets the same treatment through `perm`, the
+// permutation that sorts it, computed once per graph: idx then holds the sorted targets and the rows are read through perm.
+template <int VW>
+__global__ __launch_bounds__(256) void scatter_add_runs_kernel(float *table, const int64_t *idx, const int64_t *perm, long M, int W,
+                                                               const float *rows, long rows_per_slot, int cols_per_wg) {
+  const int slots = 256 / cols_per_wg, slot = threadIdx.x / cols_per_wg, cw = threadIdx.x % cols_per_wg;
+  const int w = (blockIdx.y * cols_per_wg + cw) * VW;
+  const long m_lo = ((long)blockIdx.x * slots + slot) * rows_per_slot, m_hi = m_lo + rows_per_slot < M ? m_lo + rows_per_slot : M;
   if (w >= W || m_lo >= m_hi) return;
   int64_t cur = idx[m_lo];
-  float acc = 0.f;
-  for (long m = m_lo; m < m_hi; ++m) {
-    const int64_t i = idx[m];
-    if (i != cur) {
-      atomicAdd(table + (size_t)cur * W + w, acc);
-      acc = 0.f;
-      cur = i;
+  float acc[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+  auto flush = [&]() {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) atomicAdd(table + (size_t)cur * W + w + j, acc[j]);
+  };
+  for (long m = m_lo; m < m_hi; m += 4) {
+    int64_t t[4];
+    float v[4][VW];
+    // the four rows' loads first: the atomics of a flush order every later load behind them
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long mm = m + u < m_hi ? m + u : m_hi - 1;
+      t[u] = idx[mm];
+      const float *src = rows + (size_t)(perm ? perm[mm] : mm) * W + w;
+      if constexpr (VW == 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(src);
+        v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+      } else v[u][0] = *src;
     }
-    acc += rows[(size_t)m * W + w];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (m + u >= m_hi) break;
+      if (t[u] != cur) {
+        flush();
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+        cur = t[u];
+      }
+#pragma unroll
+      for (int j = 0; j < VW; ++j) acc[j] += v[u][j];
+    }
   }
-  atomicAdd(table + (size_t)cur * W + w, acc);
+  flush();
 }
 // Y[m, :] = X[m, :] * s[m]
 __global__ __launch_bounds__(256) void rowscale_kernel(const float *X, const float *s, long M, int W, float *Y) {
@@ -274,7 +363,7 @@ static int gemm(const float *A, int lda, long M, int Kd, const float *Bp, long s
   } while (0)
   if (N <= 8) {
 #define FE_SMALLN(P_, E_)                                                                                                            \
-  hipLaunchKernelGGL((gemm_smalln_kernel<P_, E_>), dim3((unsigned)cdiv(M, 8)), dim3(256), 0, st, A, lda, M, Kd, Bp, sbk, sbn, N, bias, \
+  hipLaunchKernelGGL((gemm_smalln_kernel<P_, E_>), dim3((unsigned)cdiv(M, 32)), dim3(256), 0, st, A, lda, M, Kd, Bp, sbk, sbn, N, bias, \
                      base, C, ldc, accumulate, pro, Z, ldz, epi)
     FE_MODES(FE_SMALLN);
 #undef FE_SMALLN
@@ -295,29 +384,9 @@ static int gemm(const float *A, int lda, long M, int Kd, const float *Bp, long s
     long gx = cdiv(units, XWAVES);
     if (gx > 256 * wgs_per_cu) gx = 256 * wgs_per_cu;
     GemmX3 g{A, lda, M, Kd, Bp, sbk, sbn, N, bias, base, C, ldc, accumulate, pro, Z, ldz, epi, (int)cdiv(units, gx * XWAVES)};
-    const dim3 grid((unsigned)gx, (unsigned)gy), block(XWAVES * 64);
+    const dim3 grid((unsigned)gx, (unsigned)gy);
     const bool deep = nq == 4 && Kd % 128 == 0;   // (the four-buffer prefetch: whole 128-wide panels of a full-width column block)
-#define FE_X3_LAUNCH(NQ_, P_, E_)                                                                                  \
-  do {                                                                                                             \
-    if (NQ_ == 4 && deep) hipLaunchKernelGGL((gemm_x3_kernel<4, P_, E_, true>), grid, block, x3_lds_bytes(4), st, g); \
-    else hipLaunchKernelGGL((gemm_x3_kernel<NQ_, P_, E_, false>), grid, block, x3_lds_bytes(NQ_), st, g);          \
-  } while (0)
-#define FE_X3_MODES(NQ_)                                         \
-  do {                                                           \
-    if (pm == AM_SILU) FE_X3_LAUNCH(NQ_, AM_SILU, AM_NONE);      \
-    else if (pm == AM_GEN) FE_X3_LAUNCH(NQ_, AM_GEN, AM_NONE);   \
-    else if (em == AM_SILU) FE_X3_LAUNCH(NQ_, AM_NONE, AM_SILU); \
-    else if (em == AM_GEN) FE_X3_LAUNCH(NQ_, AM_NONE, AM_GEN);   \
-    else FE_X3_LAUNCH(NQ_, AM_NONE, AM_NONE);                    \
-  } while (0)
-    switch (nq) {
-      case 1: FE_X3_MODES(1); break;
-      case 2: FE_X3_MODES(2); break;
-      case 3: FE_X3_MODES(3); break;
-      default: FE_X3_MODES(4); break;
-    }
-#undef FE_X3_MODES
-#undef FE_X3_LAUNCH
+    launch_gemm_x3(g, nq, pm, em, deep, grid, st);
   }
 #undef FE_MODES
   return check_launch(what);
@@ -401,11 +470,7 @@ int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O
       rows = (rows + 31) / 32 * 32;
       TnX3 t{G, O, X, K, (long)M, O, K, dW, ldw, c0, rows, db, pro};
       const dim3 grid(gx, gy, (unsigned)cdiv(M, rows));
-      switch (am_of(act_kind)) {
-        case AM_SILU: hipLaunchKernelGGL(tn_x3_kernel<AM_SILU>, grid, dim3(256), 0, st, t); break;
-        case AM_GEN: hipLaunchKernelGGL(tn_x3_kernel<AM_GEN>, grid, dim3(256), 0, st, t); break;
-        default: hipLaunchKernelGGL(tn_x3_kernel<AM_NONE>, grid, dim3(256), 0, st, t); break;
-      }
+      launch_tn_x3(t, am_of(act_kind), grid, st);
       db = nullptr;   // done inside
     }
     int rc = check_launch("fastegnn_wide_linear_dw");
@@ -435,30 +500,74 @@ int fastegnn_wide_act_backward(const float *z, const float *dy, int64_t n, int32
   return check_launch("fastegnn_wide_act_backward");
 }
 
+static int gather2(const float *P, const int64_t *i1, const float *Q, const int64_t *i2, const float *feat, int nf, const float *Wf,
+                   int ldw, const float *base, float *out, long M, int W, hipStream_t st, const char *what) {
+  const bool v4 = (W & 3) == 0 && ((reinterpret_cast<size_t>(P) | reinterpret_cast<size_t>(Q) | reinterpret_cast<size_t>(base) |
+                                    reinterpret_cast<size_t>(out)) & 15) == 0;
+  const int nv = v4 ? W / 4 : W;
+  const int cols = nv >= 256 ? 256 : pow2_at_least(nv), slots = 256 / cols, gy = cdiv(nv, cols);
+  long gx = cdiv(M, (long)slots * 4);
+  if (gx > 8192 / gy) gx = 8192 / gy;
+  if (gx < 1) gx = 1;
+  if (v4) hipLaunchKernelGGL(gather2_kernel<4>, dim3((unsigned)gx, gy), dim3(256), 0, st, P, i1, Q, i2, feat, nf, Wf, ldw, base, out, M, W, cols);
+  else hipLaunchKernelGGL(gather2_kernel<1>, dim3((unsigned)gx, gy), dim3(256), 0, st, P, i1, Q, i2, feat, nf, Wf, ldw, base, out, M, W, cols);
+  return check_launch(what);
+}
+// (narrow rows too: the 3-vector sums by graph put N rows on a handful of addresses -- as runs they cost a few atomics per slot;
+//  FASTEGNN_WIDE_SCATTER_ATOMICS=1 brings the one-atomic-per-element kernel back for narrow rows: A/B lever)
+static int scatter_add(float *table, const int64_t *idx, const int64_t *perm, long M, int W, const float *rows, hipStream_t st,
+                       const char *what) {
+  static const bool atomics_only = getenv("FASTEGNN_WIDE_SCATTER_ATOMICS") && atoi(getenv("FASTEGNN_WIDE_SCATTER_ATOMICS")) != 0;
+  const bool v4 = (W & 3) == 0 && ((reinterpret_cast<size_t>(rows) | reinterpret_cast<size_t>(table)) & 15) == 0;
+  const int nv = v4 ? W / 4 : W;
+  if (W >= 32 || !atomics_only) {
+    const int cols = nv >= 256 ? 256 : pow2_at_least(nv), slots = 256 / cols, gy = cdiv(nv, cols);
+    long rps = 16;   // rows per slot: enough workgroups to fill the chip, runs long enough to pay
+    while (rps < 256 && cdiv(M, rps * slots) * gy > 8192) rps *= 2;
+    const long gx = cdiv(M, rps * slots);
+    FE_REQUIRE(gx <= 0x7fffffffL && gy <= 65535, "fastegnn_wide_scatter_add: too many rows or columns");
+    if (v4) hipLaunchKernelGGL(scatter_add_runs_kernel<4>, dim3((unsigned)gx, gy), dim3(256), 0, st, table, idx, perm, M, W, rows, rps, cols);
+    else hipLaunchKernelGGL(scatter_add_runs_kernel<1>, dim3((unsigned)gx, gy), dim3(256), 0, st, table, idx, perm, M, W, rows, rps, cols);
+  } else {
+    FE_REQUIRE(!perm, "fastegnn_wide_scatter_add_perm: not with FASTEGNN_WIDE_SCATTER_ATOMICS");
+    hipLaunchKernelGGL(scatter_add_kernel, dim3(grid1d((size_t)M * W)), dim3(256), 0, st, table, idx, M, W, rows);
+  }
+  return check_launch(what);
+}
+
 // out[m, :] = (base ? base[m, :] : 0) + X[idx[m], :]      (node_feat[row], virtual_node_feat[data_batch], ...)
 int fastegnn_wide_gather_add(const float *X, const int64_t *idx, int64_t M, int32_t W, const float *base, float *out, void *stream) {
   FE_REQUIRE(M >= 0 && W >= 1, "fastegnn_wide_gather_add: bad sizes");
   if (M == 0) return FASTEGNN_OK;
   FE_REQUIRE(X && idx && out, "fastegnn_wide_gather_add: null pointer");
-  hipLaunchKernelGGL(gather_add_kernel, dim3(grid1d((size_t)M * W)), dim3(256), 0, (hipStream_t)stream, X, idx, (long)M, W, base, out);
-  return check_launch("fastegnn_wide_gather_add");
+  return gather2(X, idx, nullptr, nullptr, nullptr, 0, nullptr, 0, base, out, M, W, (hipStream_t)stream, "fastegnn_wide_gather_add");
+}
+// out[m, :] = (base ? base[m, :] : 0) + P[i1[m], :] + (Q ? Q[i2[m], :] : 0) + feat[m, 0:nf] . Wf[:, c0 : c0 + nf]^T   (feat may be
+// NULL; nf <= 8): the first Linear of edge_model over cat[h[row], h[col], radial, edge_attr] (models/FastEGNN.py:102-108) given
+// P = h . W[:, 0:H]^T + b and Q = h . W[:, H:2H]^T, and of edge_mode_virtual (:111-119) in the same form
+int fastegnn_wide_gather2(const float *P, const int64_t *i1, const float *Q, const int64_t *i2, const float *feat, int32_t nf,
+                          const float *Wf, int32_t ldw, int32_t c0, const float *base, float *out, int64_t M, int32_t W, void *stream) {
+  FE_REQUIRE(M >= 0 && W >= 1 && nf >= 0 && nf <= 8, "fastegnn_wide_gather2: bad sizes");
+  if (M == 0) return FASTEGNN_OK;
+  FE_REQUIRE(P && i1 && out && (!Q || i2) && (!feat || nf == 0 || (Wf && ldw >= c0 + nf && c0 >= 0)), "fastegnn_wide_gather2: bad pointers");
+  return gather2(P, i1, Q, i2, nf ? feat : nullptr, nf, Wf ? Wf + c0 : nullptr, ldw, base, out, M, W, (hipStream_t)stream,
+                 "fastegnn_wide_gather2");
 }
 // table[idx[m], :] += rows[m, :]                          (unsorted_segment_sum, global_mean_pool's sums; fp32 atomics)
 int fastegnn_wide_scatter_add(float *table, const int64_t *idx, int64_t M, int32_t W, const float *rows, void *stream) {
   FE_REQUIRE(M >= 0 && W >= 1, "fastegnn_wide_scatter_add: bad sizes");
   if (M == 0) return FASTEGNN_OK;
   FE_REQUIRE(table && idx && rows, "fastegnn_wide_scatter_add: null pointer");
-  if (W >= 32) {
-    const int gx = cdiv(W, 256);
-    long rows_per_wg = 64;   // enough workgroups to fill the chip, runs long enough to pay
-    while (rows_per_wg < 1024 && (long)gx * cdiv(M, rows_per_wg) > 16384) rows_per_wg *= 2;
-    while (cdiv(M, rows_per_wg) > 65535) rows_per_wg *= 2;   // grid.y is a 16-bit quantity: beyond 67 M rows the ranges grow instead
-    hipLaunchKernelGGL(scatter_add_runs_kernel, dim3(gx, (unsigned)cdiv(M, rows_per_wg)), dim3(256), 0, (hipStream_t)stream, table, idx,
-                       (long)M, W, rows, rows_per_wg);
-  } else {
-    hipLaunchKernelGGL(scatter_add_kernel, dim3(grid1d((size_t)M * W)), dim3(256), 0, (hipStream_t)stream, table, idx, (long)M, W, rows);
-  }
-  return check_launch("fastegnn_wide_scatter_add");
+  return scatter_add(table, idx, nullptr, M, W, rows, (hipStream_t)stream, "fastegnn_wide_scatter_add");
+}
+// table[idx_sorted[m], :] += rows[perm[m], :]: the same sums for an index in any order, given the permutation that sorts it
+// (idx_sorted[m] = idx[perm[m]], computed once per graph) -- runs of equal targets become one atomic each
+int fastegnn_wide_scatter_add_perm(float *table, const int64_t *idx_sorted, const int64_t *perm, int64_t M, int32_t W, const float *rows,
+                                   void *stream) {
+  FE_REQUIRE(M >= 0 && W >= 1, "fastegnn_wide_scatter_add_perm: bad sizes");
+  if (M == 0) return FASTEGNN_OK;
+  FE_REQUIRE(table && idx_sorted && perm && rows, "fastegnn_wide_scatter_add_perm: null pointer");
+  return scatter_add(table, idx_sorted, perm, M, W, rows, (hipStream_t)stream, "fastegnn_wide_scatter_add_perm");
 }
 // Y[m, :] = X[m, :] * s[m]                                (attention gates, 1 / count of the segment means)
 int fastegnn_wide_rowscale(const float *X, const float *s, int64_t M, int32_t W, float *Y, void *stream) {

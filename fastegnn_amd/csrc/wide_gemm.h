@@ -63,6 +63,7 @@ struct GemmX3 {
   int units_per_wave;                    // 32-row units each wave walks (uniform: the panels' barriers are workgroup-wide)
 };
 
+#ifdef FE_WIDE_GEMM_IMPL
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
   if constexpr (I < N) {
@@ -335,6 +336,8 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
   }
 }
 
+#endif  // FE_WIDE_GEMM_IMPL
+
 // ---- dW[o, c0 + k] += sum_m G[m, o] * pro(X[m, k]) over the workgroup's row range --------------------------------------------------
 constexpr int TB = 128;                    // block of dW: TB outputs x TB inputs
 constexpr int TRS = 320;                   // bytes per row of a staged part: 128 bf16 + 64 (4 rows of a transposed read land 16 banks apart)
@@ -347,6 +350,7 @@ struct TnX3 {
   Act pro;                                 // X := act(X) when pro.kind >= 0
 };
 
+#ifdef FE_WIDE_GEMM_IMPL
 template <int PRO>
 __global__ __launch_bounds__(256) void tn_x3_kernel(TnX3 t) {
   __shared__ __attribute__((aligned(16))) char sm[TN_LDS];
@@ -468,6 +472,12 @@ __global__ __launch_bounds__(256) void tn_x3_kernel(TnX3 t) {
     }
   }
 }
+
+#endif  // FE_WIDE_GEMM_IMPL
+
+// host side of the two kernels (wide_gemm.hip -- its own translation unit: 25 instances, two minutes of compile time)
+int launch_gemm_x3(const GemmX3 &g, int nq, int pro_mode, int epi_mode, bool deep, dim3 grid, hipStream_t st);
+int launch_tn_x3(const TnX3 &t, int pro_mode, dim3 grid, hipStream_t st);
 
 }  // namespace wide
 }  // namespace fe

@@ -125,6 +125,57 @@ class _GatherAdd(torch.autograd.Function):
         return gX, None, (g if ctx.meta[1] else None)
 
 
+def _scatter(table, idx, rows, order=None):
+    """table[idx[m]] += rows[m]; `order` = (idx_sorted, perm) of an index in no particular order: its sums as sorted runs"""
+    if order is not None and rows.size(1) >= 32:
+        _call("scatter_add_perm", table, order[0], order[1], idx.numel(), rows.size(1), rows)
+    else:
+        _call("scatter_add", table, idx, idx.numel(), rows.size(1), rows)
+
+
+class _Gather2(torch.autograd.Function):
+    """out[m] = P[i1[m]] + Q[i2[m]] + feat[m] . W[:, c0:c0+nf]^T  -- the first Linear of edge_model / edge_mode_virtual over its
+    torch.cat input (models/FastEGNN.py:102-119) once the node-sized products P, Q exist: one pass that only writes [M, H].
+    Q / i2 and feat may be None; order2 = (sorted i2, its permutation) lets the backward sum Q's gradient as runs."""
+
+    @staticmethod
+    def forward(ctx, P, i1, Q, i2, feat, W, c0, order2):
+        P = _f32(P)
+        Q = _f32(Q) if Q is not None else None
+        feat = _f32(feat) if feat is not None else None
+        W = W.contiguous()
+        M, Wd = i1.numel(), P.size(1)
+        nf = feat.size(1) if feat is not None else 0
+        out = torch.empty(M, Wd, dtype=torch.float32, device=P.device)
+        _call("gather2", P, i1, Q, i2, feat, nf, W, W.size(1), c0, None, out, M, Wd)
+        ctx.save_for_backward(i1, i2, feat, W, *(order2 if order2 is not None else ()))
+        ctx.meta = (P.size(0), Q.size(0) if Q is not None else 0, c0, nf, order2 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        i1, i2, feat, W = ctx.saved_tensors[:4]
+        nP, nQ, c0, nf, has_order = ctx.meta
+        order2 = tuple(ctx.saved_tensors[4:6]) if has_order else None
+        g = _f32(g)
+        M, Wd = g.shape
+        gP = gQ = gfeat = gW = None
+        if ctx.needs_input_grad[0]:
+            gP = torch.zeros(nP, Wd, dtype=torch.float32, device=g.device)
+            _scatter(gP, i1, g)
+        if i2 is not None and ctx.needs_input_grad[2]:
+            gQ = torch.zeros(nQ, Wd, dtype=torch.float32, device=g.device)
+            _scatter(gQ, i2, g, order2)
+        if feat is not None:
+            if ctx.needs_input_grad[4]:
+                gfeat = torch.empty(M, nf, dtype=torch.float32, device=g.device)
+                _call("linear_dx", g, M, Wd, W, W.size(1), c0, nf, gfeat, 0, None, K.ACT_NONE, 0.0)
+            if ctx.needs_input_grad[5]:
+                gW = torch.zeros_like(W)
+                _call("linear_dw", g, feat, M, Wd, nf, gW, W.size(1), c0, None, K.ACT_NONE, 0.0)
+        return gP, None, gQ, None, gfeat, gW, None, None
+
+
 class _ScatterAdd(torch.autograd.Function):
     """table[idx[m]] += rows[m] into a zeroed [R, W] table"""
 
@@ -220,12 +271,19 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
     N, B = node_loc.size(0), loc_mean.size(0)
     act = lambda z: _Act.apply(z, kind, p)                       # noqa: E731
     A = (kind, p)                                                # _lin(Z, ..., act=A): the Linear of act(Z), fused
-    row, col = edge_index[0].contiguous().long(), edge_index[1].contiguous().long()
+    # the edges in row order (stable): nothing edge-sized leaves this function, and every sum over an edge's row is then a sum over
+    # RUNS of equal targets (one atomic per run in fastegnn_wide_scatter_add instead of one per edge)
+    row, eperm = torch.sort(edge_index[0].contiguous().long(), stable=True)
+    col = edge_index[1].contiguous().long()[eperm]
+    if edge_attr is not None:
+        edge_attr = edge_attr[eperm]
     batch = data_batch.contiguous().long()
     ones = dict(dtype=torch.float32, device=dev)
     inv_cnt_row = 1.0 / torch.zeros(N, **ones).index_add_(0, row, torch.ones(row.numel(), **ones)).clamp(min=1)
     inv_cnt_b = 1.0 / torch.zeros(B, **ones).index_add_(0, batch, torch.ones(N, **ones)).clamp(min=1)
     idx_n = torch.arange(N, device=dev).repeat_interleave(C)                       # row n*C + c -> n
+    col_sorted, col_perm = torch.sort(col, stable=True)          # once per graph: the column sums of every layer's backward as runs
+    col_order = (col_sorted, col_perm)
     gravity = torch.tensor(model.gravity, **ones) if model.gravity is not None else None
     coords_sum = bool(getattr(model, "_extra_flags", 0) & K.F_COORDS_SUM)         # E_GCL_vel(coords_agg='sum'), :126
     rf = bool(getattr(model, "_extra_flags", 0) & K.F_RF)   # FastRF (models/FastRF.py:155-186): no node_model / node_model_virtual,
@@ -259,8 +317,11 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         # ---- edge_model (:102-108): Linear over cat[h[row], h[col], radial, edge_attr] = P[row] + Q[col] + feat . W[:, 2H:]
         W1 = g.edge_mlp[0].weight
         feat = radial if edge_attr is None else torch.cat([radial, edge_attr.float()], 1)
-        pre = _GatherAdd.apply(_lin(h, W1, Hn, Hn), col,
-                               _GatherAdd.apply(_lin(h, W1, 0, Hn, g.edge_mlp[0].bias), row, _lin(feat, W1, 2 * Hn, feat.size(1))))
+        if feat.size(1) <= 8:
+            pre = _Gather2.apply(_lin(h, W1, 0, Hn, g.edge_mlp[0].bias), row, _lin(h, W1, Hn, Hn), col, feat, W1, 2 * Hn, col_order)
+        else:   # (more than 7 edge attributes: the feature columns as a product of their own)
+            pre = _Gather2.apply(_lin(h, W1, 0, Hn, g.edge_mlp[0].bias), row, _lin(h, W1, Hn, Hn), col, None, W1, 0, col_order)
+            pre = _lin(feat, W1, 2 * Hn, feat.size(1), None, pre)
         m = act(_lin(pre, g.edge_mlp[2].weight, 0, Hn, g.edge_mlp[2].bias, None, A))   # [E, H]
         if model.attention:
             m = _rowscale(m, torch.sigmoid(_lin(m, g.att_mlp[0].weight, 0, Hn, g.att_mlp[0].bias)))
@@ -272,7 +333,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         Bc = _lin(mX.permute(0, 2, 1).reshape(B * C, C), Wv, 2 * Hn + 1, C, None, _lin(HvT, Wv, Hn, Hn))
         # rows (n, c) <- A[n] + Bc[b(n), c]: the second gather moves whole [C*H] rows by graph (its adjoint is then a segment sum
         # over sorted indices instead of N*C atomics onto B*C rows)
-        pv = _GatherAdd.apply(_lin(h, Wv, 0, Hn, g.edge_mlp_virtual[0].bias), idx_n, _lin(vr.reshape(N * C, 1), Wv, 2 * Hn, 1))
+        pv = _Gather2.apply(_lin(h, Wv, 0, Hn, g.edge_mlp_virtual[0].bias), idx_n, None, None, vr.reshape(N * C, 1), Wv, 2 * Hn, None)
         pv = _GatherAdd.apply(Bc.view(B, C * Hn), batch, pv.view(N, C * Hn)).view(N * C, Hn)
         v = act(_lin(pv, g.edge_mlp_virtual[2].weight, 0, Hn, g.edge_mlp_virtual[2].bias, None, A))   # [N*C, H]
         if model.attention:
@@ -322,9 +383,13 @@ def egnn_forward(model, x, h, edge_index, edge_fea, v=None):
     act = lambda z: _Act.apply(z, kind, p)                       # noqa: E731
     A = (kind, p)
     N = x.size(0)
-    row, col = edge_index[0].contiguous().long(), edge_index[1].contiguous().long()
+    row, eperm = torch.sort(edge_index[0].contiguous().long(), stable=True)   # edges in row order: sums over runs (see forward)
+    col = edge_index[1].contiguous().long()[eperm]
+    if edge_fea is not None:
+        edge_fea = edge_fea[eperm]
     f32 = dict(dtype=torch.float32, device=dev)
     inv_cnt = 1.0 / torch.zeros(N, **f32).index_add_(0, row, torch.ones(row.numel(), **f32)).clamp(min=1)   # aggregate(aggr='mean'), :27-52
+    col_order = tuple(torch.sort(col, stable=True))
     x = x.float()
     vv = v.float() if v is not None else None
     h = _lin(h.float(), model.embedding.weight, 0, model.in_node_nf, model.embedding.bias)
@@ -341,10 +406,9 @@ def egnn_forward(model, x, h, edge_index, edge_fea, v=None):
         # edge_message_net: BaseMLP(last_act=True) over cat(scalar, h[row], h[col], edge_fea)  (:313, :259-261)
         net = layer.edge_message_net.scalar_net.mlp
         W0 = net[0].weight
-        pre = _lin(scalar, W0, 0, 1)
+        pre = _Gather2.apply(_lin(h, W0, 1, Hn, net[0].bias), row, _lin(h, W0, 1 + Hn, Hn), col, scalar, W0, 0, col_order)
         if edge_fea is not None:
             pre = _lin(edge_fea.float(), W0, 1 + 2 * Hn, edge_fea.size(1), None, pre)
-        pre = _GatherAdd.apply(_lin(h, W0, 1 + Hn, Hn), col, _GatherAdd.apply(_lin(h, W0, 1, Hn, net[0].bias), row, pre))
         message = act(_lin(pre, net[2].weight, 0, net[2].weight.size(1), net[2].bias, None, A))     # [E, H]
         f = rij * mlp(layer.coord_net, message)
         tot_f = torch.clamp(_segment_sum(f, row, N) * inv_cnt.unsqueeze(1), min=-100, max=100)

@@ -444,7 +444,13 @@ int fastegnn_scatter_add_rows(float *table, const int64_t *ids, int64_t n, int32
  *   linear_dw   dW[:, c0:c0+K] += G^T act(X),  db += column sums of G (either may be NULL); fp32 atomics over row ranges
  *   act         y = act_fn(z), kind = FASTEGNN_ACT_*, p = its parameter;  act_backward  dz = dy * act_fn'(z)
  *   gather_add  out[m,:] = (base ? base[m,:] : 0) + X[idx[m],:]      -- node_feat[row], virtual_node_feat[data_batch]
- *   scatter_add table[idx[m],:] += rows[m,:]                         -- unsorted_segment_sum / global_mean_pool sums (atomics)
+ *   gather2     out[m,:] = (base) + P[i1[m],:] + (Q ? Q[i2[m],:] : 0) + feat[m,0:nf] . Wf[:, c0:c0+nf]^T  (feat may be NULL, nf <= 8)
+ *               -- the first Linear of edge_model over cat[h[row], h[col], radial, edge_attr] (models/FastEGNN.py:102-108) in one
+ *               write-only pass, given the node-sized products P and Q; edge_mode_virtual (:111-119) in the same form
+ *   scatter_add table[idx[m],:] += rows[m,:]                         -- unsorted_segment_sum / global_mean_pool sums (atomics;
+ *               runs of equal targets are summed in registers first)
+ *   scatter_add_perm  table[idx_sorted[m],:] += rows[perm[m],:]      -- the same for an index in any order, given the permutation
+ *               that sorts it (idx_sorted = idx[perm], once per graph): the edge COLUMN sums of the backward as runs
  *   rowscale    Y[m,:] = X[m,:] * s[m];  rowdot  out[m] = <A[m,:], B[m,:]>   -- gates, 1/count of the segment means */
 int fastegnn_wide_linear(const float *X, int64_t M, int32_t K, const float *W, int32_t ldw, int32_t c0, const float *bias,
                          const float *base, float *out, int32_t O, int32_t act_kind, float act_p, void *stream);
@@ -455,7 +461,11 @@ int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O
 int fastegnn_wide_act(const float *z, int64_t n, int32_t kind, float p, float *y, void *stream);
 int fastegnn_wide_act_backward(const float *z, const float *dy, int64_t n, int32_t kind, float p, float *dz, void *stream);
 int fastegnn_wide_gather_add(const float *X, const int64_t *idx, int64_t M, int32_t W, const float *base, float *out, void *stream);
+int fastegnn_wide_gather2(const float *P, const int64_t *i1, const float *Q, const int64_t *i2, const float *feat, int32_t nf,
+                          const float *Wf, int32_t ldw, int32_t c0, const float *base, float *out, int64_t M, int32_t W, void *stream);
 int fastegnn_wide_scatter_add(float *table, const int64_t *idx, int64_t M, int32_t W, const float *rows, void *stream);
+int fastegnn_wide_scatter_add_perm(float *table, const int64_t *idx_sorted, const int64_t *perm, int64_t M, int32_t W, const float *rows,
+                                   void *stream);
 int fastegnn_wide_rowscale(const float *X, const float *s, int64_t M, int32_t W, float *Y, void *stream);
 int fastegnn_wide_rowdot(const float *A, const float *B, int64_t M, int32_t W, float *out, void *stream);
 

@@ -84,6 +84,38 @@ def test_wide_rowwise_operators_vs_torch():
     K.check(L.fastegnn_wide_scatter_add(K.ptr(table), K.ptr(idx), M, W, K.ptr(base), _st()), "scatter")
     ref = torch.zeros(R_, W, dtype=torch.float64).index_add_(0, idx.cpu(), base.double().cpu())
     assert rel_err(table.cpu(), ref) < 1e-6
+    # sorted targets (runs), the same through a sorting permutation, and rows wider than one workgroup's columns
+    sidx, perm = torch.sort(idx, stable=True)
+    for tgt, pm in ((sidx, None), (sidx, perm)):
+        table = torch.zeros(R_, W, device="cuda")
+        if pm is None:
+            K.check(L.fastegnn_wide_scatter_add(K.ptr(table), K.ptr(tgt), M, W, K.ptr(base), _st()), "scatter sorted")
+            ref = torch.zeros(R_, W, dtype=torch.float64).index_add_(0, tgt.cpu(), base.double().cpu())
+        else:
+            K.check(L.fastegnn_wide_scatter_add_perm(K.ptr(table), K.ptr(tgt), K.ptr(pm), M, W, K.ptr(base), _st()), "scatter perm")
+            ref = torch.zeros(R_, W, dtype=torch.float64).index_add_(0, idx.cpu(), base.double().cpu())
+        assert rel_err(table.cpu(), ref) < 1e-6
+    for Wd, nf in ((128, 3), (2048, 0), (96, 1), (30, 2), (1300, 8)):
+        P = torch.randn(R_, Wd, generator=g).cuda()
+        Q = torch.randn(77, Wd, generator=g).cuda()
+        i2 = torch.randint(0, 77, (M,), generator=g).cuda()
+        feat = torch.randn(M, max(nf, 1), generator=g).cuda()
+        Wf = torch.randn(Wd, 40, generator=g).cuda()
+        bs = torch.randn(M, Wd, generator=g).cuda()
+        o = torch.empty(M, Wd, device="cuda")
+        K.check(L.fastegnn_wide_gather2(K.ptr(P), K.ptr(idx), K.ptr(Q), K.ptr(i2), K.ptr(feat) if nf else None, nf, K.ptr(Wf), 40, 5,
+                                        K.ptr(bs), K.ptr(o), M, Wd, _st()), "gather2")
+        ref = bs.double() + P.double()[idx] + Q.double()[i2]
+        if nf:
+            ref = ref + feat.double() @ Wf[:, 5:5 + nf].double().t()
+        assert rel_err(o.cpu(), ref.cpu()) < 1e-6, (Wd, nf)
+        K.check(L.fastegnn_wide_gather2(K.ptr(P), K.ptr(idx), None, None, None, 0, None, 0, 0, None, K.ptr(o), M, Wd, _st()), "gather2 plain")
+        assert torch.equal(o, P[idx])
+        t2 = torch.zeros(R_, Wd, device="cuda")
+        K.check(L.fastegnn_wide_scatter_add_perm(K.ptr(t2), K.ptr(sidx), K.ptr(perm), M, Wd, K.ptr(bs), _st()), "scatter perm wide") if Wd >= 32 else \
+            K.check(L.fastegnn_wide_scatter_add(K.ptr(t2), K.ptr(idx), M, Wd, K.ptr(bs), _st()), "scatter narrow")
+        ref = torch.zeros(R_, Wd, dtype=torch.float64).index_add_(0, idx.cpu(), bs.double().cpu())
+        assert rel_err(t2.cpu(), ref) < 1e-6, Wd
     s = torch.randn(M, generator=g).cuda()
     Y = torch.empty(M, W, device="cuda")
     K.check(L.fastegnn_wide_rowscale(K.ptr(base), K.ptr(s), M, W, K.ptr(Y), _st()), "rowscale")

@@ -68,8 +68,21 @@ class TorchOps:
         out.copy_(X[idx] + (base if base is not None else 0))
 
     @staticmethod
+    def gather2(P, i1, Q, i2, feat, nf, W, ldw, c0, base, out, M, Wd):
+        r = P[i1]
+        if Q is not None:
+            r = r + Q[i2]
+        if feat is not None and nf:
+            r = r + feat @ W[:, c0:c0 + nf].t()
+        out.copy_(r + (base if base is not None else 0))
+
+    @staticmethod
     def scatter_add(table, idx, M, W, rows):
         table.index_add_(0, idx, rows)
+
+    @staticmethod
+    def scatter_add_perm(table, idx_sorted, perm, M, W, rows):
+        table.index_add_(0, idx_sorted, rows[perm])
 
     @staticmethod
     def rowscale(X, s, M, W, Y):

@@ -62,6 +62,10 @@ t("linear_dx [M,H] x [H,1] (radial column)", lambda: ck(L.fastegnn_wide_linear_d
 t("linear_dw [H,1] (radial column)", lambda: ck(L.fastegnn_wide_linear_dw(p(G), p(feat), M, H, 1, p(dW), W.size(1), 2 * H, None, NONE, 0.0, st()), "l"), EH)
 t("gather_add P[row] + base", lambda: ck(L.fastegnn_wide_gather_add(p(P), p(row), M, H, p(X), p(out), st()), "g"), 2 * EH)
 t("gather_add P[col] + base", lambda: ck(L.fastegnn_wide_gather_add(p(P), p(col), M, H, p(X), p(out), st()), "g"), 2 * EH)
+csort, cperm = torch.sort(col, stable=True)
+Qn = torch.randn(Nn, H, generator=g).cuda()
+t("gather2 P[row] + Q[col] + feat w", lambda: ck(L.fastegnn_wide_gather2(p(P), p(row), p(Qn), p(col), p(feat), 1, p(W), W.size(1), 2 * H, None, p(out), M, H, st()), "g2"), EH)
+t("scatter_add_perm (col as sorted runs)", lambda: ck(L.fastegnn_wide_scatter_add_perm(p(table), p(csort), p(cperm), M, H, p(G), st()), "sp"), EH)
 t("scatter_add sorted rows", lambda: ck(L.fastegnn_wide_scatter_add(p(table), p(row), M, H, p(G), st()), "s"), EH)
 t("scatter_add unsorted rows", lambda: ck(L.fastegnn_wide_scatter_add(p(table), p(col), M, H, p(G), st()), "s"), EH)
 t("act", lambda: ck(L.fastegnn_wide_act(p(X), M * H, SILU, 0.0, p(out), st()), "a"), 2 * EH)
