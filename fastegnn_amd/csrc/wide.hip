@@ -209,10 +209,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *z, const floa
 // The first Linear of edge_model / edge_mode_virtual over its torch.cat input (models/FastEGNN.py:102-119) after the node-sized
 // products: P[row] + Q[col] + radial / edge_attr columns in ONE pass that only writes [M, W] (three launches and two
 // read-modify-write passes before).  Thread = VW (4 or 1) consecutive columns, the workgroup's threads tile rows x column groups.
-template <int VW>
+// EPI: the sum times act'(Z[m, :]) -- the backward of y = act(z) whose consumers were y itself and a segment sum of y
+// (fastegnn_wide_act_scatter): dz = (g_y + g_sum[idx]) * act'(z) in one pass.
+template <int VW, int EPI>
 __global__ __launch_bounds__(256) void gather2_kernel(const float *P, const int64_t *i1, const float *Q, const int64_t *i2, const float *feat,
                                                       int nf, const float *Wf, int ldw, const float *base, float *out, long M, int W,
-                                                      int cols_per_wg) {
+                                                      int cols_per_wg, const float *Z, Act epi) {
   const int slots = 256 / cols_per_wg, slot = threadIdx.x / cols_per_wg, cw = threadIdx.x % cols_per_wg;
   const int w = (blockIdx.y * cols_per_wg + cw) * VW;   // (rows wider than a workgroup: column blocks on grid.y)
   if (w >= W) return;
@@ -248,6 +250,12 @@ __global__ __launch_bounds__(256) void gather2_kernel(const float *P, const int6
           for (int j = 0; j < VW; ++j) a[j] += f * wf[k][j];
         }
     }
+    if constexpr (EPI != AM_NONE) {
+      float z[VW];
+      ld(Z + (size_t)m * W + w, z);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) a[j] *= dact_t<EPI>(z[j], epi);
+    }
     if constexpr (VW == 4) *reinterpret_cast<float4 *>(out + (size_t)m * W + w) = float4{a[0], a[1], a[2], a[3]};
     else out[(size_t)m * W + w] = a[0];
   }
@@ -265,9 +273,12 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(float *table, const in
 // whenever the target changes -- sorted or grouped indices (segment sums by graph, by edge row, the C channel rows of a node) cost
 // one atomic per run instead of one per row.  An UNSORTED index (the edge columns) gets the same treatment through `perm`, the
 // permutation that sorts it, computed once per graph: idx then holds the sorted targets and the rows are read through perm.
-template <int VW>
+// PRO: rows are PRE-activations -- y = act(rows) is what gets summed, and it is stored to `yout` on the way (the activation and
+// the segment sum of its output in one pass: fastegnn_wide_act_scatter).
+template <int VW, int PRO>
 __global__ __launch_bounds__(256) void scatter_add_runs_kernel(float *table, const int64_t *idx, const int64_t *perm, long M, int W,
-                                                               const float *rows, long rows_per_slot, int cols_per_wg) {
+                                                               const float *rows, long rows_per_slot, int cols_per_wg, Act pro,
+                                                               float *yout) {
   const int slots = 256 / cols_per_wg, slot = threadIdx.x / cols_per_wg, cw = threadIdx.x % cols_per_wg;
   const int w = (blockIdx.y * cols_per_wg + cw) * VW;
   const long m_lo = ((long)blockIdx.x * slots + slot) * rows_per_slot, m_hi = m_lo + rows_per_slot < M ? m_lo + rows_per_slot : M;
@@ -288,11 +299,20 @@ __global__ __launch_bounds__(256) void scatter_add_runs_kernel(float *table, con
     for (int u = 0; u < 4; ++u) {
       const long mm = m + u < m_hi ? m + u : m_hi - 1;
       t[u] = idx[mm];
-      const float *src = rows + (size_t)(perm ? perm[mm] : mm) * W + w;
+      const size_t off = (size_t)(perm ? perm[mm] : mm) * W + w;
+      const float *src = rows + off;
       if constexpr (VW == 4) {
         const float4 q = *reinterpret_cast<const float4 *>(src);
         v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
       } else v[u][0] = *src;
+      if constexpr (PRO != AM_NONE) {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) v[u][j] = pro_t<PRO>(v[u][j], pro);
+        if (m + u < m_hi) {
+          if constexpr (VW == 4) *reinterpret_cast<float4 *>(yout + off) = float4{v[u][0], v[u][1], v[u][2], v[u][3]};
+          else yout[off] = v[u][0];
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -501,33 +521,56 @@ int fastegnn_wide_act_backward(const float *z, const float *dy, int64_t n, int32
 }
 
 static int gather2(const float *P, const int64_t *i1, const float *Q, const int64_t *i2, const float *feat, int nf, const float *Wf,
-                   int ldw, const float *base, float *out, long M, int W, hipStream_t st, const char *what) {
+                   int ldw, const float *base, float *out, long M, int W, hipStream_t st, const char *what, const float *Z = nullptr,
+                   Act epi = Act{ACT_NONE, 0.f}) {
   const bool v4 = (W & 3) == 0 && ((reinterpret_cast<size_t>(P) | reinterpret_cast<size_t>(Q) | reinterpret_cast<size_t>(base) |
-                                    reinterpret_cast<size_t>(out)) & 15) == 0;
+                                    reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(Z)) & 15) == 0;
   const int nv = v4 ? W / 4 : W;
   const int cols = nv >= 256 ? 256 : pow2_at_least(nv), slots = 256 / cols, gy = cdiv(nv, cols);
   long gx = cdiv(M, (long)slots * 4);
   if (gx > 8192 / gy) gx = 8192 / gy;
   if (gx < 1) gx = 1;
-  if (v4) hipLaunchKernelGGL(gather2_kernel<4>, dim3((unsigned)gx, gy), dim3(256), 0, st, P, i1, Q, i2, feat, nf, Wf, ldw, base, out, M, W, cols);
-  else hipLaunchKernelGGL(gather2_kernel<1>, dim3((unsigned)gx, gy), dim3(256), 0, st, P, i1, Q, i2, feat, nf, Wf, ldw, base, out, M, W, cols);
+  const int em = Z ? am_of(epi.kind) : AM_NONE;
+#define FE_G2(VW_, E_) \
+  hipLaunchKernelGGL((gather2_kernel<VW_, E_>), dim3((unsigned)gx, gy), dim3(256), 0, st, P, i1, Q, i2, feat, nf, Wf, ldw, base, out, M, W, cols, Z, epi)
+  if (v4) {
+    if (em == AM_SILU) FE_G2(4, AM_SILU);
+    else if (em == AM_GEN) FE_G2(4, AM_GEN);
+    else FE_G2(4, AM_NONE);
+  } else {
+    if (em == AM_SILU) FE_G2(1, AM_SILU);
+    else if (em == AM_GEN) FE_G2(1, AM_GEN);
+    else FE_G2(1, AM_NONE);
+  }
+#undef FE_G2
   return check_launch(what);
 }
 // (narrow rows too: the 3-vector sums by graph put N rows on a handful of addresses -- as runs they cost a few atomics per slot;
 //  FASTEGNN_WIDE_SCATTER_ATOMICS=1 brings the one-atomic-per-element kernel back for narrow rows: A/B lever)
 static int scatter_add(float *table, const int64_t *idx, const int64_t *perm, long M, int W, const float *rows, hipStream_t st,
-                       const char *what) {
+                       const char *what, Act pro = Act{ACT_NONE, 0.f}, float *yout = nullptr) {
   static const bool atomics_only = getenv("FASTEGNN_WIDE_SCATTER_ATOMICS") && atoi(getenv("FASTEGNN_WIDE_SCATTER_ATOMICS")) != 0;
-  const bool v4 = (W & 3) == 0 && ((reinterpret_cast<size_t>(rows) | reinterpret_cast<size_t>(table)) & 15) == 0;
+  const bool v4 = (W & 3) == 0 && ((reinterpret_cast<size_t>(rows) | reinterpret_cast<size_t>(table) | reinterpret_cast<size_t>(yout)) & 15) == 0;
   const int nv = v4 ? W / 4 : W;
-  if (W >= 32 || !atomics_only) {
+  const int pm = yout ? am_of(pro.kind) : AM_NONE;
+  if (W >= 32 || !atomics_only || pm) {
     const int cols = nv >= 256 ? 256 : pow2_at_least(nv), slots = 256 / cols, gy = cdiv(nv, cols);
     long rps = 16;   // rows per slot: enough workgroups to fill the chip, runs long enough to pay
     while (rps < 256 && cdiv(M, rps * slots) * gy > 8192) rps *= 2;
     const long gx = cdiv(M, rps * slots);
     FE_REQUIRE(gx <= 0x7fffffffL && gy <= 65535, "fastegnn_wide_scatter_add: too many rows or columns");
-    if (v4) hipLaunchKernelGGL(scatter_add_runs_kernel<4>, dim3((unsigned)gx, gy), dim3(256), 0, st, table, idx, perm, M, W, rows, rps, cols);
-    else hipLaunchKernelGGL(scatter_add_runs_kernel<1>, dim3((unsigned)gx, gy), dim3(256), 0, st, table, idx, perm, M, W, rows, rps, cols);
+#define FE_SC(VW_, P_) \
+  hipLaunchKernelGGL((scatter_add_runs_kernel<VW_, P_>), dim3((unsigned)gx, gy), dim3(256), 0, st, table, idx, perm, M, W, rows, rps, cols, pro, yout)
+    if (v4) {
+      if (pm == AM_SILU) FE_SC(4, AM_SILU);
+      else if (pm == AM_GEN) FE_SC(4, AM_GEN);
+      else FE_SC(4, AM_NONE);
+    } else {
+      if (pm == AM_SILU) FE_SC(1, AM_SILU);
+      else if (pm == AM_GEN) FE_SC(1, AM_GEN);
+      else FE_SC(1, AM_NONE);
+    }
+#undef FE_SC
   } else {
     FE_REQUIRE(!perm, "fastegnn_wide_scatter_add_perm: not with FASTEGNN_WIDE_SCATTER_ATOMICS");
     hipLaunchKernelGGL(scatter_add_kernel, dim3(grid1d((size_t)M * W)), dim3(256), 0, st, table, idx, M, W, rows);
@@ -559,6 +602,24 @@ int fastegnn_wide_scatter_add(float *table, const int64_t *idx, int64_t M, int32
   if (M == 0) return FASTEGNN_OK;
   FE_REQUIRE(table && idx && rows, "fastegnn_wide_scatter_add: null pointer");
   return scatter_add(table, idx, nullptr, M, W, rows, (hipStream_t)stream, "fastegnn_wide_scatter_add");
+}
+// y = act(z) stored, and table[idx[m], :] += y[m, :] in the same pass (the activation of edge_mlp / edge_mlp_virtual's output and
+// the segment sum of it that node_model / node_model_virtual start with, models/FastEGNN.py:108-119, 156, 170)
+int fastegnn_wide_act_scatter(const float *z, const int64_t *idx, int64_t M, int32_t W, int32_t kind, float p, float *y, float *table,
+                              void *stream) {
+  FE_REQUIRE(M >= 0 && W >= 1 && kind >= 0 && kind <= FASTEGNN_ACT_SOFTPLUS, "fastegnn_wide_act_scatter: bad arguments");
+  if (M == 0) return FASTEGNN_OK;
+  FE_REQUIRE(z && idx && y && table, "fastegnn_wide_act_scatter: null pointer");
+  return scatter_add(table, idx, nullptr, M, W, z, (hipStream_t)stream, "fastegnn_wide_act_scatter", Act{kind, p}, y);
+}
+// dz[m, :] = ((g_y ? g_y[m, :] : 0) + g_table[idx[m], :]) * act'(z[m, :]): its backward
+int fastegnn_wide_act_scatter_backward(const float *z, const int64_t *idx, int64_t M, int32_t W, int32_t kind, float p, const float *g_y,
+                                       const float *g_table, float *dz, void *stream) {
+  FE_REQUIRE(M >= 0 && W >= 1 && kind >= 0 && kind <= FASTEGNN_ACT_SOFTPLUS, "fastegnn_wide_act_scatter_backward: bad arguments");
+  if (M == 0) return FASTEGNN_OK;
+  FE_REQUIRE(z && idx && g_table && dz, "fastegnn_wide_act_scatter_backward: null pointer");
+  return gather2(g_table, idx, nullptr, nullptr, nullptr, 0, nullptr, 0, g_y, dz, M, W, (hipStream_t)stream,
+                 "fastegnn_wide_act_scatter_backward", z, Act{kind, p});
 }
 // table[idx_sorted[m], :] += rows[perm[m], :]: the same sums for an index in any order, given the permutation that sorts it
 // (idx_sorted[m] = idx[perm[m]], computed once per graph) -- runs of equal targets become one atomic each

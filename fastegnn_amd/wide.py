@@ -176,6 +176,28 @@ class _Gather2(torch.autograd.Function):
         return gP, None, gQ, None, gfeat, gW, None, None
 
 
+class _ActScatter(torch.autograd.Function):
+    """(y, table) = (act(z), segment sum of y's rows by idx into R rows) in one pass; the backward is one pass too:
+    dz = (g_y + g_table[idx]) * act'(z)."""
+
+    @staticmethod
+    def forward(ctx, z, idx, R, act):
+        z = _f32(z)
+        y = torch.empty_like(z)
+        table = torch.zeros(R, z.size(1), dtype=torch.float32, device=z.device)
+        _call("act_scatter", z, idx, idx.numel(), z.size(1), act[0], act[1], y, table)
+        ctx.save_for_backward(z, idx)
+        ctx.act = act
+        return y, table
+
+    @staticmethod
+    def backward(ctx, gy, gt):
+        z, idx = ctx.saved_tensors   # (autograd hands zeros for an output nobody used)
+        dz = torch.empty_like(z)
+        _call("act_scatter_backward", z, idx, idx.numel(), z.size(1), ctx.act[0], ctx.act[1], _f32(gy), _f32(gt), dz)
+        return dz, None, None, None
+
+
 class _ScatterAdd(torch.autograd.Function):
     """table[idx[m]] += rows[m] into a zeroed [R, W] table"""
 
@@ -322,7 +344,12 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         else:   # (more than 7 edge attributes: the feature columns as a product of their own)
             pre = _Gather2.apply(_lin(h, W1, 0, Hn, g.edge_mlp[0].bias), row, _lin(h, W1, Hn, Hn), col, None, W1, 0, col_order)
             pre = _lin(feat, W1, 2 * Hn, feat.size(1), None, pre)
-        m = act(_lin(pre, g.edge_mlp[2].weight, 0, Hn, g.edge_mlp[2].bias, None, A))   # [E, H]
+        z2 = _lin(pre, g.edge_mlp[2].weight, 0, Hn, g.edge_mlp[2].bias, None, A)
+        fuse_sum = FUSE_ACT and not model.attention and not rf   # act and node_model's segment sum of it in one pass
+        if fuse_sum:
+            m, agg_m = _ActScatter.apply(z2, row, N, A)                              # [E, H], [N, H]
+        else:
+            m = act(z2)                                                              # [E, H]
         if model.attention:
             m = _rowscale(m, torch.sigmoid(_lin(m, g.att_mlp[0].weight, 0, Hn, g.att_mlp[0].bias)))
         # ---- edge_mode_virtual (:111-119): rows (n, c); input cat[h, Hv[b], vr, m_X[b][:, c]]
@@ -335,7 +362,12 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         # over sorted indices instead of N*C atomics onto B*C rows)
         pv = _Gather2.apply(_lin(h, Wv, 0, Hn, g.edge_mlp_virtual[0].bias), idx_n, None, None, vr.reshape(N * C, 1), Wv, 2 * Hn, None)
         pv = _GatherAdd.apply(Bc.view(B, C * Hn), batch, pv.view(N, C * Hn)).view(N * C, Hn)
-        v = act(_lin(pv, g.edge_mlp_virtual[2].weight, 0, Hn, g.edge_mlp_virtual[2].bias, None, A))   # [N*C, H]
+        z2v = _lin(pv, g.edge_mlp_virtual[2].weight, 0, Hn, g.edge_mlp_virtual[2].bias, None, A)
+        if fuse_sum:   # rows (n, c) of a node are one [C*H] row of graph batch[n]: node_model_virtual's pool as sorted runs
+            v, pool_v = _ActScatter.apply(z2v.view(N, C * Hn), batch, B, A)
+            v = v.view(N * C, Hn)
+        else:
+            v = act(z2v)                                                             # [N*C, H]
         if model.attention:
             v = _rowscale(v, torch.sigmoid(_lin(v, g.att_mlp_virtual[0].weight, 0, Hn, g.att_mlp_virtual[0].bias)))
         # ---- coord_model_vel (:122-145)
@@ -356,7 +388,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
             x, Z = x_new, Z_new
             continue
         # ---- node_model (:154-166): Linear over cat[h, agg, flat(v), node_attr]; flat(v) of the reference is (h, c)-ordered
-        aggm = _rowscale(_ScatterAdd.apply(m, row, N), inv_cnt_row)
+        aggm = _rowscale(agg_m if fuse_sum else _ScatterAdd.apply(m, row, N), inv_cnt_row)
         W3 = g.node_mlp[0].weight
         W3v = W3[:, 2 * Hn:2 * Hn + Hn * C].reshape(W3.size(0), Hn, C).permute(0, 2, 1).reshape(W3.size(0), C * Hn)
         npre = _lin(aggm, W3, Hn, Hn, None, _lin(h, W3, 0, Hn, g.node_mlp[0].bias))
@@ -365,7 +397,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
             npre = _lin(node_attr.float(), W3, 2 * Hn + Hn * C, node_attr.size(1), None, npre)
         h_new = _lin(npre, g.node_mlp[2].weight, 0, Hn, g.node_mlp[2].bias, h if model.residual else None, A)
         # ---- node_model_virtual (:168-178)
-        poolV = _rowscale(_ScatterAdd.apply(v.view(N, C * Hn), batch, B), inv_cnt_b).view(B * C, Hn)
+        poolV = _rowscale(pool_v if fuse_sum else _ScatterAdd.apply(v.view(N, C * Hn), batch, B), inv_cnt_b).view(B * C, Hn)
         Wn = g.node_mlp_virtual[0].weight
         zv = _lin(poolV, Wn, Hn, Hn, None, _lin(HvT, Wn, 0, Hn, g.node_mlp_virtual[0].bias))
         HvT = _lin(zv, g.node_mlp_virtual[2].weight, 0, Hn, g.node_mlp_virtual[2].bias, HvT if model.residual else None, A)
@@ -409,13 +441,17 @@ def egnn_forward(model, x, h, edge_index, edge_fea, v=None):
         pre = _Gather2.apply(_lin(h, W0, 1, Hn, net[0].bias), row, _lin(h, W0, 1 + Hn, Hn), col, scalar, W0, 0, col_order)
         if edge_fea is not None:
             pre = _lin(edge_fea.float(), W0, 1 + 2 * Hn, edge_fea.size(1), None, pre)
-        message = act(_lin(pre, net[2].weight, 0, net[2].weight.size(1), net[2].bias, None, A))     # [E, H]
+        zm = _lin(pre, net[2].weight, 0, net[2].weight.size(1), net[2].bias, None, A)
+        if FUSE_ACT:
+            message, sum_message = _ActScatter.apply(zm, row, N, A)                   # [E, H], [N, H]
+        else:
+            message = act(zm)
         f = rij * mlp(layer.coord_net, message)
         tot_f = torch.clamp(_segment_sum(f, row, N) * inv_cnt.unsqueeze(1), min=-100, max=100)
         x_new = x + tot_f
         if vv is not None:
             x_new = x_new + mlp(layer.node_v_net, h) * vv
-        tot_message = _rowscale(_ScatterAdd.apply(message, row, N), inv_cnt)
+        tot_message = _rowscale(sum_message if FUSE_ACT else _ScatterAdd.apply(message, row, N), inv_cnt)
         Wn = layer.node_net.mlp[0].weight
         h = mlp(layer.node_net, None, _lin(tot_message, Wn, Hn, Hn, None, _lin(h, Wn, 0, Hn, layer.node_net.mlp[0].bias)))
         x = x_new

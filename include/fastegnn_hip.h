@@ -449,6 +449,9 @@ int fastegnn_scatter_add_rows(float *table, const int64_t *ids, int64_t n, int32
  *               write-only pass, given the node-sized products P and Q; edge_mode_virtual (:111-119) in the same form
  *   scatter_add table[idx[m],:] += rows[m,:]                         -- unsorted_segment_sum / global_mean_pool sums (atomics;
  *               runs of equal targets are summed in registers first)
+ *   act_scatter y = act_fn(z) stored AND table[idx[m],:] += y[m,:] in one pass (edge_mlp's output and its segment sum for node_model,
+ *               models/FastEGNN.py:108, 156; edge_mlp_virtual's and node_model_virtual's pool, :119, 170);
+ *               act_scatter_backward  dz = ((g_y ? g_y : 0) + g_table[idx]) * act_fn'(z)
  *   scatter_add_perm  table[idx_sorted[m],:] += rows[perm[m],:]      -- the same for an index in any order, given the permutation
  *               that sorts it (idx_sorted = idx[perm], once per graph): the edge COLUMN sums of the backward as runs
  *   rowscale    Y[m,:] = X[m,:] * s[m];  rowdot  out[m] = <A[m,:], B[m,:]>   -- gates, 1/count of the segment means */
@@ -464,6 +467,10 @@ int fastegnn_wide_gather_add(const float *X, const int64_t *idx, int64_t M, int3
 int fastegnn_wide_gather2(const float *P, const int64_t *i1, const float *Q, const int64_t *i2, const float *feat, int32_t nf,
                           const float *Wf, int32_t ldw, int32_t c0, const float *base, float *out, int64_t M, int32_t W, void *stream);
 int fastegnn_wide_scatter_add(float *table, const int64_t *idx, int64_t M, int32_t W, const float *rows, void *stream);
+int fastegnn_wide_act_scatter(const float *z, const int64_t *idx, int64_t M, int32_t W, int32_t kind, float p, float *y, float *table,
+                              void *stream);
+int fastegnn_wide_act_scatter_backward(const float *z, const int64_t *idx, int64_t M, int32_t W, int32_t kind, float p, const float *g_y,
+                                       const float *g_table, float *dz, void *stream);
 int fastegnn_wide_scatter_add_perm(float *table, const int64_t *idx_sorted, const int64_t *perm, int64_t M, int32_t W, const float *rows,
                                    void *stream);
 int fastegnn_wide_rowscale(const float *X, const float *s, int64_t M, int32_t W, float *Y, void *stream);

@@ -116,6 +116,21 @@ def test_wide_rowwise_operators_vs_torch():
             K.check(L.fastegnn_wide_scatter_add(K.ptr(t2), K.ptr(idx), M, Wd, K.ptr(bs), _st()), "scatter narrow")
         ref = torch.zeros(R_, Wd, dtype=torch.float64).index_add_(0, idx.cpu(), bs.double().cpu())
         assert rel_err(t2.cpu(), ref) < 1e-6, Wd
+    # the activation and the segment sum of its output in one pass, and the pair's backward
+    for Wd in (128, 2048, 20):
+        zz = torch.randn(M, Wd, generator=g).cuda()
+        y = torch.empty_like(zz)
+        tb = torch.zeros(R_, Wd, device="cuda")
+        K.check(L.fastegnn_wide_act_scatter(K.ptr(zz), K.ptr(sidx), M, Wd, K.ACT_SILU, 0.0, K.ptr(y), K.ptr(tb), _st()), "act_scatter")
+        yr = torch.nn.functional.silu(zz.double())
+        assert rel_err(y.cpu(), yr.cpu()) < 1e-6
+        assert rel_err(tb.cpu(), torch.zeros(R_, Wd, dtype=torch.float64).index_add_(0, sidx.cpu(), yr.cpu())) < 1e-6
+        gy, gt = torch.randn(M, Wd, generator=g).cuda(), torch.randn(R_, Wd, generator=g).cuda()
+        dz = torch.empty_like(zz)
+        K.check(L.fastegnn_wide_act_scatter_backward(K.ptr(zz), K.ptr(sidx), M, Wd, K.ACT_SILU, 0.0, K.ptr(gy), K.ptr(gt), K.ptr(dz), _st()), "asb")
+        zd = zz.double().requires_grad_(True)
+        torch.nn.functional.silu(zd).backward(gy.double() + gt.double()[sidx])
+        assert rel_err(dz.cpu(), zd.grad.cpu()) < 2e-6
     s = torch.randn(M, generator=g).cuda()
     Y = torch.empty(M, W, device="cuda")
     K.check(L.fastegnn_wide_rowscale(K.ptr(base), K.ptr(s), M, W, K.ptr(Y), _st()), "rowscale")

@@ -81,6 +81,16 @@ class TorchOps:
         table.index_add_(0, idx, rows)
 
     @staticmethod
+    def act_scatter(z, idx, M, W, kind, p, y, table):
+        y.copy_(_fn(kind, p)(z))
+        table.index_add_(0, idx, y)
+
+    @staticmethod
+    def act_scatter_backward(z, idx, M, W, kind, p, g_y, g_table, dz):
+        g = g_table[idx] + (g_y if g_y is not None else 0)
+        TorchOps.act_backward(z, g, z.numel(), kind, p, dz)
+
+    @staticmethod
     def scatter_add_perm(table, idx_sorted, perm, M, W, rows):
         table.index_add_(0, idx_sorted, rows[perm])
 
