@@ -368,9 +368,12 @@ inline bool act_ok(int kind) { return kind >= ACT_NONE && kind <= FASTEGNN_ACT_S
 
 static int gemm(const float *A, int lda, long M, int Kd, const float *Bp, long sbk, long sbn, int N, const float *bias,
                 const float *base, float *C, int ldc, int accumulate, Act pro, const float *Z, int ldz, Act epi, hipStream_t st,
-                const char *what) {
+                const char *what, const float *gs = nullptr, const float *w2 = nullptr) {
   if (M == 0 || N == 0) return FASTEGNN_OK;
-  const int pm = am_of(pro.kind), em = Z ? am_of(epi.kind) : AM_NONE;
+  // gs: the generated-operand form of a scalar head's backward (AM_HEAD_*): A is the head's stored pre-activation
+  const int pm = gs ? (am_of(pro.kind) == AM_SILU ? AM_HEAD_SILU : AM_HEAD_GEN) : am_of(pro.kind), em = Z ? am_of(epi.kind) : AM_NONE;
+  FE_REQUIRE(!gs || (N > 8 && Kd > 8 && !(lda & 3) && !(Kd & 3) && !(reinterpret_cast<size_t>(A) & 15)),
+             "fastegnn_wide_head_dx: widths of at least 9, the head's a multiple of 4");
   FE_REQUIRE(!(pm && em) && !(base && accumulate), "wide gemm: unsupported combination of fused steps");
 // one launch per (prologue, epilogue) mode: the two never meet in one call
 #define FE_MODES(LAUNCH)                                 \
@@ -400,10 +403,10 @@ static int gemm(const float *A, int lda, long M, int Kd, const float *Bp, long s
     // column blocks of 32 NQ <= 128 columns, as even as the width allows (160 = 96 + 64, not 128 + 32)
     const int nquads = cdiv(N, 32), nblocks = cdiv(nquads, 4), nq = cdiv(nquads, nblocks), gy = cdiv(nquads, nq);
     const long units = cdiv(M, 32);
-    const int wgs_per_cu = x3_lds_bytes(nq) * 2 <= 160 * 1024 ? 2 : 1;
+    const int wgs_per_cu = (x3_lds_bytes(nq) + (gs ? 4 * Kd + 128 : 0)) * 2 <= 160 * 1024 ? 2 : 1;
     long gx = cdiv(units, XWAVES);
     if (gx > 256 * wgs_per_cu) gx = 256 * wgs_per_cu;
-    GemmX3 g{A, lda, M, Kd, Bp, sbk, sbn, N, bias, base, C, ldc, accumulate, pro, Z, ldz, epi, (int)cdiv(units, gx * XWAVES)};
+    GemmX3 g{A, lda, M, Kd, Bp, sbk, sbn, N, bias, base, C, ldc, accumulate, pro, Z, ldz, epi, (int)cdiv(units, gx * XWAVES), gs, w2};
     const dim3 grid((unsigned)gx, (unsigned)gy);
     const bool deep = nq == 4 && Kd % 128 == 0;   // (the four-buffer prefetch: whole 128-wide panels of a full-width column block)
     launch_gemm_x3(g, nq, pm, em, deep, grid, st);
@@ -442,10 +445,11 @@ int fastegnn_wide_linear_dx(const float *G, int64_t M, int32_t O, const float *W
               (hipStream_t)stream, "fastegnn_wide_linear_dx");
 }
 // dW[:, c0 : c0 + K] += G[M, O]^T . act(X)[M, K];  db[O] += column sums of G (db may be null)
-int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O, int32_t K, float *dW, int32_t ldw, int32_t c0,
-                            float *db, int32_t act_kind, float act_p, void *stream) {
+static int linear_dw(const float *G, const float *X, int64_t M, int32_t O, int32_t K, float *dW, int32_t ldw, int32_t c0, float *db,
+                     int32_t act_kind, float act_p, void *stream, const float *gs, const float *w2, Act gen) {
   FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0 && act_ok(act_kind), "fastegnn_wide_linear_dw: bad arguments");
   FE_REQUIRE((G && X) || M == 0, "fastegnn_wide_linear_dw: null pointer");
+  FE_REQUIRE(!gs || (dW && O > 8 && K > 8), "fastegnn_wide_head_dw: widths of at least 9");
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) return FASTEGNN_OK;
   const Act pro{act_kind, act_p};
@@ -488,9 +492,9 @@ int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O
       const int gx = cdiv(O, TB), gy = cdiv(K, TB), ns = row_splits(M, (long)gx * gy, 256, 512);
       long rows = cdiv(M, ns);
       rows = (rows + 31) / 32 * 32;
-      TnX3 t{G, O, X, K, (long)M, O, K, dW, ldw, c0, rows, db, pro};
+      TnX3 t{G, O, X, K, (long)M, O, K, dW, ldw, c0, rows, db, pro, gs, w2, gen};
       const dim3 grid(gx, gy, (unsigned)cdiv(M, rows));
-      launch_tn_x3(t, am_of(act_kind), grid, st);
+      launch_tn_x3(t, am_of(act_kind), gs ? am_of(gen.kind) : AM_NONE, grid, st);
       db = nullptr;   // done inside
     }
     int rc = check_launch("fastegnn_wide_linear_dw");
@@ -502,6 +506,29 @@ int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O
     return check_launch("fastegnn_wide_linear_dw(bias)");
   }
   return FASTEGNN_OK;
+}
+int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O, int32_t K, float *dW, int32_t ldw, int32_t c0,
+                            float *db, int32_t act_kind, float act_p, void *stream) {
+  return linear_dw(G, X, M, O, K, dW, ldw, c0, db, act_kind, act_p, stream, nullptr, nullptr, Act{ACT_NONE, 0.f});
+}
+// The backward of the FIRST Linear of a scalar head  s = act(X W1^T + b1) . w2^T (+ b2)  (coord_mlp_r / _r_virtual / _v_virtual / _vel,
+// gravity_mlp: models/FastEGNN.py:55-99) straight from the head's output gradient gs [M]: the gradient of the hidden
+// pre-activation, G[m, o] = gs[m] * w2[o] * act'(Zc[m, o]), is formed inside the kernels from the stored Zc and never written.
+//   head_dx   dX[M, K] (+)= G . W1[:, c0 : c0 + K]
+//   head_dw   dW1[:, c0 : c0 + K] += G^T act_x(X),  db1 += column sums of G     (x_kind: FASTEGNN_ACT_NONE or X a pre-activation)
+// O (the head's hidden width) and K at least 9, O a multiple of 4.
+int fastegnn_wide_head_dx(const float *gs, const float *w2, const float *Zc, int64_t M, int32_t O, const float *W, int32_t ldw,
+                          int32_t c0, int32_t K, float *dX, int32_t accumulate, int32_t kind, float p, void *stream) {
+  FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0 && kind >= 0 && kind <= FASTEGNN_ACT_SOFTPLUS,
+             "fastegnn_wide_head_dx: bad arguments");
+  FE_REQUIRE(M == 0 || (gs && w2 && Zc && W && dX), "fastegnn_wide_head_dx: null pointer");
+  return gemm(Zc, O, M, O, W + c0, ldw, 1, K, nullptr, nullptr, dX, K, accumulate, Act{kind, p}, nullptr, 0, Act{ACT_NONE, 0.f},
+              (hipStream_t)stream, "fastegnn_wide_head_dx", gs, w2);
+}
+int fastegnn_wide_head_dw(const float *gs, const float *w2, const float *Zc, const float *X, int64_t M, int32_t O, int32_t K, float *dW,
+                          int32_t ldw, int32_t c0, float *db, int32_t kind, float p, int32_t x_kind, float x_p, void *stream) {
+  FE_REQUIRE(kind >= 0 && kind <= FASTEGNN_ACT_SOFTPLUS && (M == 0 || (gs && w2)), "fastegnn_wide_head_dw: bad arguments");
+  return linear_dw(Zc, X, M, O, K, dW, ldw, c0, db, x_kind, x_p, stream, gs, w2, Act{kind, p});
 }
 
 // y = act(z) / dz = dy * act'(z); kind = FASTEGNN_ACT_*, p = its parameter (act_fn of the reference constructor)

@@ -26,7 +26,10 @@ typedef float f32x16w __attribute__((ext_vector_type(16)));
 constexpr int ACT_NONE = -1;
 // how a kernel instance treats its fused activation: none, SiLU inline (the reference's default act_fn), or any kind through ONE
 // out-of-line function (the generic switch inlined per element multiplied the GEMM kernel's code by 20 and its time by 2)
-enum { AM_NONE = 0, AM_SILU = 1, AM_GEN = 2 };
+// AM_HEAD_*: (GEMM prologue only) the A operand is GENERATED: A[m, k] = gs[m] * w2[k] * act'(Zc[m, k]) from the stored
+// pre-activation Zc of a scalar head  s = act(X W1^T + b1) . w2^T  (coord_mlp_* / gravity_mlp, models/FastEGNN.py:55-99) and the
+// head's output gradient gs -- the gradient of Zc is never stored.
+enum { AM_NONE = 0, AM_SILU = 1, AM_GEN = 2, AM_HEAD_SILU = 3, AM_HEAD_GEN = 4 };
 inline int am_of(int kind) { return kind < 0 ? AM_NONE : kind == FASTEGNN_ACT_SILU ? AM_SILU : AM_GEN; }
 __device__ __noinline__ float act_gen(float z, int kind, float p) { return act_f(z, Act{kind, p}); }
 __device__ __noinline__ float dact_gen(float z, int kind, float p) { return dact_f(z, Act{kind, p}); }
@@ -61,6 +64,7 @@ struct GemmX3 {
   Act pro;                               // A := act(A) when pro.kind >= 0
   const float *Z; int ldz; Act epi;      // C *= act'(Z[m, n]) when Z
   int units_per_wave;                    // 32-row units each wave walks (uniform: the panels' barriers are workgroup-wide)
+  const float *gs, *w2;                  // AM_HEAD_*: A := gs[m] * w2[k] * act'(A[m, k])
 };
 
 #ifdef FE_WIDE_GEMM_IMPL
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
   unsigned *bimg = reinterpret_cast<unsigned *>(x3_smem);
   constexpr int KS = XKP / 16;                       // k16 steps of a full panel
   constexpr int PART_WORDS = KS * NQ * 256;          // u32 words of one part of the B image
-  constexpr int VPER = PRO == AM_NONE ? 3 : (PRO == AM_SILU ? 6 : 3);   // vector instructions scheduled behind each MFMA
+  constexpr int VPER = PRO == AM_NONE ? 3 : (PRO == AM_SILU ? 6 : (PRO == AM_HEAD_SILU ? 8 : 3));   // vector instructions scheduled behind each MFMA
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: so is all unit addressing)
   const int l32 = lane & 31, hh = lane >> 5;
   char *strip = x3_smem + x3_b_bytes(NQ) + wave * XSTRIP;
@@ -126,6 +130,22 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
   const u32x4 *bfr = reinterpret_cast<const u32x4 *>(bimg) + lane;
   const char *aread = strip + l32 * XRS + 32 * hh;
   char *awrite = strip + lr * XRS + 16 * lc;
+  constexpr bool HEAD = PRO >= AM_HEAD_SILU;
+  constexpr int DACT = PRO == AM_HEAD_SILU ? AM_SILU : AM_GEN;
+  // HEAD: w2 over the whole contraction (zero beyond K: the padded columns then contribute nothing) behind the strips, and the
+  // head gradient of the lane's row for this unit and the next (the split of a unit's first step is made in the last step of the
+  // unit before it)
+  float *w2s = reinterpret_cast<float *>(x3_smem + x3_b_bytes(NQ) + XWAVES * XSTRIP);
+  float gsc = 0.f, gsn = 0.f;
+  auto gs_of = [&](int unit) {
+    long m = (wave_id + (long)unit * wave_n) * 32 + l32;
+    return g.gs[m < g.M ? m : g.M - 1];
+  };
+  if constexpr (HEAD) {
+    for (int k = tid; k < cpu * 32; k += XWAVES * 64) w2s[k] = k < g.Kd ? g.w2[k] : 0.f;
+    gsn = gs_of(0);
+    __syncthreads();
+  }
 
   // ---- the prefetch cursor: chunk pw of unit pu
   int pu = 0, pw = 0;
@@ -156,10 +176,15 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
     *reinterpret_cast<float4 *>(awrite + 24 * XRS) = r.v3;
   };
   // activation + bf16 split of word w (two of the lane's eight values) of a step
-  auto split_word = [&](const float4 &x0, const float4 &x1, int w, u32x4 &h, u32x4 &m, u32x4 &l) {
+  // (gsv, kn -- HEAD only: the row's head gradient and the first column of the step the split is made for)
+  auto split_word = [&](const float4 &x0, const float4 &x1, int w, u32x4 &h, u32x4 &m, u32x4 &l, float gsv, int kn) {
     float a = w == 0 ? x0.x : w == 1 ? x0.z : w == 2 ? x1.x : x1.z;
     float b = w == 0 ? x0.y : w == 1 ? x0.w : w == 2 ? x1.y : x1.w;
-    if constexpr (PRO != AM_NONE) {
+    if constexpr (HEAD) {
+      const float2 wv = *reinterpret_cast<const float2 *>(w2s + kn + 8 * hh + 2 * w);
+      a = gsv * wv.x * dact_t<DACT>(a, g.pro);
+      b = gsv * wv.y * dact_t<DACT>(b, g.pro);
+    } else if constexpr (PRO != AM_NONE) {
       // (zero padding beyond K: act(0) may be nonzero, but B's rows beyond K are zero)
       a = pro_t<PRO>(a, g.pro);
       b = pro_t<PRO>(b, g.pro);
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
   {
     const float4 x0 = *reinterpret_cast<const float4 *>(aread), x1 = *reinterpret_cast<const float4 *>(aread + 16);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) split_word(x0, x1, w, ah, am, al);
+    for (int w = 0; w < 4; ++w) split_word(x0, x1, w, ah, am, al, gsn, 0);
   }
   u32x4 bh = bfr[0], bm = bfr[PART_WORDS / 4], bl = bfr[2 * (PART_WORDS / 4)];   // (garbage until the first image is built: reloaded below)
 
@@ -197,6 +222,10 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    if constexpr (HEAD) {
+      gsc = gsn;
+      gsn = gs_of(it + 1);
+    }
     for (int pn = 0; pn < npanels; ++pn) {
       const int kp0 = pn * XKP;
       const int klen = g.Kd - kp0 < XKP ? g.Kd - kp0 : XKP;
@@ -244,6 +273,13 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
         const char *ap = aread + (ODD ? 0 : 64);
         const float4 x0 = *reinterpret_cast<const float4 *>(ap), x1 = *reinterpret_cast<const float4 *>(ap + 16);
         const int sn = s < last_step ? s + 1 : 0;    // the next step's fragments (a following panel rebuilds the image and reloads)
+        float gsv = 0.f;
+        int kn = 0;
+        if constexpr (HEAD) {
+          const bool unit_end = s == last_step && pn == npanels - 1;
+          kn = s < last_step ? kp0 + 16 * (s + 1) : (unit_end ? 0 : kp0 + XKP);
+          gsv = unit_end ? gsn : gsc;
+        }
         u32x4 nh, nm, nl, th, tm, tl;
         static_for<0, NQ>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
@@ -252,7 +288,7 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
           mma6(ah, am, al, bh, bm, bl, acc[q]);
           bh = th; bm = tm; bl = tl;
 #pragma unroll
-          for (int w = 4 * q / NQ; w < 4 * (q + 1) / NQ; ++w) split_word(x0, x1, w, nh, nm, nl);
+          for (int w = 4 * q / NQ; w < 4 * (q + 1) / NQ; ++w) split_word(x0, x1, w, nh, nm, nl, gsv, kn);
           if constexpr (q == 0 && ODD) {
             __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);   // the strip writes, then the chunk's four global loads, first
             __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
@@ -294,7 +330,7 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
       // (opaque per unit: the 64 x 2 element offsets below are invariant across units, and hoisted out of the unit loop they
       //  were spilled -- 300 registers of scratch traffic whose vmcnt(0) waits also drained the A prefetch inside the stream)
       int ldc = g.ldc, ldz = g.ldz;
-      asm volatile("" : "+s"(ldc), "+s"(ldz));
+      asm volatile("" : "+v"(ldc), "+v"(ldz));
       // FULL: a whole unit inside a whole column block -- no per-element predicate (the guarded form is a branch per element).
       // The addend is `base` (forward) or the old C (accumulate) -- the host never asks for both -- and comes after the activation
       // factor; every load of a quadrant goes first (C may be the addend: the compiler cannot move a load above an earlier store).
@@ -348,10 +384,11 @@ struct TnX3 {
   const float *G; int ldg; const float *X; int ldx; long M; int O, Kd;
   float *dW; int ldw, c0; long rows_per_split; float *db;
   Act pro;                                 // X := act(X) when pro.kind >= 0
+  const float *gs, *w2; Act gen;           // GEN: G[m, o] := gs[m] * w2[o] * act'(G[m, o])  (the head form, see AM_HEAD_*)
 };
 
 #ifdef FE_WIDE_GEMM_IMPL
-template <int PRO>
+template <int PRO, int GEN>
 __global__ __launch_bounds__(256) void tn_x3_kernel(TnX3 t) {
   __shared__ __attribute__((aligned(16))) char sm[TN_LDS];
   __shared__ double bred[8][128];
@@ -412,11 +449,28 @@ __global__ __launch_bounds__(256) void tn_x3_kernel(TnX3 t) {
   };
   char *Gs = sm, *Xs = sm + 3 * TPART;
   float4 gv[4], xv[4];
+  float gsr[4] = {0.f, 0.f, 0.f, 0.f};     // GEN: the head gradient of the staged rows
+  float4 w2v = float4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (GEN != AM_NONE) {
+    const int o = o0 + 4 * sc;
+    w2v = float4{o < t.O ? t.w2[o] : 0.f, o + 1 < t.O ? t.w2[o + 1] : 0.f, o + 2 < t.O ? t.w2[o + 2] : 0.f, o + 3 < t.O ? t.w2[o + 3] : 0.f};
+  }
+  auto load_gs = [&](long r0) {
+    if constexpr (GEN != AM_NONE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gsr[i] = r0 + sr + 8 * i < r_hi ? t.gs[r0 + sr + 8 * i] : 0.f;
+    }
+  };
   load_tile(r_lo, gv, xv);
+  load_gs(r_lo);
   for (long r0 = r_lo; r0 < r_hi; r0 += 32) {
     __syncthreads();            // the previous tile's reads are done
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if constexpr (GEN != AM_NONE) {   // (columns beyond O: w2 = 0; rows beyond the range: gs = 0)
+        gv[i].x = gsr[i] * w2v.x * dact_t<GEN>(gv[i].x, t.gen); gv[i].y = gsr[i] * w2v.y * dact_t<GEN>(gv[i].y, t.gen);
+        gv[i].z = gsr[i] * w2v.z * dact_t<GEN>(gv[i].z, t.gen); gv[i].w = gsr[i] * w2v.w * dact_t<GEN>(gv[i].w, t.gen);
+      }
       if (do_bias) {
         bs[0] += (double)gv[i].x; bs[1] += (double)gv[i].y; bs[2] += (double)gv[i].z; bs[3] += (double)gv[i].w;
       }
@@ -429,7 +483,10 @@ __global__ __launch_bounds__(256) void tn_x3_kernel(TnX3 t) {
       put(Xs, sr + 8 * i, x);
     }
     __syncthreads();
-    if (r0 + 32 < r_hi) load_tile(r0 + 32, gv, xv);
+    if (r0 + 32 < r_hi) {
+      load_tile(r0 + 32, gv, xv);
+      load_gs(r0 + 32);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       u32x4 a[2][3], b[2][3];
@@ -477,7 +534,7 @@ __global__ __launch_bounds__(256) void tn_x3_kernel(TnX3 t) {
 
 // host side of the two kernels (wide_gemm.hip -- its own translation unit: 25 instances, two minutes of compile time)
 int launch_gemm_x3(const GemmX3 &g, int nq, int pro_mode, int epi_mode, bool deep, dim3 grid, hipStream_t st);
-int launch_tn_x3(const TnX3 &t, int pro_mode, dim3 grid, hipStream_t st);
+int launch_tn_x3(const TnX3 &t, int pro_mode, int gen_mode, dim3 grid, hipStream_t st);
 
 }  // namespace wide
 }  // namespace fe

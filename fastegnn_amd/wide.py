@@ -81,6 +81,49 @@ class _Linear(torch.autograd.Function):
         return gX, gW, None, None, gb, (g if has_base else None), None
 
 
+class _Head(torch.autograd.Function):
+    """s = act(X . W1^T + b1) . w2^T (+ b2), a scalar head (coord_mlp_* / gravity_mlp, models/FastEGNN.py:55-99) as ONE autograd node:
+    the backward forms the gradient of the hidden pre-activation, gs[m] * w2[o] * act'(Zc[m, o]), inside the two GEMM kernels
+    (fastegnn_wide_head_dx / _dw) instead of writing it to memory and reading it back twice."""
+
+    @staticmethod
+    def forward(ctx, X, W1, b1, w2, b2, act):
+        X, W1, w2 = _f32(X), W1.contiguous(), w2.contiguous()
+        M, Kx, O = X.size(0), X.size(1), W1.size(0)
+        zc = torch.empty(M, O, dtype=torch.float32, device=X.device)
+        _call("linear", X, M, Kx, W1, W1.size(1), 0, _f32(b1), None, zc, O, K.ACT_NONE, 0.0)
+        s = torch.empty(M, 1, dtype=torch.float32, device=X.device)
+        _call("linear", zc, M, O, w2, O, 0, _f32(b2) if b2 is not None else None, None, s, 1, act[0], act[1])
+        ctx.save_for_backward(X, W1, w2, zc)
+        ctx.meta = (act, b2 is not None)
+        return s
+
+    @staticmethod
+    def backward(ctx, gs):
+        X, W1, w2, zc = ctx.saved_tensors
+        (kind, p), has_b2 = ctx.meta
+        gs = _f32(gs)
+        M, Kx, O = X.size(0), X.size(1), W1.size(0)
+        dev = gs.device
+        gw2 = torch.zeros_like(w2)
+        gb2 = torch.zeros(1, dtype=torch.float32, device=dev) if has_b2 else None
+        _call("linear_dw", gs, zc, M, 1, O, gw2, O, 0, gb2, kind, p)
+        gX = None
+        if ctx.needs_input_grad[0]:
+            gX = torch.empty(M, Kx, dtype=torch.float32, device=dev)
+            _call("head_dx", gs, w2, zc, M, O, W1, W1.size(1), 0, Kx, gX, 0, kind, p)
+        gW1 = torch.zeros_like(W1)
+        gb1 = torch.zeros(O, dtype=torch.float32, device=dev)
+        _call("head_dw", gs, w2, zc, X, M, O, Kx, gW1, W1.size(1), 0, gb1, kind, p, K.ACT_NONE, 0.0)
+        return gX, gW1, gb1, gw2, gb2, None
+
+
+def _head_fits(X, W1):
+    """the fused head backward takes hidden widths that are multiples of 4 and inputs / hidden widths of at least 9 columns"""
+    O, Kx = W1.size(0), X.size(1)
+    return FUSE_ACT and O % 4 == 0 and O > 8 and Kx > 8 and Kx % 4 == 0 and W1.size(1) == Kx
+
+
 class _Act(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, kind, p):
@@ -318,10 +361,15 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
     h = _lin(node_feat.float(), model.embedding_in.weight, 0, model.node_feat_nf, model.embedding_in.bias)
 
     def head(seq, X):   # coord_mlp: Linear(H, H), act, Linear(H, 1, bias=False) [, Tanh]   (:55-67)
-        s = _lin(_lin(X, seq[0].weight, 0, Hn, seq[0].bias), seq[2].weight, 0, Hn, None, None, A)
+        if _head_fits(X, seq[0].weight):
+            s = _Head.apply(X, seq[0].weight, seq[0].bias, seq[2].weight, None, A)
+        else:
+            s = _lin(_lin(X, seq[0].weight, 0, Hn, seq[0].bias), seq[2].weight, 0, Hn, None, None, A)
         return torch.tanh(s) if model.tanh else s
 
     def scalar_head_in(seq, X):   # Linear(w, H), act, Linear(H, 1) over an input of any width w
+        if _head_fits(X, seq[0].weight):
+            return _Head.apply(X, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, A)
         return _lin(_lin(X, seq[0].weight, 0, X.size(1), seq[0].bias), seq[2].weight, 0, Hn, seq[2].bias, None, A)
 
     def scalar_head(seq, X):   # Linear(H, H), act, Linear(H, 1)   (:75-88)

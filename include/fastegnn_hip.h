@@ -442,6 +442,9 @@ int fastegnn_scatter_add_rows(float *table, const int64_t *ids, int64_t n, int32
  *   linear_dx   dX[M,K] (+)= (G[M,O] . W[:, c0:c0+K]) * act'(Z[M,K])   -- Z NULL: no activation factor; with Z the result is the
  *               gradient of the pre-activation Z that `linear` took
  *   linear_dw   dW[:, c0:c0+K] += G^T act(X),  db += column sums of G (either may be NULL); fp32 atomics over row ranges
+ *   head_dx / head_dw   the backward of the first Linear of a scalar head s = act(X W1^T + b1) . w2^T (coord_mlp_*, gravity_mlp:
+ *               models/FastEGNN.py:55-99) from the head's output gradient gs[M]: G[m,o] = gs[m] w2[o] act'(Zc[m,o]) is formed in
+ *               the kernels from the stored pre-activation Zc and never written; O (hidden width) a multiple of 4, O and K >= 9
  *   act         y = act_fn(z), kind = FASTEGNN_ACT_*, p = its parameter;  act_backward  dz = dy * act_fn'(z)
  *   gather_add  out[m,:] = (base ? base[m,:] : 0) + X[idx[m],:]      -- node_feat[row], virtual_node_feat[data_batch]
  *   gather2     out[m,:] = (base) + P[i1[m],:] + (Q ? Q[i2[m],:] : 0) + feat[m,0:nf] . Wf[:, c0:c0+nf]^T  (feat may be NULL, nf <= 8)
@@ -461,6 +464,10 @@ int fastegnn_wide_linear_dx(const float *G, int64_t M, int32_t O, const float *W
                             int32_t accumulate, const float *Z, int32_t act_kind, float act_p, void *stream);
 int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O, int32_t K, float *dW, int32_t ldw, int32_t c0,
                             float *db, int32_t act_kind, float act_p, void *stream);
+int fastegnn_wide_head_dx(const float *gs, const float *w2, const float *Zc, int64_t M, int32_t O, const float *W, int32_t ldw,
+                          int32_t c0, int32_t K, float *dX, int32_t accumulate, int32_t kind, float p, void *stream);
+int fastegnn_wide_head_dw(const float *gs, const float *w2, const float *Zc, const float *X, int64_t M, int32_t O, int32_t K, float *dW,
+                          int32_t ldw, int32_t c0, float *db, int32_t kind, float p, int32_t x_kind, float x_p, void *stream);
 int fastegnn_wide_act(const float *z, int64_t n, int32_t kind, float p, float *y, void *stream);
 int fastegnn_wide_act_backward(const float *z, const float *dy, int64_t n, int32_t kind, float p, float *dz, void *stream);
 int fastegnn_wide_gather_add(const float *X, const int64_t *idx, int64_t M, int32_t W, const float *base, float *out, void *stream);

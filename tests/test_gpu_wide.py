@@ -68,6 +68,36 @@ def test_wide_linear_forward_dx_dw_vs_torch(M, K_, O, ldw, c0, kind):
     assert rel_err(db.cpu(), 1 + G.double().sum(0).cpu()) < 3e-6
 
 
+@pytest.mark.parametrize("M,O,Kx", [(1000, 128, 128), (777, 96, 96), (65, 160, 160), (4100, 256, 128), (300, 64, 12)])
+@pytest.mark.parametrize("kind", [K.ACT_SILU, K.ACT_TANH])
+def test_wide_head_backward_vs_torch(M, O, Kx, kind):
+    """fastegnn_wide_head_dx / _dw: the gradient of a scalar head's hidden pre-activation formed inside the GEMM kernels
+    (gs[m] w2[o] act'(Zc[m, o])) against the same products of the materialised gradient in float64"""
+    g = torch.Generator().manual_seed(M + O + Kx)
+    fn = {K.ACT_SILU: torch.nn.functional.silu, K.ACT_TANH: torch.tanh}[kind]
+    gs = torch.randn(M, generator=g).cuda()
+    w2 = torch.randn(O, generator=g).cuda()
+    Zc = torch.randn(M, O, generator=g).cuda()
+    X = torch.randn(M, Kx, generator=g).cuda()
+    ldw, c0 = Kx + 7, 3
+    W1 = (torch.randn(O, ldw, generator=g) / Kx ** 0.5).cuda()
+    zz = Zc.double().requires_grad_(True)
+    fn(zz).sum().backward()
+    G = gs.double().unsqueeze(1) * w2.double().unsqueeze(0) * zz.grad
+    L = K.lib()
+    dX = torch.full((M, Kx), 3.0, device="cuda")
+    K.check(L.fastegnn_wide_head_dx(K.ptr(gs), K.ptr(w2), K.ptr(Zc), M, O, K.ptr(W1), ldw, c0, Kx, K.ptr(dX), 0, kind, 0.0, _st()), "head_dx")
+    assert rel_err(dX.cpu(), (G @ W1[:, c0:c0 + Kx].double()).cpu()) < 2e-6
+    dW = torch.ones(O, ldw, device="cuda")
+    db = torch.ones(O, device="cuda")
+    K.check(L.fastegnn_wide_head_dw(K.ptr(gs), K.ptr(w2), K.ptr(Zc), K.ptr(X), M, O, Kx, K.ptr(dW), ldw, c0, K.ptr(db), kind, 0.0,
+                                    K.ACT_NONE, 0.0, _st()), "head_dw")
+    refW = torch.ones(O, ldw, dtype=torch.float64)
+    refW[:, c0:c0 + Kx] += (G.t() @ X.double()).cpu()
+    assert rel_err(dW.cpu(), refW) < 3e-6
+    assert rel_err(db.cpu(), 1 + G.sum(0).cpu()) < 3e-6
+
+
 def test_wide_rowwise_operators_vs_torch():
     g = torch.Generator().manual_seed(5)
     L = K.lib()

@@ -53,6 +53,20 @@ class TorchOps:
             db += G.sum(0)
 
     @staticmethod
+    def _head_g(gs, w2, Zc, kind, p):
+        d = torch.empty_like(Zc)
+        TorchOps.act_backward(Zc, gs.reshape(-1, 1) * w2.reshape(1, -1), Zc.numel(), kind, p, d)
+        return d
+
+    @staticmethod
+    def head_dx(gs, w2, Zc, M, O, W, ldw, c0, Kc, dX, accumulate, kind, p):
+        TorchOps.linear_dx(TorchOps._head_g(gs, w2, Zc, kind, p), M, O, W, ldw, c0, Kc, dX, accumulate, None, K.ACT_NONE, 0.0)
+
+    @staticmethod
+    def head_dw(gs, w2, Zc, X, M, O, Kc, dW, ldw, c0, db, kind, p, x_kind, x_p):
+        TorchOps.linear_dw(TorchOps._head_g(gs, w2, Zc, kind, p), X, M, O, Kc, dW, ldw, c0, db, x_kind, x_p)
+
+    @staticmethod
     def act(z, n, kind, p, y):
         y.copy_(_fn(kind, p)(z))
 
