@@ -282,8 +282,13 @@ __global__ __launch_bounds__(256) void scatter_add_runs_kernel(float *table, con
   const int slots = 256 / cols_per_wg, slot = threadIdx.x / cols_per_wg, cw = threadIdx.x % cols_per_wg;
   const int w = (blockIdx.y * cols_per_wg + cw) * VW;
   const long m_lo = ((long)blockIdx.x * slots + slot) * rows_per_slot, m_hi = m_lo + rows_per_slot < M ? m_lo + rows_per_slot : M;
-  if (w >= W || m_lo >= m_hi) return;
-  int64_t cur = idx[m_lo];
+  // the slots' LAST runs meet in LDS: consecutive slots that end on the same target (sums by graph: every slot of the workgroup)
+  // cost one atomic per column together -- with one graph in the batch all N rows land on one row of the table, and an atomic
+  // per slot and column was 3 000 serialised atomics per address
+  __shared__ float tail[256 * VW];
+  __shared__ long long tcur[256];
+  const bool live = w < W && m_lo < m_hi;
+  int64_t cur = live ? idx[m_lo] : -1;
   float acc[VW];
 #pragma unroll
   for (int j = 0; j < VW; ++j) acc[j] = 0.f;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256) void scatter_add_runs_kernel(float *table, con
 #pragma unroll
     for (int j = 0; j < VW; ++j) atomicAdd(table + (size_t)cur * W + w + j, acc[j]);
   };
-  for (long m = m_lo; m < m_hi; m += 4) {
+  for (long m = m_lo; live && m < m_hi; m += 4) {
     int64_t t[4];
     float v[4][VW];
     // the four rows' loads first: the atomics of a flush order every later load behind them
@@ -327,7 +332,17 @@ __global__ __launch_bounds__(256) void scatter_add_runs_kernel(float *table, con
       for (int j = 0; j < VW; ++j) acc[j] += v[u][j];
     }
   }
-  flush();
+#pragma unroll
+  for (int j = 0; j < VW; ++j) tail[threadIdx.x * VW + j] = acc[j];
+  if (cw == 0) tcur[slot] = w < W ? (long long)cur : -1;
+  __syncthreads();
+  if (live && (slot == 0 || tcur[slot - 1] != cur)) {   // the first slot of a group of equal last targets adds the group's tails
+    for (int s2 = slot + 1; s2 < slots && tcur[s2] == cur; ++s2) {
+#pragma unroll
+      for (int j = 0; j < VW; ++j) acc[j] += tail[(s2 * cols_per_wg + cw) * VW + j];
+    }
+    flush();
+  }
 }
 // Y[m, :] = X[m, :] * s[m]
 __global__ __launch_bounds__(256) void rowscale_kernel(const float *X, const float *s, long M, int W, float *Y) {
@@ -582,8 +597,8 @@ static int scatter_add(float *table, const int64_t *idx, const int64_t *perm, lo
   const int pm = yout ? am_of(pro.kind) : AM_NONE;
   if (W >= 32 || !atomics_only || pm) {
     const int cols = nv >= 256 ? 256 : pow2_at_least(nv), slots = 256 / cols, gy = cdiv(nv, cols);
-    long rps = 16;   // rows per slot: enough workgroups to fill the chip, runs long enough to pay
-    while (rps < 256 && cdiv(M, rps * slots) * gy > 8192) rps *= 2;
+    long rps = 16;   // rows per slot: enough workgroups to fill the chip, runs long enough to pay (and few atomics per address)
+    while (rps < 256 && cdiv(M, rps * slots) * gy > 2048) rps *= 2;
     const long gx = cdiv(M, rps * slots);
     FE_REQUIRE(gx <= 0x7fffffffL && gy <= 65535, "fastegnn_wide_scatter_add: too many rows or columns");
 #define FE_SC(VW_, P_) \
