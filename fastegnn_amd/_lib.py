@@ -203,7 +203,8 @@ def lib(act: bool = False, wide=None):
     L.fastegnn_wide_linear_dx.argtypes = [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _f, _vp]
     L.fastegnn_wide_linear_dw.argtypes = [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _f, _vp]
     L.fastegnn_wide_head_dx.argtypes = [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _f, _vp]
-    L.fastegnn_wide_head_dw.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _f, _i32, _f, _vp]
+    L.fastegnn_wide_head_dw.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _f, _i32, _f, _vp]
+    L.fastegnn_wide_head_forward.argtypes = [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _i32, _f, _vp]
     L.fastegnn_wide_act.argtypes = [_vp, _i64, _i32, _f, _vp, _vp]
     L.fastegnn_wide_act_backward.argtypes = [_vp, _vp, _i64, _i32, _f, _vp, _vp]
     L.fastegnn_wide_gather_add.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp, _vp]
@@ -252,7 +253,7 @@ EXPORTED = STAGE_FUNCS + [
     "fastegnn_comm_world", "fastegnn_comm_all_reduce", "fastegnn_comm_all_gather", "fastegnn_comm_reduce_scatter",
     "fastegnn_comm_all_to_all_v", "fastegnn_gather_rows", "fastegnn_scatter_add_rows",
     "fastegnn_wgrad_batch_open", "fastegnn_wgrad_batch_close", "fastegnn_pack_weights_all",
-    "fastegnn_wide_linear", "fastegnn_wide_linear_dx", "fastegnn_wide_linear_dw", "fastegnn_wide_head_dx", "fastegnn_wide_head_dw", "fastegnn_wide_act", "fastegnn_wide_act_backward",
+    "fastegnn_wide_linear", "fastegnn_wide_linear_dx", "fastegnn_wide_linear_dw", "fastegnn_wide_head_dx", "fastegnn_wide_head_dw", "fastegnn_wide_head_forward", "fastegnn_wide_act", "fastegnn_wide_act_backward",
     "fastegnn_wide_gather_add", "fastegnn_wide_gather2", "fastegnn_wide_scatter_add", "fastegnn_wide_scatter_add_perm", "fastegnn_wide_act_scatter",
     "fastegnn_wide_act_scatter_backward", "fastegnn_wide_rowscale", "fastegnn_wide_rowdot",
 ]

@@ -381,12 +381,20 @@ inline int pow2_at_least(int n) {
 }
 inline bool act_ok(int kind) { return kind >= ACT_NONE && kind <= FASTEGNN_ACT_SOFTPLUS; }
 
+// can the head's output ride in the epilogue of its first Linear?  One column block of the streaming GEMM: 9 .. 128 hidden units,
+// an input the 16-byte loads can take
+static bool head_forward_fits(int lda, int Kd, int N, const float *A) {
+  return N > 8 && N <= 128 && Kd > 8 && !(lda & 3) && !(Kd & 3) && !(reinterpret_cast<size_t>(A) & 15);
+}
 static int gemm(const float *A, int lda, long M, int Kd, const float *Bp, long sbk, long sbn, int N, const float *bias,
                 const float *base, float *C, int ldc, int accumulate, Act pro, const float *Z, int ldz, Act epi, hipStream_t st,
-                const char *what, const float *gs = nullptr, const float *w2 = nullptr) {
+                const char *what, const float *gs = nullptr, const float *w2 = nullptr, float *sout = nullptr, const float *b2 = nullptr) {
   if (M == 0 || N == 0) return FASTEGNN_OK;
   // gs: the generated-operand form of a scalar head's backward (AM_HEAD_*): A is the head's stored pre-activation
-  const int pm = gs ? (am_of(pro.kind) == AM_SILU ? AM_HEAD_SILU : AM_HEAD_GEN) : am_of(pro.kind), em = Z ? am_of(epi.kind) : AM_NONE;
+  // sout: the head's output from the GEMM's accumulators (AM_DOT_*; `epi` holds the head's activation, w2 its second weight)
+  const int pm = gs ? (am_of(pro.kind) == AM_SILU ? AM_HEAD_SILU : AM_HEAD_GEN) : am_of(pro.kind);
+  const int em = sout ? (am_of(epi.kind) == AM_SILU ? AM_DOT_SILU : AM_DOT_GEN) : (Z ? am_of(epi.kind) : AM_NONE);
+  FE_REQUIRE(!sout || head_forward_fits(lda, Kd, N, A), "fastegnn_wide_head_forward: internal dispatch");
   FE_REQUIRE(!gs || (N > 8 && Kd > 8 && !(lda & 3) && !(Kd & 3) && !(reinterpret_cast<size_t>(A) & 15)),
              "fastegnn_wide_head_dx: widths of at least 9, the head's a multiple of 4");
   FE_REQUIRE(!(pm && em) && !(base && accumulate), "wide gemm: unsupported combination of fused steps");
@@ -421,7 +429,7 @@ static int gemm(const float *A, int lda, long M, int Kd, const float *Bp, long s
     const int wgs_per_cu = (x3_lds_bytes(nq) + (gs ? 4 * Kd + 128 : 0)) * 2 <= 160 * 1024 ? 2 : 1;
     long gx = cdiv(units, XWAVES);
     if (gx > 256 * wgs_per_cu) gx = 256 * wgs_per_cu;
-    GemmX3 g{A, lda, M, Kd, Bp, sbk, sbn, N, bias, base, C, ldc, accumulate, pro, Z, ldz, epi, (int)cdiv(units, gx * XWAVES), gs, w2};
+    GemmX3 g{A, lda, M, Kd, Bp, sbk, sbn, N, bias, base, C, ldc, accumulate, pro, Z, ldz, epi, (int)cdiv(units, gx * XWAVES), gs, w2, sout, b2};
     const dim3 grid((unsigned)gx, (unsigned)gy);
     const bool deep = nq == 4 && Kd % 128 == 0;   // (the four-buffer prefetch: whole 128-wide panels of a full-width column block)
     launch_gemm_x3(g, nq, pm, em, deep, grid, st);
@@ -461,7 +469,7 @@ int fastegnn_wide_linear_dx(const float *G, int64_t M, int32_t O, const float *W
 }
 // dW[:, c0 : c0 + K] += G[M, O]^T . act(X)[M, K];  db[O] += column sums of G (db may be null)
 static int linear_dw(const float *G, const float *X, int64_t M, int32_t O, int32_t K, float *dW, int32_t ldw, int32_t c0, float *db,
-                     int32_t act_kind, float act_p, void *stream, const float *gs, const float *w2, Act gen) {
+                     int32_t act_kind, float act_p, void *stream, const float *gs, const float *w2, Act gen, float *dw2 = nullptr) {
   FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0 && act_ok(act_kind), "fastegnn_wide_linear_dw: bad arguments");
   FE_REQUIRE((G && X) || M == 0, "fastegnn_wide_linear_dw: null pointer");
   FE_REQUIRE(!gs || (dW && O > 8 && K > 8), "fastegnn_wide_head_dw: widths of at least 9");
@@ -507,7 +515,7 @@ static int linear_dw(const float *G, const float *X, int64_t M, int32_t O, int32
       const int gx = cdiv(O, TB), gy = cdiv(K, TB), ns = row_splits(M, (long)gx * gy, 256, 512);
       long rows = cdiv(M, ns);
       rows = (rows + 31) / 32 * 32;
-      TnX3 t{G, O, X, K, (long)M, O, K, dW, ldw, c0, rows, db, pro, gs, w2, gen};
+      TnX3 t{G, O, X, K, (long)M, O, K, dW, ldw, c0, rows, db, pro, gs, w2, gen, dw2};
       const dim3 grid(gx, gy, (unsigned)cdiv(M, rows));
       launch_tn_x3(t, am_of(act_kind), gs ? am_of(gen.kind) : AM_NONE, grid, st);
       db = nullptr;   // done inside
@@ -530,8 +538,11 @@ int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O
 // gravity_mlp: models/FastEGNN.py:55-99) straight from the head's output gradient gs [M]: the gradient of the hidden
 // pre-activation, G[m, o] = gs[m] * w2[o] * act'(Zc[m, o]), is formed inside the kernels from the stored Zc and never written.
 //   head_dx   dX[M, K] (+)= G . W1[:, c0 : c0 + K]
-//   head_dw   dW1[:, c0 : c0 + K] += G^T act_x(X),  db1 += column sums of G     (x_kind: FASTEGNN_ACT_NONE or X a pre-activation)
+//   head_dw   dW1[:, c0 : c0 + K] += G^T act_x(X),  db1 += column sums of G     (x_kind: FASTEGNN_ACT_NONE or X a pre-activation),
+//             dw2[o] += sum_m gs[m] act(Zc[m, o]) (the second Linear's weight gradient, from the same pass; may be NULL)
 // O (the head's hidden width) and K at least 9, O a multiple of 4.
+//   head_forward   Zc = act_x(X) . W1[:, c0 : c0 + K]^T + b1 stored, s[m] = act(Zc[m, :]) . w2 + (b2 ? b2[0] : 0): with 9 .. 128 hidden
+//             units the output is formed from the first GEMM's accumulators, otherwise by a second launch over Zc
 int fastegnn_wide_head_dx(const float *gs, const float *w2, const float *Zc, int64_t M, int32_t O, const float *W, int32_t ldw,
                           int32_t c0, int32_t K, float *dX, int32_t accumulate, int32_t kind, float p, void *stream) {
   FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0 && kind >= 0 && kind <= FASTEGNN_ACT_SOFTPLUS,
@@ -541,9 +552,24 @@ int fastegnn_wide_head_dx(const float *gs, const float *w2, const float *Zc, int
               (hipStream_t)stream, "fastegnn_wide_head_dx", gs, w2);
 }
 int fastegnn_wide_head_dw(const float *gs, const float *w2, const float *Zc, const float *X, int64_t M, int32_t O, int32_t K, float *dW,
-                          int32_t ldw, int32_t c0, float *db, int32_t kind, float p, int32_t x_kind, float x_p, void *stream) {
+                          int32_t ldw, int32_t c0, float *db, float *dw2, int32_t kind, float p, int32_t x_kind, float x_p, void *stream) {
   FE_REQUIRE(kind >= 0 && kind <= FASTEGNN_ACT_SOFTPLUS && (M == 0 || (gs && w2)), "fastegnn_wide_head_dw: bad arguments");
-  return linear_dw(Zc, X, M, O, K, dW, ldw, c0, db, x_kind, x_p, stream, gs, w2, Act{kind, p});
+  return linear_dw(Zc, X, M, O, K, dW, ldw, c0, db, x_kind, x_p, stream, gs, w2, Act{kind, p}, dw2);
+}
+int fastegnn_wide_head_forward(const float *X, int64_t M, int32_t K, const float *W1, int32_t ldw, int32_t c0, const float *b1,
+                               const float *w2, const float *b2, float *Zc, float *s, int32_t O, int32_t kind, float p, int32_t x_kind,
+                               float x_p, void *stream) {
+  FE_REQUIRE(M >= 0 && K >= 1 && O >= 1 && ldw >= c0 + K && c0 >= 0 && kind >= 0 && kind <= FASTEGNN_ACT_SOFTPLUS && act_ok(x_kind),
+             "fastegnn_wide_head_forward: bad arguments");
+  if (M == 0) return FASTEGNN_OK;
+  FE_REQUIRE(X && W1 && w2 && Zc && s, "fastegnn_wide_head_forward: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const Act act{kind, p}, xact{x_kind, x_p}, none{ACT_NONE, 0.f};
+  if (head_forward_fits(K, K, O, X))
+    return gemm(X, K, M, K, W1 + c0, 1, ldw, O, b1, nullptr, Zc, O, 0, xact, nullptr, 0, act, st, "fastegnn_wide_head_forward", nullptr, w2, s, b2);
+  int rc = gemm(X, K, M, K, W1 + c0, 1, ldw, O, b1, nullptr, Zc, O, 0, xact, nullptr, 0, none, st, "fastegnn_wide_head_forward");
+  if (rc) return rc;
+  return gemm(Zc, O, M, O, w2, 1, O, 1, b2, nullptr, s, 1, 0, act, nullptr, 0, none, st, "fastegnn_wide_head_forward(out)");
 }
 
 // y = act(z) / dz = dy * act'(z); kind = FASTEGNN_ACT_*, p = its parameter (act_fn of the reference constructor)

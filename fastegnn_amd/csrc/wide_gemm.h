@@ -29,7 +29,9 @@ constexpr int ACT_NONE = -1;
 // AM_HEAD_*: (GEMM prologue only) the A operand is GENERATED: A[m, k] = gs[m] * w2[k] * act'(Zc[m, k]) from the stored
 // pre-activation Zc of a scalar head  s = act(X W1^T + b1) . w2^T  (coord_mlp_* / gravity_mlp, models/FastEGNN.py:55-99) and the
 // head's output gradient gs -- the gradient of Zc is never stored.
-enum { AM_NONE = 0, AM_SILU = 1, AM_GEN = 2, AM_HEAD_SILU = 3, AM_HEAD_GEN = 4 };
+// AM_DOT_*: (GEMM epilogue only) besides C = the head's hidden pre-activation, the head's OUTPUT s[m] = act(C[m, :]) . w2 + b2 is
+// formed from the accumulators (one column block: N <= 128) -- the second Linear of the head costs no pass over C.
+enum { AM_NONE = 0, AM_SILU = 1, AM_GEN = 2, AM_HEAD_SILU = 3, AM_HEAD_GEN = 4, AM_DOT_SILU = 5, AM_DOT_GEN = 6 };
 inline int am_of(int kind) { return kind < 0 ? AM_NONE : kind == FASTEGNN_ACT_SILU ? AM_SILU : AM_GEN; }
 __device__ __noinline__ float act_gen(float z, int kind, float p) { return act_f(z, Act{kind, p}); }
 __device__ __noinline__ float dact_gen(float z, int kind, float p) { return dact_f(z, Act{kind, p}); }
@@ -38,6 +40,15 @@ __device__ __forceinline__ float pro_t(float z, Act a) {
   if constexpr (AM == AM_NONE) return z;
   else if constexpr (AM == AM_SILU) return silu_f(z);
   else return act_gen(z, a.kind, a.p);
+}
+// y = act(z), d = act'(z)
+template <int AM>
+__device__ __forceinline__ void both_t(float z, Act a, float &y, float &d) {
+  if constexpr (AM == AM_SILU) silu_both(z, y, d);
+  else {
+    y = act_gen(z, a.kind, a.p);
+    d = dact_gen(z, a.kind, a.p);
+  }
 }
 template <int AM>
 __device__ __forceinline__ float dact_t(float z, Act a) {
@@ -64,7 +75,8 @@ struct GemmX3 {
   Act pro;                               // A := act(A) when pro.kind >= 0
   const float *Z; int ldz; Act epi;      // C *= act'(Z[m, n]) when Z
   int units_per_wave;                    // 32-row units each wave walks (uniform: the panels' barriers are workgroup-wide)
-  const float *gs, *w2;                  // AM_HEAD_*: A := gs[m] * w2[k] * act'(A[m, k])
+  const float *gs, *w2;                  // AM_HEAD_*: A := gs[m] * w2[k] * act'(A[m, k]);  AM_DOT_*: w2 = the head's second weight
+  float *sout; const float *b2;          // AM_DOT_*: sout[m] = act(C[m, :]) . w2 + b2[0]
 };
 
 #ifdef FE_WIDE_GEMM_IMPL
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
       const float *bsrc = g.base ? g.base : (g.accumulate ? g.C : nullptr);
       float *cu = g.C + (size_t)m0 * g.ldc;
       const float *bu = bsrc ? bsrc + (size_t)m0 * g.ldc : nullptr;
-      const float *zu = EPI != AM_NONE ? g.Z + (size_t)m0 * g.ldz : nullptr;
+      const float *zu = (EPI == AM_SILU || EPI == AM_GEN) ? g.Z + (size_t)m0 * g.ldz : nullptr;
       // (opaque per unit: the 64 x 2 element offsets below are invariant across units, and hoisted out of the unit loop they
       //  were spilled -- 300 registers of scratch traffic whose vmcnt(0) waits also drained the A prefetch inside the stream)
       int ldc = g.ldc, ldz = g.ldz;
@@ -334,13 +346,21 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
       // FULL: a whole unit inside a whole column block -- no per-element predicate (the guarded form is a branch per element).
       // The addend is `base` (forward) or the old C (accumulate) -- the host never asks for both -- and comes after the activation
       // factor; every load of a quadrant goes first (C may be the addend: the compiler cannot move a load above an earlier store).
+      constexpr bool DOT = EPI >= AM_DOT_SILU;
+      constexpr int DOTACT = EPI == AM_DOT_SILU ? AM_SILU : AM_GEN;
+      constexpr bool MUL = EPI == AM_SILU || EPI == AM_GEN;
       auto emit = [&](auto full_tag, auto addend_tag) {
         constexpr bool FULL = decltype(full_tag)::value, ADD = decltype(addend_tag)::value;
+        float sp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sp[r] = 0.f;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int n = n0 + 32 * q + l32;
           if (!FULL && n >= g.N) continue;
           const float bn = g.bias ? g.bias[n] : 0.f;
+          float w2n = 0.f;
+          if constexpr (DOT) w2n = g.w2[n];
           float bv[16], zv[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -348,15 +368,28 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
             const bool ok = FULL || row < rows;
             if constexpr (ADD) bv[r] = ok ? bu[(unsigned)(row * ldc + n)] : 0.f;
             else bv[r] = 0.f;
-            if constexpr (EPI != AM_NONE) zv[r] = ok ? zu[(unsigned)(row * ldz + n)] : 0.f;
+            if constexpr (MUL) zv[r] = ok ? zu[(unsigned)(row * ldz + n)] : 0.f;
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = 8 * (r >> 2) + 4 * hh + (r & 3);
             if (!FULL && row >= rows) continue;
             float v = acc[q][r] + bn;
-            if constexpr (EPI != AM_NONE) v *= dact_t<EPI>(zv[r], g.epi);
-            cu[(unsigned)(row * ldc + n)] = v + bv[r];
+            if constexpr (MUL) v *= dact_t<EPI>(zv[r], g.epi);
+            v += bv[r];
+            cu[(unsigned)(row * ldc + n)] = v;
+            if constexpr (DOT) sp[r] += pro_t<DOTACT>(v, g.epi) * w2n;
+          }
+        }
+        if constexpr (DOT) {   // the row sums over the 32 lanes of the half-wave that holds the row
+          const float b2v = g.b2 ? g.b2[0] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float t = sp[r];
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) t += __shfl_xor(t, d, 32);
+            const int row = 8 * (r >> 2) + 4 * hh + (r & 3);
+            if (l32 == 0 && (FULL || row < rows)) g.sout[m0 + row] = t + b2v;
           }
         }
       };
@@ -385,6 +418,7 @@ struct TnX3 {
   float *dW; int ldw, c0; long rows_per_split; float *db;
   Act pro;                                 // X := act(X) when pro.kind >= 0
   const float *gs, *w2; Act gen;           // GEN: G[m, o] := gs[m] * w2[o] * act'(G[m, o])  (the head form, see AM_HEAD_*)
+  float *dw2;                              // GEN: dw2[o] += sum_m gs[m] * act(G[m, o]), the head's second weight gradient (may be null)
 };
 
 #ifdef FE_WIDE_GEMM_IMPL
@@ -407,7 +441,8 @@ __global__ __launch_bounds__(256) void tn_x3_kernel(TnX3 t) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  double bs[4] = {0.0, 0.0, 0.0, 0.0};
+  double bs[4] = {0.0, 0.0, 0.0, 0.0}, b2s[4] = {0.0, 0.0, 0.0, 0.0};
+  const bool do_w2 = GEN != AM_NONE && t.dw2 != nullptr && blockIdx.y == 0;
   auto load4 = [&](const float *P, int ld, bool vec, long m, int c, int ncols) {
     float4 v = float4{0.f, 0.f, 0.f, 0.f};
     if (m < r_hi && c < ncols) {
@@ -468,8 +503,15 @@ __global__ __launch_bounds__(256) void tn_x3_kernel(TnX3 t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (GEN != AM_NONE) {   // (columns beyond O: w2 = 0; rows beyond the range: gs = 0)
-        gv[i].x = gsr[i] * w2v.x * dact_t<GEN>(gv[i].x, t.gen); gv[i].y = gsr[i] * w2v.y * dact_t<GEN>(gv[i].y, t.gen);
-        gv[i].z = gsr[i] * w2v.z * dact_t<GEN>(gv[i].z, t.gen); gv[i].w = gsr[i] * w2v.w * dact_t<GEN>(gv[i].w, t.gen);
+        float y[4], d[4];
+        both_t<GEN>(gv[i].x, t.gen, y[0], d[0]); both_t<GEN>(gv[i].y, t.gen, y[1], d[1]);
+        both_t<GEN>(gv[i].z, t.gen, y[2], d[2]); both_t<GEN>(gv[i].w, t.gen, y[3], d[3]);
+        gv[i].x = gsr[i] * w2v.x * d[0]; gv[i].y = gsr[i] * w2v.y * d[1];
+        gv[i].z = gsr[i] * w2v.z * d[2]; gv[i].w = gsr[i] * w2v.w * d[3];
+        if (do_w2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b2s[e] += (double)(gsr[i] * y[e]);
+        }
       }
       if (do_bias) {
         bs[0] += (double)gv[i].x; bs[1] += (double)gv[i].y; bs[2] += (double)gv[i].z; bs[3] += (double)gv[i].w;
@@ -526,6 +568,18 @@ __global__ __launch_bounds__(256) void tn_x3_kernel(TnX3 t) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) s += bred[r][tid];
       atomicAdd(t.db + o0 + tid, (float)s);
+    }
+  }
+  if (do_w2) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bred[sr][4 * sc + e] = b2s[e];
+    __syncthreads();
+    if (tid < 128 && o0 + tid < t.O) {
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += bred[r][tid];
+      atomicAdd(t.dw2 + o0 + tid, (float)s);
     }
   }
 }

@@ -27,6 +27,8 @@ int launch_gemm_x3(const GemmX3 &g, int nq, int pm, int em, bool deep, dim3 grid
     else if (pm == AM_HEAD_GEN) FE_X3_LAUNCH(NQ_, AM_HEAD_GEN, AM_NONE);   \
     else if (em == AM_SILU) FE_X3_LAUNCH(NQ_, AM_NONE, AM_SILU); \
     else if (em == AM_GEN) FE_X3_LAUNCH(NQ_, AM_NONE, AM_GEN);   \
+    else if (em == AM_DOT_SILU) FE_X3_LAUNCH(NQ_, AM_NONE, AM_DOT_SILU); \
+    else if (em == AM_DOT_GEN) FE_X3_LAUNCH(NQ_, AM_NONE, AM_DOT_GEN);   \
     else FE_X3_LAUNCH(NQ_, AM_NONE, AM_NONE);                    \
   } while (0)
   switch (nq) {

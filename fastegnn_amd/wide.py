@@ -91,9 +91,9 @@ class _Head(torch.autograd.Function):
         X, W1, w2 = _f32(X), W1.contiguous(), w2.contiguous()
         M, Kx, O = X.size(0), X.size(1), W1.size(0)
         zc = torch.empty(M, O, dtype=torch.float32, device=X.device)
-        _call("linear", X, M, Kx, W1, W1.size(1), 0, _f32(b1), None, zc, O, K.ACT_NONE, 0.0)
         s = torch.empty(M, 1, dtype=torch.float32, device=X.device)
-        _call("linear", zc, M, O, w2, O, 0, _f32(b2) if b2 is not None else None, None, s, 1, act[0], act[1])
+        _call("head_forward", X, M, Kx, W1, W1.size(1), 0, _f32(b1), w2, _f32(b2) if b2 is not None else None, zc, s, O, act[0], act[1],
+              K.ACT_NONE, 0.0)
         ctx.save_for_backward(X, W1, w2, zc)
         ctx.meta = (act, b2 is not None)
         return s
@@ -106,16 +106,59 @@ class _Head(torch.autograd.Function):
         M, Kx, O = X.size(0), X.size(1), W1.size(0)
         dev = gs.device
         gw2 = torch.zeros_like(w2)
-        gb2 = torch.zeros(1, dtype=torch.float32, device=dev) if has_b2 else None
-        _call("linear_dw", gs, zc, M, 1, O, gw2, O, 0, gb2, kind, p)
+        gb2 = gs.sum().reshape(1) if has_b2 else None
         gX = None
         if ctx.needs_input_grad[0]:
             gX = torch.empty(M, Kx, dtype=torch.float32, device=dev)
             _call("head_dx", gs, w2, zc, M, O, W1, W1.size(1), 0, Kx, gX, 0, kind, p)
         gW1 = torch.zeros_like(W1)
         gb1 = torch.zeros(O, dtype=torch.float32, device=dev)
-        _call("head_dw", gs, w2, zc, X, M, O, Kx, gW1, W1.size(1), 0, gb1, kind, p, K.ACT_NONE, 0.0)
+        _call("head_dw", gs, w2, zc, X, M, O, Kx, gW1, W1.size(1), 0, gb1, gw2, kind, p, K.ACT_NONE, 0.0)   # (gw2 from the same pass)
         return gX, gW1, gb1, gw2, gb2, None
+
+
+class _Head2(torch.autograd.Function):
+    """two scalar heads over the SAME input (coord_mlp_r_virtual and coord_mlp_v_virtual over the virtual messages,
+    models/FastEGNN.py:136-151): as _Head, with the second head's input gradient accumulated into the first's buffer by the kernel
+    (autograd would write both and add them: three more passes over an [N*C, H] tensor)."""
+
+    @staticmethod
+    def forward(ctx, X, Wa, ba, wa2, Wb, bb, wb2, act):
+        X = _f32(X)
+        M, Kx = X.shape
+        outs, saved = [], [X]
+        for W1, b1, w2 in ((Wa, ba, wa2), (Wb, bb, wb2)):
+            W1, w2 = W1.contiguous(), w2.contiguous()
+            O = W1.size(0)
+            zc = torch.empty(M, O, dtype=torch.float32, device=X.device)
+            s = torch.empty(M, 1, dtype=torch.float32, device=X.device)
+            _call("head_forward", X, M, Kx, W1, W1.size(1), 0, _f32(b1), w2, None, zc, s, O, act[0], act[1], K.ACT_NONE, 0.0)
+            outs.append(s)
+            saved += [W1, w2, zc]
+        ctx.save_for_backward(*saved)
+        ctx.act = act
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        X = ctx.saved_tensors[0]
+        kind, p = ctx.act
+        M, Kx = X.shape
+        dev = X.device
+        gX = torch.empty(M, Kx, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        res = []
+        for i, gs in enumerate((ga, gb)):
+            W1, w2, zc = ctx.saved_tensors[1 + 3 * i:4 + 3 * i]
+            gs = _f32(gs)
+            O = W1.size(0)
+            gw2 = torch.zeros_like(w2)
+            if gX is not None:
+                _call("head_dx", gs, w2, zc, M, O, W1, W1.size(1), 0, Kx, gX, i, kind, p)
+            gW1 = torch.zeros_like(W1)
+            gb1 = torch.zeros(O, dtype=torch.float32, device=dev)
+            _call("head_dw", gs, w2, zc, X, M, O, Kx, gW1, W1.size(1), 0, gb1, gw2, kind, p, K.ACT_NONE, 0.0)
+            res += [gW1, gb1, gw2]
+        return (gX, *res, None)
 
 
 def _head_fits(X, W1):
@@ -422,7 +465,14 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         trans = cd * head(g.coord_mlp_r, m)
         agg = _segment_sum(trans, row, N)
         x_new = x + (agg if coords_sum else agg * inv_cnt_row.unsqueeze(1))
-        x_new = x_new + torch.mean(-vcd * head(g.coord_mlp_r_virtual, v).reshape(N, 1, C), dim=-1)
+        hr, hv = g.coord_mlp_r_virtual, g.coord_mlp_v_virtual
+        if _head_fits(v, hr[0].weight) and _head_fits(v, hv[0].weight):   # both heads of the virtual messages as one node
+            s_rv, s_vv = _Head2.apply(v, hr[0].weight, hr[0].bias, hr[2].weight, hv[0].weight, hv[0].bias, hv[2].weight, A)
+            if model.tanh:
+                s_rv, s_vv = torch.tanh(s_rv), torch.tanh(s_vv)
+        else:
+            s_rv, s_vv = head(hr, v), head(hv, v)
+        x_new = x_new + torch.mean(-vcd * s_rv.reshape(N, 1, C), dim=-1)
         if rf:
             x_new = x_new + scalar_head_in(g.coord_mlp_vel, torch.norm(vel, p=2, dim=-1).unsqueeze(-1).detach()) * vel
         else:
@@ -430,7 +480,7 @@ def forward(model, node_feat, node_loc, node_vel, edge_index, data_batch, loc_me
         if gravity is not None:
             x_new = x_new + scalar_head(g.gravity_mlp, h) * gravity
         # ---- coord_model_virtual (:147-151)
-        transX = vcd * head(g.coord_mlp_v_virtual, v).reshape(N, 1, C)
+        transX = vcd * s_vv.reshape(N, 1, C)
         Z_new = Z + (_segment_sum(transX.reshape(N, 3 * C), batch, B) * inv_cnt_b.unsqueeze(1)).reshape(B, 3, C)
         if rf:   # the features of real and virtual nodes pass through (FastRF.py:186)
             x, Z = x_new, Z_new

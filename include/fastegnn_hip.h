@@ -444,7 +444,10 @@ int fastegnn_scatter_add_rows(float *table, const int64_t *ids, int64_t n, int32
  *   linear_dw   dW[:, c0:c0+K] += G^T act(X),  db += column sums of G (either may be NULL); fp32 atomics over row ranges
  *   head_dx / head_dw   the backward of the first Linear of a scalar head s = act(X W1^T + b1) . w2^T (coord_mlp_*, gravity_mlp:
  *               models/FastEGNN.py:55-99) from the head's output gradient gs[M]: G[m,o] = gs[m] w2[o] act'(Zc[m,o]) is formed in
- *               the kernels from the stored pre-activation Zc and never written; O (hidden width) a multiple of 4, O and K >= 9
+ *               the kernels from the stored pre-activation Zc and never written; O (hidden width) a multiple of 4, O and K >= 9;
+ *               head_dw also returns the second Linear's weight gradient dw2[o] += sum_m gs[m] act(Zc[m,o]) (may be NULL)
+ *   head_forward  Zc = act_x(X) W1^T + b1 (stored) and s = act(Zc) . w2 + b2: with 9 .. 128 hidden units s comes out of the first
+ *               GEMM's accumulators (no pass over Zc), otherwise from a second launch
  *   act         y = act_fn(z), kind = FASTEGNN_ACT_*, p = its parameter;  act_backward  dz = dy * act_fn'(z)
  *   gather_add  out[m,:] = (base ? base[m,:] : 0) + X[idx[m],:]      -- node_feat[row], virtual_node_feat[data_batch]
  *   gather2     out[m,:] = (base) + P[i1[m],:] + (Q ? Q[i2[m],:] : 0) + feat[m,0:nf] . Wf[:, c0:c0+nf]^T  (feat may be NULL, nf <= 8)
@@ -467,7 +470,10 @@ int fastegnn_wide_linear_dw(const float *G, const float *X, int64_t M, int32_t O
 int fastegnn_wide_head_dx(const float *gs, const float *w2, const float *Zc, int64_t M, int32_t O, const float *W, int32_t ldw,
                           int32_t c0, int32_t K, float *dX, int32_t accumulate, int32_t kind, float p, void *stream);
 int fastegnn_wide_head_dw(const float *gs, const float *w2, const float *Zc, const float *X, int64_t M, int32_t O, int32_t K, float *dW,
-                          int32_t ldw, int32_t c0, float *db, int32_t kind, float p, int32_t x_kind, float x_p, void *stream);
+                          int32_t ldw, int32_t c0, float *db, float *dw2, int32_t kind, float p, int32_t x_kind, float x_p, void *stream);
+int fastegnn_wide_head_forward(const float *X, int64_t M, int32_t K, const float *W1, int32_t ldw, int32_t c0, const float *b1,
+                               const float *w2, const float *b2, float *Zc, float *s, int32_t O, int32_t kind, float p, int32_t x_kind,
+                               float x_p, void *stream);
 int fastegnn_wide_act(const float *z, int64_t n, int32_t kind, float p, float *y, void *stream);
 int fastegnn_wide_act_backward(const float *z, const float *dy, int64_t n, int32_t kind, float p, float *dz, void *stream);
 int fastegnn_wide_gather_add(const float *X, const int64_t *idx, int64_t M, int32_t W, const float *base, float *out, void *stream);

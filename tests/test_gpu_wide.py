@@ -90,12 +90,24 @@ def test_wide_head_backward_vs_torch(M, O, Kx, kind):
     assert rel_err(dX.cpu(), (G @ W1[:, c0:c0 + Kx].double()).cpu()) < 2e-6
     dW = torch.ones(O, ldw, device="cuda")
     db = torch.ones(O, device="cuda")
-    K.check(L.fastegnn_wide_head_dw(K.ptr(gs), K.ptr(w2), K.ptr(Zc), K.ptr(X), M, O, Kx, K.ptr(dW), ldw, c0, K.ptr(db), kind, 0.0,
+    dw2 = torch.ones(O, device="cuda")
+    K.check(L.fastegnn_wide_head_dw(K.ptr(gs), K.ptr(w2), K.ptr(Zc), K.ptr(X), M, O, Kx, K.ptr(dW), ldw, c0, K.ptr(db), K.ptr(dw2), kind, 0.0,
                                     K.ACT_NONE, 0.0, _st()), "head_dw")
     refW = torch.ones(O, ldw, dtype=torch.float64)
     refW[:, c0:c0 + Kx] += (G.t() @ X.double()).cpu()
     assert rel_err(dW.cpu(), refW) < 3e-6
     assert rel_err(db.cpu(), 1 + G.sum(0).cpu()) < 3e-6
+    assert rel_err(dw2.cpu(), 1 + (gs.double().unsqueeze(1) * fn(Zc.double())).sum(0).cpu()) < 3e-6
+    # the head's forward: the hidden pre-activation and the scalar output (from the first GEMM's accumulators when O <= 128)
+    b1 = torch.randn(O, generator=g).cuda()
+    b2 = torch.randn(1, generator=g).cuda()
+    zc = torch.empty(M, O, device="cuda")
+    so = torch.empty(M, 1, device="cuda")
+    K.check(L.fastegnn_wide_head_forward(K.ptr(X), M, Kx, K.ptr(W1), ldw, c0, K.ptr(b1), K.ptr(w2), K.ptr(b2), K.ptr(zc), K.ptr(so), O, kind, 0.0,
+                                         K.ACT_NONE, 0.0, _st()), "head_forward")
+    zr = X.double() @ W1[:, c0:c0 + Kx].double().t() + b1.double()
+    assert rel_err(zc.cpu(), zr.cpu()) < 2e-6
+    assert rel_err(so.cpu(), (fn(zr) @ w2.double().unsqueeze(1) + b2.double()).cpu()) < 2e-6
 
 
 def test_wide_rowwise_operators_vs_torch():

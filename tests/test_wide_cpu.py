@@ -63,8 +63,15 @@ class TorchOps:
         TorchOps.linear_dx(TorchOps._head_g(gs, w2, Zc, kind, p), M, O, W, ldw, c0, Kc, dX, accumulate, None, K.ACT_NONE, 0.0)
 
     @staticmethod
-    def head_dw(gs, w2, Zc, X, M, O, Kc, dW, ldw, c0, db, kind, p, x_kind, x_p):
+    def head_dw(gs, w2, Zc, X, M, O, Kc, dW, ldw, c0, db, dw2, kind, p, x_kind, x_p):
         TorchOps.linear_dw(TorchOps._head_g(gs, w2, Zc, kind, p), X, M, O, Kc, dW, ldw, c0, db, x_kind, x_p)
+        if dw2 is not None:
+            dw2 += (gs.reshape(-1, 1) * _fn(kind, p)(Zc)).sum(0).reshape(dw2.shape)
+
+    @staticmethod
+    def head_forward(X, M, Kc, W1, ldw, c0, b1, w2, b2, Zc, s, O, kind, p, x_kind, x_p):
+        TorchOps.linear(X, M, Kc, W1, ldw, c0, b1, None, Zc, O, x_kind, x_p)
+        s.copy_(_fn(kind, p)(Zc) @ w2.reshape(-1, 1) + (b2 if b2 is not None else 0))
 
     @staticmethod
     def act(z, n, kind, p, y):
