@@ -423,16 +423,20 @@ static int gemm(const float *A, int lda, long M, int Kd, const float *Bp, long s
     FE_MODES(FE_SMALLK);
 #undef FE_SMALLK
   } else {
-    // column blocks of 32 NQ <= 128 columns, as even as the width allows (160 = 96 + 64, not 128 + 32)
-    const int nquads = cdiv(N, 32), nblocks = cdiv(nquads, 4), nq = cdiv(nquads, nblocks), gy = cdiv(nquads, nq);
+    // The four-buffer prefetch (DEEP) exists for full 128-column blocks and panels of four chunks; it takes every shape whose
+    // padding to those costs less than a third of the work (96, 128, 192 .. 256 wide; 160 = 128 + 32 columns / 5 + 3 chunks does
+    // not).  Otherwise: column blocks of 32 NQ <= 128 columns, as even as the width allows (160 = 96 + 64, not 128 + 32).
+    const int nquads = cdiv(N, 32), chunks = cdiv(Kd, 32);
+    const bool deep = 3 * cdiv(nquads, 4) * 4 <= 4 * nquads && 3 * cdiv(chunks, 4) * 4 <= 4 * chunks;
+    const int nblocks = cdiv(nquads, 4), nq = deep ? 4 : cdiv(nquads, nblocks), gy = cdiv(nquads, nq);
     const long units = cdiv(M, 32);
     const int wgs_per_cu = (x3_lds_bytes(nq) + (gs ? 4 * Kd + 128 : 0)) * 2 <= 160 * 1024 ? 2 : 1;
     long gx = cdiv(units, XWAVES);
     if (gx > 256 * wgs_per_cu) gx = 256 * wgs_per_cu;
     GemmX3 g{A, lda, M, Kd, Bp, sbk, sbn, N, bias, base, C, ldc, accumulate, pro, Z, ldz, epi, (int)cdiv(units, gx * XWAVES), gs, w2, sout, b2};
     const dim3 grid((unsigned)gx, (unsigned)gy);
-    const bool deep = nq == 4 && Kd % 128 == 0;   // (the four-buffer prefetch: whole 128-wide panels of a full-width column block)
-    launch_gemm_x3(g, nq, pm, em, deep, grid, st);
+    FE_REQUIRE(launch_gemm_x3(g, nq, pm, em, deep, grid, st) == 0,
+               "fastegnn_wide_head_dx: hidden and input widths of 96, 128, 192 .. 256 (+ multiples of 128) only");
   }
 #undef FE_MODES
   return check_launch(what);

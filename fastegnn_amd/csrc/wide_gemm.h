@@ -123,7 +123,8 @@ __device__ __forceinline__ void mma6(const u32x4 &ah, const u32x4 &am, const u32
 // DEEP: four chunk buffers instead of one -- a wave keeps 16 KB of A in flight (a whole 128-wide unit ahead) instead of 4 KB; with one
 // buffer the 8 waves of a compute unit had 32 KB outstanding, a quarter of what HBM's latency asks for, and every chunk waited.
 // The four buffers rotate through a chunk loop unrolled by four with fixed names (a rotation by index or by copy made the compiler
-// move freshly loaded registers, i.e. wait for them), so DEEP takes contractions whose 32-column chunk count is a multiple of 4.
+// move freshly loaded registers, i.e. wait for them), so DEEP runs every panel as four chunks (the host picks it when the padding of
+// the last panel costs less than a third).
 template <int NQ, int PRO, int EPI, bool DEEP>
 __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
   extern __shared__ __attribute__((aligned(16))) char x3_smem[];
@@ -136,7 +137,9 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
   char *strip = x3_smem + x3_b_bytes(NQ) + wave * XSTRIP;
   const int n0 = blockIdx.y * (32 * NQ);
   const int npanels = (g.Kd + XKP - 1) / XKP;
-  const int cpu = (g.Kd + 31) >> 5;                   // chunks per unit
+  // chunks per unit (DEEP: every panel as four chunks -- a contraction that is not a multiple of 128 wide runs its last panel
+  // padded: the columns beyond K re-read valid ones against B's zero rows)
+  const int cpu = DEEP ? ((g.Kd + XKP - 1) / XKP) * 4 : (g.Kd + 31) >> 5;
   const int lr = lane >> 3, lc = lane & 7;            // loader: rows lr + 8 i, float4 column lc of a 32 x 32 chunk
   const long wave_id = (long)blockIdx.x * XWAVES + wave, wave_n = (long)gridDim.x * XWAVES;
   const u32x4 *bfr = reinterpret_cast<const u32x4 *>(bimg) + lane;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(XWAVES * 64) void gemm_x3_kernel(GemmX3 g) {
     for (int pn = 0; pn < npanels; ++pn) {
       const int kp0 = pn * XKP;
       const int klen = g.Kd - kp0 < XKP ? g.Kd - kp0 : XKP;
-      const int nchunks = (klen + 31) >> 5;
+      const int nchunks = DEEP ? 4 : (klen + 31) >> 5;
       if (npanels > 1 || it == 0) {
         // ---- B image of the panel: word (part, k16 step s, quadrant q, lane, w) = bf16 pair k = kp0 + 16 s + 8 hh + 2 w, + 1 of column n0 + 32 q + l32
         if (npanels > 1) __syncthreads();

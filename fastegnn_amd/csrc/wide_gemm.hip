@@ -13,7 +13,10 @@ namespace wide {
 
 int launch_gemm_x3(const GemmX3 &g, int nq, int pm, int em, bool deep, dim3 grid, hipStream_t st) {
   const dim3 block(XWAVES * 64);
-  const int extra = pm >= AM_HEAD_SILU ? ((g.Kd + 31) / 32) * 32 * (int)sizeof(float) : 0;   // w2 behind the strips
+  // the generated-operand (head) prologue exists in the four-buffer form only: in the one-buffer form the compiler keeps the
+  // stream's state in scratch memory (1 KB per lane, 25 x the time) -- the host asks for it on DEEP shapes only
+  if (pm >= AM_HEAD_SILU && !(deep && nq == 4)) return 1;
+  const int extra = pm >= AM_HEAD_SILU ? ((g.Kd + 127) / 128) * 128 * (int)sizeof(float) : 0;   // w2 behind the strips
 #define FE_X3_LAUNCH(NQ_, P_, E_)                                                                                          \
   do {                                                                                                                     \
     if (NQ_ == 4 && deep) hipLaunchKernelGGL((gemm_x3_kernel<4, P_, E_, true>), grid, block, x3_lds_bytes(4) + extra, st, g); \
@@ -23,8 +26,8 @@ int launch_gemm_x3(const GemmX3 &g, int nq, int pm, int em, bool deep, dim3 grid
   do {                                                           \
     if (pm == AM_SILU) FE_X3_LAUNCH(NQ_, AM_SILU, AM_NONE);      \
     else if (pm == AM_GEN) FE_X3_LAUNCH(NQ_, AM_GEN, AM_NONE);   \
-    else if (pm == AM_HEAD_SILU) FE_X3_LAUNCH(NQ_, AM_HEAD_SILU, AM_NONE); \
-    else if (pm == AM_HEAD_GEN) FE_X3_LAUNCH(NQ_, AM_HEAD_GEN, AM_NONE);   \
+    else if (pm == AM_HEAD_SILU) FE_X3_LAUNCH(4, AM_HEAD_SILU, AM_NONE); \
+    else if (pm == AM_HEAD_GEN) FE_X3_LAUNCH(4, AM_HEAD_GEN, AM_NONE);   \
     else if (em == AM_SILU) FE_X3_LAUNCH(NQ_, AM_NONE, AM_SILU); \
     else if (em == AM_GEN) FE_X3_LAUNCH(NQ_, AM_NONE, AM_GEN);   \
     else if (em == AM_DOT_SILU) FE_X3_LAUNCH(NQ_, AM_NONE, AM_DOT_SILU); \

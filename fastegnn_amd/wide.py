@@ -161,10 +161,17 @@ class _Head2(torch.autograd.Function):
         return (gX, *res, None)
 
 
+def _deep_width(n):
+    """csrc/wide.hip's rule for the GEMM kernel's four-buffer form: 32-column groups padded to a multiple of four cost at most a third more"""
+    q = -(-n // 32)
+    return 3 * (-(-q // 4) * 4) <= 4 * q
+
+
 def _head_fits(X, W1):
-    """the fused head backward takes hidden widths that are multiples of 4 and inputs / hidden widths of at least 9 columns"""
+    """the fused head takes hidden and input widths that are multiples of 4 on the GEMM kernel's four-buffer form (96, 128, 192 .. 256,
+    multiples of 128): fastegnn_wide_head_dx exists in that form only"""
     O, Kx = W1.size(0), X.size(1)
-    return FUSE_ACT and O % 4 == 0 and O > 8 and Kx > 8 and Kx % 4 == 0 and W1.size(1) == Kx
+    return FUSE_ACT and O % 4 == 0 and Kx % 4 == 0 and W1.size(1) == Kx and _deep_width(O) and _deep_width(Kx)
 
 
 class _Act(torch.autograd.Function):

@@ -1,21 +1,27 @@
 #!/bin/bash
-# round 5: the wide path on the bf16x3 GEMM kernels (csrc/wide_gemm.h) -- operator and model parity, then the step times with
-# the fused activations on and off, then the rocprofv3 kernel table of the 100 000-node run.  gpurun_out/wide_r5/
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/wide_r5; mkdir -p $O
+# round 5: the wide path's price on one box -- step times at cfg4-shaped frames (fused activations on and off), the per-operator
+# table, and the rocprofv3 kernel table of the 100 000-node run.  Result: gpurun_out/wide_r5/report.txt (-> profiles/r05_wide_path.txt)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/wide_r5; mkdir -p $O; rm -rf $O/stats
 cd $R
-timeout 900 python -m pytest tests/test_gpu_wide.py -x -q 2>&1 | tail -15 > $O/tests.txt
-cat $O/tests.txt
-if ! grep -q "passed" $O/tests.txt || grep -q "failed" $O/tests.txt; then echo "TESTS FAILED"; fi
 {
-  timeout 600 python $R/tools/gpu_wide_timing.py 20000 16 128 2>&1 | tail -1
-  timeout 600 python $R/tools/gpu_wide_timing.py 100000 16 128 2>&1 | tail -1
-  FASTEGNN_WIDE_FUSE=0 timeout 600 python $R/tools/gpu_wide_timing.py 100000 16 128 2>&1 | tail -1 | sed 's/^/FUSE=0: /'
-  timeout 600 python $R/tools/gpu_wide_timing.py 100000 16 96 2>&1 | tail -1
-  timeout 600 python $R/tools/gpu_wide_timing.py 20000 16 256 2>&1 | tail -1
+  echo "wide path (hidden_nf > 64; csrc/wide.hip + csrc/wide_gemm.h + fastegnn_amd/wide.py), one MI355X, fwd + loss + bwd, eager launches"
+  timeout 600 python $R/tools/gpu_wide_timing.py 20000 16 128 2>/dev/null | tail -1
+  timeout 600 python $R/tools/gpu_wide_timing.py 100000 16 128 2>/dev/null | tail -1
+  FASTEGNN_WIDE_FUSE=0 timeout 600 python $R/tools/gpu_wide_timing.py 100000 16 128 2>/dev/null | tail -1 | sed 's/^/FASTEGNN_WIDE_FUSE=0 (every activation, head and segment sum its own launch): /'
+  timeout 600 python $R/tools/gpu_wide_timing.py 100000 16 96 2>/dev/null | tail -1
+  timeout 600 python $R/tools/gpu_wide_timing.py 20000 16 256 2>/dev/null | tail -1
+  echo ""
+  echo "per-operator timing at cfg4's edge count (tools/gpu_wide_ops.py: 1 919 172 rows x 128 columns; TB/s = algorithmic bytes / time)"
+  timeout 300 python $R/tools/gpu_wide_ops.py 2>/dev/null | tail -22
 } > $O/report.txt
-cat $O/report.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/tools/gpu_wide_timing.py ${1:-100000} 16 128 > $O/log.txt 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/tools/gpu_wide_timing.py 100000 16 128 > $O/log.txt 2>&1
 cd $R
-f=$(ls $O/stats/*/*kernel_stats.csv | head -1)
-head -24 $f | cut -d, -f1-5 | cut -c1-160 | tee $O/kernel_stats_head.txt
+f=$(ls -t $O/stats/*/*kernel_stats.csv | head -1)
+{
+  echo ""
+  echo "rocprofv3 --kernel-trace --stats of: python3 tools/gpu_wide_timing.py 100000 16 128   (4 steps; Name, Calls, TotalDurationNs, AverageNs, Percentage)"
+  head -26 $f | cut -d, -f1-5 | sed 's/([^"]*"/"/' | cut -c1-150
+} >> $O/report.txt
+cp $f $O/kernel_stats.csv
+cat $O/report.txt | cut -c1-200
