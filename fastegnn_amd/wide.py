@@ -1,16 +1,24 @@
 """The WIDE path: ``FastEGNN`` with ``64 < hidden_nf <= 256`` (the reference takes any ``--dim_hidden``:
-``main_nbody.py:27``, ``models/FastEGNN.py:28-99``).
+``main_nbody.py:27``, ``models/FastEGNN.py:28-99``), the shapes beyond the fused kernels' argument ceilings, ``EGNN(flat=True)``.
 
-The fused stage kernels are built on 64-wide register tiles; a wider model runs UNFUSED: the op sequence of
+The fused stage kernels are built on 64-wide register tiles; a wider model runs the op sequence of
 ``models/FastEGNN.py:102-223`` (edge_model, edge_mode_virtual, coord_model_vel, coord_model_virtual, node_model,
-node_model_virtual), every hidden-sized tensor op of it one launch of ``csrc/wide.hip`` behind the C ABI
-(``fastegnn_wide_*`` in ``include/fastegnn_hip.h``): nn.Linear as ``fastegnn_wide_linear`` over the weight's column blocks (a
-Linear over a ``torch.cat`` is the sum of Linears over the pieces, so nothing is concatenated), the activations, the row
-gathers ``node_feat[row]`` / ``virtual_node_feat[data_batch]``, the segment sums, the gates.  The backward is composed by
-autograd from the matching ``_dx`` / ``_dw`` / ``_backward`` entry points.  What stays in torch is the elementwise 3-vector geometry
-(``[E,3]``, ``[N,3,C]``, ``[B,C,C]`` tensors) and views.  Correctness first (fp32 FMA GEMMs, fp32 atomics): this path is
-several times slower per FLOP than the fused one -- DESIGN.md section 9 -- and exists so that the constructor takes the
-reference's whole ``hidden_nf`` range.  No CPU fallback: the library is loaded on first use and its absence raises."""
+node_model_virtual) on the operators of ``csrc/wide.hip`` + ``csrc/wide_gemm.h`` behind the C ABI (``fastegnn_wide_*`` in
+``include/fastegnn_hip.h``), wrapped here as ``torch.autograd.Function``s:
+
+* ``_Linear``: nn.Linear over the weight's column blocks (a Linear over a ``torch.cat`` is the sum of Linears over the pieces, so
+  nothing is concatenated), optionally of ``act(X)`` with X the pre-activation -- the activation runs in the GEMM's prologue and its
+  backward in the input gradient's epilogue, so ``act(X)`` is never stored;
+* ``_Gather2``: the first Linear of an edge MLP, ``P[row] + Q[col] + feat . W^T``, in one write-only pass;
+* ``_ActScatter``: an activation and the segment sum of its output in one pass (and one pass back);
+* ``_Head`` / ``_Head2``: a scalar head ``act(X W1^T + b1) . w2`` as one node -- output from the first GEMM's accumulators, the hidden
+  gradient formed inside the backward GEMM kernels;
+* ``_GatherAdd`` / ``_ScatterAdd`` / ``_RowScale`` / ``_Act``: row gathers, segment sums (runs of equal targets), gates, plain activations.
+
+The edges are put in row order once per forward and the column sums go through a sorting permutation, so every edge-sized sum is a
+sum over runs.  What stays in torch is the elementwise 3-vector geometry (``[E,3]``, ``[N,3,C]``, ``[B,C,C]`` tensors) and views.
+``FASTEGNN_WIDE_FUSE=0`` runs every activation, head and segment sum as its own launch (A/B lever).  DESIGN.md section 9 prices the
+path.  No CPU fallback: the library is loaded on first use and its absence raises."""
 from __future__ import annotations
 
 import os
@@ -25,7 +33,7 @@ MAX_WIDE = 256
 
 class HipOps:
     """The operators on libfastegnn_hip.so (the product path).  tests/test_wide_cpu.py drives the same orchestration through a
-    torch restatement of these nine calls on CPU (test infrastructure, as tests/cpu_stage_backend.py does for the sharded path)."""
+    torch restatement of these calls on CPU (test infrastructure, as tests/cpu_stage_backend.py does for the sharded path)."""
 
     @staticmethod
     def call(name, *args):

@@ -1,5 +1,5 @@
 """CPU: the orchestration of the wide path (fastegnn_amd/wide.py: hidden_nf > 64, EGNN flat=True) through a torch restatement of
-the nine fastegnn_wide_* operators -- TEST INFRASTRUCTURE standing in for csrc/wide.hip, as tests/cpu_stage_backend.py does for
+the fastegnn_wide_* operators -- TEST INFRASTRUCTURE standing in for csrc/wide.hip, as tests/cpu_stage_backend.py does for
 the sharded path -- against the goldens captured from the reference classes.  What this pins without a GPU: the op sequence, the
 column-block bookkeeping of every Linear over a torch.cat, the (n, c) row layouts, the autograd wiring.  The operators themselves
 are checked against the same torch arithmetic on the GPU (tests/test_gpu_wide.py)."""
