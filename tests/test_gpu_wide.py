@@ -204,7 +204,10 @@ def test_wide_rowwise_operators_vs_torch():
 @pytest.mark.parametrize("hidden,flags", [(128, dict(gravity=[0, -1, 0])),
                                           (128, dict(attention=True, tanh=True, gravity=[0.3, -1, 0.2])),
                                           (96, dict(residual=False)),
-                                          (160, dict(attention=True, act="gelu"))])
+                                          (160, dict(attention=True, act="gelu")),
+                                          (256, dict(gravity=[0, -1, 0])),          # two column blocks, two contraction panels
+                                          (192, dict(act="tanh", residual=False)),  # the four-buffer GEMM on padded panels, generic head forms
+                                          (224, dict())])
 def test_wide_model_vs_oracle(hidden, flags):
     """FastEGNN(hidden_nf > 64): outputs <= 1e-5 of the fp32 oracle, displacement and every parameter gradient within the
     repo's rule (2 x the fp32 reference's own error against fp64 + 1e-6, tests/helpers.py)."""
