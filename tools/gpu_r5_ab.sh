@@ -7,7 +7,7 @@ i=0
 for extra in "$@"; do
   envv=""
   case "$extra" in ENV:*) envv="${extra#ENV:}"; extra="";; esac
-  ( cd fastegnn_amd/csrc && rm -f *.o && make -j16 ../libfastegnn_hip.so EXTRA="$extra" > /dev/null 2>&1 ) || { echo "build failed: $extra"; continue; }
+  ( cd fastegnn_amd/csrc && ls *.o | grep -v "^wide" | xargs rm -f && make -j16 ../libfastegnn_hip.so EXTRA="$extra" > /dev/null 2>&1 ) || { echo "build failed: $extra"; continue; }
   env $envv timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline ${BENCH_ARGS} 2>$O/v$i.err | grep '{"metric"' > $O/v$i.json || tail -3 $O/v$i.err
   python - "$extra$envv" $O/v$i.json <<'PY'
 import json, sys
@@ -19,4 +19,4 @@ PY
   i=$((i+1))
 done
 # leave the tree's default build behind
-( cd fastegnn_amd/csrc && rm -f *.o && make -j16 ../libfastegnn_hip.so > /dev/null 2>&1 )
+( cd fastegnn_amd/csrc && ls *.o | grep -v "^wide" | xargs rm -f && make -j16 ../libfastegnn_hip.so > /dev/null 2>&1 )
