@@ -777,7 +777,8 @@ __device__ __forceinline__ void part2_pack(float a0, float a1, unsigned &ph, uns
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(a0));
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(a1));
   unsigned l;
-  asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(l) : "v"(r0), "v"(r1), "s"(F2_UP));
+  // (ends with the VALU -> MFMA-operand wait states: the weight images go to memory, but edge_fwd32.hip feeds these to MFMAs; see vsplit2)
+  asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0\n\ts_nop 1" : "=&v"(l) : "v"(r0), "v"(r1), "s"(F2_UP));
   ph = h;
   pl = l;
 }
@@ -787,18 +788,42 @@ __device__ __forceinline__ unsigned split2_word(float w0, float w1, int part) {
   part2_pack(w0, w1, h, l);
   return part == 0 ? h : l;
 }
+// Inline assembly is opaque to the compiler's hazard recognizer: a register written inside an asm string and read by an MFMA as its
+// A / B operand needs the two VALU -> MFMA-operand wait states INSIDE the string (cdna_hip_programming.md section 5.7 item 2).  The
+// scaled low parts of a k-step (and the scaled high parts of vsplit2_scaled / wg32_split) are therefore written by ONE asm block per
+// four words that ends with `s_nop 1`.  Rounds 4-5 had one block per word and no pad: the default machine scheduler happened to keep
+// two instructions between the last block and the first MFMA; -amdgpu-sched-strategy=max-memory-clause did not (stale low parts:
+// errors of 2^-11 relative, the EGNN golden and smoke() at 1e-4 -- found in round 5, tools/gpu_r5_sched_bisect.sh).
+// l[w] = {fp16(r[2w] * sc), fp16(r[2w+1] * sc)} for w = 0..3
+__device__ __forceinline__ void mix_pack4(const float (&r)[8], float sc, unsigned (&l)[4]) {
+  asm("v_fma_mixlo_f16 %0, %4, %12, 0\n\tv_fma_mixhi_f16 %0, %5, %12, 0\n\t"
+      "v_fma_mixlo_f16 %1, %6, %12, 0\n\tv_fma_mixhi_f16 %1, %7, %12, 0\n\t"
+      "v_fma_mixlo_f16 %2, %8, %12, 0\n\tv_fma_mixhi_f16 %2, %9, %12, 0\n\t"
+      "v_fma_mixlo_f16 %3, %10, %12, 0\n\tv_fma_mixhi_f16 %3, %11, %12, 0\n\t"
+      "s_nop 1"
+      : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
+      : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(sc));
+}
 __device__ __forceinline__ Split2 vsplit2(const Vec &v) {
   Split2 S;
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < 2; ++s) {
+    float r[8];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const int e = 2 * w;
-      unsigned ph, pl;
-      part2_pack(v.t[2 * s + (e >> 2)][e & 3], v.t[2 * s + ((e + 1) >> 2)][(e + 1) & 3], ph, pl);
-      S.p[0][s][w] = ph;
-      S.p[1][s][w] = pl;
+      const float a0 = v.t[2 * s + (e >> 2)][e & 3], a1 = v.t[2 * s + ((e + 1) >> 2)][(e + 1) & 3];
+      const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, f16x2));   // (compiler-visible: padded by hipcc)
+      // r = a - float(h): src0 is read as the low / high half of the packed pair (op_sel_hi: f16 source, op_sel: which half)
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[e]) : "v"(h), "v"(a0));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[e + 1]) : "v"(h), "v"(a1));
+      S.p[0][s][w] = h;
     }
+    unsigned l[4];
+    mix_pack4(r, F2_UP, l);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) S.p[1][s][w] = l[w];
+  }
   return S;
 }
 // acc += W x on an f16x2 image (img3 layout, parts h | l).  Output tile by output tile: the two cross products of both
@@ -924,20 +949,24 @@ __device__ __forceinline__ Split2s vsplit2_scaled(const Vec &v) {
   Split2s S;
   S.inv = __builtin_bit_cast(float, (unsigned)(254 - se) << 23);
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < 2; ++s) {
+    float a[8], r[8];
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = v.t[2 * s + (e >> 2)][e & 3];
+    mix_pack4(a, sc, h);   // (h and l are MFMA operands written by inline assembly: blocks that end with the wait states, see vsplit2)
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const int e = 2 * w;
-      const float a0 = v.t[2 * s + (e >> 2)][e & 3], a1 = v.t[2 * s + ((e + 1) >> 2)][(e + 1) & 3];
-      unsigned h, l;
-      float r0, r1;
-      asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(h) : "v"(a0), "v"(a1), "v"(sc));
-      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(sc), "v"(h));
-      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(sc), "v"(h));
-      asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(l) : "v"(r0), "v"(r1), "s"(F2_UP));
-      S.s.p[0][s][w] = h;
-      S.s.p[1][s][w] = l;
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r[2 * w]) : "v"(a[2 * w]), "v"(sc), "v"(h[w]));
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[2 * w + 1]) : "v"(a[2 * w + 1]), "v"(sc), "v"(h[w]));
     }
+    mix_pack4(r, F2_UP, l);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      S.s.p[0][s][w] = h[w];
+      S.s.p[1][s][w] = l[w];
+    }
+  }
   return S;
 }
 // f16x2 products on a ROW-MAJOR image whose parts 0 | 1 hold the fp16 h | l of the weight (pack.hip, slots RM_F16 + k): plain and
@@ -1066,18 +1095,19 @@ struct WgScale {
 __device__ __forceinline__ WgOp32 wg32_split(const float (&x)[2][8], float sc) {
   WgOp32 O;
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < 2; ++b) {
+    unsigned h[4];
+    mix_pack4(x[b], sc, h);   // (an MFMA operand written by inline assembly: the block ends with the wait states, see vsplit2)
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float a0 = x[b][2 * w], a1 = x[b][2 * w + 1];
-      unsigned h;
       float r0, r1;
-      asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(h) : "v"(a0), "v"(a1), "v"(sc));
-      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(sc), "v"(h));
-      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(sc), "v"(h));
-      O.h[b][w] = h;
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(sc), "v"(h[w]));
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(sc), "v"(h[w]));
+      O.h[b][w] = h[w];
       O.l[b][w] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
     }
+  }
   return O;
 }
 __device__ __forceinline__ void wg32_scale_acc(WgAcc32 &a, float f) {
