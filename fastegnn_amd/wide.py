@@ -540,6 +540,8 @@ def egnn_forward(model, x, h, edge_index, edge_fea, v=None):
     h = _lin(h.float(), model.embedding.weight, 0, model.in_node_nf, model.embedding.bias)
 
     def mlp(net, X, base_first=None):   # BaseMLP without last_act: Linear, act, Linear
+        if base_first is None and net.mlp[2].weight.size(0) == 1 and _head_fits(X, net.mlp[0].weight):   # coord_net / node_v_net: scalar heads
+            return _Head.apply(X, net.mlp[0].weight, net.mlp[0].bias, net.mlp[2].weight, net.mlp[2].bias, A)
         return _lin(_lin(X, net.mlp[0].weight, 0, X.size(1), net.mlp[0].bias) if base_first is None else base_first,
                     net.mlp[2].weight, 0, net.mlp[2].weight.size(1), net.mlp[2].bias, None, A)
 
