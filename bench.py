@@ -694,9 +694,12 @@ def main():
                     ent["mfma_busy"] = busy
             if name == "edge_col_reduce_kernel":
                 ent["operand_gbs"] = round(ob[name] / launch_s / 1e9, 1)
-            if name == "wgrad_tn_kernel":   # the layer-wide batch (and, before round 5, the per-channel node_mlp.0 job)
-                tot = ob["wgrad_tn_kernel[layer batch]"] + ob["wgrad_tn_kernel[v job]"]
-                ent["operand_gbs"] = round(tot / (2 * launch_s) / 1e9, 1)
+            if name == "wgrad_tn_kernel":
+                if phased:   # ONE launch per layer: the layer-wide batch (dW3c goes through the phased kernel's own slabs + wgrad_reduce)
+                    ent["operand_gbs"] = round(ob["wgrad_tn_kernel[layer batch]"] / launch_s / 1e9, 1)
+                else:        # tile-major form: two launches per layer, the second is the per-channel node_mlp.0 job over v
+                    tot = ob["wgrad_tn_kernel[layer batch]"] + ob["wgrad_tn_kernel[v job]"]
+                    ent["operand_gbs"] = round(tot / (2 * launch_s) / 1e9, 1)
             kernels[name] = ent
         dom = max((n for n in kernels if n in km), key=lambda n: kernels[n]["ms_per_step"])
         fl, by = km[dom]
@@ -713,8 +716,11 @@ def main():
             # MFMA peak of the arithmetic type (fp32: 157.3 TFLOP/s).  Recomputation and the 16-bit split products therefore show up
             # as lost efficiency, never as achieved work.
             ach = fl_alg / launch_s / 1e12
+            # `frac` is a FP32-EQUIVALENT figure (algorithmic fp32 FLOPs over the fp32-input MFMA peak), NOT the utilisation of the pipe the
+            # kernel runs on: that is `matrix_pipe_util` right beside it
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": peak_mfma,
-                    "unit": "TFLOP/s", "frac": round(ach / peak_mfma, 4), "traffic": traffic,
+                    "unit": "TFLOP/s", "frac": round(ach / peak_mfma, 4), "frac_is": "fp32-equivalent algorithmic FLOPs / fp32-input MFMA peak; "
+                    "the 16-bit matrix pipe's own utilisation is matrix_pipe_util", "traffic": traffic,
                     "algorithmic_flops_per_launch": fl_alg, "executed_product_flops_per_launch": fl}
             util, busy = matrix_pipe(sq, dom, launch_s)
             roof["matrix_pipe_util"] = util      # 16-bit MFMA FLOPs the counters saw / duration / 2.5 PFLOP/s dense

@@ -14,8 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SAFE_WAITS = os.environ.get("FASTEGNN_SAFE_WAITS", "0") not in ("", "0")
 # Operand range.  The default build multiplies on 2-part fp16 splits (f16x2): hidden activations and [64,64] weights must stay below
 # 65 504 in magnitude, which the reference's plain fp32 (models/FastEGNN.py:102-119) does not require.  The modules therefore guard
-# every eager forward (fastegnn_check_finite on the outputs) and re-run a call that left the range on the wide-range build
-# (libfastegnn_hip_x3.so / _act_x3.so: 3-part bf16 splits, fp32's exponent range, ~8 % slower), staying there.
+# every forward (fastegnn_check_finite on the outputs, into a host-mapped word that is polled without synchronisation) and move to the
+# wide-range build (libfastegnn_hip_x3.so / _act_x3.so: 3-part bf16 splits, fp32's exponent range, ~8 % slower) once a pass has left
+# the range, staying there (fastegnn_amd.model.RangeGuard; FASTEGNN_RANGE_CHECK=sync re-runs the overflowing call itself).
 #   FASTEGNN_WIDE_RANGE unset : automatic (above)        =1 : wide-range build from the first call        =0 : f16x2 build, overflow raises
 _wr = os.environ.get("FASTEGNN_WIDE_RANGE", "")
 WIDE_RANGE = None if _wr == "" else _wr != "0"
@@ -34,7 +35,7 @@ def lib_path(act: bool = False, wide: bool = False) -> str:
 
 LIB_PATH = lib_path(False, bool(WIDE_RANGE))   # the library the stage-independent helpers (CSR, graphs, training step, comm) use
 
-ABI_VERSION = 106   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
+ABI_VERSION = 107   # FASTEGNN_ABI_VERSION of include/fastegnn_hip.h this mirror was written against
 H = 64
 QX_LD = 68
 FEATW = 8
@@ -90,7 +91,8 @@ _LAYER_PTRS_A = ["batch", "gptr", "ea_sorted", "vel", "node_attr", "params", "gr
                  "P", "QX", "QX_src", "A", "svel", "sgrav", "xsum", "Bc", "aggm", "aggx", "npre", "poolV", "poolX",
                  "g_h_out", "g_x_out", "g_Z_out", "g_HvT_out", "g_h", "g_x", "g_Z", "g_HvT", "g_vel", "g_ea_sorted", "g_node_attr",
                  "g_poolV", "g_poolX", "g_Bc", "g_Zp", "g_xbar", "g_A", "g_P", "g_aggm", "g_aggx",
-                 "g_svel", "g_sgrav", "g_QXe", "g_QX_src", "g_QX", "g_xrow", "wg_edge", "wg_virt", "wg_node", "wg_slab", "wgrad_batch"]
+                 "g_svel", "g_sgrav", "g_QXe", "g_QX_src", "g_QX", "g_xrow", "wg_edge", "wg_virt", "wg_node", "wg_slab", "wgrad_batch",
+                 "edge_mp", "edge_up", "virt_vp"]
 
 
 class LayerT(C.Structure):
@@ -192,6 +194,9 @@ def lib(act: bool = False, wide=None):
     L.fastegnn_comm_reduce_scatter.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp]
     L.fastegnn_comm_all_to_all_v.argtypes = [_vp, _vp, C.POINTER(C.c_int64), _vp, C.POINTER(C.c_int64), _i32, _vp]
     L.fastegnn_check_finite.argtypes = [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp]
+    L.fastegnn_host_words_alloc.argtypes = [_i32, C.POINTER(C.POINTER(_i32))]
+    L.fastegnn_host_words_free.argtypes = [C.POINTER(_i32)]
+    L.fastegnn_zero_if_flagged.argtypes = [_vp, C.c_int64, _vp, _vp]
     L.fastegnn_gather_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_scatter_add_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_wg_slab_floats.restype = C.c_size_t
@@ -242,7 +247,7 @@ STAGE_FUNCS = [
 # every symbol include/fastegnn_hip.h declares (checked by tests/test_abi_cpu.py)
 EXPORTED = STAGE_FUNCS + [
     "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_wg_edge_floats", "fastegnn_wg_virt_floats", "fastegnn_wg_virt_floats_for", "fastegnn_backward_scratch_floats_for", "fastegnn_wg_node_floats", "fastegnn_backward_scratch_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes", "fastegnn_chunk_rows", "fastegnn_chunk_edges",
-    "fastegnn_build_csr", "fastegnn_pad_params", "fastegnn_generic_activations", "fastegnn_f16_operands", "fastegnn_check_finite", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
+    "fastegnn_build_csr", "fastegnn_pad_params", "fastegnn_generic_activations", "fastegnn_f16_operands", "fastegnn_check_finite", "fastegnn_host_words_alloc", "fastegnn_host_words_free", "fastegnn_zero_if_flagged", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_rm", "fastegnn_selftest_jreduce", "fastegnn_selftest_lane_sums", "fastegnn_selftest_wgrad", "fastegnn_selftest_wgrad_plan", "fastegnn_selftest_wgrad_guard", "fastegnn_selftest_stream", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
     "fastegnn_augment_edge_attr", "fastegnn_loss_mse_mmd", "fastegnn_adam_step",

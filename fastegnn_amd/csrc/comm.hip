@@ -4,6 +4,7 @@
 // reused), so libfastegnn_hip.so itself has no link-time dependency on it and loads on a box without RCCL.
 // The reference has no distributed code: nothing to cite but the contract of section 8e.
 #include <dlfcn.h>
+#include <string.h>
 #include <mutex>
 #include <vector>
 #include "kernels.h"
@@ -176,13 +177,28 @@ __global__ void scatter_add_rows_kernel(float *table, const int64_t *ids, long n
   if (i >= n * w) return;
   atomicAdd(&table[ids[i / w] * w + i % w], rows[i]);
 }
-// *flag |= 1 when a value of a / b is Inf or NaN (the exponent field is all ones); grid-stride, one atomic per offending wave
-__global__ __launch_bounds__(256) void check_finite_kernel(const unsigned *a, long na, const unsigned *b, long nb, int *flag) {
+// *flag = 1 when a value of a / b is Inf or NaN (the exponent field is all ones); grid-stride, one store per offending wave.
+// A plain store of a constant (every writer writes the same value): `flag` may be a host-mapped word, and a store crosses PCIe on
+// every platform where a device atomic on host memory may not
+__global__ __launch_bounds__(256) void check_finite_kernel(const unsigned *a, long na, const unsigned *b, long nb, volatile int *flag) {
   bool bad = false;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) bad |= (a[i] & 0x7f800000u) == 0x7f800000u;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) bad |= (b[i] & 0x7f800000u) == 0x7f800000u;
-  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) {
+    *flag = 1;
+    __threadfence_system();
+  }
+}
+// buf = 0 when the word is set (one read of the word per workgroup)
+__global__ __launch_bounds__(256) void zero_if_flagged_kernel(f32x4 *buf, long n4, float *tail, int ntail, const volatile int *flag) {
+  __shared__ int set;
+  if (threadIdx.x == 0) set = *flag;
+  __syncthreads();
+  if (!set) return;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) buf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
 }
 }  // namespace fe
 
@@ -197,6 +213,37 @@ int fastegnn_check_finite(const float *a, int64_t na, const float *b, int64_t nb
   hipLaunchKernelGGL(fe::check_finite_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned *>(a),
                      (long)na, reinterpret_cast<const unsigned *>(b), (long)nb, flag);
   return fe::check_launch("check_finite_kernel");
+}
+int fastegnn_host_words_alloc(int32_t n, int32_t **words) {
+  FE_REQUIRE(words && n > 0, "fastegnn_host_words_alloc: bad arguments");
+  void *p = nullptr;
+  if (hipHostMalloc(&p, (size_t)n * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    fe::set_error("fastegnn_host_words_alloc: hipHostMalloc failed");
+    return FASTEGNN_E_LAUNCH;
+  }
+  memset(p, 0, (size_t)n * sizeof(int32_t));
+  *words = static_cast<int32_t *>(p);
+  return FASTEGNN_OK;
+}
+int fastegnn_host_words_free(int32_t *words) {
+  if (words && hipHostFree(words) != hipSuccess) {
+    (void)hipGetLastError();
+    fe::set_error("fastegnn_host_words_free: hipHostFree failed");
+    return FASTEGNN_E_LAUNCH;
+  }
+  return FASTEGNN_OK;
+}
+int fastegnn_zero_if_flagged(float *buf, int64_t n, const int32_t *flag, void *stream) {
+  FE_REQUIRE(flag && (buf || n == 0) && n >= 0, "fastegnn_zero_if_flagged: null pointer");
+  FE_REQUIRE((reinterpret_cast<uintptr_t>(buf) & 15) == 0, "fastegnn_zero_if_flagged: buf must be 16-byte aligned");
+  if (n == 0) return FASTEGNN_OK;
+  const long n4 = n / 4;
+  int grid = fe::cdiv(n4 > 0 ? n4 : 1, 256 * 4);
+  if (grid > 512) grid = 512;
+  hipLaunchKernelGGL(fe::zero_if_flagged_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<fe::f32x4 *>(buf), n4,
+                     buf + 4 * n4, (int)(n - 4 * n4), flag);
+  return fe::check_launch("zero_if_flagged_kernel");
 }
 int fastegnn_gather_rows(const float *table, const int64_t *ids, int64_t n, int32_t width, float *out, void *stream) {
   FE_REQUIRE(width > 0 && width % 4 == 0, "fastegnn_gather_rows: width must be a multiple of 4");

@@ -794,13 +794,20 @@ __device__ __forceinline__ unsigned split2_word(float w0, float w1, int part) {
 // four words that ends with `s_nop 1`.  Rounds 4-5 had one block per word and no pad: the default machine scheduler happened to keep
 // two instructions between the last block and the first MFMA; -amdgpu-sched-strategy=max-memory-clause did not (stale low parts:
 // errors of 2^-11 relative, the EGNN golden and smoke() at 1e-4 -- found in round 5, tools/gpu_r5_sched_bisect.sh).
+// Round 6: tools/isa_hazards.py checks the DISASSEMBLY of every built library for this (and the other hand-offs asm can break);
+// -DFE_HAZARD_SELFTEST drops the pad so that tests/test_isa_hazards_cpu.py can see the checker fail on a tree without it.
+#ifdef FE_HAZARD_SELFTEST
+#define FE_MIX_PAD ""
+#else
+#define FE_MIX_PAD "s_nop 1"
+#endif
 // l[w] = {fp16(r[2w] * sc), fp16(r[2w+1] * sc)} for w = 0..3
 __device__ __forceinline__ void mix_pack4(const float (&r)[8], float sc, unsigned (&l)[4]) {
   asm("v_fma_mixlo_f16 %0, %4, %12, 0\n\tv_fma_mixhi_f16 %0, %5, %12, 0\n\t"
       "v_fma_mixlo_f16 %1, %6, %12, 0\n\tv_fma_mixhi_f16 %1, %7, %12, 0\n\t"
       "v_fma_mixlo_f16 %2, %8, %12, 0\n\tv_fma_mixhi_f16 %2, %9, %12, 0\n\t"
       "v_fma_mixlo_f16 %3, %10, %12, 0\n\tv_fma_mixhi_f16 %3, %11, %12, 0\n\t"
-      "s_nop 1"
+      FE_MIX_PAD
       : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
       : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(sc));
 }
@@ -828,10 +835,55 @@ __device__ __forceinline__ Split2 vsplit2(const Vec &v) {
 }
 // acc += W x on an f16x2 image (img3 layout, parts h | l).  Output tile by output tile: the two cross products of both
 // k-steps into a 4-register accumulator, one fma per element folds it (scaled by 2^-11) into acc, then the (h, h) products.
+// PIPE: the software-pipelined order of gemm64_f2_rm_ below -- next tile's fragments requested ahead, independent low / high chains,
+// fold one tile late; see there.  Measured on one box (profiles/r06_lever_f2_pipe.txt): edge_fwd 0.802 -> 0.793 ms per step with it,
+// virt_fwd 1.246 -> 1.268 without it: the edge kernel takes it (-DFE_F2_PIPE_FWD=0 switches it off), the virtual kernel does not.
+#ifndef FE_F2_PIPE_FWD
+#define FE_F2_PIPE_FWD 1
+#endif
+template <bool PIPE = false>
 __device__ __forceinline__ void gemm64_f2(const unsigned *img3, const Split2 &in, Vec &acc) {
   const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + lane_id();
   const f16x8 xh0 = __builtin_bit_cast(f16x8, in.p[0][0]), xh1 = __builtin_bit_cast(f16x8, in.p[0][1]);
   const f16x8 xl0 = __builtin_bit_cast(f16x8, in.p[1][0]), xl1 = __builtin_bit_cast(f16x8, in.p[1][1]);
+  if constexpr (PIPE && FE_F2_PIPE_FWD != 0) {
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4 fr[2][4];   // [buffer][ah0 | ah1 | al0 | al1]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) fr[0][k] = ip[(k >> 1) * 512 + (k & 1) * 64];
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads (one ds_read_b128 per fragment)
+  f32x4 lo_p = {0.f, 0.f, 0.f, 0.f}, hi_p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int cb = t & 1;
+    if (t + 1 < 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fr[cb ^ 1][k] = ip[(k >> 1) * 512 + ((t + 1) * 2 + (k & 1)) * 64];
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    }
+    const f16x8 ah0 = __builtin_bit_cast(f16x8, fr[cb][0]), ah1 = __builtin_bit_cast(f16x8, fr[cb][1]);
+    const f16x8 al0 = __builtin_bit_cast(f16x8, fr[cb][2]), al1 = __builtin_bit_cast(f16x8, fr[cb][3]);
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f};
+    f32x4 hi = acc.t[t];
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, xh0, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh0, hi, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xl0, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh1, hi, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, xh1, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xl1, lo, 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // 6 MFMAs
+    if (t > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc.t[t - 1][r] = __builtin_fmaf(lo_p[r], F2_DOWN, hi_p[r]);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU
+    }
+    lo_p = lo;
+    hi_p = hi;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc.t[3][r] = __builtin_fmaf(lo_p[r], F2_DOWN, hi_p[r]);
+  __builtin_amdgcn_sched_barrier(0);
+  } else {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const f16x8 ah0 = __builtin_bit_cast(f16x8, ip[(t * 2 + 0) * 64]), ah1 = __builtin_bit_cast(f16x8, ip[(t * 2 + 1) * 64]);
@@ -847,6 +899,7 @@ __device__ __forceinline__ void gemm64_f2(const unsigned *img3, const Split2 &in
     hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh0, hi, 0, 0, 0);
     hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh1, hi, 0, 0, 0);
     acc.t[t] = hi;
+  }
   }
 }
 
@@ -972,10 +1025,65 @@ __device__ __forceinline__ Split2s vsplit2_scaled(const Vec &v) {
 // f16x2 products on a ROW-MAJOR image whose parts 0 | 1 hold the fp16 h | l of the weight (pack.hip, slots RM_F16 + k): plain and
 // transposed reads as for the bf16 parts (16-bit elements either way).  SCALED: the operand is a Split2s, the result is
 // multiplied by the item's 1 / scale before it is added to acc.
+// Round 6: the four output tiles of a product are software-pipelined by hand (FE_F2_PIPE, default on).  The compiler's own schedule
+// reused ONE set of fragment registers for every tile -- read 8 fragments, wait out the LDS round trip, four dependent MFMAs on `lo`,
+// s_nop 7, fold, two dependent MFMAs on `hi`, then the next tile's reads: four exposed LDS latencies and four exposed MFMA -> VALU
+// drains per product, with only two waves per SIMD to cover them (the backward producers ran at 0.55 of the issue slots, each wave at
+// its solo latency-bound speed).  Here the fragments of tile t + 1 are requested BEFORE the MFMAs of tile t (double buffer, +16
+// registers), the low-part chain and the (h, h) chain of a tile are independent accumulators issued interleaved, and the fold of tile t
+// (hi + lo / 2^11) is issued behind the MFMAs of tile t + 1, when its operands have long left the matrix pipe.  The (h, h) chain now
+// starts from acc and the fold adds the low part last: the same sum in another order.  -DFE_F2_PIPE=0 restores the old form.
+#ifndef FE_F2_PIPE
+#define FE_F2_PIPE 1
+#endif
 template <bool TR, bool SCALED>
 __device__ __forceinline__ void gemm64_f2_rm_(const char *img, const Split2 &in, float inv, Vec &acc) {
   const f16x8 xh0 = __builtin_bit_cast(f16x8, in.p[0][0]), xh1 = __builtin_bit_cast(f16x8, in.p[0][1]);
   const f16x8 xl0 = __builtin_bit_cast(f16x8, in.p[1][0]), xl1 = __builtin_bit_cast(f16x8, in.p[1][1]);
+#if FE_F2_PIPE
+  __builtin_amdgcn_sched_barrier(0);
+  bf16x8 fr[2][4];   // [buffer][ah0 | ah1 | al0 | al1]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) fr[0][k] = rm_frag<TR>(img, k >> 1, 0, k & 1);
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // 8 DS reads (two ds_read_b64 per fragment)
+  f32x4 lo_p = {0.f, 0.f, 0.f, 0.f}, hi_p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int cb = t & 1;
+    if (t + 1 < 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fr[cb ^ 1][k] = rm_frag<TR>(img, k >> 1, t + 1, k & 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    }
+    const f16x8 ah0 = __builtin_bit_cast(f16x8, fr[cb][0]), ah1 = __builtin_bit_cast(f16x8, fr[cb][1]);
+    const f16x8 al0 = __builtin_bit_cast(f16x8, fr[cb][2]), al1 = __builtin_bit_cast(f16x8, fr[cb][3]);
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f};
+    f32x4 hi = SCALED ? f32x4{0.f, 0.f, 0.f, 0.f} : acc.t[t];
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, xh0, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh0, hi, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xl0, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh1, hi, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, xh1, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xl1, lo, 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // 6 MFMAs
+    if (t > 0) {   // the fold of the PREVIOUS tile: its accumulators left the matrix pipe while this tile's MFMAs were issued
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (SCALED) acc.t[t - 1][r] = __builtin_fmaf(__builtin_fmaf(lo_p[r], F2_DOWN, hi_p[r]), inv, acc.t[t - 1][r]);
+        else acc.t[t - 1][r] = __builtin_fmaf(lo_p[r], F2_DOWN, hi_p[r]);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x002, SCALED ? 8 : 4, 0);   // VALU
+    }
+    lo_p = lo;
+    hi_p = hi;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if constexpr (SCALED) acc.t[3][r] = __builtin_fmaf(__builtin_fmaf(lo_p[r], F2_DOWN, hi_p[r]), inv, acc.t[3][r]);
+    else acc.t[3][r] = __builtin_fmaf(lo_p[r], F2_DOWN, hi_p[r]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const f16x8 ah0 = __builtin_bit_cast(f16x8, rm_frag<TR>(img, 0, t, 0)), ah1 = __builtin_bit_cast(f16x8, rm_frag<TR>(img, 0, t, 1));
@@ -1002,6 +1110,7 @@ __device__ __forceinline__ void gemm64_f2_rm_(const char *img, const Split2 &in,
       acc.t[t] = hi;
     }
   }
+#endif
 }
 
 // ---- f16x2 for the in-workgroup WEIGHT-GRADIENT consumers (round 5): sticky power-of-two scale, 32x32x16 MFMAs ----------------
@@ -1191,11 +1300,11 @@ __host__ __device__ inline int img32_word(int part, int o, int k) {
   return part * 2048 + ((bo * 4 + s) * 64 + hf * 32 + i) * 4 + (e >> 1);
 }
 // image i of a resident image array (fp32 images for GM_F32, split images otherwise)
-template <int MODE>
+template <int MODE, bool PIPE = false>
 __device__ __forceinline__ void gemm_op(const void *img, int i, const typename OperandOf<MODE>::type &in, Vec &acc) {
   if constexpr (MODE == GM_X3) gemm64_x3(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
   else if constexpr (MODE == GM_BF16) gemm64_b1(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
-  else if constexpr (MODE == GM_F16) gemm64_f2(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
+  else if constexpr (MODE == GM_F16) gemm64_f2<PIPE>(reinterpret_cast<const unsigned *>(img) + i * IMG3, in, acc);
   else gemm64(reinterpret_cast<const float *>(img) + i * IMG, in, acc);
 }
 // a product on an fp32 image (fp32-input MFMA) inside a kernel of form MODE: in bf16 mode the activation is rounded

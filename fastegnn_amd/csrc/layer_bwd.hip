@@ -269,7 +269,8 @@ __device__ __forceinline__ void pc_tile_store(float *tile, int j, int q, const V
 // EA: edge_attr slots whose weight-column sums are accumulated in the row walk, without guards (2 covers edge_attr_nf <= 2 --
 // every BASELINE configuration --, 7 the rest): a per-slot `k < ea_dim` test inside the 16-edge walk compiled into ~130
 // scalar branches per tile and made the walk 23 % of the producers' time (phase stamps).
-template <int MODE, int EA>
+// STORED: the forward kernel kept the two pre-activations of every edge (EdgeArgs::st_mp / st_up): no forward product is recomputed
+template <int MODE, int EA, bool STORED = false>
 __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const EdgeArgs &a = A.f;
@@ -596,6 +597,13 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       for (int k = 0; k < 3; ++k) gax[k] = A.g_aggx[(size_t)cur_i.row * 3 + k];
       Vec gam;   // (EA = 7 variant: 16 more live registers would spill; it keeps this row's load at its use)
       if constexpr (PF_IDX) gam = vload_row(A.g_aggm + (size_t)cur_i.row * H, q);
+      if constexpr (STORED) {
+        EdgeRows G;
+        edge_gather(a, cur_i, q, G);
+        const Vec mp_st = vload_row(a.st_mp + (size_t)e * H, q), up_st = vload_row(a.st_up + (size_t)e * H, q);
+        edge_tile_pre<edge_fold_first<MODE>()>(a, vec, cur_i, G, q, S, pre FE_TA);
+        edge_tile_mlp_stored<MODE>(a, vec, q, S, pre, mp_st, up_st FE_TA);
+      } else
       edge_tile_forward<true, MODE, true>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
       const int dg = rp1 - rp0;
       const float inv = valid ? rcp_f((float)(dg > 1 ? dg : 1)) : 0.f;
@@ -669,7 +677,11 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         xv[ee] = pt[ee * TS + H + (l & 3)];
       }
       const int rowv = S.row;
+#ifdef FE_DIAG_NOATOMIC   // diagnostic (wrong col-side gradients): what do the scatter atomics cost the producers?
+      if (false) {
+#else
       if (A.g_QXs_atomic) {   // default (no FASTEGNN_F_DETERMINISTIC): one coalesced 256-byte atomic row per edge ...
+#endif
         const int colv = S.col;
         char *gb = reinterpret_cast<char *>(A.g_QXs_atomic);   // wave-uniform base + 32-bit lane offsets (tables < 2^30 floats)
         const unsigned lo = 4u * (unsigned)l;
@@ -805,8 +817,10 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
       const dim3 g3(grid), b3(64 * PC_WAVES);
       if (L->ea <= 2) {
         if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_BF16, 2>), g3, b3, lds, st, A);
+        else if (A.f.st_mp) hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_EDGE_BWD, 2, true>), g3, b3, lds, st, A);
         else hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_EDGE_BWD, 2>), g3, b3, lds, st, A);
       } else {
+        A.f.st_mp = A.f.st_up = nullptr;   // (the stored form is built for edge_attr_nf <= 2 only: every BASELINE configuration)
         if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_BF16, 7>), g3, b3, lds, st, A);
         else hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_EDGE_BWD, 7>), g3, b3, lds, st, A);
       }
@@ -824,13 +838,18 @@ extern "C" size_t fastegnn_wg_edge_floats(int32_t E) { (void)E; return (size_t)2
 // graph_post_backward, graph_pre_backward, node_pre_backward above).  The flag-less query is the upper bound over both forms of B4
 // (the tile-major form: v / Gv + the per-group parts of g_A / g_x + consumer scratch); the _for variant sizes by the form that runs.
 extern "C" size_t fastegnn_wg_virt_floats(int32_t N, int32_t C) {
-  const size_t n = C >= 1 ? fe::virt_pc_wg_floats((size_t)(N > 0 ? N : 0), (size_t)C) : 0;
+  // the upper bound over BOTH forms of B4: which one runs depends on N, C, the flags and the FASTEGNN_VIRT_CS* switches, and the phased
+  // form's workspace (256 (5 + C) tiles, independent of N) exceeds the tile-major one on small inputs
+  const size_t pc = C >= 1 ? fe::virt_pc_wg_floats((size_t)(N > 0 ? N : 0), (size_t)C) : 0;
+  const size_t cs = C >= 1 ? fe::virt_cs_wg_floats((size_t)C) : 0;
+  const size_t n = pc > cs ? pc : cs;
   return n > 4 ? n : 4;
 }
 extern "C" size_t fastegnn_wg_virt_floats_for(int32_t N, int32_t C, int32_t flags) {
   // the channel-phased form of B4 (round 5) keeps no [C][N][64] array: consumer scratch + the partial slabs of dW3c only
   if (fe::virt_cs_applies(N, C, flags)) return fe::virt_cs_wg_floats((size_t)C);
-  return fastegnn_wg_virt_floats(N, C);
+  const size_t n = C >= 1 ? fe::virt_pc_wg_floats((size_t)(N > 0 ? N : 0), (size_t)C) : 0;
+  return n > 4 ? n : 4;
 }
 extern "C" size_t fastegnn_wg_node_floats(int32_t N, int32_t B, int32_t C) {
   const size_t m = (size_t)(N > 0 ? N : 0), g = (size_t)(B > 0 ? B : 0) * (size_t)(C > 0 ? C : 0);

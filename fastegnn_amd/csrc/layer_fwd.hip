@@ -298,6 +298,10 @@ __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs 
         Vec pre;
         edge_tile_forward<false, MODE>(a, img, vec, cur_i, q, S, pre FE_TA);
         cur_i = nxt_i;
+        if (a.st_mp && j < nvalid) {   // (wave-uniform pointer test) the store-vs-recompute lever: 512 bytes per edge for the backward
+          vstore_row(a.st_mp + (size_t)(base + j) * H, q, S.mp);
+          vstore_row(a.st_up + (size_t)(base + j) * H, q, S.up);
+        }
         tile_store(mt, j, q, S.m);
         if (q == 0) {
           xt[j * 4 + 0] = S.dn[0] * S.s;
@@ -369,7 +373,9 @@ int edge_forward(const fastegnn_layer_t *L, hipStream_t st) {
   EdgeArgs a = make_edge_args(L);
   FE_REQUIRE((size_t)L->N * QXLD < (1u << 30) && (size_t)g.n_src * QXLD < (1u << 30) && (size_t)g.n_edges * 8 < (1u << 30),
              "edge_forward: tables exceed the 32-bit offset range of the gather path");
-  if (edge_forward32_applies(L)) return edge_forward32(L, st);   // 32-edge tiles (edge_fwd32.hip)
+#if FE_EDGE_FWD32   // the 32-edge lever kernel (edge_fwd32.hip) is only part of a `make lever32` build
+  if (edge_forward32_applies(L)) return edge_forward32(L, st);
+#endif
   // one workgroup per CU once there are >= 256 x 16 row chunks; small graphs spread their chunks (32 edges) over as
   // many waves as there are chunks instead of serialising them in a few workgroups (the N-body mini-batches)
   int grid = cdiv(g.n_chunks, EDGE_FWD_WAVES);
@@ -534,6 +540,7 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       if (active) {
         VirtFwdState<MODE> S;
         virt_tile_forward<MODE>(a, img, vec, Ai, xi, b, c, q, fast ? Bc_l : nullptr, fast ? Z_l : nullptr, S VF_TA);
+        if (a.st_vp && valid) vstore_row(a.st_vp + ((size_t)c * a.N + n) * H, q, S.vp);   // (the store-vs-recompute lever: stages.h)
         transv[0] -= S.vd[0] * S.sx;
         transv[1] -= S.vd[1] * S.sx;
         transv[2] -= S.vd[2] * S.sx;

@@ -968,7 +968,8 @@ __device__ int g_vbs_dog[64];
 #define VBS_SPIN(id, cond, sl) while (cond) __builtin_amdgcn_s_sleep(sl)
 #define VBS_MARK(x)
 #endif
-template <bool ATT>
+// STVP: virt_fwd_kernel kept the pre-activation of the second layer (VirtArgs::st_vp): the V2 product is not recomputed
+template <bool ATT, bool STVP = false>
 __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A) {
   constexpr int SM = GM_F16;
   typedef typename OperandOf<SM>::type SOp;
@@ -1260,10 +1261,22 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
       gemm_rm_g<SM, true>(rmimg + which * RMS, op, acc);
     };
     int pend_tile = -1, pend_c = 0;   // the unit whose rows this wave stored last: not yet handed on
+    VB2_T0()   // (phase stamps of the producers, -DFE_STAMP builds only: tools/gpu_stamp_vbs.py)
+    auto take = [&]() {
+      int u_ = 0;
+      if (l == 0) u_ = atomicAdd(&ctrl[VBSC_UNIT], 1);
+      return __builtin_amdgcn_readfirstlane(u_);
+    };
+    auto unit_of = [&](int u_, int &blk_, int &nb_, int &c_, int &tile_) {
+      const int per_blk = BT * C;
+      blk_ = min(u_ / per_blk, nblk - 1);
+      nb_ = min(BT, nt - blk_ * BT);
+      const int ru = u_ - blk_ * per_blk;
+      c_ = ru / nb_;
+      tile_ = t_lo + blk_ * BT + (ru - c_ * nb_);
+    };
     for (;;) {
-      int u = 0;
-      if (l == 0) u = atomicAdd(&ctrl[VBSC_UNIT], 1);
-      u = __builtin_amdgcn_readfirstlane(u);
+      const int u = take();
       if (u >= total) {
         if (pend_tile >= 0) {   // (units of other waves may still wait for this wave's last rows)
           __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -1273,11 +1286,8 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
         break;
       }
       // unit -> (block, channel, tile): blocks of VBS_BLOCK tiles (the last one shorter), channel-major inside a block
-      const int per_blk = BT * C;
-      const int blk = min(u / per_blk, nblk - 1);
-      const int nb = min(BT, nt - blk * BT);                        // tiles of this block
-      const int ru = u - blk * per_blk;
-      const int c = ru / nb, tile = t_lo + blk * BT + (ru - c * nb);
+      int blk, nb, c, tile;                                         // nb: tiles of this block
+      unit_of(u, blk, nb, c, tile);
       const int ph = blk * C + c;                                   // phase: stage slot / pool rows ph & 1, flags ph % VBS_NPH
       VBS_MARK(u);
       if (pend_tile >= 0 && (vb_ld(&ctrl[VBSC_READY + ph % VBS_NPH]) != ph + 1 || vb_ld(&ctrl[VBSC_TSEQ + (tile - t_lo)]) < c)) {
@@ -1296,6 +1306,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
       // loads (below), so nobody ever waits for a store: this spin practically never turns
       VBS_SPIN(7, vb_ld(&ctrl[VBSC_TSEQ + (tile - t_lo)]) < c, 1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      VB2_T(0)   // unit ticket, waits for the phase's image / the tile's rows
       const int n0 = tile * 16, nend = min(a.N, n0 + 16);
       // (one graph in the batch -- the frames this form is for: no batch lookups at the head of the dependent-load chain)
       const int b0 = a.B == 1 ? 0 : a.batch[n0], b1 = a.B == 1 ? 0 : a.batch[nend - 1];
@@ -1324,6 +1335,10 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
       const float vr = sqrt_f(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
       Vec vp = vload_vec(vec + VV_C2 * H, q);
       Vec d_pre = vload_u(a.A, offN);
+      Vec vp_st;
+#ifndef FE_VBS_STVP_LATE   // (requested with the unit's other rows: 16 more live registers through SiLU 1; -DFE_VBS_STVP_LATE: at its use)
+      if constexpr (STVP) vp_st = vload_row(a.st_vp + ((size_t)c * a.N + nc) * H, q);
+#endif
       vadd(d_pre, vload_u(a.Bc, offB));
       vaxpy(d_pre, vr, vload_vec(vec + VV_WVR * H, q));
       const Vec t = vsilu_keep_d(d_pre FE_ACT(a));        // d_pre <- silu'(pre)
@@ -1335,7 +1350,13 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
         if (l == 0) __hip_atomic_store(&ctrl[VBSC_TSEQ + pend_tile], pend_c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
       }
-      mm(0, make_operand<SM>(t), vp);
+      VB2_T(1)   // head loads (rows of A / Bc, coordinates), pre-activation, SiLU 1 (+ the hand-on of the previous unit's rows)
+#ifdef FE_VBS_STVP_LATE
+      if constexpr (STVP) vp_st = vload_row(a.st_vp + ((size_t)c * a.N + nc) * H, q);
+#endif
+      if constexpr (STVP) vp = vp_st;
+      else mm(0, make_operand<SM>(t), vp);
+      VB2_T(2)   // operand split + V2 product
       const Vec v0 = vsilu_keep_d(vp FE_ACT(a));          // vp <- silu'(vp)
       float att = 1.f;
       Vec v = v0;
@@ -1343,6 +1364,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
         att = sigmoid_f(vdot(v0, vload_vec(vec + VV_ATT * H, q)) + attb0);
         v = vscale(v0, att);
       }
+      VB2_T(3)   // SiLU 2
       float sx, sX;
       Vec g_ux, g_uX;
       {
@@ -1352,6 +1374,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
           mm(1, vs, uxp);
           mm(2, vs, uXp);
         }
+        VB2_T(4)   // operand split of v + the two head products
         {
           Vec ux = vsilu_keep_d(uxp FE_ACT(a));
           const float sr = vdot(ux, vload_vec(vec + VV_WXV2 * H, q));
@@ -1363,6 +1386,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
           vb_accum_items(racc + 0 * H, vscale(ux, g_sr), j, q);
           g_ux = vmul(vscale(vload_vec(vec + VV_WXV2 * H, q), g_sr), uxp);
         }
+        VB2_T(5)   // head x: SiLU, head dot, rank-1 sum (DPP + LDS atomic), g_ux
         {
           Vec uX = vsilu_keep_d(uXp FE_ACT(a));
           const float sr = vdot(uX, vload_vec(vec + VV_WXX2 * H, q));
@@ -1375,6 +1399,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
           g_uX = vmul(vscale(vload_vec(vec + VV_WXX2 * H, q), g_sr), uXp);
         }
       }
+      VB2_T(6)   // head X: the same
       // Gv = g_poolV[b, c] + W3c[c]^T g_np is formed in registers; the g_np row also rides to wave 7 in the ring slot
       const Vec gnp = vb_mask(vload_u(A.g_np, offN), valid);
       {   // (g_ux, v), (g_uX, v), (g_np, v) to waves 3 and 7: one slot of ring A, free once both have drained it
@@ -1395,10 +1420,12 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
         if (l == 0) vb_st(&ctrl[VBSC_FILLED + sl], round + 1);
         asm volatile("" ::: "memory");
       }
+      VB2_T(7)   // g_np row, publish (g_ux, g_uX, v, g_np) to ring A (incl. the wait for a drained slot)
       Vec g_v = vb_mask(vload_u(A.g_poolV, offB), valid);
       gemm64_f2_scaled(w3 + (ph & 1) * VBS_W3_WORDS, vsplit2_scaled(gnp), g_v);
       mmT(1, g_ux, g_v);
       mmT(2, g_uX, g_v);
+      VB2_T(8)   // three scaled gradient splits + W3c^T g_np and the two transposed head products
       float g_vd[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) g_vd[k] = -sx * invC * gxn[k] + sX * gpX[k];
@@ -1433,6 +1460,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
         if (c > 0) ga = vload_u(A.g_A, offN);     // requested here, consumed after the product: the tile's running g_A
         mmT(0, g_vp, g_t);
       }
+      VB2_T(9)   // g_vp, publish (g_vp, t) to ring B, scaled split + V2^T product
       const Vec g_pre = vmul(g_t, d_pre);
       vadd(ga, g_pre);
       if (valid) vstore_u(A.g_A, offN, ga);
@@ -1500,9 +1528,14 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
           asm volatile("" ::: "memory");
         }
       }
+      VB2_T(10)   // g_pre: g_A read-modify-write, w_vr rank-1 sum, g_x, pools, phase counter (+ the next image when this unit closes a phase)
     }
+    VB2_TEND(0)
   }
+  VB2_T0()
   __syncthreads();
+  VB2_T(11)   // wait for the rest of the workgroup
+  VB2_TEND(consumer ? 12 : 0)
   if (threadIdx.x < H) {
     const int o = threadIdx.x;
     float s5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1596,6 +1629,7 @@ static int virt_backward_channels_cs(const fastegnn_layer_t *L, hipStream_t st, 
     ProfScope ps(K_VIRT_BWD, st);
     const dim3 g3(grid), b3(64 * VB_WAVES);
     if (att) hipLaunchKernelGGL((virt_bwd_cs_kernel<true>), g3, b3, lds, st, A);
+    else if (A.f.st_vp) hipLaunchKernelGGL((virt_bwd_cs_kernel<false, true>), g3, b3, lds, st, A);   // (the stored-operand lever: no attention)
     else hipLaunchKernelGGL((virt_bwd_cs_kernel<false>), g3, b3, lds, st, A);
   }
   if ((rc = check_launch("virt_bwd_cs_kernel"))) return rc;

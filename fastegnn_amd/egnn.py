@@ -249,14 +249,13 @@ class EGNN(nn.Module):
         if self.hidden_nf < H:   # 64-wide images of the parameters (fastegnn_pad_params; the reverse mode slices the gradients back)
             plist = list(_PadParams.apply(tuple(self._spec.names), self.hidden_nf, 0, _egnn_pad_layout, *plist))
         guard, spec = self._range, self._spec
-        if guard.pending and not guard.wide and guard.tripped(x.device):
-            guard.switch("EGNN", "a replayed HIP graph of this module")
+        if not guard.wide:
+            guard.poll("EGNN", self._plist)      # no synchronisation: an overflow of an EARLIER pass switches the build here (model.RangeGuard)
         spec.wide = guard.wide
         x_out, h_out = _EGNNFunction.apply(spec, graph, edge_fea, x, h, vv, *plist)
         if not guard.wide:
-            guard.launch(K.lib(act=spec.act_kind != K.ACT_SILU, wide=False), x_out, h_out)
-            if guard.tripped(x.device):
-                guard.switch("EGNN")
+            guard.launch(K.lib(act=spec.act_kind != K.ACT_SILU, wide=False), (x_out, h_out), (x, h))
+            if guard.mode == "sync" and guard.sync_and_poll(x.device, "EGNN", self._plist):
                 spec.wide = True
                 x_out, h_out = _EGNNFunction.apply(spec, graph, edge_fea, x, h, vv, *plist)
         if self.hidden_nf < H:

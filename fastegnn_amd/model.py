@@ -62,59 +62,131 @@ class E_GCL_vel(nn.Module):
 # out-of-range col is an out-of-bounds gather, an unsorted data_batch breaks the graph pointer search; the
 # reference raises an index error in these cases.
 _DEBUG_CHECKS = os.environ.get("FASTEGNN_DEBUG_CHECKS", "0") not in ("", "0")
+# FASTEGNN_EDGE_STORE=1: the store-vs-recompute lever of the edge stage -- the forward keeps the two
+# pre-activations of every edge, the backward reads them instead of recomputing two products.  Measured slower.
+_EDGE_STORE = os.environ.get("FASTEGNN_EDGE_STORE", "0") not in ("", "0")
+_VIRT_STORE = os.environ.get("FASTEGNN_VIRT_STORE", "0") not in ("", "0")
 
 
 class RangeGuard:
-    """Automatic wide-range fallback of one module (FastEGNN / FastRF / EGNN / ShardedFastEGNN).
+    """Automatic wide-range fallback of one module (FastEGNN / FastRF / EGNN / ShardedFastEGNN) -- WITHOUT a host synchronisation.
 
     The default library multiplies on 2-part fp16 splits: a hidden activation or a [64,64] weight beyond 65 504 overflows there
     and the outputs turn non-finite, where the reference's plain fp32 (models/FastEGNN.py:102-119) stays finite.  Every forward on
-    the f16x2 build is therefore followed by ONE capturable launch (fastegnn_check_finite) that ORs a device word when an output is
-    Inf / NaN.  An eager forward reads the word before it returns (one 4-byte copy: the only synchronisation, ~0.3 % of a cfg4
-    step) and, if it is set, re-runs the call on the wide-range build (libfastegnn_hip_x3.so / _act_x3.so), warns once and stays
-    there.  Inside a HIP-graph capture nothing can be read: the launch is captured with the step, the word accumulates over the
-    replays and the next eager forward of the module looks at it first.  FASTEGNN_WIDE_RANGE=1 starts on the wide-range build,
-    =0 pins the f16x2 build and turns the overflow into a FloatingPointError."""
+    the f16x2 build is therefore followed by ONE capturable launch (fastegnn_check_finite) that writes 1 into a pinned,
+    host-MAPPED word when an output is Inf / NaN (and into a second word when an INPUT already was).  Nothing waits for it: the
+    host polls the words with plain loads -- at the start of the next forward, at the start of the backward, in
+    ``fastegnn_amd.train.train_step`` -- and only a set word does anything (round 6; the reference's one synchronisation,
+    ``data_batch[-1].item()`` at models/FastEGNN.py:267, is not needed here either).  A set word switches the module to the
+    wide-range build (libfastegnn_hip_x3.so / _act_x3.so) with one warning; the forward that overflowed has returned non-finite
+    outputs by then, its backward hands ZERO parameter gradients to the optimizer (fastegnn_zero_if_flagged: the device reads the
+    same word, so this does not depend on when the host looks) and the step is lost, like a skipped step of a loss scaler.
+    Non-finite INPUTS or PARAMETERS do not switch the build (the wide-range build cannot repair them): they warn.
+    HIP graphs captured before the switch keep replaying the f16x2 kernels and must be re-captured; the guard launch inside them
+    keeps writing the words, so ``poll()`` sees an overflow of a replay too.
+
+    ``mode``: "deferred" (default, above) or "sync" (``FASTEGNN_RANGE_CHECK=sync`` / ``module.range_check = "sync"``): the eager
+    forward waits for its own guard launch and re-runs the call on the wide-range build before it returns -- what round 5 did,
+    at one stream synchronisation per forward.  FASTEGNN_WIDE_RANGE=1 starts on the wide-range build, =0 pins the f16x2 build and
+    turns the overflow into a FloatingPointError (at the poll that sees it)."""
+
+    OUT, IN = 0, 1
 
     def __init__(self):
         self.forced = K.WIDE_RANGE            # None: automatic
         self.wide = bool(K.WIDE_RANGE)        # the build in use
-        self._flags: Dict[torch.device, torch.Tensor] = {}
-        self.pending = False                  # a guard launch was captured into a HIP graph and has not been read since
+        self.mode = "sync" if os.environ.get("FASTEGNN_RANGE_CHECK", "deferred") == "sync" else "deferred"
+        self._words = None                    # ctypes int32[2], host-mapped (fastegnn_host_words_alloc)
         self.warned = False
+        self.warned_inputs = False
+        self.launched = False                 # a guard launch has been queued since the last poll
 
-    def flag(self, dev) -> torch.Tensor:
-        f = self._flags.get(dev)
-        if f is None:
-            f = torch.zeros(1, dtype=torch.int32, device=dev)
-            self._flags[dev] = f
-        return f
+    def words(self):
+        """the host-mapped words; allocated on first use (a host allocation: legal outside AND inside a stream capture)"""
+        if self._words is None:
+            p = C.POINTER(C.c_int32)()
+            K.check(K.lib().fastegnn_host_words_alloc(2, C.byref(p)), "fastegnn_host_words_alloc")
+            self._words = p
+        return self._words
 
-    def launch(self, lib, a: torch.Tensor, b: Optional[torch.Tensor] = None):
-        """queue the check of up to two fp32 tensors on the current stream"""
-        dev = a.device
-        a = a.detach()
-        b = b.detach() if b is not None else None
-        K.check(lib.fastegnn_check_finite(K.ptr(a), a.numel(), K.ptr(b), b.numel() if b is not None else 0,
-                                          K.ptr(self.flag(dev)), _stream(dev)), "fastegnn_check_finite")
+    def word_ptr(self, i: int = 0) -> C.c_void_p:
+        return C.c_void_p(C.addressof(self.words().contents) + 4 * i)
 
-    def tripped(self, dev, group=None) -> bool:
-        """Eager: read (and clear) the device word -- over all ranks of `group` when given.  Capturing: defer."""
-        if torch.cuda.is_current_stream_capturing():
-            self.pending = True
+    def __del__(self):
+        try:
+            if self._words is not None:
+                K.lib().fastegnn_host_words_free(self._words)
+        except Exception:
+            pass
+
+    def launch(self, lib, outs, ins=()):
+        """queue the check of up to two fp32 output tensors (word OUT) and up to two input tensors (word IN) on the current stream"""
+        def two(ts):
+            ts = [t.detach() for t in ts if t is not None and t.dtype == torch.float32 and t.is_contiguous() and t.numel()]
+            return (ts + [None, None])[:2]
+        dev = outs[0].device
+        a, b = two(outs)
+        K.check(lib.fastegnn_check_finite(K.ptr(a), a.numel() if a is not None else 0, K.ptr(b), b.numel() if b is not None else 0,
+                                          self.word_ptr(self.OUT), _stream(dev)), "fastegnn_check_finite")
+        a, b = two(ins)
+        if a is not None:
+            K.check(lib.fastegnn_check_finite(K.ptr(a), a.numel(), K.ptr(b), b.numel() if b is not None else 0,
+                                              self.word_ptr(self.IN), _stream(dev)), "fastegnn_check_finite")
+        self.launched = True
+
+    def zero_if_flagged(self, lib, buf: torch.Tensor):
+        """device side: buf = 0 if the OUT word is set (the parameter gradients of a backward whose forward ran on the f16x2 build)"""
+        if self._words is None:
+            return
+        K.check(lib.fastegnn_zero_if_flagged(K.ptr(buf), buf.numel(), self.word_ptr(self.OUT), _stream(buf.device)),
+                "fastegnn_zero_if_flagged")
+
+    def peek(self) -> bool:
+        """has a guard launch that already ran seen non-finite outputs?  (plain host loads; no synchronisation)"""
+        return not self.wide and self._words is not None and self._words[self.OUT] != 0
+
+    def poll(self, who: str, params=None, group=None, why: str = "an earlier forward pass") -> bool:
+        """Look at the words (no synchronisation) and act on a set one.  -> True when the module was switched to the wide-range
+        build by this call.  `group`: a torch.distributed group -- the decision is then taken over all its ranks (one small
+        all-reduce of the two words: the sharded caller, whose builds must agree because halo rows carry build-specific units)."""
+        if self.wide or self._words is None:
             return False
-        f = self.flag(dev)
+        w = self._words
+        out_bad, in_bad = int(w[self.OUT]), int(w[self.IN])
         if group is not None:
             import torch.distributed as dist
-            g = f if dist.get_backend(group) == "nccl" else f.cpu()
-            dist.all_reduce(g, op=dist.ReduceOp.MAX, group=group)
-            hit = bool(int(g.item()))
-        else:
-            hit = bool(int(f.item()))
-        self.pending = False
-        if hit:
-            f.zero_()
-        return hit
+            t = torch.tensor([out_bad, in_bad], dtype=torch.int32)
+            if dist.get_backend(group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            out_bad, in_bad = (int(v) for v in t.tolist())
+        if not out_bad:
+            return False
+        self.launched = False
+        import warnings
+
+        def decline():
+            # the words are cleared only when the build stays: after a switch they are dead (no guard launch on the wide-range
+            # build), and the backward of the pass that overflowed still reads OUT on the device (zero_if_flagged)
+            w[self.OUT] = 0
+            w[self.IN] = 0
+            return False
+        if in_bad:
+            if not self.warned_inputs:
+                warnings.warn(f"fastegnn_amd.{who}: {why} received non-finite INPUTS (its outputs are non-finite on any build); "
+                              "the arithmetic build is unchanged", RuntimeWarning, stacklevel=3)
+                self.warned_inputs = True
+            return decline()
+        if params is not None:   # (rare path: one reduction + synchronisation per parameter list)
+            bad = [i for i, p in enumerate(params) if p is not None and not bool(torch.isfinite(p.detach()).all())]
+            if bad:
+                if not self.warned_inputs:
+                    warnings.warn(f"fastegnn_amd.{who}: {len(bad)} parameter tensors hold non-finite values (a diverged or "
+                                  "poisoned optimizer step); the arithmetic build is unchanged", RuntimeWarning, stacklevel=3)
+                    self.warned_inputs = True
+                return decline()
+        self.switch(who, why)
+        return True
 
     def switch(self, who: str, why: str = "a forward pass"):
         if self.forced is False:
@@ -127,11 +199,21 @@ class RangeGuard:
         self.wide = True
         if not self.warned:
             import warnings
-            warnings.warn(f"fastegnn_amd.{who}: {why} left the operand range of the default f16x2 arithmetic (|x| > 65 504); this "
-                          "module now runs on the wide-range build (bf16x3 products, fp32's exponent range, ~8 % slower). "
-                          "FASTEGNN_WIDE_RANGE=1 selects it from the start.", RuntimeWarning, stacklevel=3)
+            warnings.warn(f"fastegnn_amd.{who}: {why} left the operand range of the default f16x2 arithmetic (|x| > 65 504) and "
+                          "returned non-finite outputs; this module now runs on the wide-range build (bf16x3 products, fp32's "
+                          "exponent range, ~8 % slower).  The parameter gradients of that pass were zeroed on the device; HIP "
+                          "graphs captured from this module before now still replay the f16x2 kernels and must be re-captured.  "
+                          "FASTEGNN_WIDE_RANGE=1 selects the wide-range build from the start, FASTEGNN_RANGE_CHECK=sync re-runs "
+                          "an overflowing call before it returns (one stream synchronisation per forward).", RuntimeWarning,
+                          stacklevel=4)
             self.warned = True
 
+    def sync_and_poll(self, dev, who: str, params=None, group=None) -> bool:
+        """the "sync" mode / the sharded caller: wait for this forward's guard launch, then poll"""
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        torch.cuda.current_stream(dev).synchronize()
+        return self.poll(who, params, group, why="a forward pass")
 
 
 # ------------------------------------------------------------------------------------------
@@ -281,6 +363,7 @@ class _Spec:
         flags |= self.act_kind << K.F_ACT_SHIFT
         self.flags = flags | model._extra_flags
         self.wide = False      # the build the NEXT call runs on (set by the module from its RangeGuard before every call)
+        self.guard = None      # the module's RangeGuard while calls run on the f16x2 build (the backward polls it and zeroes by it)
         self.gravity = [float(v) for v in model.gravity] if model.gravity is not None else [0.0, 0.0, 0.0]
         # parameter order handed to the autograd function
         self.names = ["virtual_node_feat", "embedding_in.weight", "embedding_in.bias"]
@@ -435,6 +518,7 @@ class _FastEGNNFunction(torch.autograd.Function):
                 node_feat, node_loc, node_vel, loc_mean, *params):
         lib = K.lib(act=spec.act_kind != K.ACT_SILU, wide=spec.wide)
         ctx.wide = spec.wide   # the backward reads what this build saved (P / Q in units of ln 2 on the f16x2 build): same build
+        ctx.guard = getattr(spec, "guard", None)   # RangeGuard of the module when this forward runs on the f16x2 build
         # edge_attr / node_attr are differentiable inputs (the reference harness detaches them, utils/train.py:33,46-47,
         # but the module itself is differentiable in them): their gradients are accumulated by the edge / virtual backward
         # kernels when asked for
@@ -478,6 +562,11 @@ class _FastEGNNFunction(torch.autograd.Function):
                 Bc=(B, Cn, H), aggm=(N, H), npre=(N, H), poolV=(B, Cn, H))))
             # outputs / forward-only scratch: separate allocations so that they can be freed individually
             b.update(_carve(dev, dict(aggx=(N, 3), poolX=(B, 3, Cn))))
+            if _EDGE_STORE and graph.E and not spec.flags & K.F_BF16 and spec.ea <= 2:
+                # the store-vs-recompute lever (include/fastegnn_hip.h: edge_mp / edge_up): 512 bytes per edge and layer, kept for the backward
+                b.update(edge_mp=torch.empty(graph.E, H, **f32), edge_up=torch.empty(graph.E, H, **f32))
+            if _VIRT_STORE and Cn and not spec.flags & (K.F_BF16 | K.F_RF | K.F_ATTENTION):
+                b.update(virt_vp=torch.empty(Cn, N, H, **f32))   # the same lever for the virtual stage: 256 bytes per (node, channel)
             b.update(h_out=torch.empty(N, H, **f32), x_out=torch.empty(N, 3, **f32),
                      Z_out=torch.empty(B, 3, Cn, **f32), HvT_out=torch.empty(B, Cn, H, **f32))
             L = _new_layer(spec, N, B, graph)
@@ -503,6 +592,9 @@ class _FastEGNNFunction(torch.autograd.Function):
     def backward(ctx, g_loc, g_vloc):
         lib = K.lib(act=ctx.spec.act_kind != K.ACT_SILU, wide=ctx.wide)
         spec, graph, saved = ctx.spec, ctx.graph, ctx.saved
+        guard = ctx.guard
+        if guard is not None:
+            guard.poll("FastEGNN", ctx.misc[-1])   # (no synchronisation: if the forward's guard launch has run and tripped, switch now)
         if saved is None or any(b is None for b in saved):
             raise RuntimeError("fastegnn_amd: backward through the graph a second time: the saved stage products are "
                                "freed layer by layer during the first backward (retain_graph is not supported)")
@@ -568,6 +660,8 @@ class _FastEGNNFunction(torch.autograd.Function):
                 "fastegnn_embed_backward")
         # The last layer's node_mlp / node_mlp_virtual only feed h and Hv, which nothing reads after the last layer: the
         # reference's autograd leaves their .grad None (and torch.optim.Adam then skips them); the kernels wrote zeros.
+        if guard is not None:   # an overflowed forward (outputs non-finite) hands zero parameter gradients on, whenever the host learns of it
+            guard.zero_if_flagged(lib, flat)
         last = spec.n_layers - 1
         for s_, suffix in zip(spec.layer_slots[last], K.PARAM_SLOTS):
             if s_ is not None and suffix.startswith(("node_mlp.", "node_mlp_virtual.")) and not (spec.flags & K.F_RF):
@@ -734,19 +828,20 @@ class FastEGNN(nn.Module):
             rf = bool(spec.flags & K.F_RF)
             plist = list(_PadParams.apply(tuple(spec.names), self.hidden_nf, spec.C, rf, *plist))
         guard, who = self._range, type(self).__name__
-        if guard.pending and not guard.wide and guard.tripped(dev):
-            guard.switch(who, "a replayed HIP graph of this module")
+        guarded = spec.flags & K.F_BF16 == 0       # (the bf16 operand mode has fp32's exponent range)
+        if guarded and not guard.wide:
+            guard.poll(who, self._plist)           # plain host loads of two words: an overflow of an EARLIER pass switches the build here
         spec.wide = guard.wide
+        spec.guard = guard if guarded and not guard.wide else None
 
         def run():
             return _FastEGNNFunction.apply(spec, graph, batch32, gptr, edge_attr, node_attr, node_feat, node_loc, node_vel,
                                            loc_mean, *plist)
         out = run()
-        if not guard.wide and spec.flags & K.F_BF16 == 0:   # (the bf16 operand mode has fp32's exponent range)
-            guard.launch(K.lib(act=spec.act_kind != K.ACT_SILU, wide=False), out[0], out[1])
-            if guard.tripped(dev):
-                guard.switch(who)
-                spec.wide = True
+        if guarded and not guard.wide:
+            guard.launch(K.lib(act=spec.act_kind != K.ACT_SILU, wide=False), (out[0], out[1]), (node_loc, node_vel))
+            if guard.mode == "sync" and guard.sync_and_poll(dev, who, self._plist):
+                spec.wide, spec.guard = True, None
                 out = run()        # the same call on the wide-range build; what it returns is what fp32 gives
         if _DEBUG_CHECKS and not (bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[1]).all())):
             raise FloatingPointError("fastegnn_amd: non-finite outputs (on the wide-range build as well: the inputs or the "

@@ -949,8 +949,8 @@ class ShardedFastEGNN(torch.nn.Module):
         guarded = self.backend is None and not (m._spec.flags & K.F_BF16)
         world, _ = self._world_rank()
         group = (self.group if self.group is not None else dist.group.WORLD) if (dist.is_initialized() and self.emulate is None and world > 1) else None
-        if guarded and guard.pending and not guard.wide and guard.tripped(dev, group):
-            guard.switch("ShardedFastEGNN", "a replayed HIP graph of this module")
+        if guarded and not guard.wide and group is None:
+            guard.poll("ShardedFastEGNN", m._plist)     # one process: the deferred check of fastegnn_amd.model.RangeGuard (no synchronisation)
         be = self.backend or HipBackend(dev, act=m._spec.act_kind != K.ACT_SILU, wide=guard.wide)
         spec = m._spec
         csc = bool(m._spec.flags & K.F_DETERMINISTIC)
@@ -979,11 +979,11 @@ class ShardedFastEGNN(torch.nn.Module):
                                           local["loc_mean"], *plist)
         out = run(be)
         if guarded and not guard.wide:
-            # every rank checks ITS rows and the replicated virtual coordinates; the decision is taken over all ranks (one 4-byte
-            # all-reduce) so that they switch builds together
-            guard.launch(be.lib, out[0], out[1])
-            if guard.tripped(dev, group):
-                guard.switch("ShardedFastEGNN")
+            # every rank checks ITS rows and the replicated virtual coordinates.  Several ranks: the builds must agree (halo rows carry
+            # Q in the build's units), so the decision is taken over all ranks after every eager forward -- one stream synchronisation
+            # and one 8-byte all-reduce, beside the blocking collectives this transport already has.  One process: deferred, as FastEGNN.
+            guard.launch(be.lib, (out[0], out[1]), (local["node_loc"], local["node_vel"]))
+            if (group is not None or guard.mode == "sync") and guard.sync_and_poll(dev, "ShardedFastEGNN", m._plist, group):
                 out = run(HipBackend(dev, act=spec.act_kind != K.ACT_SILU, wide=True))
         return out
 

@@ -109,5 +109,11 @@ def train_step(model, optimizer: FusedAdam, data: dict, sample_nodes, sigma, wei
                            data_batch=data["batch"], edge_attr=edge_attr)
     loss, mse = mse_mmd_loss(loc_pred, vloc, data["loc_t"], sample_nodes, sigma, weight)
     loss.backward()
+    # the range guard of the f16x2 build (fastegnn_amd.model.RangeGuard), polled without synchronisation: when THIS poll finds that a
+    # pass left the fp16 operand range the module moves to the wide-range build and the update is skipped (its gradients were zeroed
+    # on the device anyway), like a skipped step of a loss scaler
+    guard = getattr(model, "_range", None)
+    if guard is not None and guard.poll(type(model).__name__, getattr(model, "_plist", None), why="a training step"):
+        return loss.detach(), mse
     optimizer.step()
     return loss.detach(), mse

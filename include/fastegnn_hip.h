@@ -237,16 +237,26 @@ typedef struct {
    * (the sharded path, which has collectives between them).  The operands a stage queues (its g_* outputs and its region
    * of wg_node) must stay untouched until fastegnn_wgrad_batch_close.  NULL: the stage finishes its own jobs. */
   void *wgrad_batch;
+  /* Round 6 (ABI 107), the store-vs-recompute lever of the edge stage: when BOTH are non-null, fastegnn_edge_forward also stores the
+   * pre-activations of edge_mlp.2 and coord_mlp_r.0 of every edge ([E,64] each, sorted-edge order, in the forward kernel's units) and
+   * fastegnn_edge_backward reads them instead of recomputing the two forward products (fp32 operand modes only).  NULL (the default,
+   * and what fastegnn_amd passes unless FASTEGNN_EDGE_STORE=1): the backward recomputes -- measured faster, profiles/r06_lever_store_vs_recompute.txt. */
+  float *edge_mp, *edge_up;
+  /* the same lever for the virtual stage: non-null = fastegnn_virt_forward stores the pre-activation of edge_mlp_virtual.2 of every
+   * (node, channel) as [C][N][64] and the channel-phased form of fastegnn_virt_backward reads it instead of recomputing that product
+   * (FASTEGNN_VIRT_STORE=1 in fastegnn_amd).  NULL (default): recompute. */
+  float *virt_vp;
 } fastegnn_layer_t;
 
 /* ---- library ---- */
 const char *fastegnn_last_error(void);
 /* ABI revision: FASTEGNN_ABI_VERSION of the header the library was built from.  It changes whenever the layout of
  * fastegnn_layer_t / fastegnn_graph_t or the meaning of an argument changes (round 3 inserted act_param: 100 -> 101; round 4 appended wgrad_batch and added fastegnn_pack_weights_all / FASTEGNN_F_WPACK_READY: 103; the fastegnn_wide_* entry points: 104;
- * round 5: fastegnn_f16_operands / fastegnn_check_finite: 105; the fused activation arguments of fastegnn_wide_linear / _dx / _dw: 106).
+ * round 5: fastegnn_f16_operands / fastegnn_check_finite: 105; the fused activation arguments of fastegnn_wide_linear / _dx / _dw: 106;
+ * round 6: fastegnn_host_words_alloc / _free, fastegnn_zero_if_flagged, fastegnn_check_finite writes 1 instead of OR-ing: 107).
  * A binding MUST compare it with the FASTEGNN_ABI_VERSION it was written against AND check fastegnn_sizeof_layer() /
  * fastegnn_sizeof_graph() against its own mirror of the descriptors before the first call (fastegnn_amd/_lib.py does). */
-#define FASTEGNN_ABI_VERSION 106
+#define FASTEGNN_ABI_VERSION 107
 int fastegnn_version(void);
 /* floats of the packed weight-image buffer for C virtual channels */
 size_t fastegnn_wpack_floats(int32_t C);
@@ -320,11 +330,20 @@ int fastegnn_generic_activations(void);
 /* 1 if the fp32-grade products of this build run on 2-part fp16 splits (operands must stay below 65 504 in magnitude: the default
  * library), 0 if on 3-part bf16 splits with fp32's exponent range (libfastegnn_hip_x3.so / _act_x3.so).  ABI revision 105. */
 int fastegnn_f16_operands(void);
-/* Range guard of the f16x2 build (the reference is plain fp32, models/FastEGNN.py:102-119: it has no such limit): *flag |= 1 if any
- * of a[0..na) / b[0..nb) is not finite.  One capturable launch on `stream`, no host synchronisation; the caller reads the device
- * word when it may (fastegnn_amd.FastEGNN: after every eager forward -- a set flag re-runs the call on the wide-range library).
- * Either array may be NULL with its count 0.  ABI revision 105. */
+/* Range guard of the f16x2 build (the reference is plain fp32, models/FastEGNN.py:102-119: it has no such limit): *flag = 1 if any
+ * of a[0..na) / b[0..nb) is not finite (a plain store of the constant: `flag` may be device memory OR a host-mapped word of
+ * fastegnn_host_words_alloc, which the host then reads without any synchronisation).  One capturable launch on `stream`.
+ * Either array may be NULL with its count 0.  ABI revision 105; store instead of atomic OR since 107. */
 int fastegnn_check_finite(const float *a, int64_t na, const float *b, int64_t nb, int32_t *flag, void *stream);
+/* n zero-initialised int32 words of pinned, host-MAPPED, coherent memory: kernels write them through the same address (the guard
+ * launch above), the host polls them with plain loads -- no stream synchronisation, no copy, valid inside a captured HIP graph as
+ * well.  The reference's only host synchronisation on this path is data_batch[-1].item() (models/FastEGNN.py:267), which the module
+ * does not need; this keeps the range guard from adding one.  ABI revision 107. */
+int fastegnn_host_words_alloc(int32_t n, int32_t **words);
+int fastegnn_host_words_free(int32_t *words);
+/* buf[0..n) = 0 if *flag != 0 (flag: device or host-mapped word).  The backward of a forward whose outputs left the f16x2 range
+ * hands ZERO parameter gradients to the optimizer instead of NaNs (the host may not have seen the flag yet).  ABI revision 107. */
+int fastegnn_zero_if_flagged(float *buf, int64_t n, const int32_t *flag, void *stream);
 /* batch int64 [N] (ascending) -> batch int32 [N], gptr int32 [B+1] */
 int fastegnn_build_batch(const int64_t *batch64, int32_t N, int32_t B, int32_t *batch, int32_t *gptr,
                          void *stream);

@@ -205,22 +205,5 @@ def test_layer_list_pointer_table_does_not_outlive_its_tensors():
         gc.enable()
 
 
-def test_inline_asm_blocks_that_write_mfma_operands_end_with_their_wait_states():
-    """Inline assembly is opaque to the compiler's hazard recognizer: a packed fp16 operand written inside an asm string
-    (v_fma_mixlo_f16 / v_fma_mixhi_f16 pairs of the f16x2 splits, csrc/common.h) and read by an MFMA needs the two
-    VALU -> MFMA-operand wait states INSIDE the string.  Round 5 found them missing (wrong low parts under another machine
-    scheduler strategy); this pins the rule on the sources: every such block ends with `s_nop 1`."""
-    import os
-    import re
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fastegnn_amd", "csrc")
-    found = 0
-    for name in sorted(os.listdir(root)):
-        if not name.endswith((".h", ".hip")):
-            continue
-        src = open(os.path.join(root, name)).read()
-        for m in re.finditer(r'asm(?:\s+volatile)?\s*\(((?:\s*"(?:[^"\\]|\\.)*")+)', src):
-            text = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', m.group(1)))
-            if "v_fma_mixhi_f16" in text or "v_fma_mixlo_f16" in text:
-                found += 1
-                assert text.rstrip().endswith("s_nop 1"), (name, text[:80])
-    assert found >= 2   # mix_pack4 and part2_pack
+# (the wait states of inline-assembly blocks that write MFMA operands are checked on the DISASSEMBLY of the built libraries since
+#  round 6: tests/test_isa_hazards_cpu.py, tools/isa_hazards.py)
