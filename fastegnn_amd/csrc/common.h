@@ -802,7 +802,24 @@ __device__ __forceinline__ unsigned split2_word(float w0, float w1, int part) {
 #define FE_MIX_PAD "s_nop 1"
 #endif
 // l[w] = {fp16(r[2w] * sc), fp16(r[2w+1] * sc)} for w = 0..3
+// IN_PLACE (the residuals are dead afterwards -- the low-part blocks): l[w] is tied to the register of r[2w].  Round 6: the binary hazard
+// checker found an "=&v" output of this block allocated to a register that a 4-pass MFMA had written two instructions earlier (the low-part
+// accumulator of the previous product, dead once the next MFMA had taken it as C): v_fma_mixlo_f16 reads and rewrites its destination,
+// and an MFMA's write-back needs its wait states before ANY later access (the compiler pads its own instructions, not an asm string).
+// Tied to its input the output lands in a register that the vector ALU wrote last.
+template <bool IN_PLACE = false>
 __device__ __forceinline__ void mix_pack4(const float (&r)[8], float sc, unsigned (&l)[4]) {
+  if constexpr (IN_PLACE) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) l[w] = f2u(r[2 * w]);
+    asm("v_fma_mixlo_f16 %0, %0, %8, 0\n\tv_fma_mixhi_f16 %0, %4, %8, 0\n\t"
+        "v_fma_mixlo_f16 %1, %1, %8, 0\n\tv_fma_mixhi_f16 %1, %5, %8, 0\n\t"
+        "v_fma_mixlo_f16 %2, %2, %8, 0\n\tv_fma_mixhi_f16 %2, %6, %8, 0\n\t"
+        "v_fma_mixlo_f16 %3, %3, %8, 0\n\tv_fma_mixhi_f16 %3, %7, %8, 0\n\t"
+        FE_MIX_PAD
+        : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3])
+        : "v"(r[1]), "v"(r[3]), "v"(r[5]), "v"(r[7]), "v"(sc));
+  } else {
   asm("v_fma_mixlo_f16 %0, %4, %12, 0\n\tv_fma_mixhi_f16 %0, %5, %12, 0\n\t"
       "v_fma_mixlo_f16 %1, %6, %12, 0\n\tv_fma_mixhi_f16 %1, %7, %12, 0\n\t"
       "v_fma_mixlo_f16 %2, %8, %12, 0\n\tv_fma_mixhi_f16 %2, %9, %12, 0\n\t"
@@ -810,6 +827,7 @@ __device__ __forceinline__ void mix_pack4(const float (&r)[8], float sc, unsigne
       FE_MIX_PAD
       : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
       : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(sc));
+  }
 }
 __device__ __forceinline__ Split2 vsplit2(const Vec &v) {
   Split2 S;
@@ -827,7 +845,7 @@ __device__ __forceinline__ Split2 vsplit2(const Vec &v) {
       S.p[0][s][w] = h;
     }
     unsigned l[4];
-    mix_pack4(r, F2_UP, l);
+    mix_pack4<true>(r, F2_UP, l);
 #pragma unroll
     for (int w = 0; w < 4; ++w) S.p[1][s][w] = l[w];
   }
@@ -1013,7 +1031,7 @@ __device__ __forceinline__ Split2s vsplit2_scaled(const Vec &v) {
       asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r[2 * w]) : "v"(a[2 * w]), "v"(sc), "v"(h[w]));
       asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[2 * w + 1]) : "v"(a[2 * w + 1]), "v"(sc), "v"(h[w]));
     }
-    mix_pack4(r, F2_UP, l);
+    mix_pack4<true>(r, F2_UP, l);
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       S.s.p[0][s][w] = h[w];
@@ -1033,14 +1051,16 @@ __device__ __forceinline__ Split2s vsplit2_scaled(const Vec &v) {
 // registers), the low-part chain and the (h, h) chain of a tile are independent accumulators issued interleaved, and the fold of tile t
 // (hi + lo / 2^11) is issued behind the MFMAs of tile t + 1, when its operands have long left the matrix pipe.  The (h, h) chain now
 // starts from acc and the fold adds the low part last: the same sum in another order.  -DFE_F2_PIPE=0 restores the old form.
+// Measured on one box each, ms per step at cfg4 (profiles/r06_lever_f2_pipe.txt): edge_bwd 2.935 -> 2.906, virt_bwd (phased form) 3.753 -> 3.700;
+// the tile-major virt_bwd_pc, already at 256 registers with 12 spilled, LOSES with it (24 spilled: 2.93 -> 3.01) and passes P16 = false.
 #ifndef FE_F2_PIPE
 #define FE_F2_PIPE 1
 #endif
-template <bool TR, bool SCALED>
+template <bool TR, bool SCALED, bool PIPE = true>
 __device__ __forceinline__ void gemm64_f2_rm_(const char *img, const Split2 &in, float inv, Vec &acc) {
   const f16x8 xh0 = __builtin_bit_cast(f16x8, in.p[0][0]), xh1 = __builtin_bit_cast(f16x8, in.p[0][1]);
   const f16x8 xl0 = __builtin_bit_cast(f16x8, in.p[1][0]), xl1 = __builtin_bit_cast(f16x8, in.p[1][1]);
-#if FE_F2_PIPE
+  if constexpr (PIPE && FE_F2_PIPE != 0) {
   __builtin_amdgcn_sched_barrier(0);
   bf16x8 fr[2][4];   // [buffer][ah0 | ah1 | al0 | al1]
 #pragma unroll
@@ -1083,7 +1103,7 @@ __device__ __forceinline__ void gemm64_f2_rm_(const char *img, const Split2 &in,
     else acc.t[3][r] = __builtin_fmaf(lo_p[r], F2_DOWN, hi_p[r]);
   }
   __builtin_amdgcn_sched_barrier(0);
-#else
+  } else {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const f16x8 ah0 = __builtin_bit_cast(f16x8, rm_frag<TR>(img, 0, t, 0)), ah1 = __builtin_bit_cast(f16x8, rm_frag<TR>(img, 0, t, 1));
@@ -1110,7 +1130,7 @@ __device__ __forceinline__ void gemm64_f2_rm_(const char *img, const Split2 &in,
       acc.t[t] = hi;
     }
   }
-#endif
+  }
 }
 
 // ---- f16x2 for the in-workgroup WEIGHT-GRADIENT consumers (round 5): sticky power-of-two scale, 32x32x16 MFMAs ----------------
@@ -1310,19 +1330,20 @@ __device__ __forceinline__ void gemm_op(const void *img, int i, const typename O
 // a product on an fp32 image (fp32-input MFMA) inside a kernel of form MODE: in bf16 mode the activation is rounded
 // (the image already holds bf16-representable weights), so the product has the bf16-mode semantics exactly
 // product (TR = false) or transposed product (TR = true) on a row-major split image, forms GM_X3 / GM_BF16
-template <int MODE, bool TR, bool PIPE = true>
+// (PIPE: the hand-pipelined order of the bf16x3 form, P16: of the f16x2 form -- separate switches, the two forms differ by 32 registers)
+template <int MODE, bool TR, bool PIPE = true, bool P16 = true>
 __device__ __forceinline__ void gemm_rm(const char *img, const typename OperandOf<MODE>::type &in, Vec &acc) {
   static_assert(MODE == GM_X3 || MODE == GM_BF16 || MODE == GM_F16, "row-major images hold 16-bit parts");
   if constexpr (MODE == GM_X3) gemm64_x3_rm<TR, PIPE>(img, in, acc);
-  else if constexpr (MODE == GM_F16) gemm64_f2_rm_<TR, false>(img, in, 1.f, acc);
+  else if constexpr (MODE == GM_F16) gemm64_f2_rm_<TR, false, P16>(img, in, 1.f, acc);
   else gemm64_b1_rm<TR>(img, in, acc);
 }
 // bytes of one row-major image as a kernel of form MODE keeps it in LDS: an f16x2 image has two parts
 template <int MODE> constexpr int rm_lds_bytes() { return MODE == GM_F16 ? 2 * RM_PART : RM_BYTES; }
 // the same with a gradient operand (make_grad_operand)
-template <int MODE, bool TR, bool PIPE = true>
+template <int MODE, bool TR, bool PIPE = true, bool P16 = true>
 __device__ __forceinline__ void gemm_rm_g(const char *img, const typename GradOperandOf<MODE>::type &in, Vec &acc) {
-  if constexpr (MODE == GM_F16) gemm64_f2_rm_<TR, true>(img, in.s, in.inv, acc);
+  if constexpr (MODE == GM_F16) gemm64_f2_rm_<TR, true, P16>(img, in.s, in.inv, acc);
   else gemm_rm<MODE, TR, PIPE>(img, in, acc);
 }
 template <int MODE>

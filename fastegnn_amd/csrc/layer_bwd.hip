@@ -269,10 +269,12 @@ __device__ __forceinline__ void pc_tile_store(float *tile, int j, int q, const V
 // EA: edge_attr slots whose weight-column sums are accumulated in the row walk, without guards (2 covers edge_attr_nf <= 2 --
 // every BASELINE configuration --, 7 the rest): a per-slot `k < ea_dim` test inside the 16-edge walk compiled into ~130
 // scalar branches per tile and made the walk 23 % of the producers' time (phase stamps).
-// STORED: the forward kernel kept the two pre-activations of every edge (EdgeArgs::st_mp / st_up): no forward product is recomputed
-template <int MODE, int EA, bool STORED = false>
+template <int MODE, int EA>
 __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef FE_ISA_CONST   // assembly-only builds of tools/isa_budget_bwd.py: the layer flags as a constant (straight-line code of ONE configuration)
+  A.f.flags = FE_ISA_CONST; A.f.ea_dim = 2; A.f.bx2 = nullptr; A.f.attw = nullptr; A.g_ea = nullptr; A.d_bx2 = nullptr;
+#endif
   const EdgeArgs &a = A.f;
   float *img = lds;                    // W2, WX1 (row-major split images, common.h)
   float *vec = lds + pc_img_floats<MODE>();
@@ -597,13 +599,6 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
       for (int k = 0; k < 3; ++k) gax[k] = A.g_aggx[(size_t)cur_i.row * 3 + k];
       Vec gam;   // (EA = 7 variant: 16 more live registers would spill; it keeps this row's load at its use)
       if constexpr (PF_IDX) gam = vload_row(A.g_aggm + (size_t)cur_i.row * H, q);
-      if constexpr (STORED) {
-        EdgeRows G;
-        edge_gather(a, cur_i, q, G);
-        const Vec mp_st = vload_row(a.st_mp + (size_t)e * H, q), up_st = vload_row(a.st_up + (size_t)e * H, q);
-        edge_tile_pre<edge_fold_first<MODE>()>(a, vec, cur_i, G, q, S, pre FE_TA);
-        edge_tile_mlp_stored<MODE>(a, vec, q, S, pre, mp_st, up_st FE_TA);
-      } else
       edge_tile_forward<true, MODE, true>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
       const int dg = rp1 - rp0;
       const float inv = valid ? rcp_f((float)(dg > 1 ? dg : 1)) : 0.f;
@@ -677,7 +672,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
         xv[ee] = pt[ee * TS + H + (l & 3)];
       }
       const int rowv = S.row;
-#ifdef FE_DIAG_NOATOMIC   // diagnostic (wrong col-side gradients): what do the scatter atomics cost the producers?
+#ifdef FE_DIAG_NOATOMIC   // diagnostic (wrong col-side gradients): what do the scatter atomics cost the producers?  (round 6: 14 % of the kernel)
       if (false) {
 #else
       if (A.g_QXs_atomic) {   // default (no FASTEGNN_F_DETERMINISTIC): one coalesced 256-byte atomic row per edge ...
@@ -817,10 +812,8 @@ int edge_backward(const fastegnn_layer_t *L, hipStream_t st, WgradBatch *shared)
       const dim3 g3(grid), b3(64 * PC_WAVES);
       if (L->ea <= 2) {
         if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_BF16, 2>), g3, b3, lds, st, A);
-        else if (A.f.st_mp) hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_EDGE_BWD, 2, true>), g3, b3, lds, st, A);
         else hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_EDGE_BWD, 2>), g3, b3, lds, st, A);
       } else {
-        A.f.st_mp = A.f.st_up = nullptr;   // (the stored form is built for edge_attr_nf <= 2 only: every BASELINE configuration)
         if (has(L, FASTEGNN_F_BF16)) hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_BF16, 7>), g3, b3, lds, st, A);
         else hipLaunchKernelGGL((edge_bwd_pc_kernel<GM_EDGE_BWD, 7>), g3, b3, lds, st, A);
       }

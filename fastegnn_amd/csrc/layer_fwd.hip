@@ -298,10 +298,6 @@ __global__ __launch_bounds__(64 * EDGE_FWD_WAVES) void edge_fwd_kernel(EdgeArgs 
         Vec pre;
         edge_tile_forward<false, MODE>(a, img, vec, cur_i, q, S, pre FE_TA);
         cur_i = nxt_i;
-        if (a.st_mp && j < nvalid) {   // (wave-uniform pointer test) the store-vs-recompute lever: 512 bytes per edge for the backward
-          vstore_row(a.st_mp + (size_t)(base + j) * H, q, S.mp);
-          vstore_row(a.st_up + (size_t)(base + j) * H, q, S.up);
-        }
         tile_store(mt, j, q, S.m);
         if (q == 0) {
           xt[j * 4 + 0] = S.dn[0] * S.s;
@@ -540,7 +536,6 @@ __global__ __launch_bounds__(64 * VIRT_WAVES) void virt_fwd_kernel(VirtArgs a) {
       if (active) {
         VirtFwdState<MODE> S;
         virt_tile_forward<MODE>(a, img, vec, Ai, xi, b, c, q, fast ? Bc_l : nullptr, fast ? Z_l : nullptr, S VF_TA);
-        if (a.st_vp && valid) vstore_row(a.st_vp + ((size_t)c * a.N + n) * H, q, S.vp);   // (the store-vs-recompute lever: stages.h)
         transv[0] -= S.vd[0] * S.sx;
         transv[1] -= S.vd[1] * S.sx;
         transv[2] -= S.vd[2] * S.sx;

@@ -32,7 +32,6 @@ struct EdgeArgs {
   int n_chunks, ea_dim, flags;
   float eps;
   float act_param = 0.f;   // parameter of the activation kind in the flags (generic-activation build only)
-  float *st_mp = nullptr, *st_up = nullptr;   // store-vs-recompute lever (fastegnn_layer_t.edge_mp / edge_up): [E,64] pre-activations
 };
 
 constexpr int EV_WR = 0, EV_WE = 1, EV_B2 = 9, EV_BX1 = 10, EV_WX2 = 11, EV_ATT = 12, EV_COUNT = 13;
@@ -258,37 +257,6 @@ __device__ __forceinline__ void edge_tile_mlp(const EdgeArgs &a, const void *img
   S.s = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sraw) : sraw;
   FE_T(4)   // silu 3 + head dot
 }
-// The backward's reading of a tile whose two pre-activations were STORED by the forward kernel (EdgeArgs::st_mp / st_up): SiLU 1 from the
-// gathered rows as always (its output t is an operand of the weight gradient), the two products replaced by two row loads.  The stored
-// values are in the forward kernel's units (ln 2 when it runs folded).  S.mp, S.up and pre return silu'(.) as with KEEP_D.
-template <int MODE>
-__device__ __forceinline__ void edge_tile_mlp_stored(const EdgeArgs &a, const float *vec, int q, EdgeFwdState &S, Vec &pre,
-                                                     const Vec &mp_st, const Vec &up_st FE_TP) {
-  constexpr bool FOLD1 = edge_fold_first<MODE>();
-  constexpr bool SFOLD = edge_fold<false, GM_EDGE_FWD, false>();   // what edge_fwd_kernel of this build stored
-  if constexpr (FOLD1) S.t = vsilu_keep_d2(pre);
-  else S.t = vsilu_keep_d(pre FE_ACT(a));
-  FE_T(2)
-  S.mp = mp_st;
-  FE_T(3)
-  if constexpr (SFOLD) S.m0 = vsilu_keep_d2(S.mp);
-  else S.m0 = vsilu_keep_d(S.mp FE_ACT(a));
-  if (a.flags & FASTEGNN_F_ATTENTION) {
-    S.att = sigmoid_f(vdot(S.m0, vload_vec(vec + EV_ATT * H, q)) + a.attb[0]);
-    S.m = vscale(S.m0, S.att);
-  } else {
-    S.att = 1.f;
-    S.m = S.m0;
-  }
-  FE_T(2)
-  S.up = up_st;
-  FE_T(3)
-  if constexpr (SFOLD) S.u = vsilu_keep_d2(S.up);
-  else S.u = vsilu_keep_d(S.up FE_ACT(a));
-  const float sraw = vdot(S.u, vload_vec(vec + EV_WX2 * H, q)) + (a.bx2 ? a.bx2[0] : 0.f);
-  S.s = (a.flags & FASTEGNN_F_TANH) ? tanh_f(sraw) : sraw;
-  FE_T(4)
-}
 template <bool KEEP_D, int MODE = GM_F32, bool RM = false>
 __device__ __forceinline__ void edge_tile_forward(const EdgeArgs &a, const void *img, const float *vec,
                                                   const EdgeIdx &I, int q, EdgeFwdState &S, Vec &pre FE_TP) {
@@ -306,7 +274,6 @@ inline EdgeArgs make_edge_args(const fastegnn_layer_t *L) {
              p[FASTEGNN_P_ATT_W], p[FASTEGNN_P_ATT_B], p[FASTEGNN_P_CR2_B], g.rowptr, g.erow, g.col, g.chunk_row, L->aggm, L->aggx,
              g.n_chunks, L->ea, L->flags, L->epsilon};
   a.act_param = L->act_param;
-  if (L->edge_mp && L->edge_up && !(L->flags & FASTEGNN_F_BF16)) { a.st_mp = L->edge_mp; a.st_up = L->edge_up; }
   return a;
 }
 
@@ -318,7 +285,6 @@ struct VirtArgs {
   int N, B, C, na, flags;
   float g[3];
   float act_param = 0.f;
-  float *st_vp = nullptr;   // store-vs-recompute lever (fastegnn_layer_t.virt_vp): [C][N][64] pre-activations of edge_mlp_virtual.2
 };
 constexpr int VV_WVR = 0, VV_C2 = 1, VV_BXV0 = 2, VV_WXV2 = 3, VV_BXX0 = 4, VV_WXX2 = 5, VV_ATT = 6, VV_B3 = 7,
               VV_B4 = 8, VV_COUNT = 9;
@@ -431,7 +397,6 @@ inline VirtArgs make_virt_args(const fastegnn_layer_t *L) {
              L->h_out, L->x_out, L->npre, L->poolV, L->poolX, L->N, L->B, L->C, L->na, L->flags,
              {L->gravity[0], L->gravity[1], L->gravity[2]}};
   a.act_param = L->act_param;
-  if (L->virt_vp && !(L->flags & (FASTEGNN_F_BF16 | FASTEGNN_F_RF | FASTEGNN_F_EGNN))) a.st_vp = L->virt_vp;
   return a;
 }
 inline size_t virt_lds_bytes(int C, int n_img, int waves = VIRT_WAVES) {

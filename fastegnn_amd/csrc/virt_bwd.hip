@@ -35,6 +35,10 @@ __device__ unsigned long long g_vb2_stamps[32];
 #define VB2_T(i) { __builtin_amdgcn_sched_barrier(0); const unsigned _t = (unsigned)__builtin_amdgcn_s_memtime(); \
                    _va[i] += _t - _vp; _vp = _t; __builtin_amdgcn_sched_barrier(0); }
 #define VB2_TEND(base) if (lane_id() == 0) { for (int _k = 0; _k < 12; ++_k) atomicAdd(&g_vb2_stamps[(base) + _k], (unsigned long long)_va[_k]); }
+#elif defined(FE_ISA_MARK)   // assembly-only builds of tools/isa_budget_bwd.py: the phase boundaries as comments between scheduling fences
+#define VB2_T0()
+#define VB2_T(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("; FE_MARK " #i); __builtin_amdgcn_sched_barrier(0); }
+#define VB2_TEND(base)
 #else
 #define VB2_T0()
 #define VB2_T(i)
@@ -582,11 +586,12 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_pc_kernel(VirtBwd2Args
 #define VB_PRIO_ON()
 #define VB_PRIO_OFF()
 #endif
-    auto mm = [&](int which, const SOp &op, Vec &acc) { VB_PRIO_ON(); gemm_rm<SM, false>(rmimg + which * RMS, op, acc); VB_PRIO_OFF(); };
+    // (P16 = false: this kernel sits at 256 registers with spills; the pipelined f16x2 product costs it more than it hides, common.h)
+    auto mm = [&](int which, const SOp &op, Vec &acc) { VB_PRIO_ON(); gemm_rm<SM, false, true, false>(rmimg + which * RMS, op, acc); VB_PRIO_OFF(); };
     auto mmT = [&](int which, const Vec &g, Vec &acc) {
       const auto op = make_grad_operand<SM>(g);   // (the f16x2 form scales a gradient per item)
       VB_PRIO_ON();
-      gemm_rm_g<SM, true>(rmimg + which * RMS, op, acc);
+      gemm_rm_g<SM, true, true, false>(rmimg + which * RMS, op, acc);
       VB_PRIO_OFF();
     };
     VB2_T0()
@@ -968,14 +973,16 @@ __device__ int g_vbs_dog[64];
 #define VBS_SPIN(id, cond, sl) while (cond) __builtin_amdgcn_s_sleep(sl)
 #define VBS_MARK(x)
 #endif
-// STVP: virt_fwd_kernel kept the pre-activation of the second layer (VirtArgs::st_vp): the V2 product is not recomputed
-template <bool ATT, bool STVP = false>
+template <bool ATT>
 __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A) {
   constexpr int SM = GM_F16;
   typedef typename OperandOf<SM>::type SOp;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef FE_VBS_WATCHDOG
   int _mark = 0;
+#endif
+#ifdef FE_ISA_CONST   // assembly-only builds of tools/isa_budget_bwd.py: the layer flags as a constant, one graph
+  A.f.flags = FE_ISA_CONST; A.f.B = 1;
 #endif
   const VirtArgs &a = A.f;
   const int C = a.C;
@@ -1335,10 +1342,6 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
       const float vr = sqrt_f(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
       Vec vp = vload_vec(vec + VV_C2 * H, q);
       Vec d_pre = vload_u(a.A, offN);
-      Vec vp_st;
-#ifndef FE_VBS_STVP_LATE   // (requested with the unit's other rows: 16 more live registers through SiLU 1; -DFE_VBS_STVP_LATE: at its use)
-      if constexpr (STVP) vp_st = vload_row(a.st_vp + ((size_t)c * a.N + nc) * H, q);
-#endif
       vadd(d_pre, vload_u(a.Bc, offB));
       vaxpy(d_pre, vr, vload_vec(vec + VV_WVR * H, q));
       const Vec t = vsilu_keep_d(d_pre FE_ACT(a));        // d_pre <- silu'(pre)
@@ -1351,11 +1354,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
         asm volatile("" ::: "memory");
       }
       VB2_T(1)   // head loads (rows of A / Bc, coordinates), pre-activation, SiLU 1 (+ the hand-on of the previous unit's rows)
-#ifdef FE_VBS_STVP_LATE
-      if constexpr (STVP) vp_st = vload_row(a.st_vp + ((size_t)c * a.N + nc) * H, q);
-#endif
-      if constexpr (STVP) vp = vp_st;
-      else mm(0, make_operand<SM>(t), vp);
+      mm(0, make_operand<SM>(t), vp);
       VB2_T(2)   // operand split + V2 product
       const Vec v0 = vsilu_keep_d(vp FE_ACT(a));          // vp <- silu'(vp)
       float att = 1.f;
@@ -1629,7 +1628,6 @@ static int virt_backward_channels_cs(const fastegnn_layer_t *L, hipStream_t st, 
     ProfScope ps(K_VIRT_BWD, st);
     const dim3 g3(grid), b3(64 * VB_WAVES);
     if (att) hipLaunchKernelGGL((virt_bwd_cs_kernel<true>), g3, b3, lds, st, A);
-    else if (A.f.st_vp) hipLaunchKernelGGL((virt_bwd_cs_kernel<false, true>), g3, b3, lds, st, A);   // (the stored-operand lever: no attention)
     else hipLaunchKernelGGL((virt_bwd_cs_kernel<false>), g3, b3, lds, st, A);
   }
   if ((rc = check_launch("virt_bwd_cs_kernel"))) return rc;

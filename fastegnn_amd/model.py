@@ -62,10 +62,6 @@ class E_GCL_vel(nn.Module):
 # out-of-range col is an out-of-bounds gather, an unsorted data_batch breaks the graph pointer search; the
 # reference raises an index error in these cases.
 _DEBUG_CHECKS = os.environ.get("FASTEGNN_DEBUG_CHECKS", "0") not in ("", "0")
-# FASTEGNN_EDGE_STORE=1: the store-vs-recompute lever of the edge stage -- the forward keeps the two
-# pre-activations of every edge, the backward reads them instead of recomputing two products.  Measured slower.
-_EDGE_STORE = os.environ.get("FASTEGNN_EDGE_STORE", "0") not in ("", "0")
-_VIRT_STORE = os.environ.get("FASTEGNN_VIRT_STORE", "0") not in ("", "0")
 
 
 class RangeGuard:
@@ -562,11 +558,6 @@ class _FastEGNNFunction(torch.autograd.Function):
                 Bc=(B, Cn, H), aggm=(N, H), npre=(N, H), poolV=(B, Cn, H))))
             # outputs / forward-only scratch: separate allocations so that they can be freed individually
             b.update(_carve(dev, dict(aggx=(N, 3), poolX=(B, 3, Cn))))
-            if _EDGE_STORE and graph.E and not spec.flags & K.F_BF16 and spec.ea <= 2:
-                # the store-vs-recompute lever (include/fastegnn_hip.h: edge_mp / edge_up): 512 bytes per edge and layer, kept for the backward
-                b.update(edge_mp=torch.empty(graph.E, H, **f32), edge_up=torch.empty(graph.E, H, **f32))
-            if _VIRT_STORE and Cn and not spec.flags & (K.F_BF16 | K.F_RF | K.F_ATTENTION):
-                b.update(virt_vp=torch.empty(Cn, N, H, **f32))   # the same lever for the virtual stage: 256 bytes per (node, channel)
             b.update(h_out=torch.empty(N, H, **f32), x_out=torch.empty(N, 3, **f32),
                      Z_out=torch.empty(B, 3, Cn, **f32), HvT_out=torch.empty(B, Cn, H, **f32))
             L = _new_layer(spec, N, B, graph)

@@ -237,15 +237,6 @@ typedef struct {
    * (the sharded path, which has collectives between them).  The operands a stage queues (its g_* outputs and its region
    * of wg_node) must stay untouched until fastegnn_wgrad_batch_close.  NULL: the stage finishes its own jobs. */
   void *wgrad_batch;
-  /* Round 6 (ABI 107), the store-vs-recompute lever of the edge stage: when BOTH are non-null, fastegnn_edge_forward also stores the
-   * pre-activations of edge_mlp.2 and coord_mlp_r.0 of every edge ([E,64] each, sorted-edge order, in the forward kernel's units) and
-   * fastegnn_edge_backward reads them instead of recomputing the two forward products (fp32 operand modes only).  NULL (the default,
-   * and what fastegnn_amd passes unless FASTEGNN_EDGE_STORE=1): the backward recomputes -- measured faster, profiles/r06_lever_store_vs_recompute.txt. */
-  float *edge_mp, *edge_up;
-  /* the same lever for the virtual stage: non-null = fastegnn_virt_forward stores the pre-activation of edge_mlp_virtual.2 of every
-   * (node, channel) as [C][N][64] and the channel-phased form of fastegnn_virt_backward reads it instead of recomputing that product
-   * (FASTEGNN_VIRT_STORE=1 in fastegnn_amd).  NULL (default): recompute. */
-  float *virt_vp;
 } fastegnn_layer_t;
 
 /* ---- library ---- */

@@ -68,3 +68,41 @@ print("RESULT " + json.dumps({"gv": prof.get("virt_bwd_gv_kernel", (0, 0))[1], "
     assert res["cs"]["gv"] == 0 and res["cs"]["vb"] == 2, res       # no Gv kernel: the phased form ran both layers
     assert res["tile"]["gv"] == 2, res
     assert abs(res["cs"]["gsum"] - res["tile"]["gsum"]) <= 1e-4 * res["tile"]["gsum"], res
+
+
+def _default_path(cfg, inp, seed, case="test_cfg4_headline_shape_vs_oracle"):
+    """oracle comparison IN THIS PROCESS, no switch: asserts that the channel-phased kernel is what ran (profiler ids: a virtual backward
+    without a Gv kernel) -- the production configuration (grid 256, >= 12 tiles per workgroup, blocks of ~24)"""
+    import torch
+    from fastegnn_amd import _lib as K
+    from tests import test_gpu_properties as P
+    K.lib().fastegnn_profile_enable(1)
+    K.profile_collect()
+    try:
+        P._check_vs_oracle(cfg, inp, seed=seed, case=case)
+        torch.cuda.synchronize()
+        prof = K.profile_collect()
+    finally:
+        K.lib().fastegnn_profile_enable(0)
+    assert prof.get("virt_bwd_kernel", (0, 0))[1] == cfg.n_layers and "virt_bwd_gv_kernel" not in prof, prof
+
+
+@pytest.mark.skipif(os.environ.get("FASTEGNN_VIRT_CS", "1") == "0" or "FASTEGNN_VIRT_CS_MIN_GRID" in os.environ,
+                    reason="the default switches of the virtual backward are overridden in the environment")
+def test_default_path_at_the_size_where_it_is_the_default_vs_oracle():
+    """VERDICT / ADVICE round 5: the phased kernel at the size where it IS the default -- the cfg4 shape (radius graph, C = 16, L = 4,
+    gravity) at 52 000 nodes (3 250 tiles on 256 workgroups: 12-13 tiles each): outputs <= 1e-5 and every gradient against the fp32 +
+    fp64 CPU oracle under the calibrated rule."""
+    from tests import test_gpu_properties as P
+    cfg = P.R.Config(2, 0, 2, 64, 16, n_layers=4, gravity=[0, -1, 0])
+    _default_path(cfg, P._frame_cpu(52000, 16, 45), 45, case="cfg4_shape_at_52k_nodes")
+
+
+@pytest.mark.skipif(os.environ.get("FASTEGNN_VIRT_CS", "1") == "0" or "FASTEGNN_VIRT_CS_MIN_GRID" in os.environ,
+                    reason="the default switches of the virtual backward are overridden in the environment")
+def test_default_path_three_graphs_c3_vs_oracle():
+    """the same path with three graphs in the batch (pools of several graphs per workgroup, tiles that straddle a graph boundary) and an
+    odd channel count (phase parity differs from channel parity), 53 000 nodes"""
+    from tests import test_gpu_properties as P
+    cfg = P.R.Config(2, 0, 2, 64, 3, n_layers=2, gravity=[0, -1, 0])
+    _default_path(cfg, P._batch([30000, 16000, 7000], 4, 3, seed=21), 21)

@@ -6,8 +6,11 @@ instructions in between.  These tests read what the compil
   * every product library in the tree (what ships to the GPU box and what the round-end run maps) has no hand-off below its wait
     states, over every kernel (also the wide path's);
   * the checker itself is pinned on hand-written instruction streams, one per rule;
-  * a build of csrc/layer_fwd.hip without the pad of common.h: mix_pack4 (-DFE_HAZARD_SELFTEST) under the max-memory-clause
-    scheduler strategy -- the exact tree round 5 found broken -- is reported; the same build with the pad is clean.
+  * a build of csrc/layer_fwd.hip without the pad of common.h: mix_pack4 (-DFE_HAZARD_SELFTEST, with the round-5 order of the f16x2
+    products: -DFE_F2_PIPE_FWD=0) under the max-memory-clause scheduler strategy -- the exact tree round 5 found broken -- is
+    reported; the same build with the pad is clean.
+Round 6's own catch with this checker: an "=&v" output of the operand-split asm block allocated to a register that an MFMA had written
+two instructions earlier (R5; common.h: mix_pack4<IN_PLACE>).
 """
 import glob
 import os
@@ -91,6 +94,15 @@ def test_checker_rules_on_handwritten_streams():
     assert _rules("""
         v_mfma_f32_16x16x32_f16 v[74:77], v[70:73], v[62:65], v[74:77]
         v_mfma_f32_16x16x32_f16 v[18:21], v[74:77], v[58:61], v[18:21]""") == ["R6"]
+    # ... and retires the producer: its registers may be rewritten behind the consuming MFMA (the low-part accumulator of an f16x2 product
+    # is dead once the next MFMA has taken it as C, and the allocator hands it to the next asm block)
+    assert _rules("""
+        v_mfma_f32_16x16x32_f16 v[12:15], v[88:91], v[8:11], v[12:15]
+        v_mfma_f32_16x16x32_f16 v[84:87], v[84:87], v[0:3], v[12:15]
+        v_fma_mixlo_f16 v12, v16, v55, 0""") == []
+    assert _rules("""
+        v_mfma_f32_16x16x32_f16 v[12:15], v[88:91], v[8:11], v[12:15]
+        v_fma_mixlo_f16 v12, v16, v55, 0""") == ["R5"]
     # state is dropped behind an unconditional branch
     assert _rules("""
         v_fma_mixhi_f16 v62, v67, v161, 0
@@ -115,10 +127,10 @@ def _device_object(tmp_path, name, extra):
 
 def test_a_tree_without_the_operand_split_pad_fails_the_check(tmp_path):
     """the round-5 bug, reproduced: mix_pack4 without `s_nop 1` under -amdgpu-sched-strategy=max-memory-clause"""
-    bad = _device_object(tmp_path, "nopad", ["-DFE_HAZARD_SELFTEST"])
+    bad = _device_object(tmp_path, "nopad", ["-DFE_HAZARD_SELFTEST", "-DFE_F2_PIPE_FWD=0"])
     nk, ni, viol = HZ.check_file(bad)
     r1 = [v for v in viol if v[1] == "R1"]
     assert r1, "the checker did not see the missing VALU -> MFMA wait states"
     assert any("v_fma_mix" in v[3] for v in r1), r1[:3]   # the producer is the asm-written packed half
-    good = _device_object(tmp_path, "pad", [])
+    good = _device_object(tmp_path, "pad", ["-DFE_F2_PIPE_FWD=0"])
     assert HZ.check_file(good)[2] == []

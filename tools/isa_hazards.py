@@ -18,6 +18,8 @@ dropped behind an unconditional branch / s_endpgm / s_setpc):
   R5  an MFMA writes VGPRs, a non-MFMA instruction reads (or a VALU overwrites) one       >= N(mfma)
   R6  an MFMA writes VGPRs, another MFMA reads one as A or B (or as a C that is not the
       exact same register range: an accumulate chain on the same range needs none)        >= N(mfma)
+      (an accumulate chain RETIRES the producer: the consuming MFMA is interlocked until the result exists, so a vector access of
+      those registers behind it no longer races with the producer's write-back -- R5 then applies to the consumer's destination only)
 N(mfma) is CALIBRATED: the smallest distance hipcc's own recognizer leaves for that MFMA opcode in compiler-scheduled code of the same
 binary is what the hardware needs at most; the tool takes the gfx950 numbers (XDL shapes: passes + 4 for a VALU / memory reader, i.e.
 8 for v_mfma_f32_16x16x32_f16 and 12 for v_mfma_f32_32x32x16_f16; the fp32-input shapes: passes + 2, i.e. 10 for
@@ -222,6 +224,7 @@ def check_kernel(insts: List[Inst], observed: Optional[dict] = None) -> List[Tup
     w_mfma: Dict[int, Tuple[int, Inst]] = {}
     pos = 0
     out = []
+    retired = set()
 
     def since(entry):
         return pos - entry[0] - 1   # wait states strictly between the two instructions (the producer itself took one slot)
@@ -243,6 +246,8 @@ def check_kernel(insts: List[Inst], observed: Optional[dict] = None) -> List[Tup
                     prod = e[1]
                     same_chain = ins.mfma_c is not None and prod.dst and ins.mfma_c == (min(prod.dst), max(prod.dst)) and \
                         ins.mfma_c[0] <= r <= ins.mfma_c[1] and r not in _ab_regs(ins)
+                    if same_chain:
+                        retired.add(r)
                     if not same_chain:
                         need = need_mfma_ab_read(prod.op)
                         if observed is not None:
@@ -277,6 +282,13 @@ def check_kernel(insts: List[Inst], observed: Optional[dict] = None) -> List[Tup
                         observed[k] = min(observed.get(k, FAR), since(e))
                     if since(e) < need:
                         out.append(("R5", f"v{r}", e[1], ins, since(e), need))
+        # An MFMA that takes a whole earlier result as its C operand (an accumulate chain) is interlocked by the hardware until that
+        # result exists: behind it the earlier MFMA's write-back is done, and a later vector access of those registers races with
+        # nothing (LLVM's static count would still pad it; the elapsed time is >= the producer's passes).  The consumer's own
+        # destination is tracked as usual.
+        for r in retired:
+            w_mfma.pop(r, None)
+        retired.clear()
         # ---- producer side ----
         if ins.is_mfma:
             for r in ins.dst:
