@@ -1,8 +1,5 @@
 // Forward stages S1..S5 of one E_GCL_vel layer (reference: models/FastEGNN.py:192-223).
 // Math per stage: oracle/factored.py (same stage names); layout conventions: common.h.
-#ifdef FE_DIAG_Q256   // lever build only (this translation unit: node_pre_fwd writes the tables, edge_fwd gathers from them)
-#define FE_DIAG_Q256_USE
-#endif
 #include "stages.h"
 
 namespace fe {
@@ -58,15 +55,9 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodeP
     gemm_op<MODE>(img, 1, hv, acc);
     if (valid) {
       vstore_row(a.QX + (size_t)n * QXLD, q, acc);
-#ifdef FE_DIAG_Q256   // diagnostic lever: a second copy of the source table as 256-byte Q rows + 16-byte x rows
-      vstore_row(g_diag_q256 + (size_t)n * H, q, acc);
-#endif
       if (q == 0) {
         f32x4 xv = {a.x[(size_t)n * 3], a.x[(size_t)n * 3 + 1], a.x[(size_t)n * 3 + 2], 0.f};
         *reinterpret_cast<f32x4 *>(a.QX + (size_t)n * QXLD + H) = xv;
-#ifdef FE_DIAG_Q256
-        *reinterpret_cast<f32x4 *>(g_diag_x16 + (size_t)n * 4) = xv;
-#endif
       }
     }
     acc = vzero();
@@ -95,17 +86,6 @@ __global__ __launch_bounds__(64 * NODE_PRE_WAVES) void node_pre_fwd_kernel(NodeP
 
 int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(L->h && L->x && L->wpack && L->P && L->QX && L->A && L->svel, "node_pre_forward: null buffer");
-#ifdef FE_DIAG_Q256
-  {   // the diagnostic tables: allocated once (1 M rows), never freed -- a lever build, never a product library
-    static float *q256 = nullptr, *x16 = nullptr;
-    if (!q256) {
-      (void)hipMalloc(&q256, (size_t)(1 << 20) * H * sizeof(float));
-      (void)hipMalloc(&x16, (size_t)(1 << 20) * 4 * sizeof(float));
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_q256), &q256, sizeof(float *));
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_x16), &x16, sizeof(float *));
-    }
-  }
-#endif
   if (L->N == 0) return FASTEGNN_OK;
   const bool grav = has(L, FASTEGNN_F_GRAVITY);
   FE_REQUIRE(!grav || L->sgrav, "node_pre_forward: sgrav null");

@@ -24,9 +24,6 @@ constexpr int VIRT_WAVES = FE_VIRT_WAVES;
 #endif
 constexpr int VIRT_BWD_WAVES = FE_VIRT_BWD_WAVES;   // 1 wave/SIMD: the adjoint of the virtual block needs > 256 registers
 
-#ifdef FE_DIAG_Q256_USE
-__device__ float *g_diag_q256 = nullptr, *g_diag_x16 = nullptr;   // (lever build of layer_fwd.hip: VERDICT round 5 item 6)
-#endif
 struct EdgeArgs {
   const float *P, *QX, *QXs, *ea, *wpack;
   const float *E0W, *b2, *bx1, *wx2, *attw, *attb, *bx2;   // bx2: coordinate-head bias (EGNN baseline) or null
@@ -95,18 +92,10 @@ struct EdgeRows {
 // (32-bit element offsets from wave-uniform bases: the launchers require the tables to stay below 2^30 floats)
 __device__ __forceinline__ void edge_gather(const EdgeArgs &a, const EdgeIdx &I, int q, EdgeRows &G) {
   const unsigned qoff = (unsigned)I.col * QXLD, roff = (unsigned)I.row * QXLD;
-#ifdef FE_DIAG_Q256_USE   // (edge_fwd only, lever build: the neighbour's coordinates from a 16-byte row, its Q from a 256-byte aligned row)
-  G.xc = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(g_diag_x16) + (unsigned)I.col * 16u);
-#else
   G.xc = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(a.QXs) + (qoff + H) * 4u);
-#endif
   G.xr = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(a.QX) + (roff + H) * 4u);
   G.p = vload_u(a.P, (unsigned)I.row * H + 4 * q);
-#ifdef FE_DIAG_Q256_USE
-  G.qv = vload_u(g_diag_q256, (unsigned)I.col * H + 4 * q);
-#else
   G.qv = vload_u(a.QXs, qoff + 4 * q);
-#endif
 }
 
 // forward math of one 16-edge tile (shared with the backward kernel for recomputation).
