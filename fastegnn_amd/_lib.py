@@ -196,6 +196,7 @@ def lib(act: bool = False, wide=None):
     L.fastegnn_host_words_alloc.argtypes = [_i32, C.POINTER(C.POINTER(_i32))]
     L.fastegnn_host_words_free.argtypes = [C.POINTER(_i32)]
     L.fastegnn_zero_if_flagged.argtypes = [_vp, C.c_int64, _vp, _vp]
+    L.fastegnn_spin_timeouts.argtypes = [_i32]
     L.fastegnn_gather_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_scatter_add_rows.argtypes = [_vp, _vp, C.c_int64, _i32, _vp, _vp]
     L.fastegnn_wg_slab_floats.restype = C.c_size_t
@@ -246,7 +247,7 @@ STAGE_FUNCS = [
 # every symbol include/fastegnn_hip.h declares (checked by tests/test_abi_cpu.py)
 EXPORTED = STAGE_FUNCS + [
     "fastegnn_last_error", "fastegnn_version", "fastegnn_wpack_floats", "fastegnn_wg_slab_floats", "fastegnn_wg_edge_floats", "fastegnn_wg_virt_floats", "fastegnn_wg_virt_floats_for", "fastegnn_backward_scratch_floats_for", "fastegnn_wg_node_floats", "fastegnn_backward_scratch_floats", "fastegnn_sizeof_layer", "fastegnn_sizeof_graph", "fastegnn_csr_tmp_bytes", "fastegnn_chunk_rows", "fastegnn_chunk_edges",
-    "fastegnn_build_csr", "fastegnn_pad_params", "fastegnn_generic_activations", "fastegnn_f16_operands", "fastegnn_check_finite", "fastegnn_host_words_alloc", "fastegnn_host_words_free", "fastegnn_zero_if_flagged", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
+    "fastegnn_build_csr", "fastegnn_pad_params", "fastegnn_generic_activations", "fastegnn_f16_operands", "fastegnn_check_finite", "fastegnn_host_words_alloc", "fastegnn_host_words_free", "fastegnn_zero_if_flagged", "fastegnn_spin_timeouts", "fastegnn_permute_rows", "fastegnn_build_batch", "fastegnn_embed_forward",
     "fastegnn_embed_backward", "fastegnn_virtual_init", "fastegnn_virtual_init_backward",
     "fastegnn_layer_forward", "fastegnn_layer_backward", "fastegnn_selftest_gemm", "fastegnn_selftest_rm", "fastegnn_selftest_jreduce", "fastegnn_selftest_lane_sums", "fastegnn_selftest_wgrad", "fastegnn_selftest_wgrad_plan", "fastegnn_selftest_wgrad_guard", "fastegnn_selftest_stream", "fastegnn_selftest_chain", "fastegnn_selftest_chain_bf3",
     "fastegnn_augment_edge_attr", "fastegnn_loss_mse_mmd", "fastegnn_adam_step",

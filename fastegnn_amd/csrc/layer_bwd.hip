@@ -232,9 +232,13 @@ struct EdgeBwdArgs {
 // they are the two CONSUMERS, one per ring (wave 3: edge_mlp.2, wave 7: coord_mlp_r.0); the six producers sit two per SIMD
 // on SIMDs 0..2.  A single consumer serving both rings was latency-exposed (dependent LDS reads -> split -> MFMA chain at
 // one wave on its SIMD): with the contractions skipped the kernel ran 18 % faster (-DFE_DIAG_NOCONS).
-constexpr int PC_WAVES = 8;
+// -DFE_PC_WAVES=12 (round 6 experiment): three waves per SIMD -- ten producers (waves 0,1,2,4,5,6,8,9,10,11) + the two consumers, 168 registers
+#ifndef FE_PC_WAVES
+#define FE_PC_WAVES 8
+#endif
+constexpr int PC_WAVES = FE_PC_WAVES;
 constexpr int PC_CONS = 3, PC_CONS2 = 7;
-constexpr int PC_PROD = 6;                  // producer waves
+constexpr int PC_PROD = PC_WAVES - 2;       // producer waves
 // Round 5, f16x2 build: the consumers contract on f16x2 products with a sticky scale and 32x32x16 MFMAs (common.h, WgAcc32), one
 // ticket (16 edges) per step.  -DFE_PC_CONS32=0 restores the bf16x3 consumers.
 #ifndef FE_PC_CONS32
@@ -270,7 +274,7 @@ __device__ __forceinline__ void pc_tile_store(float *tile, int j, int q, const V
 // every BASELINE configuration --, 7 the rest): a per-slot `k < ea_dim` test inside the 16-edge walk compiled into ~130
 // scalar branches per tile and made the walk 23 % of the producers' time (phase stamps).
 template <int MODE, int EA>
-__global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
+__global__ __launch_bounds__(64 * PC_WAVES) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef FE_ISA_CONST   // assembly-only builds of tools/isa_budget_bwd.py: the layer flags as a constant (straight-line code of ONE configuration)
   A.f.flags = FE_ISA_CONST; A.f.ea_dim = 2; A.f.bx2 = nullptr; A.f.attw = nullptr; A.g_ea = nullptr; A.d_bx2 = nullptr;
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(64 * 8) void edge_bwd_pc_kernel(EdgeBwdArgs A) {
   const int l = lane_id(), j = l & 15, q = l >> 4, wv = wave_id();
   const bool consumer = wv == PC_CONS || wv == PC_CONS2;
   const int ckind = wv == PC_CONS ? 0 : 1;     // the ring a consumer wave serves
-  const int pw = wv > PC_CONS ? wv - 1 : wv;   // producer index (waves 0,1,2,4,5,6 -> 0..5)
+  const int pw = wv - (wv > PC_CONS ? 1 : 0) - (wv > PC_CONS2 ? 1 : 0);   // producer index (waves 0,1,2,4,5,6[,8..11] -> 0..5[..9])
   float *pt = tiles + (consumer ? 0 : pw) * 16 * TS;
   const int wave = (int)blockIdx.x * PC_PROD + pw, nwaves = (int)gridDim.x * PC_PROD;
   const bool mean = !(a.flags & FASTEGNN_F_COORDS_SUM);

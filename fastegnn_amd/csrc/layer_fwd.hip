@@ -123,8 +123,9 @@ int node_pre_forward(const fastegnn_layer_t *L, hipStream_t st) {
 #define FE_XSUM_PER_WAVE 1024
 #endif
 constexpr int XSUM_PER_WAVE = FE_XSUM_PER_WAVE;
-__global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const int32_t *batch, int N, float *xsum) {
-  constexpr int PER_WAVE = XSUM_PER_WAVE;
+// (round 6: the nodes per wave are a launch argument -- XSUM_PER_WAVE for large inputs; a small input (a 12 500-node shard, the N-body
+//  mini-batches) gets shorter walks on more waves: at 1 024 nodes per wave a shard's launch was 13 waves x 16 dependent iterations = 15 us)
+__global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const int32_t *batch, int N, float *xsum, int PER_WAVE) {
   const int l = lane_id();
   const int n0 = global_wave_id() * PER_WAVE, n1 = min(N, n0 + PER_WAVE);
   if (n0 >= n1) return;
@@ -186,7 +187,10 @@ __global__ __launch_bounds__(256) void graph_xsum_kernel(const float *x, const i
 int graph_xsum(const fastegnn_layer_t *L, hipStream_t st) {
   FE_REQUIRE(L->xsum && L->batch && L->x, "graph_xsum: null buffer");
   (void)hipMemsetAsync(L->xsum, 0, (size_t)L->B * 4 * sizeof(float), st);
-  if (L->N > 0) { ProfScope _ps_graph_xsum_kernel(K_XSUM, st); hipLaunchKernelGGL(graph_xsum_kernel, dim3(cdiv(L->N, 4 * XSUM_PER_WAVE)), dim3(256), 0, st, L->x, L->batch, L->N, L->xsum); }   // 4 waves x XSUM_PER_WAVE nodes
+  // nodes per wave: ~64 waves in flight for a small input (same-address atomics: one set per wave), XSUM_PER_WAVE at most
+  int per_wave = (cdiv(L->N, 64) + 63) / 64 * 64;
+  per_wave = per_wave < 64 ? 64 : (per_wave > XSUM_PER_WAVE ? XSUM_PER_WAVE : per_wave);
+  if (L->N > 0) { ProfScope _ps_graph_xsum_kernel(K_XSUM, st); hipLaunchKernelGGL(graph_xsum_kernel, dim3(cdiv(L->N, 4 * per_wave)), dim3(256), 0, st, L->x, L->batch, L->N, L->xsum, per_wave); }   // 4 waves x per_wave nodes
   return check_launch("graph_xsum_kernel");
 }
 

@@ -970,9 +970,15 @@ __device__ int g_vbs_dog[64];
 #define VBS_SPIN(id, cond, sl) { long _n = 0; while (cond) { __builtin_amdgcn_s_sleep(sl); if (++_n > 3000000) { if (lane_id() == 0) { atomicAdd(&g_vbs_dog[id], 1); if (blockIdx.x == 0 && g_vbs_dog[48 + wave_id()] == 0) g_vbs_dog[48 + wave_id()] = (id) * 1000000 + _mark; } break; } } }
 #define VBS_MARK(x) _mark = (x)
 #else
-#define VBS_SPIN(id, cond, sl) while (cond) __builtin_amdgcn_s_sleep(sl)
+// release builds (round 6): every spin of the channel-phased kernel is BOUNDED -- a hand-off flag that never comes (a bug in
+// the READY / TSEQ / ring protocols) ends the wait after ~0.3 s and counts in g_vbs_timeouts instead of hanging the GPU; the launch then
+// finishes with wrong numbers, fastegnn_spin_timeouts() (a synchronising query for tests and post-mortems) says so.  Costs one scalar add
+// and compare per turn of a spin that practically never turns.
+#define VBS_SPIN(id, cond, sl) { int _n = 0; while (cond) { __builtin_amdgcn_s_sleep(sl); if (++_n > VBS_SPIN_LIMIT) { if (lane_id() == 0) atomicAdd(&g_vbs_timeouts, 1); break; } } }
 #define VBS_MARK(x)
 #endif
+constexpr int VBS_SPIN_LIMIT = 1 << 23;
+__device__ int g_vbs_timeouts = 0;
 template <bool ATT>
 __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A) {
   constexpr int SM = GM_F16;
@@ -1176,6 +1182,7 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
 #ifdef FE_VBS_WATCHDOG
       long dog = 0;
 #endif
+      int idle = 0;   // (release: bounded like VBS_SPIN)
       while ((doW && doneA < total) || (doV2 && doneB < total)) {
         bool did = false;
         if (doV2 && doneB < total) {
@@ -1242,8 +1249,10 @@ __global__ __launch_bounds__(64 * VB_WAVES) void virt_bwd_cs_kernel(VirtCsArgs A
             did = true;
           }
         }
+        if (did) idle = 0;
         if (!did) {
           __builtin_amdgcn_s_sleep(1);
+          if (++idle > VBS_SPIN_LIMIT) { if (l == 0) atomicAdd(&g_vbs_timeouts, 1); break; }
 #ifdef FE_VBS_WATCHDOG
           if (++dog > 6000000) { if (l == 0) { atomicAdd(&g_vbs_dog[6], 1); if (blockIdx.x == 0) { g_vbs_dog[38] = doneA; g_vbs_dog[39] = doneB; g_vbs_dog[40] = total; g_vbs_dog[41] = ctrl[VBSC_UNIT]; g_vbs_dog[42] = ctrl[VBSC_HEAD]; g_vbs_dog[43] = ctrl[VBSC_HEAD + 1]; for (int _k = 0; _k < 8; ++_k) { g_vbs_dog[8 + _k] = ctrl[VBSC_READY + _k]; g_vbs_dog[16 + _k] = ctrl[VBSC_DONE + _k]; } } } break; }
 #endif
@@ -1787,6 +1796,15 @@ extern "C" int fastegnn_debug_read_vb2_stamps(unsigned long long *out, int reset
 }
 #endif
 
+extern "C" int fastegnn_spin_timeouts(int reset) {
+  int n = -1;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(fe::g_vbs_timeouts), sizeof(int)) != hipSuccess) return -1;
+  if (reset) {
+    const int z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(fe::g_vbs_timeouts), &z, sizeof(int));
+  }
+  return n;
+}
 #ifdef FE_VBS_WATCHDOG
 extern "C" int fastegnn_debug_read_vbs_dog(int *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::g_vbs_dog), sizeof(int) * 64) != hipSuccess) return -1;

@@ -80,6 +80,7 @@ class _EGNNFunction(torch.autograd.Function):
     def forward(ctx, spec, graph, edge_fea, x, h_in, v, *params):
         lib = K.lib(act=spec.act_kind != K.ACT_SILU, wide=spec.wide)
         ctx.wide = spec.wide
+        ctx.guard = getattr(spec, "guard", None)   # the module's RangeGuard while it runs on the f16x2 build (fastegnn_amd.model)
         # edge_fea is a differentiable input (basic.py:313 concatenates it into the message MLP's input): its gradient is
         # accumulated by the edge backward kernel in sorted-edge order when asked for
         ea_sorted = graph.permute(edge_fea.detach() if edge_fea is not None else None)
@@ -162,6 +163,8 @@ class _EGNNFunction(torch.autograd.Function):
         if g_ea_sorted is not None:   # back to the caller's edge order: sorted edge k is input edge perm[k]
             g_ea = torch.empty_like(g_ea_sorted)
             g_ea.index_copy_(0, graph.perm[:E].long(), g_ea_sorted)
+        if ctx.guard is not None:   # a forward that left the fp16 operand range hands ZERO parameter gradients on (model.RangeGuard)
+            ctx.guard.zero_if_flagged(lib, flat)
         return (None, None, g_ea, g_x, g_hin, g_vel, *grads)
 
 
@@ -252,11 +255,12 @@ class EGNN(nn.Module):
         if not guard.wide:
             guard.poll("EGNN", self._plist)      # no synchronisation: an overflow of an EARLIER pass switches the build here (model.RangeGuard)
         spec.wide = guard.wide
+        spec.guard = None if guard.wide else guard
         x_out, h_out = _EGNNFunction.apply(spec, graph, edge_fea, x, h, vv, *plist)
         if not guard.wide:
             guard.launch(K.lib(act=spec.act_kind != K.ACT_SILU, wide=False), (x_out, h_out), (x, h))
             if guard.mode == "sync" and guard.sync_and_poll(x.device, "EGNN", self._plist):
-                spec.wide = True
+                spec.wide, spec.guard = True, None
                 x_out, h_out = _EGNNFunction.apply(spec, graph, edge_fea, x, h, vv, *plist)
         if self.hidden_nf < H:
             h_out = h_out[:, :self.hidden_nf]     # the padded features are identically zero

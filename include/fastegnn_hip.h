@@ -335,6 +335,11 @@ int fastegnn_host_words_free(int32_t *words);
 /* buf[0..n) = 0 if *flag != 0 (flag: device or host-mapped word).  The backward of a forward whose outputs left the f16x2 range
  * hands ZERO parameter gradients to the optimizer instead of NaNs (the host may not have seen the flag yet).  ABI revision 107. */
 int fastegnn_zero_if_flagged(float *buf, int64_t n, const int32_t *flag, void *stream);
+/* The channel-phased virtual backward hands work between the waves of a workgroup through LDS flags; since round 6 every wait on such a
+ * flag is bounded (~0.3 s).  Returns how many waits have given up since the last reset -- 0 unless the hand-off protocol has a bug (the
+ * launch then finished with wrong results instead of hanging the device); < 0: the query failed.  SYNCHRONISES the device: for tests and
+ * post-mortems, not for the step.  ABI revision 107. */
+int fastegnn_spin_timeouts(int reset);
 /* batch int64 [N] (ascending) -> batch int32 [N], gptr int32 [B+1] */
 int fastegnn_build_batch(const int64_t *batch64, int32_t N, int32_t B, int32_t *batch, int32_t *gptr,
                          void *stream);

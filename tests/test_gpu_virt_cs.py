@@ -85,6 +85,7 @@ def _default_path(cfg, inp, seed, case="test_cfg4_headline_shape_vs_oracle"):
     finally:
         K.lib().fastegnn_profile_enable(0)
     assert prof.get("virt_bwd_kernel", (0, 0))[1] == cfg.n_layers and "virt_bwd_gv_kernel" not in prof, prof
+    assert K.lib().fastegnn_spin_timeouts(1) == 0      # no hand-off wait of the phased kernel gave up (bounded spins, round 6)
 
 
 @pytest.mark.skipif(os.environ.get("FASTEGNN_VIRT_CS", "1") == "0" or "FASTEGNN_VIRT_CS_MIN_GRID" in os.environ,
