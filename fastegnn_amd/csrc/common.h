@@ -859,9 +859,11 @@ __device__ __forceinline__ Split2 vsplit2(const Vec &v) {
 #ifndef FE_F2_PIPE_FWD
 #define FE_F2_PIPE_FWD 1
 #endif
+// off4: a run-time offset of the image in 16-byte units, added to the LANE index rather than to the pointer (virt_fwd's PAIR walk picks one
+// of four stage slots per iteration: as pointer arithmetic ahead of the generic cast that crashed this hipcc's backend, layer_fwd.hip)
 template <bool PIPE = false>
-__device__ __forceinline__ void gemm64_f2(const unsigned *img3, const Split2 &in, Vec &acc) {
-  const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + lane_id();
+__device__ __forceinline__ void gemm64_f2(const unsigned *img3, const Split2 &in, Vec &acc, int off4 = 0) {
+  const u32x4 *ip = reinterpret_cast<const u32x4 *>(img3) + (lane_id() + off4);
   const f16x8 xh0 = __builtin_bit_cast(f16x8, in.p[0][0]), xh1 = __builtin_bit_cast(f16x8, in.p[0][1]);
   const f16x8 xl0 = __builtin_bit_cast(f16x8, in.p[1][0]), xl1 = __builtin_bit_cast(f16x8, in.p[1][1]);
   if constexpr (PIPE && FE_F2_PIPE_FWD != 0) {

@@ -399,6 +399,7 @@ inline VirtArgs make_virt_args(const fastegnn_layer_t *L) {
   a.act_param = L->act_param;
   return a;
 }
+void launch_virt_fwd_pair(const VirtArgs &a, int grid, size_t lds, hipStream_t st);   // virt_fwd_pair.hip
 inline size_t virt_lds_bytes(int C, int n_img, int waves = VIRT_WAVES) {
   return (size_t)(n_img * IMG + 16 * H + waves * 16 * TS + C * H + 4 * C) * sizeof(float);
 }
