@@ -602,7 +602,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void edge_bwd_pc_kernel(EdgeBwdArgs 
 #pragma unroll
       for (int k = 0; k < 3; ++k) gax[k] = A.g_aggx[(size_t)cur_i.row * 3 + k];
       Vec gam;   // (EA = 7 variant: 16 more live registers would spill; it keeps this row's load at its use)
-      if constexpr (PF_IDX) gam = vload_row(A.g_aggm + (size_t)cur_i.row * H, q);
+      constexpr bool GAM_EARLY = PF_IDX && PC_WAVES <= 8;   // (12 waves: 168 registers -- the row is requested at its use)
+      if constexpr (GAM_EARLY) gam = vload_row(A.g_aggm + (size_t)cur_i.row * H, q);
       edge_tile_forward<true, MODE, true>(a, img, vec, cur_i, q, S, pre FE_TA);   // pre, S.mp, S.up now hold silu'()
       const int dg = rp1 - rp0;
       const float inv = valid ? rcp_f((float)(dg > 1 ? dg : 1)) : 0.f;
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void edge_bwd_pc_kernel(EdgeBwdArgs 
       FE_T(5)   // degree / g_aggx rows, head adjoint, g_up
       publish(1, g_up, S.m);
       FE_T(6)   // publish (g_up, m)
-      if constexpr (!PF_IDX) gam = vload_row(A.g_aggm + (size_t)S.row * H, q);
+      if constexpr (!GAM_EARLY) gam = vload_row(A.g_aggm + (size_t)S.row * H, q);
       Vec g_m = vscale(gam, inv);
       gemm_e<MODE, 3, true>(img, g_up, g_m);
       Vec g_m0 = g_m;

@@ -122,6 +122,9 @@ __device__ __forceinline__ void gemm_i(const void *img, int i, const Vec &in, Ve
 #define VF_PRIO_ON()
 #define VF_PRIO_OFF()
 #endif
+#ifndef FE_EB_P16   // the software-pipelined f16x2 product in the producers of edge_bwd_pc (common.h); 0 in the three-waves-per-SIMD experiment
+#define FE_EB_P16 1
+#endif
 #ifdef EF_PRIO
 #define EF_PRIO_ON() __builtin_amdgcn_s_setprio(EF_PRIO)
 #define EF_PRIO_OFF() __builtin_amdgcn_s_setprio(0)
@@ -136,12 +139,12 @@ __device__ __forceinline__ void gemm_e(const void *img, const Vec &in, Vec &acc)
   if constexpr (RM && I >= 2) {   // the transposed products take gradients: the f16x2 form scales them per item
     const auto op = make_grad_operand<MODE>(in);
     EF_PRIO_ON();
-    gemm_rm_g<MODE, true, false>(static_cast<const char *>(img) + (I & 1) * rm_lds_bytes<MODE>(), op, acc);
+    gemm_rm_g<MODE, true, false, FE_EB_P16 != 0>(static_cast<const char *>(img) + (I & 1) * rm_lds_bytes<MODE>(), op, acc);
     EF_PRIO_OFF();
   } else {
     const auto op = make_operand<MODE>(in);
     EF_PRIO_ON();
-    if constexpr (RM) gemm_rm<MODE, false, false>(static_cast<const char *>(img) + (I & 1) * rm_lds_bytes<MODE>(), op, acc);
+    if constexpr (RM) gemm_rm<MODE, false, false, FE_EB_P16 != 0>(static_cast<const char *>(img) + (I & 1) * rm_lds_bytes<MODE>(), op, acc);
     else gemm_op<MODE, true>(img, I, op, acc);   // (edge_fwd: the software-pipelined f16x2 product, common.h)
     EF_PRIO_OFF();
   }
