@@ -101,7 +101,11 @@ class RangeGuard:
         """the host-mapped words; allocated on first use (a host allocation: legal outside AND inside a stream capture)"""
         if self._words is None:
             p = C.POINTER(C.c_int32)()
-            K.check(K.lib().fastegnn_host_words_alloc(2, C.byref(p)), "fastegnn_host_words_alloc")
+            rc = K.lib().fastegnn_host_words_alloc(2, C.byref(p))
+            if rc != 0 and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("fastegnn_amd: the range guard's host-mapped words could not be allocated inside a stream capture; "
+                                   "run one eager forward of the module before capturing it into a HIP graph")
+            K.check(rc, "fastegnn_host_words_alloc")
             self._words = p
         return self._words
 
