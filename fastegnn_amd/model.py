@@ -84,14 +84,15 @@ class RangeGuard:
     ``mode``: "deferred" (default, above) or "sync" (``FASTEGNN_RANGE_CHECK=sync`` / ``module.range_check = "sync"``): the eager
     forward waits for its own guard launch and re-runs the call on the wide-range build before it returns -- what round 5 did,
     at one stream synchronisation per forward.  FASTEGNN_WIDE_RANGE=1 starts on the wide-range build, =0 pins the f16x2 build and
-    turns the overflow into a FloatingPointError (at the poll that sees it)."""
+    turns the overflow into a FloatingPointError (at the poll that sees it); FASTEGNN_RANGE_CHECK=off queues no guard launch at all."""
 
     OUT, IN = 0, 1
 
     def __init__(self):
         self.forced = K.WIDE_RANGE            # None: automatic
         self.wide = bool(K.WIDE_RANGE)        # the build in use
-        self.mode = "sync" if os.environ.get("FASTEGNN_RANGE_CHECK", "deferred") == "sync" else "deferred"
+        rc = os.environ.get("FASTEGNN_RANGE_CHECK", "deferred")
+        self.mode = rc if rc in ("sync", "off") else "deferred"   # "off": no guard launches at all (the caller vouches for the operand range)
         self._words = None                    # ctypes int32[2], host-mapped (fastegnn_host_words_alloc)
         self.warned = False
         self.warned_inputs = False
@@ -121,6 +122,8 @@ class RangeGuard:
 
     def launch(self, lib, outs, ins=()):
         """queue the check of up to two fp32 output tensors (word OUT) and up to two input tensors (word IN) on the current stream"""
+        if self.mode == "off":
+            return
         def two(ts):
             ts = [t.detach() for t in ts if t is not None and t.dtype == torch.float32 and t.is_contiguous() and t.numel()]
             return (ts + [None, None])[:2]
