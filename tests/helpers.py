@@ -130,11 +130,13 @@ GRAD_EXCEPTIONS = [
      "the attention goldens are moderately ill-conditioned (reference 1e-5 from exact arithmetic on the layer-1 edge "
      "stage, 10x its usual level): HIP measures <= 3.3x the reference's draw on the edge-stage tensors of that layer "
      "(gcl_1.coord_mlp_r.0.bias 3.59e-6 vs 1.09e-6; 2.5-6.0x and factor 8 with the truncating split of rounds 1-2)"),
-    (r"attention|allflags", r"att_mlp(_virtual)?\.0\.(weight|bias)", 12.0, 8e-6,
+    (r"attention|allflags|wide_h160", r"att_mlp(_virtual)?\.0\.(weight|bias)", 12.0, 8e-6,
      "attention gates: scalar / 64-vector gradients that are cancelling sums over ~100 edges whose per-edge term "
      "g_a = <g_m, m0> is itself a cancelling 64-term dot product; the CPU re-association above measures 10.8x the "
      "reference's draw on att_mlp.0.bias (9.1e-6 vs 8.4e-7); HIP: 8.0x (6.77e-6, ragged3_attention gcl_1), 5.65e-6 "
-     "against a reference draw of 1.4e-8 on the 4 000-node GELU case (23.5-33x and factor 40 with the truncating split)"),
+     "against a reference draw of 1.4e-8 on the 4 000-node GELU case (23.5-33x and factor 40 with the truncating split).  Round 6: the wide path's "
+     "attention case (wide_h160: fp32 atomics in arrival order) joins -- gcl_0.att_mlp.0.bias sits at 1.60e-6 / 1.69e-6 of a plain tolerance of 1.81e-6 "
+     "in 12 of 12 repeats and went over it once in a full-suite run (tools/gpu_r6_wide_repeat.sh)"),
     (r".", r"(edge_mlp|coord_mlp_r|edge_message_net\.scalar_net\.mlp|coord_net\.mlp)\.", 2.0, 1e-5,
      "parameter gradients of the edge stage: sums over up to 370 k edges with cancellation (max|g| ~1e-8 on the last "
      "layers of the radius-graph cases): measured <= 1.02e-5 over 2 x ref (cfg5 shape at 20 k nodes, "
