@@ -12,14 +12,17 @@ seen = {}
 for i, fn in enumerate(args):
     for line in open(fn):
         r = json.loads(line)
-        row = seen.setdefault((r["case"], r["tensor"]), {"tol": r["tol"], "ref": r["ref"], "got": [[] for _ in args]})
-        row["got"][i].append(r["got"])
+        # a (case, tensor) pair can occur several times in one run (parametrised tests under one case name), each with its own
+        # reference error and tolerance: the ratio is taken per record, the row shows the record with the largest one
+        row = seen.setdefault((r["case"], r["tensor"]), {"tol": r["tol"], "ref": r["ref"], "ratio": 0.0, "got": [[] for _ in args]})
+        if r["tol"] > 0 and r["got"] / r["tol"] > row["ratio"]:
+            row["ratio"], row["tol"], row["ref"] = r["got"] / r["tol"], r["tol"], r["ref"]
+        row["got"][i].append(r["got"] / r["tol"] if r["tol"] > 0 else 0.0)
 rows = []
 for (case, tensor), r in seen.items():
-    worst = max((max(g) for g in r["got"] if g), default=0.0)
-    if r["tol"] > 0 and worst / r["tol"] >= thr:
-        rows.append((worst / r["tol"], case, tensor, r))
+    if r["ratio"] >= thr:
+        rows.append((r["ratio"], case, tensor, r))
 print(f"{len(seen)} (case, tensor) pairs in {len(args)} file(s); {len(rows)} with got/tol >= {thr}")
 for ratio, case, tensor, r in sorted(rows, reverse=True):
-    vals = " ".join("%.2e" % max(g) if g else "-" for g in r["got"])
-    print("  %.2f  %-36s %-40s tol %.2e ref %.2e got %s" % (ratio, case[:36], tensor[:40], r["tol"], r["ref"], vals))
+    vals = " ".join("%.2f" % max(g) if g else "-" for g in r["got"])
+    print("  %.2f  %-36s %-40s tol %.2e ref %.2e  got/tol per file: %s" % (ratio, case[:36], tensor[:40], r["tol"], r["ref"], vals))
