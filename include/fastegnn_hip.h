@@ -282,6 +282,9 @@ size_t fastegnn_sizeof_graph(void);
  * rowptr[n_rows+1], erow/col/perm/csc_eid[E], cscptr[n_src+1], chunk_row[fastegnn_chunk_rows(E)]
  * (row boundaries nearest to every 32nd edge: the edge kernels give each wave a contiguous run of them);
  * tmp: fastegnn_csr_tmp_bytes(E, n_rows, n_src) bytes.  *n_chunks is a host int.
+ * The index is the STABLE sort's (edges of a row keep the caller's order): built with rocPRIM radix sorts, or -- edge lists of
+ * at most 600 000 edges with at most 64 edges per id on average -- by counting (count, scan, place, rank inside the id), which gives
+ * the same arrays element for element; FASTEGNN_CSR_SORT=radix|count in the environment forces one form.
  * The edge stages address their tables with 32-bit offsets: n_rows * 68 and n_src * 68 must stay below 2^30
  * (15.7 M nodes) and E * 8 below 2^30 (134 M edges); fastegnn_edge_forward / _backward return
  * FASTEGNN_E_INVALID beyond that. */

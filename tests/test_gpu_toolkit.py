@@ -64,10 +64,26 @@ def test_wgrad_tn(M):
     assert torch.equal(db.cpu(), G.cpu().sum(0))
 
 
-@pytest.mark.parametrize("N,E", [(1, 0), (5, 3), (37, 400), (1000, 20000), (300, 70000)])
-def test_build_csr_matches_oracle(N, E):
-    g = torch.Generator().manual_seed(N + E)
+def _hub(N, E, hub_edges, g):
+    """random edges plus one row AND one column that hold `hub_edges` edges each, scattered over the edge list"""
     ei = torch.randint(0, N, (2, E), generator=g)
+    at = torch.randperm(E, generator=g)
+    ei[0][at[:hub_edges]] = N // 3
+    ei[1][at[hub_edges // 2: hub_edges // 2 + hub_edges]] = N // 2
+    return ei
+
+
+# (1000, 20000), (37, 400), (5, 3): <= 64 edges per id on average -- the index is built by COUNTING (csr.hip: count_index; one workgroup scans
+# the bins); (40000, 590000): the same with rocprim's scan; (300, 70000): the radix sorts; "hub": ids beyond CS_BIG = 2048 edges inside a
+# sparse graph (their edges are compacted by cs_big_kernel); the result is the stable sort's in every case
+@pytest.mark.parametrize("N,E", [(1, 0), (5, 3), (37, 400), (1000, 20000), (300, 70000), (40000, 590000), ("hub", 0)])
+def test_build_csr_matches_oracle(N, E):
+    if N == "hub":
+        N, E = 3000, 60000
+        ei = _hub(N, E, 5000, torch.Generator().manual_seed(5))
+    else:
+        g = torch.Generator().manual_seed(N + E)
+        ei = torch.randint(0, N, (2, E), generator=g)
     if N > 3:
         ei[0][ei[0] == 2] = 3     # node 2 has no in-edges
     ref = F.build_csr(ei, N)
@@ -84,9 +100,38 @@ def test_build_csr_matches_oracle(N, E):
     assert cr[0] == 0 and cr[-1] == N and bool((cr[1:] >= cr[:-1]).all())
     rp = sg.rowptr.cpu()
     T = K.lib().fastegnn_chunk_edges()
-    for k in range(sg.n_chunks):   # chunk k owns the rows whose first edge lies in [T k, T (k+1))
+    for k in range(min(sg.n_chunks, 3000)):   # chunk k owns the rows whose first edge lies in [T k, T (k+1))
         for r in range(int(cr[k]), int(cr[k + 1])):
             assert T * k <= int(rp[r]) and (int(rp[r]) < T * (k + 1) or k == sg.n_chunks - 1)
+
+
+def test_build_csr_counting_and_radix_forms_agree():
+    """FASTEGNN_CSR_SORT forces one form (read once per process: child processes); a shard-shaped input (rows [row_begin, row_begin + n_rows)
+    of a larger graph, a source table wider than the row range) and a dense one, both forms on both"""
+    import subprocess, sys, os
+    code = r'''
+import sys, torch, hashlib
+sys.path.insert(0, ".")
+from fastegnn_amd.model import SortedGraph
+g = torch.Generator().manual_seed(9)
+out = []
+for n_rows, n_src, row_begin, E in ((5000, 7000, 12000, 90000), (200, 200, 0, 30000)):
+    ei = torch.stack([torch.randint(row_begin, row_begin + n_rows, (E,), generator=g), torch.randint(0, n_src, (E,), generator=g)])
+    sg = SortedGraph(ei.cuda(), n_rows, n_src=n_src, row_begin=row_begin)
+    torch.cuda.synchronize()
+    h = hashlib.sha1()
+    for t in (sg.rowptr, sg.erow, sg.col, sg.perm, sg.cscptr, sg.csc_eid, sg.chunk_row[: sg.n_chunks + 1]):
+        h.update(t.cpu().numpy().tobytes())
+    out.append(h.hexdigest())
+print("RESULT " + " ".join(out))
+'''
+    res = {}
+    for form in ("count", "radix"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           env=dict(os.environ, FASTEGNN_CSR_SORT=form), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[form] = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    assert res["count"] == res["radix"], res
 
 
 def test_bf16x3_split_gemm_is_fp32_accurate():
