@@ -97,8 +97,9 @@ def _oracle_results(cfg, p, inp, tgt):
         assert sum(t.grad is not None for t in pp.values()) > len(pp) - 12   # only the last layer's unused heads are None
         res[dt] = (l.detach(), v.detach(), {k: (t.grad if t.grad is not None else torch.zeros_like(t)) for k, t in pp.items()})
     if path:
-        torch.save(res, path + ".tmp")
-        os.replace(path + ".tmp", path)
+        tmp = f"{path}.{os.getpid()}.tmp"   # (two processes may evaluate the same key at once: each writes its own file, the rename is atomic)
+        torch.save(res, tmp)
+        os.replace(tmp, path)
     return res
 
 
